@@ -1,0 +1,254 @@
+/*
+ * raftgroups.h -- C ABI of the MI355X multi-raft progress/commit engine.
+ *
+ * This is the drop-in boundary for ONE hot path of pingcap/raft-rs v0.6.0 (all
+ * file:line citations are relative to the reference tree): what a leader does for
+ * every MsgAppendResponse -- Raft::handle_append_response (src/raft.rs:1559-1775) ->
+ * Progress::{update_committed,maybe_decr_to,maybe_update,become_*} (src/tracker/progress.rs)
+ * -> Raft::maybe_commit (src/raft.rs:893-904) -> ProgressTracker::maximal_committed_index
+ * (src/tracker.rs:294-298) -> JointConfig/MajorityConfig::committed_index
+ * (src/quorum/joint.rs:47-51, src/quorum/majority.rs:70-124) -> RaftLog::maybe_commit
+ * (src/raft_log.rs:487-499) -- evaluated for N independent raft groups per call on the GPU.
+ *
+ * The reference has no FFI: everything is generic Rust (Raft<T: Storage>, src/raft.rs:267).
+ * The seam chosen is the ProgressTracker + RaftLog.committed state behind
+ * handle_append_response; INTEGRATION.md shows the Rust `extern "C"` block that binds
+ * these entry points and where Raft::step would call them.
+ *
+ * Conventions
+ *  - plain C types only; all buffers are caller-owned; the engine keeps no host pointer
+ *    after a call returns (async H2D copies are completed or staged before return);
+ *  - every call returns RG_OK (0) or a negative rg_status; rg_last_error() has the text;
+ *  - one caller thread per handle (mirrors "thread-unsafe" RawNode, src/raw_node.rs:284);
+ *  - a group has up to 8 peer slots; slot s of a group is one Progress (src/tracker/progress.rs:8-56);
+ *  - device state is struct-of-arrays: per-slot u64 columns are peer-major [P][stride]
+ *    (stride = n_groups rounded up to 256), per-slot flag bytes are one u64 row per group
+ *    ([G][8], byte s = slot s), per-group scalars are [G].
+ */
+#ifndef RAFTGROUPS_H
+#define RAFTGROUPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_MAX_SLOTS 8
+
+/* ---- status codes; the negative values mirror src/errors.rs:6-50 where one applies ---- */
+typedef enum {
+    RG_OK = 0,
+    RG_ERR_INVALID_ARG = -1,
+    RG_ERR_NO_DEVICE = -2,       /* no HIP device / HIP runtime error: there is NO CPU fallback */
+    RG_ERR_OUT_OF_MEMORY = -3,
+    RG_ERR_STEP_LOCAL_MSG = -4,  /* Error::StepLocalMsg   (src/errors.rs:19, src/raw_node.rs:404-406) */
+    RG_ERR_STEP_PEER_NOT_FOUND = -5, /* Error::StepPeerNotFound (src/errors.rs:22, src/raw_node.rs:407-410) */
+    RG_ERR_SLOT_BUSY = -6,       /* a second message for the same (group, peer) before rg_tick */
+    RG_ERR_HIGHER_TERM = -7,     /* m.term > term: the host must step down (src/raft.rs:1284-1348) */
+    RG_ERR_STATE = -8            /* call sequence error (e.g. results before any tick) */
+} rg_status;
+
+/* ---- Progress flag byte (one per slot; src/tracker/progress.rs:8-56, src/tracker/state.rs:22-29) ---- */
+#define RG_PF_STATE_MASK 0x03u /* 0 Probe, 1 Replicate, 2 Snapshot */
+#define RG_STATE_PROBE 0u
+#define RG_STATE_REPLICATE 1u
+#define RG_STATE_SNAPSHOT 2u
+#define RG_PF_PAUSED 0x04u        /* Progress.paused */
+#define RG_PF_RECENT_ACTIVE 0x08u /* Progress.recent_active */
+
+/* ---- message flag byte (one per slot per tick) ---- */
+#define RG_MF_VALID 0x01u    /* an AppendResponse from this peer (on the self slot: on_persist_entries(m_index), src/raft.rs:994-1016) */
+#define RG_MF_REJECT 0x02u   /* Message.reject */
+#define RG_MF_HAS_RS 0x04u   /* Message.request_snapshot != 0 (value in m_rs) */
+#define RG_MF_INS_FULL 0x08u /* host's Inflights::full() for this peer (Progress::is_paused, progress.rs:210-216) */
+#define RG_MF_SENT 0x10u     /* the host sent a MsgAppend up to last_index since the previous tick:
+                                apply Progress::update_state(last) first (progress.rs:231-243, src/raft.rs:726-729) */
+#define RG_MF_APPEND 0x20u   /* self slot only: leader appended entries, new last_index in m_commit
+                                (Raft::append_entry, src/raft.rs:976-991) */
+
+/* ---- per-group configuration word ---- */
+#define RG_CFG_INCOMING(c) ((uint32_t)(c) & 0xffu)        /* voters.incoming as a slot bitmask (tracker.rs:37-40) */
+#define RG_CFG_OUTGOING(c) (((uint32_t)(c) >> 8) & 0xffu) /* voters.outgoing; 0 = not joint */
+#define RG_CFG_SELF(c) (((uint32_t)(c) >> 16) & 0x7u)     /* slot of the leader itself */
+#define RG_CFG_GROUP_COMMIT 0x00080000u                   /* ProgressTracker.group_commit (tracker.rs:207) */
+#define RG_CFG_TRANSFEREE(c) (((uint32_t)(c) >> 20) & 0xfu) /* lead_transferee slot + 1, 0 = none */
+#define RG_CFG_PRESENT(c) (((uint32_t)(c) >> 24) & 0xffu) /* slots that have a Progress (voters + learners) */
+#define RG_CFG_MAKE(incoming, outgoing, self_slot, group_commit, transferee_plus1, present)            \
+    (((uint32_t)(incoming)&0xffu) | (((uint32_t)(outgoing)&0xffu) << 8) |                              \
+     (((uint32_t)(self_slot)&0x7u) << 16) | ((group_commit) ? RG_CFG_GROUP_COMMIT : 0u) |              \
+     (((uint32_t)(transferee_plus1)&0xfu) << 20) | (((uint32_t)(present)&0xffu) << 24))
+
+/* ---- per-group result word written by every tick ---- */
+#define RG_OUT_CHANGED 0x1u     /* some maybe_commit() returned true (src/raft.rs:1745): host runs bcast_append if should_bcast_commit() */
+#define RG_OUT_FAULT 0x2u       /* a precondition of the path was violated (where the reference panics or input is malformed) */
+#define RG_OUT_TIMEOUT_NOW 0x4u /* send_timeout_now(transferee) (src/raft.rs:1764-1774) */
+#define RG_OUT_SEND_APPEND(o) (((uint32_t)(o) >> 8) & 0xffu) /* per slot: send_append(from) (raft.rs:1719, :1750) */
+#define RG_OUT_SEND_MORE(o) (((uint32_t)(o) >> 16) & 0xffu)  /* per slot: the maybe_send_append loop (raft.rs:1761) */
+#define RG_OUT_FREE_TO(o) (((uint32_t)(o) >> 24) & 0xffu)    /* per slot: ins.free_to(m.index) (raft.rs:1742) */
+
+/* ---- columns (for rg_load_column / rg_read_column / rg_column_ptr) ---- */
+typedef enum {
+    RG_COL_MATCH = 0,     /* u64 [P][stride]  Progress.matched */
+    RG_COL_NEXT = 1,      /* u64 [P][stride]  Progress.next_idx */
+    RG_COL_PR_COMMIT = 2, /* u64 [P][stride]  Progress.committed_index */
+    RG_COL_PEND_SNAP = 3, /* u64 [P][stride]  Progress.pending_snapshot */
+    RG_COL_PEND_RS = 4,   /* u64 [P][stride]  Progress.pending_request_snapshot */
+    RG_COL_GID = 5,       /* u64 [P][stride]  Progress.commit_group_id */
+    RG_COL_PFLAGS = 6,    /* u8  [G][8]       RG_PF_* */
+    RG_COL_COMMIT = 7,    /* u64 [G]          RaftLog.committed */
+    RG_COL_TERM_LO = 8,   /* u64 [G]          first index whose term == current term */
+    RG_COL_TERM_HI = 9,   /* u64 [G]          last_index (last index whose term == current term) */
+    RG_COL_CFG = 10,      /* u32 [G]          RG_CFG_* */
+    RG_COL_OUT = 11,      /* u32 [G]          RG_OUT_* of the last tick */
+    RG_COL_COUNT = 12
+} rg_column;
+
+/* ---- a tick's messages, struct-of-arrays, HOST or DEVICE memory (see rg_tick / rg_tick_device) ---- */
+typedef struct {
+    const uint64_t *m_index;  /* [P][stride] Message.index (self slot: persisted index) */
+    const uint64_t *m_commit; /* [P][stride] Message.commit (self slot with RG_MF_APPEND: new last_index) */
+    const uint64_t *m_hint;   /* [P][stride] Message.reject_hint, after find_conflict_by_term when log_term>0 (raft.rs:1562,1657-1660); read only for rejects; may be NULL if no rejects */
+    const uint64_t *m_rs;     /* [P][stride] Message.request_snapshot; read only when RG_MF_HAS_RS; may be NULL */
+    const uint8_t *m_flags;   /* [G][8] RG_MF_* */
+} rg_msgs;
+
+typedef struct rg_engine rg_engine;
+
+typedef struct {
+    uint64_t n_groups; /* groups held by THIS engine (= this rank's shard) */
+    uint32_t n_slots;  /* peer slots per group, 1..8 */
+    int32_t device;    /* HIP device ordinal */
+    uint32_t variant;  /* kernel variant: 0 = default (RG_VARIANT_*) */
+    uint32_t reserved;
+} rg_config;
+
+#define RG_VARIANT_DEFAULT 0u
+#define RG_VARIANT_LANE 1u /* one lane per group, columns straight into registers */
+#define RG_VARIANT_LDS 2u  /* one wave per 64-group batch, peer columns staged through LDS */
+
+/* ---- lifecycle ---- */
+const char *rg_version(void);
+const char *rg_last_error(void);
+int rg_device_count(void);
+int rg_create(const rg_config *cfg, rg_engine **out);
+void rg_destroy(rg_engine *h);
+uint64_t rg_stride(const rg_engine *h); /* column stride in elements */
+/* Run all engine work on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int rg_set_stream(rg_engine *h, void *hip_stream);
+int rg_sync(rg_engine *h);
+
+/* ---- state in/out (parity checks, checkpoint/restore; ProgressTracker::get / Status) ---- */
+/* Copy a whole column host->device / device->host. `bytes` must equal rg_column_bytes(). */
+uint64_t rg_column_bytes(const rg_engine *h, int column);
+int rg_load_column(rg_engine *h, int column, const void *host_src, uint64_t bytes);
+int rg_read_column(rg_engine *h, int column, void *host_dst, uint64_t bytes);
+/* Device address of a column (for zero-copy consumers, e.g. an RCCL all-gather of RG_COL_COMMIT). */
+void *rg_column_ptr(rg_engine *h, int column);
+/* Snapshot / restore the complete device state inside the engine (bench replays, rollbacks). */
+int rg_checkpoint(rg_engine *h);
+int rg_restore(rg_engine *h);
+
+/* Sparse overwrite of Progress cells between ticks -- the send path and the other host-side
+ * writers co-own these cells (Progress::update_state/become_snapshot/reset, heartbeat response,
+ * unreachable: src/tracker/progress.rs:82-121,231-243; src/raft.rs:664-712,1791-1798,1945-1947). */
+typedef struct {
+    uint64_t group;
+    uint32_t slot;
+    uint32_t field_mask; /* bit i = write column i (RG_COL_MATCH..RG_COL_PFLAGS) */
+    uint64_t match, next, pr_commit, pend_snap, pend_rs, gid;
+    uint8_t pflags;
+    uint8_t pad[7];
+} rg_cell_write;
+int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n);
+
+/* ---- the hot path ---- */
+/* One tick: for every group, apply its <=1 message per slot in slot order exactly as
+ * handle_append_response would (commit re-evaluated after every accepted ack), update state in
+ * place and write RG_COL_OUT. Host-buffer form: copies the message columns H2D, then launches. */
+int rg_tick(rg_engine *h, const rg_msgs *host_msgs);
+/* Same, message columns already in device memory (layout identical). Asynchronous. */
+int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
+/* Raft::maybe_commit() for every group with no messages (post_conf_change src/raft.rs:2630,
+ * enable_group_commit :513-518, assign_commit_groups :531-544). Asynchronous. */
+int rg_recompute(rg_engine *h);
+/* ProgressTracker::maximal_committed_index for every group -> device/host u64[G] (no gate, no
+ * state change); used_gc (u8[G], may be NULL) receives the group-commit flag. Host destination. */
+int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint8_t *host_used_gc);
+/* Results of the last tick: commit[G] and out[G] to host memory (either may be NULL). Synchronises. */
+int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out);
+/* Sum of RG_OUT_CHANGED / RG_OUT_FAULT bits over all groups for the last tick (device reduction). */
+int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault);
+
+/* Census of a tick's message flags in DEVICE memory: counts[0] = VALID messages, [1] = rejects,
+ * [2] = slots with a Progress, [3] = groups with at least one event (bench: algorithmic bytes). */
+int rg_msg_stats(rg_engine *h, const uint8_t *dev_m_flags, uint64_t counts[4]);
+
+/* ---- vote / quorum-liveness bitmaps (src/quorum/majority.rs:130-154, src/quorum/joint.rs:56-67,
+ *      src/tracker.rs:313-372) ---- */
+/* yes/no: u8[G] slot bitmasks of recorded votes (record_vote keeps the first, tracker.rs:307-309);
+ * result u8[G]: 0 Pending, 1 Lost, 2 Won. Host buffers. */
+int rg_vote_result(rg_engine *h, const uint8_t *host_yes, const uint8_t *host_no, uint8_t *host_result);
+/* quorum_recently_active for every group: result u8[G] (1 = active quorum); clears recent_active of
+ * every other slot and sets the self slot's, exactly as tracker.rs:346-361. */
+int rg_quorum_recently_active(rg_engine *h, uint8_t *host_result);
+
+/* ---- message-at-a-time host mirror of RawNode::step for MsgAppendResponse
+ *      (src/raw_node.rs:402-411 -> src/raft.rs:1280-1411 term gate -> :2096-2098) ---- */
+typedef struct {
+    uint64_t from;             /* Message.from (peer id) */
+    uint64_t term;             /* Message.term */
+    uint64_t index;            /* Message.index */
+    uint64_t commit;           /* Message.commit */
+    uint64_t reject_hint;      /* Message.reject_hint (resolved through find_conflict_by_term by the caller when log_term>0) */
+    uint64_t request_snapshot; /* Message.request_snapshot */
+    uint8_t reject;            /* Message.reject */
+    uint8_t ins_full;          /* caller's Inflights::full() for `from` */
+    uint8_t pad[6];
+} rg_append_response;
+/* Register peer ids and the leader term of a group so rg_step can map Message.from to a slot. */
+int rg_set_peers(rg_engine *h, uint64_t group, const uint64_t *peer_ids, uint32_t n, uint64_t term);
+/* Queue one MsgAppendResponse for the next rg_flush. Errors mirror RawNode::step / Raft::step. */
+int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m);
+/* Leader-local events, queued the same way (src/raft.rs:976-1016). */
+int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index);
+int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index);
+int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id);
+/* Run one tick over everything queued since the last flush and clear the queue. */
+int rg_flush(rg_engine *h);
+
+/* ---- synthetic AppendResponse stream; same code on host and device ---- */
+typedef struct {
+    uint64_t seed;
+    uint32_t workload; /* RG_WL_* */
+    uint32_t reserved;
+} rg_workload;
+#define RG_WL_MAJORITY 2u /* BASELINE config 2 (and 1, 4): majority quorum over all P slots */
+#define RG_WL_JOINT 3u    /* config 3: incoming {0,1,2} && outgoing {1,2,3}, slot 4.. learners */
+#define RG_WL_MIXED 5u    /* config 5: P in {3,5,7} by group, 10% groups in post-election probe/reject */
+/* Initialise all engine state for the workload (device-side generator). */
+int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t first_group_global);
+/* Generate tick `tick`'s messages from the CURRENT device state into device message columns. */
+int rg_workload_gen(rg_engine *h, const rg_workload *w, uint64_t first_group_global, uint64_t tick,
+                    uint64_t *d_m_index, uint64_t *d_m_commit, uint64_t *d_m_hint, uint64_t *d_m_rs,
+                    uint8_t *d_m_flags);
+/* Host twins of the two calls above over caller-provided SoA arrays (no GPU involved): used by
+ * CPU-only tests and to feed the CPU baseline the identical stream. */
+typedef struct {
+    uint64_t n_groups, stride;
+    uint32_t n_slots, reserved;
+    uint64_t *match, *next, *pr_commit, *pend_snap, *pend_rs, *gid;
+    uint8_t *pflags;
+    uint64_t *commit, *term_lo, *term_hi;
+    uint32_t *cfg;
+} rg_host_state;
+int rg_workload_init_host(const rg_workload *w, uint64_t first_group_global, rg_host_state *s);
+int rg_workload_gen_host(const rg_workload *w, uint64_t first_group_global, uint64_t tick,
+                         const rg_host_state *s, uint64_t *m_index, uint64_t *m_commit,
+                         uint64_t *m_hint, uint64_t *m_rs, uint8_t *m_flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTGROUPS_H */

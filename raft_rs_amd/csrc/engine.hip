@@ -1,0 +1,930 @@
+// engine.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of the multi-raft progress/commit engine.
+//
+// The hot path is HBM-bound integer work: per group ~9P+58A+37 algorithmic bytes and
+// a few hundred integer ops. Layout and launch choices:
+//   * per-slot u64 columns are peer-major [P][stride]: lane i of a wave reads group g0+i, so every
+//     column access of a wave is one contiguous 512-B (dwordx2) or 1-KiB (dwordx4) segment;
+//   * the per-slot flag bytes of a group are packed into ONE u64 row, so flags cost one 8-B load;
+//   * one lane owns one group (RG_VARIANT_LANE) and keeps the whole group in VGPRs: all column loads
+//     of a group are issued back to back (>= 16 KB in flight per wave) before any arithmetic;
+//   * RG_VARIANT_LDS stages the peer columns of a 64-group batch through LDS with 16-B/lane global
+//     loads (two groups per lane on the global side, one group per lane on the compute side);
+//   * no atomics, no inter-workgroup communication: groups are independent;
+//   * grid = one group per thread; consecutive workgroups walk consecutive 256-group tiles, so the 8
+//     XCDs (block b -> XCD b%8) stream disjoint, interleaved 2-KiB column segments.
+// There is NO CPU fallback anywhere in this file: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rg_group.h"
+#include "rg_workload.h"
+
+#define RG_BLOCK 256
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int rg_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define RG_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return rg_fail(e__ == hipErrorOutOfMemory ? RG_ERR_OUT_OF_MEMORY : RG_ERR_NO_DEVICE,   \
+                           "%s failed: %s", #expr, hipGetErrorString(e__));                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick (RG_VARIANT_LANE)
+// ------------------------------------------------------------------------------------------------
+template <int P> RG_D void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
+    r.mf = ms.mflags[g];
+    r.pf = st.pflags[g];
+    r.cfg = st.cfg[g];
+    r.commit = st.commit[g];
+    r.lo = st.lo[g];
+    r.hi = st.hi[g];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        r.mt[p] = st.match[o];
+        r.nx[p] = st.next[o];
+        r.pc[p] = st.prc[o];
+        r.mi[p] = ms.mi[o];
+        r.mc[p] = ms.mc[o];
+    }
+}
+
+template <int P> RG_D void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
+    const u32 d = r.dirty;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        if (d & (1u << p)) st.match[o] = r.mt[p];
+        if (d & (1u << (8 + p))) st.next[o] = r.nx[p];
+        if (d & (1u << (16 + p))) st.prc[o] = r.pc[p];
+    }
+    if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
+    if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
+    if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
+    st.out[g] = r.out;
+}
+
+template <int P, bool GC> __global__ __launch_bounds__(RG_BLOCK) void k_tick_lane(RgState st, RgMsgs ms) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    RgGroup<P> r;
+    rg_load_group<P>(r, st, ms, g);
+    rg_group_tick<P, GC>(r, st, ms, g);
+    rg_store_group<P>(r, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick (RG_VARIANT_LDS) -- one wave per 128-group batch, columns staged through LDS.
+// Global side: lane l moves groups {2l, 2l+1} of the batch with 16-B loads/stores (1 KiB per wave
+// instruction). Compute side: lane l owns groups l and l+64 of the batch in turn. LDS holds the
+// batch's 5 hot columns as [col][P][128] u64; a lane's ds_read_b64 at stride 8 B is conflict-free.
+// ------------------------------------------------------------------------------------------------
+#define RG_LDS_WAVES 1
+#define RG_LDS_BATCH 128
+
+template <int P, bool GC>
+__global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMsgs ms) {
+    __shared__ u64 lds[RG_LDS_WAVES][5][P][RG_LDS_BATCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 b0 = ((u64)blockIdx.x * RG_LDS_WAVES + wave) * RG_LDS_BATCH;
+    if (b0 >= st.G) return; // whole wave out of range (stride is a multiple of 256, so loads below stay in bounds)
+    // LDS operations of one wave execute in issue order, so a wave-level fence (a compiler ordering
+    // point; no s_barrier needed for a single-wave batch) is all the staging needs.
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    u64(*L)[P][RG_LDS_BATCH] = lds[wave];
+    const u64 *cols[5] = {st.match, st.next, st.prc, ms.mi, ms.mc};
+    // stage in: 5*P coalesced 16-B loads per lane, all issued before the first LDS write
+    u64x2 tmp[5][P];
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            tmp[c][p] = *reinterpret_cast<const u64x2 *>(cols[c] + (u64)p * st.stride + b0 + 2 * lane);
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            *reinterpret_cast<u64x2 *>(&L[c][p][2 * lane]) = tmp[c][p];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int li = lane + 64 * half;
+        const u64 g = b0 + li;
+        if (g < st.G) {
+            RgGroup<P> r;
+            r.mf = ms.mflags[g];
+            r.pf = st.pflags[g];
+            r.cfg = st.cfg[g];
+            r.commit = st.commit[g];
+            r.lo = st.lo[g];
+            r.hi = st.hi[g];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                r.mt[p] = L[0][p][li];
+                r.nx[p] = L[1][p][li];
+                r.pc[p] = L[2][p][li];
+                r.mi[p] = L[3][p][li];
+                r.mc[p] = L[4][p][li];
+            }
+            rg_group_tick<P, GC>(r, st, ms, g);
+            const u32 d = r.dirty;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if (d & (1u << p)) L[0][p][li] = r.mt[p];
+                if (d & (1u << (8 + p))) L[1][p][li] = r.nx[p];
+                if (d & (1u << (16 + p))) L[2][p][li] = r.pc[p];
+            }
+            if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
+            if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
+            if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
+            st.out[g] = r.out;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // stage out: the three state columns, 16-B stores (whole rows; unchanged cells rewrite their value)
+    u64 *ocols[3] = {st.match, st.next, st.prc};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(&L[c][p][2 * lane]);
+            if (b0 + 2 * lane < st.G) // never write padding past G (keeps padding zero)
+                *reinterpret_cast<u64x2 *>(ocols[c] + (u64)p * st.stride + b0 + 2 * lane) = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: Raft::maybe_commit for all groups without messages, and maximal_committed_index
+// ------------------------------------------------------------------------------------------------
+template <int P, bool COMMIT>
+__global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out, u8 *gc_out) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    const u32 cfg = st.cfg[g];
+    const u32 present = RG_CFG_PRESENT(cfg), incoming = RG_CFG_INCOMING(cfg), outgoing = RG_CFG_OUTGOING(cfg);
+    u64 mt[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) mt[p] = st.match[(u64)p * st.stride + g];
+#pragma unroll
+    for (int p = 0; p < P; p++)
+        if (!((present >> p) & 1u)) mt[p] = 0; // a voter without a Progress acks 0 (majority.rs:80-82)
+    u64 mci;
+    bool used = false;
+    if (cfg & RG_CFG_GROUP_COMMIT) {
+        u64 gidv[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) gidv[p] = ((present >> p) & 1u) ? st.gid[(u64)p * st.stride + g] : 0ULL;
+        mci = rg_mci_group<P>(mt, gidv, incoming, outgoing, used);
+    } else {
+        RgQuorum<P> qm;
+        qm.init(mt);
+        mci = qm.mci(mt, incoming, outgoing);
+        // joint.rs:47-51 flag: only an empty majority reports true without group commit (majority.rs:71-75,:99-101)
+        used = incoming == 0 && outgoing == 0;
+    }
+    if (COMMIT) {
+        u64 commit = st.commit[g];
+        const u64 lo = st.lo[g], hi = st.hi[g];
+        u32 out = 0;
+        if (rg_log_maybe_commit(mci, commit, lo, hi)) { // src/raft.rs:893-904
+            st.commit[g] = commit;
+            const u32 self = RG_CFG_SELF(cfg);
+            if ((present >> self) & 1u) {
+                const u64 o = (u64)self * st.stride + g;
+                if (st.prc[o] < commit) st.prc[o] = commit;
+            }
+            out = RG_OUT_CHANGED;
+        }
+        st.out[g] = out;
+    } else {
+        mci_out[g] = mci;
+        if (gc_out) gc_out[g] = used ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: votes and quorum liveness (src/quorum/majority.rs:130-154, joint.rs:56-67, tracker.rs:346-372)
+// ------------------------------------------------------------------------------------------------
+RG_D u32 rg_vote_majority(u32 M, u32 yes, u32 no) {
+    const u32 n = (u32)__popc(M);
+    if (n == 0) return 2u; // empty config wins
+    const u32 q = n / 2u + 1u;
+    const u32 y = (u32)__popc(M & yes), missing = (u32)__popc(M & ~(yes | no));
+    if (y >= q) return 2u;            // Won
+    if (y + missing >= q) return 0u;  // Pending
+    return 1u;                        // Lost
+}
+RG_D u32 rg_vote_joint(u32 i, u32 o) {
+    if (i == 2u && o == 2u) return 2u;
+    if (i == 1u || o == 1u) return 1u;
+    return 0u;
+}
+
+__global__ __launch_bounds__(RG_BLOCK) void k_vote(RgState st, const u8 *yes, const u8 *no, u8 *res) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    const u32 cfg = st.cfg[g];
+    const u32 y = yes[g], n = no[g] & ~y; // record_vote keeps the first vote (tracker.rs:307-309): yes wins a clash
+    res[g] = (u8)rg_vote_joint(rg_vote_majority(RG_CFG_INCOMING(cfg), y, n),
+                               rg_vote_majority(RG_CFG_OUTGOING(cfg), y, n));
+}
+
+__global__ __launch_bounds__(RG_BLOCK) void k_quorum_active(RgState st, u8 *res) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    const u32 cfg = st.cfg[g];
+    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
+    u64 pf = st.pflags[g];
+    u32 active = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        if (!((present >> p) & 1u)) continue;
+        const u64 bit = (u64)RG_PF_RECENT_ACTIVE << (8 * p);
+        if ((u32)p == self) {
+            pf |= bit;
+            active |= 1u << p;
+        } else if (pf & bit) {
+            active |= 1u << p;
+            pf &= ~bit;
+        }
+    }
+    st.pflags[g] = pf;
+    // has_quorum: vote_result(|id| set.get(id).map(|_| true)) == Won (tracker.rs:367-372)
+    res[g] = rg_vote_joint(rg_vote_majority(RG_CFG_INCOMING(cfg), active, 0),
+                           rg_vote_majority(RG_CFG_OUTGOING(cfg), active, 0)) == 2u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: sparse cell writes, counters, workload
+// ------------------------------------------------------------------------------------------------
+__global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32 P) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rg_cell_write c = cells[i];
+    if (c.group >= st.G || c.slot >= P) return;
+    const u64 o = (u64)c.slot * st.stride + c.group;
+    if (c.field_mask & (1u << RG_COL_MATCH)) st.match[o] = c.match;
+    if (c.field_mask & (1u << RG_COL_NEXT)) st.next[o] = c.next;
+    if (c.field_mask & (1u << RG_COL_PR_COMMIT)) st.prc[o] = c.pr_commit;
+    if (c.field_mask & (1u << RG_COL_PEND_SNAP)) st.psnap[o] = c.pend_snap;
+    if (c.field_mask & (1u << RG_COL_PEND_RS)) st.prs[o] = c.pend_rs;
+    if (c.field_mask & (1u << RG_COL_GID)) st.gid[o] = c.gid;
+    if (c.field_mask & (1u << RG_COL_PFLAGS)) reinterpret_cast<u8 *>(st.pflags)[c.group * 8 + c.slot] = c.pflags;
+}
+
+__global__ __launch_bounds__(RG_BLOCK) void k_count_out(const u32 *out, u64 G, u64 *counts) {
+    u64 ch = 0, fl = 0;
+    for (u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * RG_BLOCK) {
+        const u32 o = out[g];
+        ch += o & RG_OUT_CHANGED ? 1 : 0;
+        fl += o & RG_OUT_FAULT ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ch += __shfl_down(ch, off, 64);
+        fl += __shfl_down(fl, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)&counts[0], (unsigned long long)ch);
+        atomicAdd((unsigned long long *)&counts[1], (unsigned long long)fl);
+    }
+}
+
+// message census of a tick: [0] VALID messages, [1] rejects, [2] slots in use (present), [3] groups with >=1 event
+__global__ __launch_bounds__(RG_BLOCK) void k_msg_stats(const u64 *mflags, const u32 *cfg, u64 G, u64 *counts) {
+    u64 a = 0, r = 0, s = 0, e = 0;
+    for (u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * RG_BLOCK) {
+        const u64 mf = mflags[g];
+        a += __popcll(mf & 0x0101010101010101ULL);
+        r += __popcll((mf >> 1) & mf & 0x0101010101010101ULL);
+        s += __popc(RG_CFG_PRESENT(cfg[g]));
+        e += mf != 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        r += __shfl_down(r, off, 64);
+        s += __shfl_down(s, off, 64);
+        e += __shfl_down(e, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)&counts[0], (unsigned long long)a);
+        atomicAdd((unsigned long long *)&counts[1], (unsigned long long)r);
+        atomicAdd((unsigned long long *)&counts[2], (unsigned long long)s);
+        atomicAdd((unsigned long long *)&counts[3], (unsigned long long)e);
+    }
+}
+
+__global__ __launch_bounds__(RG_BLOCK) void k_wl_init(RgState st, u64 seed, u32 workload, u32 P, u64 first) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    rg_wl_init_group(seed, workload, P, st.stride, g, first + g, st.match, st.next, st.prc, st.psnap,
+                     st.prs, st.gid, reinterpret_cast<u8 *>(st.pflags), st.commit, st.lo, st.hi, st.cfg);
+    st.out[g] = 0;
+}
+
+__global__ __launch_bounds__(RG_BLOCK) void k_wl_gen(RgState st, u64 seed, u32 workload, u32 P, u64 first,
+                                                     u64 tick, u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u8 *mf) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    rg_wl_gen_group(seed, workload, P, st.stride, g, first + g, tick, st.match, st.next,
+                    reinterpret_cast<const u8 *>(st.pflags), st.commit, st.hi, mi, mc, mh, mrs, mf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine object
+// ------------------------------------------------------------------------------------------------
+struct rg_engine {
+    rg_config cfg;
+    u64 G, stride;
+    u32 P;
+    hipStream_t stream;
+    char *arena;      // state columns
+    size_t state_bytes;
+    char *ckpt;       // checkpoint copy of the state columns (lazy)
+    char *msg_arena;  // device staging for rg_tick(host msgs) / rg_flush (lazy)
+    u64 *zero_col;    // [P][stride] zeros, substituted for NULL m_hint / m_rs
+    u64 *d_counts;    // 4 x u64 scratch for reductions
+    void *d_scratch;  // G x 8 B scratch for host<->device result shuttles
+    size_t col_off[RG_COL_COUNT];
+    RgState st;
+    RgMsgs staged;    // views into msg_arena
+    bool ticked;
+    bool any_group_commit; // some group's cfg word has RG_CFG_GROUP_COMMIT (tracked on cfg loads)
+    // host mirror of RawNode::step (rg_set_peers / rg_step / rg_flush)
+    std::vector<u64> peer_ids; // [G][8], 0 = unused
+    std::vector<u64> terms;    // [G]
+    std::vector<u64> q_mi, q_mc, q_mh, q_mrs; // [P][stride] host queues
+    std::vector<u8> q_mf;                      // [G][8]
+    std::vector<u64> q_dirty;                  // groups touched since the last flush
+    bool host_mirror;
+};
+
+static size_t rg_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t rg_col_elem(int c) {
+    if (c == RG_COL_PFLAGS) return 8; // one u64 row per group
+    if (c == RG_COL_CFG || c == RG_COL_OUT) return 4;
+    return 8;
+}
+static bool rg_col_per_slot(int c) { return c <= RG_COL_GID; }
+
+extern "C" const char *rg_version(void) { return "raftgroups 0.1 (gfx950)"; }
+extern "C" const char *rg_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int rg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" uint64_t rg_column_bytes(const rg_engine *h, int c) {
+    if (!h || c < 0 || c >= RG_COL_COUNT) return 0;
+    if (rg_col_per_slot(c)) return (uint64_t)h->P * h->stride * 8;
+    return (uint64_t)h->G * rg_col_elem(c);
+}
+
+static void *rg_col(rg_engine *h, int c) { return h->arena + h->col_off[c]; }
+
+extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
+    if (!cfg || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: null argument");
+    if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_create: n_groups=%llu n_slots=%u out of range",
+                       (unsigned long long)cfg->n_groups, cfg->n_slots);
+    if (cfg->variant > RG_VARIANT_LDS) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return rg_fail(RG_ERR_NO_DEVICE, "rg_create: no HIP device visible (this engine has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_create: device %d of %d", cfg->device, ndev);
+    RG_HIP(hipSetDevice(cfg->device));
+    rg_engine *h = new (std::nothrow) rg_engine();
+    if (!h) return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: host allocation failed");
+    h->cfg = *cfg;
+    h->G = cfg->n_groups;
+    h->P = cfg->n_slots;
+    h->stride = (h->G + 255) / 256 * 256;
+    h->stream = nullptr;
+    h->ckpt = nullptr;
+    h->msg_arena = nullptr;
+    h->ticked = false;
+    h->any_group_commit = false;
+    h->host_mirror = false;
+    size_t off = 0;
+    for (int c = 0; c < RG_COL_COUNT; c++) {
+        h->col_off[c] = off;
+        const size_t bytes = rg_col_per_slot(c) ? (size_t)h->P * h->stride * 8 : (size_t)h->stride * rg_col_elem(c);
+        off += rg_align(bytes);
+    }
+    h->state_bytes = off;
+    const size_t zero_bytes = rg_align((size_t)h->P * h->stride * 8);
+    hipError_t e = hipMalloc(&h->arena, off + zero_bytes + 256 + rg_align(h->stride * 8));
+    if (e != hipSuccess) {
+        delete h;
+        return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+    }
+    e = hipMemset(h->arena, 0, off + zero_bytes + 256 + rg_align(h->stride * 8));
+    if (e != hipSuccess) {
+        (void)hipFree(h->arena);
+        delete h;
+        return rg_fail(RG_ERR_NO_DEVICE, "rg_create: hipMemset failed: %s", hipGetErrorString(e));
+    }
+    h->zero_col = reinterpret_cast<u64 *>(h->arena + off);
+    h->d_counts = reinterpret_cast<u64 *>(h->arena + off + zero_bytes);
+    h->d_scratch = h->arena + off + zero_bytes + 256;
+    RgState &s = h->st;
+    s.match = (u64 *)rg_col(h, RG_COL_MATCH);
+    s.next = (u64 *)rg_col(h, RG_COL_NEXT);
+    s.prc = (u64 *)rg_col(h, RG_COL_PR_COMMIT);
+    s.psnap = (u64 *)rg_col(h, RG_COL_PEND_SNAP);
+    s.prs = (u64 *)rg_col(h, RG_COL_PEND_RS);
+    s.gid = (u64 *)rg_col(h, RG_COL_GID);
+    s.pflags = (u64 *)rg_col(h, RG_COL_PFLAGS);
+    s.commit = (u64 *)rg_col(h, RG_COL_COMMIT);
+    s.lo = (u64 *)rg_col(h, RG_COL_TERM_LO);
+    s.hi = (u64 *)rg_col(h, RG_COL_TERM_HI);
+    s.cfg = (u32 *)rg_col(h, RG_COL_CFG);
+    s.out = (u32 *)rg_col(h, RG_COL_OUT);
+    s.G = h->G;
+    s.stride = h->stride;
+    *out = h;
+    return RG_OK;
+}
+
+extern "C" void rg_destroy(rg_engine *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->ckpt) (void)hipFree(h->ckpt);
+    if (h->msg_arena) (void)hipFree(h->msg_arena);
+    delete h;
+}
+
+extern "C" uint64_t rg_stride(const rg_engine *h) { return h ? h->stride : 0; }
+
+extern "C" int rg_set_stream(rg_engine *h, void *hip_stream) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_stream: null engine");
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return RG_OK;
+}
+
+extern "C" int rg_sync(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_sync: null engine");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t bytes) {
+    if (!h || !src || c < 0 || c >= RG_COL_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: bad argument");
+    if (bytes != rg_column_bytes(h, c))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column(%d): %llu bytes given, %llu expected", c,
+                       (unsigned long long)bytes, (unsigned long long)rg_column_bytes(h, c));
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemcpyAsync(rg_col(h, c), src, bytes, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    if (c == RG_COL_CFG) {
+        const u32 *w = static_cast<const u32 *>(src);
+        bool any = false;
+        for (u64 g = 0; g < h->G && !any; g++) any = (w[g] & RG_CFG_GROUP_COMMIT) != 0;
+        h->any_group_commit = any;
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_read_column(rg_engine *h, int c, void *dst, uint64_t bytes) {
+    if (!h || !dst || c < 0 || c >= RG_COL_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_column: bad argument");
+    if (bytes != rg_column_bytes(h, c))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_read_column(%d): %llu bytes given, %llu expected", c,
+                       (unsigned long long)bytes, (unsigned long long)rg_column_bytes(h, c));
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemcpyAsync(dst, rg_col(h, c), bytes, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+extern "C" void *rg_column_ptr(rg_engine *h, int c) {
+    if (!h || c < 0 || c >= RG_COL_COUNT) return nullptr;
+    return rg_col(h, c);
+}
+
+extern "C" int rg_checkpoint(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_checkpoint: null engine");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    if (!h->ckpt) RG_HIP(hipMalloc(&h->ckpt, h->state_bytes));
+    RG_HIP(hipMemcpyAsync(h->ckpt, h->arena, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_restore(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_restore: null engine");
+    if (!h->ckpt) return rg_fail(RG_ERR_STATE, "rg_restore: no checkpoint taken");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    return RG_OK;
+}
+
+static unsigned rg_grid(u64 n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n) {
+    if (!h || (!cells && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_write_cells: bad argument");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    rg_cell_write *d = nullptr;
+    RG_HIP(hipMalloc(&d, n * sizeof(rg_cell_write)));
+    hipError_t e = hipMemcpyAsync(d, cells, n * sizeof(rg_cell_write), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_write_cells, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, d, (u64)n, h->P);
+        e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_write_cells: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the hot path
+// ------------------------------------------------------------------------------------------------
+template <int P, bool GC> static void rg_launch_tick2(rg_engine *h, const RgMsgs &ms) {
+    const u32 variant = h->cfg.variant == RG_VARIANT_DEFAULT ? RG_VARIANT_LANE : h->cfg.variant;
+    if (variant == RG_VARIANT_LDS) {
+        hipLaunchKernelGGL((k_tick_lds<P, GC>), dim3(rg_grid(h->G, RG_LDS_BATCH * RG_LDS_WAVES)),
+                           dim3(64 * RG_LDS_WAVES), 0, h->stream, h->st, ms);
+    } else {
+        hipLaunchKernelGGL((k_tick_lane<P, GC>), dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms);
+    }
+}
+template <int P> static void rg_launch_tick(rg_engine *h, const RgMsgs &ms) {
+    // the group-commit kernel is only needed when some group has ProgressTracker.group_commit set
+    if (h->any_group_commit) rg_launch_tick2<P, true>(h, ms);
+    else rg_launch_tick2<P, false>(h, ms);
+}
+
+static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
+    switch (h->P) {
+    case 1: rg_launch_tick<1>(h, ms); break;
+    case 2: rg_launch_tick<2>(h, ms); break;
+    case 3: rg_launch_tick<3>(h, ms); break;
+    case 4: rg_launch_tick<4>(h, ms); break;
+    case 5: rg_launch_tick<5>(h, ms); break;
+    case 6: rg_launch_tick<6>(h, ms); break;
+    case 7: rg_launch_tick<7>(h, ms); break;
+    default: rg_launch_tick<8>(h, ms); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
+    h->ticked = true;
+    return RG_OK;
+}
+
+extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
+    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device: m_index, m_commit and m_flags are required");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RgMsgs ms;
+    ms.mi = (const u64 *)m->m_index;
+    ms.mc = (const u64 *)m->m_commit;
+    ms.mh = m->m_hint ? (const u64 *)m->m_hint : h->zero_col;
+    ms.mrs = m->m_rs ? (const u64 *)m->m_rs : h->zero_col;
+    ms.mflags = (const u64 *)m->m_flags;
+    return rg_tick_impl(h, ms);
+}
+
+static int rg_ensure_msg_arena(rg_engine *h) {
+    if (h->msg_arena) return RG_OK;
+    const size_t col = rg_align((size_t)h->P * h->stride * 8);
+    RG_HIP(hipMalloc(&h->msg_arena, 4 * col + rg_align(h->stride * 8)));
+    RG_HIP(hipMemsetAsync(h->msg_arena, 0, 4 * col + rg_align(h->stride * 8), h->stream));
+    h->staged.mi = (u64 *)(h->msg_arena);
+    h->staged.mc = (u64 *)(h->msg_arena + col);
+    h->staged.mh = (u64 *)(h->msg_arena + 2 * col);
+    h->staged.mrs = (u64 *)(h->msg_arena + 3 * col);
+    h->staged.mflags = (u64 *)(h->msg_arena + 4 * col);
+    return RG_OK;
+}
+
+extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
+    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick: m_index, m_commit and m_flags are required");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_ensure_msg_arena(h);
+    if (rc) return rc;
+    const size_t colb = (size_t)h->P * h->stride * 8;
+    RG_HIP(hipMemcpyAsync((void *)h->staged.mi, m->m_index, colb, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync((void *)h->staged.mc, m->m_commit, colb, hipMemcpyHostToDevice, h->stream));
+    RgMsgs ms = h->staged;
+    if (m->m_hint) RG_HIP(hipMemcpyAsync((void *)h->staged.mh, m->m_hint, colb, hipMemcpyHostToDevice, h->stream));
+    else ms.mh = h->zero_col;
+    if (m->m_rs) RG_HIP(hipMemcpyAsync((void *)h->staged.mrs, m->m_rs, colb, hipMemcpyHostToDevice, h->stream));
+    else ms.mrs = h->zero_col;
+    RG_HIP(hipMemcpyAsync((void *)h->staged.mflags, m->m_flags, h->G * 8, hipMemcpyHostToDevice, h->stream));
+    rc = rg_tick_impl(h, ms);
+    if (rc) return rc;
+    RG_HIP(hipStreamSynchronize(h->stream)); // caller-owned host buffers may be reused after return
+    return RG_OK;
+}
+
+template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *gc) {
+    const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
+    switch (h->P) {
+    case 1: hipLaunchKernelGGL((k_recompute<1, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 2: hipLaunchKernelGGL((k_recompute<2, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 3: hipLaunchKernelGGL((k_recompute<3, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 4: hipLaunchKernelGGL((k_recompute<4, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 5: hipLaunchKernelGGL((k_recompute<5, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 6: hipLaunchKernelGGL((k_recompute<6, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 7: hipLaunchKernelGGL((k_recompute<7, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    default: hipLaunchKernelGGL((k_recompute<8, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_recompute(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_recompute: null engine");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_recompute_impl<true>(h, nullptr, nullptr);
+    if (rc == RG_OK) h->ticked = true;
+    return rc;
+}
+
+extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint8_t *host_gc) {
+    if (!h || !host_mci) return rg_fail(RG_ERR_INVALID_ARG, "rg_maximal_committed_index: bad argument");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u64 *d_mci = nullptr;
+    u8 *d_gc = nullptr;
+    RG_HIP(hipMalloc(&d_mci, h->G * 8));
+    if (host_gc && hipMalloc(&d_gc, h->G) != hipSuccess) {
+        (void)hipFree(d_mci);
+        return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_maximal_committed_index: hipMalloc failed");
+    }
+    int rc = rg_recompute_impl<false>(h, d_mci, d_gc);
+    hipError_t e = hipSuccess;
+    if (rc == RG_OK) e = hipMemcpyAsync(host_mci, d_mci, h->G * 8, hipMemcpyDeviceToHost, h->stream);
+    if (rc == RG_OK && e == hipSuccess && host_gc) e = hipMemcpyAsync(host_gc, d_gc, h->G, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_mci);
+    if (d_gc) (void)hipFree(d_gc);
+    if (rc) return rc;
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_maximal_committed_index: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_results: null engine");
+    if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_results: no tick has run yet");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    if (host_commit) RG_HIP(hipMemcpyAsync(host_commit, h->st.commit, h->G * 8, hipMemcpyDeviceToHost, h->stream));
+    if (host_out) RG_HIP(hipMemcpyAsync(host_out, h->st.out, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_result_counts: null engine");
+    if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_result_counts: no tick has run yet");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
+    const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
+    hipLaunchKernelGGL(k_count_out, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u32 *)h->st.out, h->G, h->d_counts);
+    u64 c[2] = {0, 0};
+    RG_HIP(hipMemcpyAsync(c, h->d_counts, 16, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    if (n_changed) *n_changed = c[0];
+    if (n_fault) *n_fault = c[1];
+    return RG_OK;
+}
+
+extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t counts[4]) {
+    if (!h || !d_m_flags || !counts) return rg_fail(RG_ERR_INVALID_ARG, "rg_msg_stats: bad argument");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
+    const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
+    hipLaunchKernelGGL(k_msg_stats, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u64 *)d_m_flags,
+                       (const u32 *)h->st.cfg, h->G, h->d_counts);
+    RG_HIP(hipMemcpyAsync(counts, h->d_counts, 32, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// votes / liveness
+// ------------------------------------------------------------------------------------------------
+extern "C" int rg_vote_result(rg_engine *h, const uint8_t *yes, const uint8_t *no, uint8_t *result) {
+    if (!h || !yes || !no || !result) return rg_fail(RG_ERR_INVALID_ARG, "rg_vote_result: bad argument");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u8 *d = reinterpret_cast<u8 *>(h->d_scratch); // 8*stride bytes: yes | no | result
+    RG_HIP(hipMemcpyAsync(d, yes, h->G, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(d + h->stride, no, h->G, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_vote, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, d,
+                       d + h->stride, d + 2 * h->stride);
+    RG_HIP(hipMemcpyAsync(result, d + 2 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_quorum_recently_active(rg_engine *h, uint8_t *result) {
+    if (!h || !result) return rg_fail(RG_ERR_INVALID_ARG, "rg_quorum_recently_active: bad argument");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u8 *d = reinterpret_cast<u8 *>(h->d_scratch);
+    hipLaunchKernelGGL(k_quorum_active, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, d);
+    RG_HIP(hipMemcpyAsync(result, d, h->G, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host mirror of RawNode::step for MsgAppendResponse
+// ------------------------------------------------------------------------------------------------
+static void rg_mirror_init(rg_engine *h) {
+    if (h->host_mirror) return;
+    h->peer_ids.assign(h->G * 8, 0);
+    h->terms.assign(h->G, 0);
+    const size_t n = (size_t)h->P * h->stride;
+    h->q_mi.assign(n, 0);
+    h->q_mc.assign(n, 0);
+    h->q_mh.assign(n, 0);
+    h->q_mrs.assign(n, 0);
+    h->q_mf.assign(h->G * 8, 0);
+    h->host_mirror = true;
+}
+
+extern "C" int rg_set_peers(rg_engine *h, uint64_t group, const uint64_t *peer_ids, uint32_t n, uint64_t term) {
+    if (!h || !peer_ids || group >= h->G || n > h->P) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_peers: bad argument");
+    rg_mirror_init(h);
+    for (u32 i = 0; i < 8; i++) h->peer_ids[group * 8 + i] = i < n ? peer_ids[i] : 0; // id 0 is illegal (raw_node.rs:303)
+    h->terms[group] = term;
+    return RG_OK;
+}
+
+static int rg_find_slot(rg_engine *h, u64 group, u64 id) {
+    if (id == 0) return -1;
+    for (u32 i = 0; i < h->P; i++)
+        if (h->peer_ids[group * 8 + i] == id) return (int)i;
+    return -1;
+}
+
+static void rg_touch(rg_engine *h, u64 group) {
+    u64 row = 0;
+    memcpy(&row, &h->q_mf[group * 8], 8);
+    if (row == 0) h->q_dirty.push_back(group);
+}
+
+extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m) {
+    if (!h || !m || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step: bad argument");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step: rg_set_peers was never called");
+    // Raft::step term gate (src/raft.rs:1282-1411)
+    if (m->term == 0) return rg_fail(RG_ERR_STEP_LOCAL_MSG, "rg_step: term 0 marks a local message (raw_node.rs:404-406)");
+    if (m->term > h->terms[group])
+        return rg_fail(RG_ERR_HIGHER_TERM, "rg_step: message term %llu > leader term %llu: step down (raft.rs:1284-1348)",
+                       (unsigned long long)m->term, (unsigned long long)h->terms[group]);
+    if (m->term < h->terms[group]) return RG_OK; // stale term: ignored (raft.rs:1349-1411)
+    const int slot = rg_find_slot(h, group, m->from);
+    if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_step: peer %llu not in group %llu (raw_node.rs:407-410)",
+                                 (unsigned long long)m->from, (unsigned long long)group);
+    u8 &f = h->q_mf[group * 8 + slot];
+    if (f & RG_MF_VALID) return rg_fail(RG_ERR_SLOT_BUSY, "rg_step: peer %llu already has a message queued; rg_flush first",
+                                        (unsigned long long)m->from);
+    rg_touch(h, group);
+    const size_t o = (size_t)slot * h->stride + group;
+    h->q_mi[o] = m->index;
+    h->q_mc[o] = m->commit;
+    h->q_mh[o] = m->reject_hint;
+    h->q_mrs[o] = m->request_snapshot;
+    f |= RG_MF_VALID | (m->reject ? RG_MF_REJECT : 0) | (m->request_snapshot ? RG_MF_HAS_RS : 0) |
+         (m->ins_full ? RG_MF_INS_FULL : 0);
+    return RG_OK;
+}
+
+static int rg_self_slot(rg_engine *h, u64 group, u32 *slot) {
+    // the self slot lives in the device cfg word; mirror keeps no copy, so read the one word
+    u32 cfg = 0;
+    RG_HIP(hipMemcpyAsync(&cfg, h->st.cfg + group, 4, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    *slot = RG_CFG_SELF(cfg);
+    return RG_OK;
+}
+
+extern "C" int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_append: bad argument");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_append: rg_set_peers was never called");
+    u32 slot;
+    int rc = rg_self_slot(h, group, &slot);
+    if (rc) return rc;
+    rg_touch(h, group);
+    h->q_mc[(size_t)slot * h->stride + group] = new_last_index;
+    h->q_mf[group * 8 + slot] |= RG_MF_APPEND;
+    return RG_OK;
+}
+
+extern "C" int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_persisted: bad argument");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_persisted: rg_set_peers was never called");
+    u32 slot;
+    int rc = rg_self_slot(h, group, &slot);
+    if (rc) return rc;
+    u8 &f = h->q_mf[group * 8 + slot];
+    if (f & RG_MF_VALID) return rg_fail(RG_ERR_SLOT_BUSY, "rg_local_persisted: already queued; rg_flush first");
+    rg_touch(h, group);
+    h->q_mi[(size_t)slot * h->stride + group] = index;
+    f |= RG_MF_VALID;
+    return RG_OK;
+}
+
+extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_mark_sent: bad argument");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_mark_sent: rg_set_peers was never called");
+    const int slot = rg_find_slot(h, group, peer_id);
+    if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_mark_sent: peer %llu not in group %llu",
+                                 (unsigned long long)peer_id, (unsigned long long)group);
+    rg_touch(h, group);
+    h->q_mf[group * 8 + slot] |= RG_MF_SENT;
+    return RG_OK;
+}
+
+extern "C" int rg_flush(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
+    rg_msgs m;
+    m.m_index = h->q_mi.data();
+    m.m_commit = h->q_mc.data();
+    m.m_hint = h->q_mh.data();
+    m.m_rs = h->q_mrs.data();
+    m.m_flags = h->q_mf.data();
+    int rc = rg_tick(h, &m);
+    for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
+    h->q_dirty.clear();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic stream
+// ------------------------------------------------------------------------------------------------
+extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t first) {
+    if (!h || !w) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: bad argument");
+    if (w->workload != RG_WL_MAJORITY && w->workload != RG_WL_JOINT && w->workload != RG_WL_MIXED)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: unknown workload %u", w->workload);
+    RG_HIP(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_wl_init, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
+                       w->workload, h->P, (u64)first);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_init: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_workload_gen(rg_engine *h, const rg_workload *w, uint64_t first, uint64_t tick, uint64_t *mi,
+                               uint64_t *mc, uint64_t *mh, uint64_t *mrs, uint8_t *mf) {
+    if (!h || !w || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen: bad argument");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_wl_gen, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
+                       w->workload, h->P, (u64)first, (u64)tick, (u64 *)mi, (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_gen: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_workload_init_host(const rg_workload *w, uint64_t first, rg_host_state *s) {
+    if (!w || !s || s->n_slots == 0 || s->n_slots > 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init_host: bad argument");
+    for (u64 g = 0; g < s->n_groups; g++)
+        rg_wl_init_group(w->seed, w->workload, s->n_slots, s->stride, g, first + g, (u64 *)s->match, (u64 *)s->next,
+                         (u64 *)s->pr_commit, (u64 *)s->pend_snap, (u64 *)s->pend_rs, (u64 *)s->gid, s->pflags,
+                         (u64 *)s->commit, (u64 *)s->term_lo, (u64 *)s->term_hi, s->cfg);
+    return RG_OK;
+}
+
+extern "C" int rg_workload_gen_host(const rg_workload *w, uint64_t first, uint64_t tick, const rg_host_state *s,
+                                    uint64_t *mi, uint64_t *mc, uint64_t *mh, uint64_t *mrs, uint8_t *mf) {
+    if (!w || !s || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen_host: bad argument");
+    for (u64 g = 0; g < s->n_groups; g++)
+        rg_wl_gen_group(w->seed, w->workload, s->n_slots, s->stride, g, first + g, tick, (const u64 *)s->match,
+                        (const u64 *)s->next, s->pflags, (const u64 *)s->commit, (const u64 *)s->term_hi, (u64 *)mi,
+                        (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
+    return RG_OK;
+}

@@ -1,0 +1,45 @@
+// rg_common.h -- shared host/device definitions for the MI355X multi-raft progress/commit engine.
+//
+// Everything here is the engine's own restatement of the reference semantics cited in
+// include/raftgroups.h; file:line citations are relative to the pingcap/raft-rs v0.6.0 tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/raftgroups.h"
+
+typedef uint64_t u64;
+typedef unsigned int u32;
+typedef unsigned char u8;
+
+#define RG_HD __host__ __device__ __forceinline__
+#define RG_D __device__ __forceinline__
+
+// Column views handed to kernels (plain pointers, no ownership).
+struct RgState {
+    u64 *match, *next, *prc, *psnap, *prs, *gid; // [P][stride]
+    u64 *pflags;                                 // [G] one byte per slot
+    u64 *commit, *lo, *hi;                       // [G]
+    u32 *cfg, *out;                              // [G]
+    u64 G, stride;
+};
+
+struct RgMsgs {
+    const u64 *mi, *mc, *mh, *mrs; // [P][stride]
+    const u64 *mflags;             // [G] one byte per slot
+};
+
+RG_HD u64 rg_min(u64 a, u64 b) { return a < b ? a : b; }
+RG_HD u64 rg_max(u64 a, u64 b) { return a > b ? a : b; }
+
+// splitmix64 finaliser: the counter-based PRNG of the synthetic stream.
+RG_HD u64 rg_splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+RG_HD u64 rg_hash(u64 seed, u64 tick, u64 group, u64 slot) {
+    return rg_splitmix64(seed ^ (tick << 40) ^ (group << 3) ^ slot);
+}

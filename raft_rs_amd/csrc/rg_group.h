@@ -1,0 +1,385 @@
+// rg_group.h -- per-group arithmetic of the hot path, written for one lane = one raft group.
+//
+// All loops are over compile-time slot counts so every array lives in VGPRs (no dynamic register
+// indexing, no scratch). Citations are file:line in the pingcap/raft-rs v0.6.0 tree.
+#pragma once
+
+#include "rg_common.h"
+
+// compile-time slot sequence (a minimal std::integer_sequence)
+template <int... S> struct rg_seq {};
+template <int N, int... S> struct rg_make_seq : rg_make_seq<N - 1, N - 1, S...> {};
+template <int... S> struct rg_make_seq<0, S...> { typedef rg_seq<S...> type; };
+
+// ---------------------------------------------------------------------------------------------
+// Quorum index. MajorityConfig::committed_index (src/quorum/majority.rs:70-124) sorts the voters'
+// matched indices descending and takes element n/2 (the q-th largest, q = n/2+1, src/util.rs:118-120).
+// Here: the q-th largest of {v_i : i in M} is max{ v_i : #{ j in M : v_j >= v_i } >= q }, evaluated
+// from a bit matrix ge[i] (bit j = v_j >= v_i) that is maintained incrementally: an accepted ack
+// changes one v_s, i.e. one row and one column (2(P-1) compares), so re-evaluating the commit index
+// after EVERY accepted ack -- exactly as Raft::handle_append_response does (src/raft.rs:1745) -- costs
+// O(P) per message instead of a sort.
+// ---------------------------------------------------------------------------------------------
+template <int P> struct RgQuorum {
+    // v = the group's matched registers; the caller zeroes slots without a Progress first
+    // (a voter without a Progress acks 0: unwrap_or_default, majority.rs:80-82)
+    u32 ge[P]; // bit j of ge[i] = (v[j] >= v[i])
+
+    RG_D void init(const u64 (&v)[P]) {
+#pragma unroll
+        for (int i = 0; i < P; i++) ge[i] = 1u << i;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+#pragma unroll
+            for (int j = i + 1; j < P; j++) {
+                const bool lt = v[i] < v[j];  // v_j >  v_i
+                const bool eq = v[i] == v[j];
+                ge[i] |= (u32)(lt | eq) << j;  // v_j >= v_i
+                ge[j] |= (u32)(!lt) << i;      // v_i >= v_j
+            }
+        }
+    }
+
+    // slot S's value was raised to nv = v[S]: refresh row S and column S.
+    template <int S> RG_D void update(const u64 (&v)[P]) {
+        const u64 nv = v[S];
+        u32 row = 1u << S;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            if (j == S) continue;
+            const bool lt = nv < v[j];
+            const bool eq = nv == v[j];
+            row |= (u32)(lt | eq) << j;                                // v_j >= v_S
+            ge[j] = (ge[j] & ~(1u << S)) | ((u32)(!lt) << S);          // v_S >= v_j
+        }
+        ge[S] = row;
+    }
+
+    // q-th largest over the voter mask M (majority.rs:95-101); empty config => u64::MAX (:71-75).
+    RG_D u64 kth(const u64 (&v)[P], u32 M) const {
+        const u32 n = (u32)__popc(M);
+        if (n == 0) return ~0ULL;
+        const u32 q = n / 2u + 1u;
+        u64 t = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const bool in = (M >> i) & 1u;
+            const bool ok = in && ((u32)__popc(ge[i] & M) >= q);
+            const u64 c = ok ? v[i] : 0ULL;
+            t = c > t ? c : t;
+        }
+        return t;
+    }
+
+    // JointConfig::committed_index (src/quorum/joint.rs:47-51): min of both majorities.
+    RG_D u64 mci(const u64 (&v)[P], u32 incoming, u32 outgoing) const {
+        const u64 a = kth(v, incoming);
+        const u64 b = kth(v, outgoing);
+        return a < b ? a : b;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Group commit (src/quorum/majority.rs:99-123), the literal algorithm: stable descending sort by
+// index (voter order = slot order), Q = sorted[q-1], then the scan over sorted order. Ranks replace
+// the sort so that all indexing stays static. Rare path (ProgressTracker.group_commit, tracker.rs:207).
+// ---------------------------------------------------------------------------------------------
+template <int P>
+RG_D u64 rg_majority_ci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 M, bool &flag) {
+    const u32 n = (u32)__popc(M);
+    if (n == 0) {
+        flag = true;
+        return ~0ULL;
+    }
+    const u32 q = n / 2u + 1u;
+    u32 rank[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        u32 r = 0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            const bool before = (v[j] > v[i]) || (v[j] == v[i] && j < i);
+            r += (((M >> j) & 1u) && before) ? 1u : 0u;
+        }
+        rank[i] = r;
+    }
+    u64 q_index = 0, q_gid = 0, last_index = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const bool in = (M >> i) & 1u;
+        if (in && rank[i] == q - 1u) {
+            q_index = v[i];
+            q_gid = gid[i];
+        }
+        if (in && rank[i] == n - 1u) last_index = v[i];
+    }
+    u64 checked = q_gid, res = 0;
+    bool single = true, done = false;
+#pragma unroll
+    for (int pos = 0; pos < P; pos++) {
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const bool here = ((M >> i) & 1u) && rank[i] == (u32)pos && !done;
+            if (here) {
+                const u64 g = gid[i];
+                if (g == 0) {
+                    single = false;
+                } else if (checked == 0) {
+                    checked = g;
+                } else if (checked != g) {
+                    res = v[i] < q_index ? v[i] : q_index;
+                    done = true;
+                }
+            }
+        }
+    }
+    if (done) {
+        flag = true;
+        return res;
+    }
+    flag = false;
+    return single ? q_index : last_index;
+}
+
+// ProgressTracker::maximal_committed_index with group commit on (tracker.rs:294-298, joint.rs:47-51).
+template <int P>
+RG_D u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
+    bool fi, fo;
+    const u64 a = rg_majority_ci_group<P>(v, gid, incoming, fi);
+    const u64 b = rg_majority_ci_group<P>(v, gid, outgoing, fo);
+    used = fi && fo;
+    return a < b ? a : b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One group's registers for a tick.
+// ---------------------------------------------------------------------------------------------
+template <int P> struct RgGroup {
+    u64 mt[P], nx[P], pc[P]; // Progress.matched / next_idx / committed_index   (in/out)
+    u64 mi[P], mc[P];        // Message.index / Message.commit                  (in)
+    u64 pf, mf;              // flag rows: RG_PF_* / RG_MF_* byte per slot
+    u64 commit, lo, hi;      // RaftLog.committed, current-term index range [lo, hi], hi = last_index
+    u32 cfg, out;
+    u32 dirty;               // bit s: mt[s] changed, bit 8+s: nx[s], bit 16+s: pc[s], bit 24: pf, 25: commit, 26: hi
+};
+#define RG_DIRTY_PF (1u << 24)
+#define RG_DIRTY_COMMIT (1u << 25)
+#define RG_DIRTY_HI (1u << 26)
+
+// RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
+// (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
+// ends at last_index); commit_to (:286-300) can then never exceed last_index.
+RG_D bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
+    if (mci > commit && mci >= lo && mci <= hi) {
+        commit = mci;
+        return true;
+    }
+    return false;
+}
+
+// Raft::handle_append_response for every slot of one group, in slot order (src/raft.rs:1559-1775),
+// on_persist_entries for the leader's own slot (src/raft.rs:994-1016).
+// Cold columns (pending_snapshot, pending_request_snapshot, commit_group_id, reject_hint,
+// request_snapshot) are touched through `st`/`ms` only on the rare paths that need them.
+// GC = false compiles the group-commit path out (the engine launches the GC = true kernel only
+// when some group has ProgressTracker.group_commit set).
+template <int P, bool GC> struct RgTick {
+    RgGroup<P> &r;
+    const RgState &st;
+    const RgMsgs &ms;
+    const u64 g;
+    RgQuorum<P> qm;
+    u64 last0; // last_index the send path saw before this tick
+    u32 incoming, outgoing, self, present, xfer, out;
+    bool any_commit;
+
+    RG_D RgTick(RgGroup<P> &r_, const RgState &st_, const RgMsgs &ms_, u64 g_)
+        : r(r_), st(st_), ms(ms_), g(g_) {
+        const u32 cfg = r.cfg;
+        incoming = RG_CFG_INCOMING(cfg);
+        outgoing = RG_CFG_OUTGOING(cfg);
+        self = RG_CFG_SELF(cfg);
+        present = RG_CFG_PRESENT(cfg);
+        xfer = RG_CFG_TRANSFEREE(cfg);
+        last0 = r.hi;
+        out = 0;
+        any_commit = false;
+        r.dirty = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++) // slots without a Progress ack 0 and are never written back
+            if (!((present >> i) & 1u)) r.mt[i] = 0;
+        qm.init(r.mt);
+    }
+
+    // Raft::maybe_commit (src/raft.rs:893-904) on the current matches. The leader's own
+    // update_committed (:896-900) is applied once at the end (commit only grows within a tick).
+    RG_D bool maybe_commit() {
+        u64 mci;
+        if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
+            u64 gidv[P];
+#pragma unroll
+            for (int i = 0; i < P; i++)
+                gidv[i] = ((present >> i) & 1u) ? st.gid[(u64)i * st.stride + g] : 0ULL;
+            bool used;
+            mci = rg_mci_group<P>(r.mt, gidv, incoming, outgoing, used);
+        } else {
+            mci = qm.mci(r.mt, incoming, outgoing);
+        }
+        const bool ch = rg_log_maybe_commit(mci, r.commit, r.lo, r.hi);
+        any_commit |= ch;
+        return ch;
+    }
+
+    // Progress::reset_state (progress.rs:75-80): paused=false, pending_snapshot=0, state; the
+    // Inflights reset is the host's (it sees the transition through the state column).
+    RG_D void reset_state(u32 &pb, u32 new_state, u64 o) {
+        pb = (pb & ~(RG_PF_PAUSED | RG_PF_STATE_MASK)) | new_state;
+        st.psnap[o] = 0;
+    }
+
+    template <int S> RG_D void set_next(u64 n) {
+        if (r.nx[S] != n) {
+            r.nx[S] = n;
+            r.dirty |= 1u << (8 + S);
+        }
+    }
+
+    // Progress::maybe_update (progress.rs:138-150); returns need_update
+    template <int S> RG_D bool maybe_update(u64 idx, u32 &pb) {
+        const bool upd = r.mt[S] < idx;
+        if (upd) {
+            r.mt[S] = idx;
+            r.dirty |= 1u << S;
+            pb &= ~RG_PF_PAUSED; // resume()
+            qm.template update<S>(r.mt);
+        }
+        if (r.nx[S] < idx + 1) set_next<S>(idx + 1);
+        return upd;
+    }
+
+    template <int S> RG_D void slot() {
+        const u32 f = (u32)(r.mf >> (8 * S)) & 0xffu;
+        if (f == 0 || !((present >> S) & 1u)) return; // no event / no Progress (raft.rs:1663-1673)
+        const u32 pb0 = (u32)(r.pf >> (8 * S)) & 0xffu;
+        u32 pb = pb0;
+        const u64 o = (u64)S * st.stride + g;
+
+        if ((u32)S == self) {
+            if (f & RG_MF_APPEND) { // Raft::append_entry (raft.rs:976-991): last_index grows, same term
+                const u64 nl = r.mc[S];
+                if (nl > r.hi) {
+                    r.hi = nl;
+                    r.dirty |= RG_DIRTY_HI;
+                }
+            }
+            if (f & RG_MF_VALID) { // on_persist_entries (raft.rs:994-1016)
+                const u64 idx = r.mi[S];
+                if ((idx >> 63) || idx > r.hi) out |= RG_OUT_FAULT;
+                if (maybe_update<S>(idx, pb) && maybe_commit()) out |= RG_OUT_CHANGED;
+            }
+        } else {
+            const u32 state = pb & RG_PF_STATE_MASK;
+            if (f & RG_MF_SENT) { // Progress::update_state(last) (progress.rs:231-243) via raft.rs:726-729
+                if (state == RG_STATE_REPLICATE) set_next<S>(last0 + 1); // optimistic_update
+                else if (state == RG_STATE_PROBE) pb |= RG_PF_PAUSED;
+                else out |= RG_OUT_FAULT; // the reference panics
+            }
+            if (f & RG_MF_VALID) {
+                const u64 idx = r.mi[S];
+                const bool reject = (f & RG_MF_REJECT) != 0;
+                if ((idx >> 63) || (!reject && idx > r.hi)) out |= RG_OUT_FAULT;
+                pb |= RG_PF_RECENT_ACTIVE;  // raft.rs:1674
+                if (r.mc[S] > r.pc[S]) {    // update_committed, raft.rs:1677
+                    r.pc[S] = r.mc[S];
+                    r.dirty |= 1u << (16 + S);
+                }
+                if (reject) {
+                    // Progress::maybe_decr_to(m.index, hint, m.request_snapshot) (progress.rs:168-206)
+                    const u64 rs = (f & RG_MF_HAS_RS) ? ms.mrs[o] : 0ULL;
+                    bool dec = false;
+                    if (state == RG_STATE_REPLICATE) {
+                        const bool stale = idx < r.mt[S] || (idx == r.mt[S] && rs == 0);
+                        if (!stale) {
+                            if (rs == 0) set_next<S>(r.mt[S] + 1);
+                            else st.prs[o] = rs;
+                            dec = true;
+                        }
+                    } else {
+                        const bool stale = (r.nx[S] == 0 || r.nx[S] - 1 != idx) && rs == 0;
+                        if (!stale) {
+                            if (rs == 0) {
+                                const u64 h = ms.mh[o] + 1;
+                                u64 n = idx < h ? idx : h;
+                                if (n < 1) n = 1;
+                                set_next<S>(n);
+                            } else if (st.prs[o] == 0) {
+                                st.prs[o] = rs;
+                            }
+                            pb &= ~RG_PF_PAUSED; // resume()
+                            dec = true;
+                        }
+                    }
+                    if (dec) {
+                        if (state == RG_STATE_REPLICATE) { // become_probe (progress.rs:95-107)
+                            reset_state(pb, RG_STATE_PROBE, o);
+                            set_next<S>(r.mt[S] + 1);
+                        }
+                        out |= 1u << (8 + S); // send_append(m.from), raft.rs:1719
+                    }
+                } else {
+                    // Progress::is_paused (progress.rs:210-216); Inflights::full() comes from the host
+                    const bool old_paused = state == RG_STATE_PROBE       ? (pb & RG_PF_PAUSED) != 0
+                                            : state == RG_STATE_REPLICATE ? (f & RG_MF_INS_FULL) != 0
+                                                                          : true;
+                    if (maybe_update<S>(idx, pb)) {
+                        if (state == RG_STATE_PROBE) { // become_replicate (progress.rs:111-114)
+                            reset_state(pb, RG_STATE_REPLICATE, o);
+                            set_next<S>(r.mt[S] + 1);
+                        } else if (state == RG_STATE_SNAPSHOT) { // maybe_snapshot_abort (progress.rs:132-134)
+                            const u64 ps = st.psnap[o];
+                            if (r.mt[S] >= ps) { // become_probe from Snapshot (progress.rs:99-102)
+                                reset_state(pb, RG_STATE_PROBE, o);
+                                const u64 a = r.mt[S] + 1, b = ps + 1;
+                                set_next<S>(a > b ? a : b);
+                            }
+                        } else {
+                            out |= 1u << (24 + S); // ins.free_to(m.index), raft.rs:1742
+                        }
+                        if (maybe_commit()) out |= RG_OUT_CHANGED;  // raft.rs:1745-1748
+                        else if (old_paused) out |= 1u << (8 + S);  // raft.rs:1749-1751
+                        out |= 1u << (16 + S);                      // raft.rs:1761
+                        if (xfer == (u32)S + 1u && r.mt[S] == r.hi) // raft.rs:1764-1774
+                            out |= RG_OUT_TIMEOUT_NOW;
+                    }
+                }
+            }
+        }
+        if (pb != pb0) {
+            r.pf = (r.pf & ~(0xffULL << (8 * S))) | ((u64)pb << (8 * S));
+            r.dirty |= RG_DIRTY_PF;
+        }
+    }
+
+    template <int S> RG_D void self_committed() { // prs[self].update_committed(committed), raft.rs:896-900
+        if ((u32)S == self && ((present >> S) & 1u) && r.pc[S] < r.commit) {
+            r.pc[S] = r.commit;
+            r.dirty |= 1u << (16 + S);
+        }
+    }
+
+    template <int... S> RG_D void run(rg_seq<S...>) {
+        (slot<S>(), ...);
+        if (any_commit) {
+            r.dirty |= RG_DIRTY_COMMIT;
+            (self_committed<S>(), ...);
+        }
+        r.out = out;
+    }
+};
+
+template <int P, bool GC>
+RG_D void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
+    RgTick<P, GC> t(r, st, ms, g);
+    t.run(typename rg_make_seq<P>::type{});
+}

@@ -1,0 +1,205 @@
+// rg_workload.h -- the synthetic AppendResponse stream of BASELINE.md section 4 / SURVEY.md 8(d).
+//
+// One definition compiled for host and device, so the GPU bench, the CPU baseline and the parity
+// tests consume bit-identical streams. Counter-based: every value is a pure function of
+// (seed, tick, global group, slot) and of the CURRENT engine state of that group, which is what a
+// real cluster's followers would be answering to.
+//
+// What it models (reference behaviour cited per case):
+//  * steady state: followers in Replicate acknowledge the entries the leader sent after the last
+//    tick (accept acks, some stale acks, some silence); the leader appends 0..7 entries per tick and
+//    persists them (Raft::append_entry + on_persist_entries, src/raft.rs:976-1016);
+//  * the send path's writes to Progress (Progress::update_state, src/tracker/progress.rs:231-243)
+//    as the RG_MF_SENT event: Replicate => optimistic next = last+1, Probe => paused;
+//  * RG_WL_MIXED: 10% of the groups start right after an election (Raft::reset + become_leader,
+//    src/raft.rs:942-971,1151-1202): followers Probe/match 0/next last+1; the first probe is
+//    rejected with the follower's real last index as hint (maybe_decr_to, progress.rs:186-205), the
+//    second accepted (Probe -> Replicate); plus rare Replicate-state rejects, request_snapshot
+//    rejects and full-inflight acks so every branch of handle_append_response runs.
+#pragma once
+
+#include "rg_common.h"
+
+struct RgWlGroup { // static (tick-independent) facts of a group
+    u32 n_peers;   // slots in use (P_g)
+    u32 incoming, outgoing, present;
+    u64 last0;     // last_index before the run starts
+    u64 lo0;
+    bool post_election;
+};
+
+RG_HD RgWlGroup rg_wl_group(u64 seed, u32 workload, u32 n_slots, u64 gg) {
+    RgWlGroup w;
+    const u64 h = rg_hash(seed, 0, gg, 0);
+    w.n_peers = n_slots;
+    if (workload == RG_WL_MIXED) {
+        const u32 k = (u32)(gg % 3);
+        w.n_peers = k == 0 ? 3u : (k == 1 ? 5u : 7u);
+        if (w.n_peers > n_slots) w.n_peers = n_slots;
+    }
+    const u32 all = (1u << w.n_peers) - 1u;
+    w.present = all;
+    w.incoming = all;
+    w.outgoing = 0;
+    if (workload == RG_WL_JOINT) { // joint {0,1,2} && {1,2,3}; slots >= 4 are learners
+        w.incoming = 0x07u & all;
+        w.outgoing = 0x0eu & all;
+    }
+    w.last0 = 1000 + (h & 0xFFFFF);
+    w.lo0 = w.last0 - ((h >> 20) & 63);
+    w.post_election = (workload == RG_WL_MIXED) && (((h >> 32) % 10) == 0);
+    return w;
+}
+
+// follower p's real log end at the start of the run (what a rejected probe reports as hint)
+RG_HD u64 rg_wl_follower_last(u64 seed, u64 gg, u32 p, u64 last0) {
+    return last0 - (rg_hash(seed, 0, gg, p) & 31);
+}
+
+// q-th largest of up to 8 values under a mask (generator-side, for the initial commit only)
+RG_HD u64 rg_wl_kth(const u64 *v, u32 mask) {
+    u32 n = 0;
+    for (int i = 0; i < 8; i++) n += (mask >> i) & 1u;
+    if (n == 0) return ~0ULL;
+    const u32 q = n / 2 + 1;
+    u64 best = 0;
+    for (int i = 0; i < 8; i++) {
+        if (!((mask >> i) & 1u)) continue;
+        u32 c = 0;
+        for (int j = 0; j < 8; j++)
+            if (((mask >> j) & 1u) && v[j] >= v[i]) c++;
+        if (c >= q && v[i] > best) best = v[i];
+    }
+    return best;
+}
+
+// Initial state of group g (local index) / gg (global index). Writes every column of the group.
+RG_HD void rg_wl_init_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64 g, u64 gg, u64 *match,
+                            u64 *next, u64 *prc, u64 *psnap, u64 *prs, u64 *gid, u8 *pflags,
+                            u64 *commit, u64 *lo, u64 *hi, u32 *cfg) {
+    const RgWlGroup w = rg_wl_group(seed, workload, n_slots, gg);
+    u64 v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 last = w.last0, tlo = w.lo0;
+    if (w.post_election) { // become_leader: noop appended at last0+1 (raft.rs:1163-1194)
+        last = w.last0 + 1;
+        tlo = last;
+    }
+    for (u32 p = 0; p < n_slots; p++) {
+        const u64 o = (u64)p * stride + g;
+        u64 m = 0, n = 0;
+        u8 f = 0;
+        if (p < w.n_peers) {
+            if (p == 0) { // the leader: Replicate, matched = persisted
+                m = w.last0;
+                n = m + 1;
+                f = RG_STATE_REPLICATE;
+            } else if (w.post_election) { // Progress::reset(last_index + 1) (progress.rs:82-92)
+                m = 0;
+                n = w.last0 + 1;
+                f = RG_STATE_PROBE;
+            } else {
+                m = rg_wl_follower_last(seed, gg, p, w.last0);
+                n = m + 1;
+                f = RG_STATE_REPLICATE;
+            }
+        }
+        v[p] = m;
+        match[o] = m;
+        next[o] = n;
+        psnap[o] = 0;
+        prs[o] = 0;
+        gid[o] = 0;
+        pflags[g * 8 + p] = f;
+    }
+    for (u32 p = n_slots; p < 8; p++) pflags[g * 8 + p] = 0;
+    u64 c;
+    if (w.post_election) {
+        c = w.last0 - ((rg_hash(seed, 0, gg, 0) >> 26) & 31);
+    } else {
+        const u64 a = rg_wl_kth(v, w.incoming), b = rg_wl_kth(v, w.outgoing);
+        c = rg_min(rg_min(a, b), last);
+    }
+    for (u32 p = 0; p < n_slots; p++) prc[(u64)p * stride + g] = p < w.n_peers ? c : 0;
+    commit[g] = c;
+    lo[g] = tlo;
+    hi[g] = last;
+    cfg[g] = RG_CFG_MAKE(w.incoming, w.outgoing, 0, 0, 0, w.present);
+}
+
+// Messages of tick `tick` for group g, generated from the group's CURRENT state.
+RG_HD void rg_wl_gen_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64 g, u64 gg, u64 tick,
+                           const u64 *match, const u64 *next, const u8 *pflags, const u64 *commit,
+                           const u64 *hi, u64 *m_index, u64 *m_commit, u64 *m_hint, u64 *m_rs,
+                           u8 *m_flags) {
+    const RgWlGroup w = rg_wl_group(seed, workload, n_slots, gg);
+    const u64 last = hi[g], cm = commit[g];
+    const bool mixed = workload == RG_WL_MIXED; // rejects / snapshot requests / full windows: config 5 only
+    for (u32 p = 0; p < 8; p++) {
+        u8 f = 0;
+        u64 idx = 0, mcm = 0, hint = 0, rs = 0;
+        if (p < w.n_peers) {
+            const u64 o = (u64)p * stride + g;
+            const u64 r = rg_hash(seed, tick + 1, gg, p);
+            if (p == 0) { // leader: append d entries and persist them
+                const u64 d = r & 7;
+                f = RG_MF_APPEND | RG_MF_VALID;
+                idx = last + d;
+                mcm = last + d;
+            } else {
+                const u32 pb = pflags[g * 8 + p];
+                const u32 state = pb & RG_PF_STATE_MASK;
+                const u64 mt = match[o], nx = next[o];
+                const u32 u = (u32)(r % 100);
+                const u32 rare = (u32)(r >> 16) & 63;
+                if (state == RG_STATE_REPLICATE) {
+                    f = RG_MF_SENT; // the leader streamed entries up to `last` after the previous tick
+                    if (mixed && ((r >> 24) & 255) == 0) f |= RG_MF_INS_FULL;
+                    if (u < 90) { // accept
+                        f |= RG_MF_VALID;
+                        idx = rg_min(last, mt + ((r >> 8) & 15));
+                        mcm = rg_min(cm, idx);
+                    } else if (u < 95) { // stale (duplicate / reordered) ack
+                        f |= RG_MF_VALID;
+                        const u64 back = (r >> 8) & 3;
+                        idx = mt - rg_min(mt, back);
+                        mcm = rg_min(cm, idx);
+                    } else if (mixed && u == 99 && rare == 0 && last > mt) { // follower lost its tail: real reject
+                        f |= RG_MF_VALID | RG_MF_REJECT;
+                        idx = last;
+                        hint = mt;
+                        mcm = rg_min(cm, mt);
+                    } else if (mixed && u == 98 && rare == 1) { // follower asks for a snapshot
+                        f |= RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_RS;
+                        idx = mt;
+                        hint = mt;
+                        rs = cm ? cm : 1;
+                        mcm = rg_min(cm, mt);
+                    }
+                } else if (state == RG_STATE_PROBE) {
+                    const bool paused = (pb & RG_PF_PAUSED) != 0;
+                    if (!paused) f = RG_MF_SENT; // one probe, then paused (progress.rs:238)
+                    if (u < 90 && nx > 0) {
+                        const u64 flast = rg_wl_follower_last(seed, gg, p, w.last0);
+                        f |= RG_MF_VALID;
+                        if (mt == 0 && nx - 1 > flast) { // probe beyond the follower's log: reject
+                            f |= RG_MF_REJECT;
+                            idx = nx - 1;
+                            hint = flast;
+                            mcm = rg_min(cm, flast);
+                        } else { // probe accepted, follower appends what was sent
+                            const u64 base = rg_max(nx - 1, mt);
+                            idx = rg_min(last, base + ((r >> 8) & 15));
+                            mcm = rg_min(cm, idx);
+                        }
+                    }
+                }
+                // Snapshot state: the follower is silent until the snapshot lands (host-side path)
+            }
+            m_index[o] = idx;
+            m_commit[o] = mcm;
+            m_hint[o] = hint;
+            m_rs[o] = rs;
+        }
+        m_flags[g * 8 + p] = f;
+    }
+}

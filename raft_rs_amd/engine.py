@@ -1,0 +1,384 @@
+"""ctypes binding of the C ABI in include/raftgroups.h (raft_rs_amd/libraftgroups.so).
+
+Names follow the reference's domain (groups, peers/slots, progress, commit), mirroring
+ProgressTracker / RaftLog accessors where one exists (citations in include/raftgroups.h).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libraftgroups.so")
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"raftgroups error {code}: {msg}")
+        self.code = code
+
+
+class COL:
+    MATCH, NEXT, PR_COMMIT, PEND_SNAP, PEND_RS, GID, PFLAGS, COMMIT, TERM_LO, TERM_HI, CFG, OUT = range(12)
+    PER_SLOT = (0, 1, 2, 3, 4, 5)
+    NAMES = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
+             "term_lo", "term_hi", "cfg", "out")
+
+
+class PF:
+    STATE_MASK, PROBE, REPLICATE, SNAPSHOT, PAUSED, RECENT_ACTIVE = 0x3, 0, 1, 2, 0x4, 0x8
+
+
+class MF:
+    VALID, REJECT, HAS_RS, INS_FULL, SENT, APPEND = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+
+
+class OUT:
+    CHANGED, FAULT, TIMEOUT_NOW = 0x1, 0x2, 0x4
+
+    @staticmethod
+    def send_append(o):
+        return (int(o) >> 8) & 0xff
+
+    @staticmethod
+    def send_more(o):
+        return (int(o) >> 16) & 0xff
+
+    @staticmethod
+    def free_to(o):
+        return (int(o) >> 24) & 0xff
+
+
+ERR = {"INVALID_ARG": -1, "NO_DEVICE": -2, "OUT_OF_MEMORY": -3, "STEP_LOCAL_MSG": -4,
+       "STEP_PEER_NOT_FOUND": -5, "SLOT_BUSY": -6, "HIGHER_TERM": -7, "STATE": -8}
+
+WL_MAJORITY, WL_JOINT, WL_MIXED = 2, 3, 5
+VARIANT_DEFAULT, VARIANT_LANE, VARIANT_LDS = 0, 1, 2
+
+
+def cfg_make(incoming, outgoing=0, self_slot=0, group_commit=False, transferee_plus1=0, present=None):
+    """RG_CFG_MAKE of include/raftgroups.h."""
+    if present is None:
+        present = incoming | outgoing
+    return ((incoming & 0xff) | ((outgoing & 0xff) << 8) | ((self_slot & 7) << 16) |
+            (0x00080000 if group_commit else 0) | ((transferee_plus1 & 0xf) << 20) | ((present & 0xff) << 24))
+
+
+class _Config(C.Structure):
+    _fields_ = [("n_groups", C.c_uint64), ("n_slots", C.c_uint32), ("device", C.c_int32),
+                ("variant", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class _Msgs(C.Structure):
+    _fields_ = [("m_index", C.c_void_p), ("m_commit", C.c_void_p), ("m_hint", C.c_void_p),
+                ("m_rs", C.c_void_p), ("m_flags", C.c_void_p)]
+
+
+class _Workload(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("workload", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class _HostState(C.Structure):
+    _fields_ = [("n_groups", C.c_uint64), ("stride", C.c_uint64), ("n_slots", C.c_uint32),
+                ("reserved", C.c_uint32)] + \
+               [(n, C.c_void_p) for n in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid",
+                                          "pflags", "commit", "term_lo", "term_hi", "cfg")]
+
+
+class AppendResponse(C.Structure):
+    _fields_ = [("from_", C.c_uint64), ("term", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
+                ("reject_hint", C.c_uint64), ("request_snapshot", C.c_uint64), ("reject", C.c_uint8),
+                ("ins_full", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+class CellWrite(C.Structure):
+    _fields_ = [("group", C.c_uint64), ("slot", C.c_uint32), ("field_mask", C.c_uint32),
+                ("match", C.c_uint64), ("next", C.c_uint64), ("pr_commit", C.c_uint64),
+                ("pend_snap", C.c_uint64), ("pend_rs", C.c_uint64), ("gid", C.c_uint64),
+                ("pflags", C.c_uint8), ("pad", C.c_uint8 * 7)]
+
+
+# every symbol include/raftgroups.h declares: (restype, argtypes)
+_vp, _u64, _i = C.c_void_p, C.c_uint64, C.c_int
+SYMBOLS = {
+    "rg_version": (C.c_char_p, []),
+    "rg_last_error": (C.c_char_p, []),
+    "rg_device_count": (_i, []),
+    "rg_create": (_i, [C.POINTER(_Config), C.POINTER(_vp)]),
+    "rg_destroy": (None, [_vp]),
+    "rg_stride": (_u64, [_vp]),
+    "rg_set_stream": (_i, [_vp, _vp]),
+    "rg_sync": (_i, [_vp]),
+    "rg_column_bytes": (_u64, [_vp, _i]),
+    "rg_load_column": (_i, [_vp, _i, _vp, _u64]),
+    "rg_read_column": (_i, [_vp, _i, _vp, _u64]),
+    "rg_column_ptr": (_vp, [_vp, _i]),
+    "rg_checkpoint": (_i, [_vp]),
+    "rg_restore": (_i, [_vp]),
+    "rg_write_cells": (_i, [_vp, C.POINTER(CellWrite), _u64]),
+    "rg_tick": (_i, [_vp, C.POINTER(_Msgs)]),
+    "rg_tick_device": (_i, [_vp, C.POINTER(_Msgs)]),
+    "rg_recompute": (_i, [_vp]),
+    "rg_maximal_committed_index": (_i, [_vp, _vp, _vp]),
+    "rg_results": (_i, [_vp, _vp, _vp]),
+    "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 4)]),
+    "rg_vote_result": (_i, [_vp, _vp, _vp, _vp]),
+    "rg_quorum_recently_active": (_i, [_vp, _vp]),
+    "rg_set_peers": (_i, [_vp, _u64, C.POINTER(_u64), C.c_uint32, _u64]),
+    "rg_step": (_i, [_vp, _u64, C.POINTER(AppendResponse)]),
+    "rg_local_append": (_i, [_vp, _u64, _u64]),
+    "rg_local_persisted": (_i, [_vp, _u64, _u64]),
+    "rg_mark_sent": (_i, [_vp, _u64, _u64]),
+    "rg_flush": (_i, [_vp]),
+    "rg_workload_init": (_i, [_vp, C.POINTER(_Workload), _u64]),
+    "rg_workload_gen": (_i, [_vp, C.POINTER(_Workload), _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "rg_workload_init_host": (_i, [C.POINTER(_Workload), _u64, C.POINTER(_HostState)]),
+    "rg_workload_gen_host": (_i, [C.POINTER(_Workload), _u64, _u64, C.POINTER(_HostState), _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP engine. Fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m raft_rs_amd.build` "
+                          "(hipcc, gfx950). The engine has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    return int(a)
+
+
+class MsgBuffers:
+    """Host-side message columns of one tick (layout of rg_msgs)."""
+
+    def __init__(self, n_groups, n_slots, stride):
+        self.n_groups, self.n_slots, self.stride = n_groups, n_slots, stride
+        self.m_index = np.zeros((n_slots, stride), dtype=np.uint64)
+        self.m_commit = np.zeros((n_slots, stride), dtype=np.uint64)
+        self.m_hint = np.zeros((n_slots, stride), dtype=np.uint64)
+        self.m_rs = np.zeros((n_slots, stride), dtype=np.uint64)
+        self.m_flags = np.zeros((n_groups, 8), dtype=np.uint8)
+
+    def clear(self):
+        for a in (self.m_index, self.m_commit, self.m_hint, self.m_rs, self.m_flags):
+            a[...] = 0
+
+    def as_dict(self):
+        return {"n_groups": self.n_groups, "n_slots": self.n_slots, "stride": self.stride,
+                "m_index": self.m_index, "m_commit": self.m_commit, "m_hint": self.m_hint,
+                "m_rs": self.m_rs, "m_flags": self.m_flags}
+
+
+class Engine:
+    """One shard of raft groups resident on one MI355X (rg_engine)."""
+
+    def __init__(self, n_groups, n_slots, device=0, variant=VARIANT_DEFAULT):
+        self.L = load_library()
+        self.h = _vp()
+        cfg = _Config(n_groups, n_slots, device, variant, 0)
+        self._check(self.L.rg_create(C.byref(cfg), C.byref(self.h)))
+        self.n_groups, self.n_slots, self.device = n_groups, n_slots, device
+        self.stride = self.L.rg_stride(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.L.rg_last_error().decode())
+        return rc
+
+    # ---- plumbing --------------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._check(self.L.rg_set_stream(self.h, _vp(stream_handle)))
+
+    def sync(self):
+        self._check(self.L.rg_sync(self.h))
+
+    def column_shape_dtype(self, col):
+        if col in COL.PER_SLOT:
+            return (self.n_slots, self.stride), np.uint64
+        if col == COL.PFLAGS:
+            return (self.n_groups, 8), np.uint8
+        if col in (COL.CFG, COL.OUT):
+            return (self.n_groups,), np.uint32
+        return (self.n_groups,), np.uint64
+
+    def load_column(self, col, arr):
+        shape, dt = self.column_shape_dtype(col)
+        a = np.ascontiguousarray(arr, dtype=dt)
+        assert a.shape == shape, (COL.NAMES[col], a.shape, shape)
+        self._check(self.L.rg_load_column(self.h, col, a.ctypes.data, a.nbytes))
+
+    def read_column(self, col):
+        shape, dt = self.column_shape_dtype(col)
+        a = np.empty(shape, dtype=dt)
+        self._check(self.L.rg_read_column(self.h, col, a.ctypes.data, a.nbytes))
+        return a
+
+    def column_ptr(self, col):
+        return self.L.rg_column_ptr(self.h, col)
+
+    def load_state(self, st):
+        """st: dict with the column names of COL.NAMES[:11] (tests/oracle_lib.alloc_state layout)."""
+        for col in range(COL.CFG + 1):
+            self.load_column(col, st[COL.NAMES[col]])
+
+    def read_state(self):
+        st = {"n_groups": self.n_groups, "n_slots": self.n_slots, "stride": self.stride}
+        for col in range(COL.OUT + 1):
+            st[COL.NAMES[col]] = self.read_column(col)
+        return st
+
+    def checkpoint(self):
+        self._check(self.L.rg_checkpoint(self.h))
+
+    def restore(self):
+        self._check(self.L.rg_restore(self.h))
+
+    def write_cells(self, cells):
+        """cells: list of dicts {group, slot, <column name>: value, ...}."""
+        arr = (CellWrite * max(1, len(cells)))()
+        for i, c in enumerate(cells):
+            arr[i].group, arr[i].slot = c["group"], c["slot"]
+            mask = 0
+            for col in range(COL.PFLAGS + 1):
+                name = COL.NAMES[col]
+                if name in c:
+                    mask |= 1 << col
+                    setattr(arr[i], name, int(c[name]))
+            arr[i].field_mask = mask
+        self._check(self.L.rg_write_cells(self.h, arr, len(cells)))
+
+    # ---- hot path --------------------------------------------------------------------------
+    def tick(self, msgs):
+        """Host-buffer tick (H2D copy + kernel + sync)."""
+        m = _Msgs(_ptr(msgs.m_index), _ptr(msgs.m_commit), _ptr(msgs.m_hint), _ptr(msgs.m_rs), _ptr(msgs.m_flags))
+        self._check(self.L.rg_tick(self.h, C.byref(m)))
+
+    def tick_device(self, m_index, m_commit, m_hint, m_rs, m_flags):
+        """Device-pointer tick (asynchronous on the engine's stream)."""
+        m = _Msgs(_ptr(m_index), _ptr(m_commit), _ptr(m_hint), _ptr(m_rs), _ptr(m_flags))
+        self._check(self.L.rg_tick_device(self.h, C.byref(m)))
+
+    def recompute(self):
+        self._check(self.L.rg_recompute(self.h))
+
+    def maximal_committed_index(self, with_flag=False):
+        mci = np.empty(self.n_groups, dtype=np.uint64)
+        gc = np.empty(self.n_groups, dtype=np.uint8) if with_flag else None
+        self._check(self.L.rg_maximal_committed_index(self.h, mci.ctypes.data, _ptr(gc)))
+        return (mci, gc) if with_flag else mci
+
+    def results(self):
+        commit = np.empty(self.n_groups, dtype=np.uint64)
+        out = np.empty(self.n_groups, dtype=np.uint32)
+        self._check(self.L.rg_results(self.h, commit.ctypes.data, out.ctypes.data))
+        return commit, out
+
+    def result_counts(self):
+        a, b = _u64(0), _u64(0)
+        self._check(self.L.rg_result_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def msg_stats(self, dev_m_flags):
+        c = (_u64 * 4)()
+        self._check(self.L.rg_msg_stats(self.h, _ptr(dev_m_flags), C.byref(c)))
+        return {"valid": c[0], "rejects": c[1], "slots": c[2], "groups_with_events": c[3]}
+
+    def vote_result(self, yes, no):
+        yes = np.ascontiguousarray(yes, dtype=np.uint8)
+        no = np.ascontiguousarray(no, dtype=np.uint8)
+        res = np.empty(self.n_groups, dtype=np.uint8)
+        self._check(self.L.rg_vote_result(self.h, yes.ctypes.data, no.ctypes.data, res.ctypes.data))
+        return res
+
+    def quorum_recently_active(self):
+        res = np.empty(self.n_groups, dtype=np.uint8)
+        self._check(self.L.rg_quorum_recently_active(self.h, res.ctypes.data))
+        return res
+
+    # ---- message-at-a-time mirror of RawNode::step -----------------------------------------------
+    def set_peers(self, group, peer_ids, term):
+        arr = (_u64 * len(peer_ids))(*peer_ids)
+        self._check(self.L.rg_set_peers(self.h, group, arr, len(peer_ids), term))
+
+    def step(self, group, from_, term, index, commit=0, reject=False, reject_hint=0, request_snapshot=0,
+             ins_full=False):
+        m = AppendResponse(from_, term, index, commit, reject_hint, request_snapshot, int(reject), int(ins_full))
+        self._check(self.L.rg_step(self.h, group, C.byref(m)))
+
+    def local_append(self, group, new_last_index):
+        self._check(self.L.rg_local_append(self.h, group, new_last_index))
+
+    def local_persisted(self, group, index):
+        self._check(self.L.rg_local_persisted(self.h, group, index))
+
+    def mark_sent(self, group, peer_id):
+        self._check(self.L.rg_mark_sent(self.h, group, peer_id))
+
+    def flush(self):
+        self._check(self.L.rg_flush(self.h))
+
+    # ---- synthetic stream --------------------------------------------------------------------
+    def workload_init(self, workload, seed=0x5EED5EED, first_group=0):
+        w = _Workload(seed, workload, 0)
+        self._check(self.L.rg_workload_init(self.h, C.byref(w), first_group))
+
+    def workload_gen(self, workload, tick, m_index, m_commit, m_hint, m_rs, m_flags, seed=0x5EED5EED, first_group=0):
+        w = _Workload(seed, workload, 0)
+        self._check(self.L.rg_workload_gen(self.h, C.byref(w), first_group, tick, _ptr(m_index), _ptr(m_commit),
+                                           _ptr(m_hint), _ptr(m_rs), _ptr(m_flags)))
+
+
+def _host_state_struct(st):
+    return _HostState(st["n_groups"], st["stride"], st["n_slots"], 0,
+                      *[st[k].ctypes.data for k in COL.NAMES[:11]])
+
+
+def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0):
+    """Host twin of Engine.workload_init over numpy columns (no GPU)."""
+    L = load_library()
+    w = _Workload(seed, workload, 0)
+    s = _host_state_struct(st)
+    rc = L.rg_workload_init_host(C.byref(w), first_group, C.byref(s))
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())
+
+
+def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0):
+    """Host twin of Engine.workload_gen: messages of `tick` from the numpy state columns."""
+    L = load_library()
+    w = _Workload(seed, workload, 0)
+    s = _host_state_struct(st)
+    rc = L.rg_workload_gen_host(C.byref(w), first_group, tick, C.byref(s), msgs.m_index.ctypes.data,
+                                msgs.m_commit.ctypes.data, msgs.m_hint.ctypes.data, msgs.m_rs.ctypes.data,
+                                msgs.m_flags.ctypes.data)
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def rg():
+    """The product package; the HIP library must already be built (python -m raft_rs_amd.build)."""
+    import raft_rs_amd
+    raft_rs_amd.load_library()
+    return raft_rs_amd

@@ -1,0 +1,67 @@
+"""CPU-only: the synthetic stream's host twin driven through the oracle (no GPU involved).
+
+Checks the stream is well-formed (no FAULT), that commit indices advance, and that every branch of
+handle_append_response the workload claims to exercise actually fires.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raft_rs_amd import engine as E
+
+
+def run_stream(workload, n_groups, n_slots, ticks):
+    st = O.alloc_state(n_groups, n_slots)
+    E.workload_init_host(st, workload)
+    cl = O.Cluster(n_groups)
+    cl.load_soa(st, term=5)
+    msgs = E.MsgBuffers(n_groups, n_slots, st["stride"])
+    gout = np.zeros(n_groups, dtype=np.uint32)
+    stats = {"changed": 0, "fault": 0, "send_append": 0, "valid": 0, "reject": 0}
+    commits = [st["commit"].copy()]
+    for t in range(ticks):
+        E.workload_gen_host(st, msgs, workload, t)
+        stats["valid"] += int((msgs.m_flags & 1).sum())
+        stats["reject"] += int(((msgs.m_flags & 3) == 3).sum())
+        cl.tick_soa(msgs.as_dict(), gout)
+        cl.store_soa(st)
+        stats["changed"] += int((gout & 1).sum())
+        stats["fault"] += int(((gout >> 1) & 1).sum())
+        stats["send_append"] += int(((gout >> 8) & 0xff != 0).sum())
+        commits.append(st["commit"].copy())
+    return st, stats, commits
+
+
+@pytest.mark.parametrize("workload,n_slots", [(E.WL_MAJORITY, 3), (E.WL_MAJORITY, 5), (E.WL_JOINT, 5),
+                                              (E.WL_MIXED, 7), (E.WL_MAJORITY, 7)])
+def test_stream_is_well_formed(workload, n_slots):
+    st, stats, commits = run_stream(workload, 3000, n_slots, 6)
+    assert stats["fault"] == 0
+    assert stats["valid"] > 0.8 * 3000 * 6 * 2
+    for a, b in zip(commits, commits[1:]):
+        assert (b >= a).all(), "commit never decreases (raft_log.rs:286-300)"
+    assert (commits[-1] > commits[0]).mean() > 0.9, "nearly every group commits something in 6 ticks"
+    assert (st["commit"] <= st["term_hi"]).all()
+    assert stats["changed"] > 0
+
+
+def test_mixed_stream_exercises_probe_and_reject_paths():
+    st, stats, _ = run_stream(E.WL_MIXED, 6000, 7, 5)
+    assert stats["reject"] > 100, "post-election groups reject the first probe"
+    assert stats["send_append"] > 100
+    # after a few ticks the post-election followers have been probed into Replicate
+    states = st["pflags"] & 3
+    present = (st["cfg"] >> 24) & 0xff
+    n_probe = sum(int(((states[:, p] == 0) & ((present >> p) & 1 == 1)).sum()) for p in range(7))
+    n_slots = sum(int(((present >> p) & 1).sum()) for p in range(7))
+    assert n_probe < 0.02 * n_slots
+
+
+def test_host_generator_is_deterministic_and_shardable():
+    a = O.alloc_state(512, 5)
+    b = O.alloc_state(256, 5)
+    E.workload_init_host(a, E.WL_MAJORITY)
+    E.workload_init_host(b, E.WL_MAJORITY, first_group=256)
+    assert (a["match"][:, 256:512] == b["match"][:, :256]).all()
+    assert (a["commit"][256:512] == b["commit"][:256]).all()
+    assert (a["cfg"][256:512] == b["cfg"][:256]).all()
