@@ -126,7 +126,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
-    first_group = rank * G  # disjoint group ranges per rank
+    first_group = rank * G  # disjoint group ranges per rank (sharding.weak_shard)
     eng = rg.Engine(G, P, device=local_rank, variant=args.variant)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
@@ -155,12 +155,9 @@ def main():
 
     # ---- commit publication (N>1): double-buffered snapshot of commit_idx, all-gather on a side stream ----
     if distributed:
+        from raft_rs_amd import sharding
         commit_view = torch.as_tensor(DevCommitView(eng.column_ptr(rg.COL.COMMIT), G), device="cuda")
-        side = torch.cuda.Stream()
-        stage = [torch.empty(G, dtype=torch.int64, device="cuda") for _ in range(2)]
-        gathered = [torch.empty(world * G, dtype=torch.int64, device="cuda") for _ in range(2)]
-        ev_ready = [torch.cuda.Event() for _ in range(2)]
-        ev_done = [torch.cuda.Event() for _ in range(2)]
+        pub = sharding.CommitPublisher(dist, G, world, "cuda")
 
     def run_ticks(t0, n):
         for i in range(n):
@@ -168,14 +165,7 @@ def main():
             eng.tick_device(cols[0][t].data_ptr(), cols[1][t].data_ptr(), cols[2][t].data_ptr(),
                             cols[3][t].data_ptr(), flags[t].data_ptr())
             if distributed:
-                b = i & 1
-                stream.wait_event(ev_done[b])          # the previous gather out of this buffer finished
-                stage[b].copy_(commit_view, non_blocking=True)
-                ev_ready[b].record(stream)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev_ready[b])
-                    dist.all_gather_into_tensor(gathered[b], stage[b])
-                    ev_done[b].record(side)
+                pub.publish(i, commit_view)
 
     # ---- timed region ----
     eng.restore()
@@ -201,8 +191,7 @@ def main():
     if not (np.array_equal(commit, ref_commit) and np.array_equal(out, ref_out)):
         raise SystemExit("timed replay diverged from the recorded pass")
     if distributed:
-        last = (K - 1) & 1
-        got = gathered[last].view(world, G)[rank].cpu().numpy().view(np.uint64)
+        got = pub.result((K - 1) & 1)[rank].cpu().numpy().view(np.uint64)
         if not np.array_equal(got, commit):
             raise SystemExit("all-gathered commit indices do not match this rank's shard")
         tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")

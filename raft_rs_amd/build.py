@@ -1,21 +1,26 @@
 """Build the HIP engine (libraftgroups.so) in-tree with hipcc for gfx950.
 
-    python -m raft_rs_amd.build [--force]
+    python -m raft_rs_amd.build [--force] [--opt N ...]
 
-hipcc cross-compiles without a GPU. The .so is git-ignored but travels with gpurun snapshots.
+hipcc cross-compiles without a GPU. The tick kernels are instantiated once per slot count
+(csrc/tick_inst.hip, -DRG_P=1..8) and compiled in parallel, then linked with csrc/engine.hip.
+The .so is git-ignored but travels with gpurun snapshots.
 """
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libraftgroups.so")
-SOURCES = ["engine.hip"]
-HEADERS = ["rg_common.h", "rg_group.h", "rg_workload.h", os.path.join("..", "..", "include", "raftgroups.h")]
+DEPS = ["engine.hip", "tick_inst.hip", "rg_common.h", "rg_group.h", "rg_workload.h", "rg_tick_kernels.h",
+        os.path.join("..", "..", "include", "raftgroups.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+          "-Wno-pass-failed"]
 
 
 def hipcc():
@@ -25,25 +30,54 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP engine cannot be built (there is no CPU fallback)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+def is_stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in DEPS]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, extra_flags=(), verbose=False):
-    if not force and not is_stale():
-        return LIB
-    if not all(os.path.exists(os.path.join(CSRC, f)) for f in SOURCES):
-        raise RuntimeError("engine sources missing under " + CSRC)
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+def _compile(args):
+    src, obj, defs, verbose = args
+    cmd = [hipcc()] + CFLAGS + defs + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return obj
+
+
+def _build(lib, tag, defs, verbose):
+    if not all(os.path.exists(os.path.join(CSRC, f)) for f in ("engine.hip", "tick_inst.hip")):
+        raise RuntimeError("engine sources missing under " + CSRC)
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = [(os.path.join(CSRC, "engine.hip"), os.path.join(OBJ, f"engine{tag}.o"), defs, verbose)]
+    for p in range(1, 9):
+        jobs.append((os.path.join(CSRC, "tick_inst.hip"), os.path.join(OBJ, f"tick_p{p}{tag}.o"),
+                     defs + [f"-DRG_P={p}"], verbose))
+    with ThreadPoolExecutor(max_workers=min(9, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(_compile, jobs))
+    cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", lib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return lib
+
+
+def build_opt(opt, verbose=False):
+    """Experiment build: libraftgroups_opt<N>.so with -DRG_OPT=N (select it with RG_LIB_PATH)."""
+    return _build(os.path.join(PKG, f"libraftgroups_opt{opt}.so"), f"_opt{opt}", [f"-DRG_OPT={opt}"], verbose)
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    return _build(LIB, "", [], verbose)
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--opt" in sys.argv:
+        for o in sys.argv[sys.argv.index("--opt") + 1:]:
+            print(build_opt(int(o), verbose=False))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -26,7 +26,7 @@
 #include "rg_group.h"
 #include "rg_workload.h"
 
-#define RG_BLOCK 256
+#include "rg_tick_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -50,135 +50,6 @@ static int rg_fail(int code, const char *fmt, ...) {
             return rg_fail(e__ == hipErrorOutOfMemory ? RG_ERR_OUT_OF_MEMORY : RG_ERR_NO_DEVICE,   \
                            "%s failed: %s", #expr, hipGetErrorString(e__));                        \
     } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// kernels: the tick (RG_VARIANT_LANE)
-// ------------------------------------------------------------------------------------------------
-template <int P> RG_D void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
-    r.mf = ms.mflags[g];
-    r.pf = st.pflags[g];
-    r.cfg = st.cfg[g];
-    r.commit = st.commit[g];
-    r.lo = st.lo[g];
-    r.hi = st.hi[g];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        const u64 o = (u64)p * st.stride + g;
-        r.mt[p] = st.match[o];
-        r.nx[p] = st.next[o];
-        r.pc[p] = st.prc[o];
-        r.mi[p] = ms.mi[o];
-        r.mc[p] = ms.mc[o];
-    }
-}
-
-template <int P> RG_D void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
-    const u32 d = r.dirty;
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        const u64 o = (u64)p * st.stride + g;
-        if (d & (1u << p)) st.match[o] = r.mt[p];
-        if (d & (1u << (8 + p))) st.next[o] = r.nx[p];
-        if (d & (1u << (16 + p))) st.prc[o] = r.pc[p];
-    }
-    if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
-    if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
-    if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
-    st.out[g] = r.out;
-}
-
-template <int P, bool GC> __global__ __launch_bounds__(RG_BLOCK) void k_tick_lane(RgState st, RgMsgs ms) {
-    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (g >= st.G) return;
-    RgGroup<P> r;
-    rg_load_group<P>(r, st, ms, g);
-    rg_group_tick<P, GC>(r, st, ms, g);
-    rg_store_group<P>(r, st, g);
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernels: the tick (RG_VARIANT_LDS) -- one wave per 128-group batch, columns staged through LDS.
-// Global side: lane l moves groups {2l, 2l+1} of the batch with 16-B loads/stores (1 KiB per wave
-// instruction). Compute side: lane l owns groups l and l+64 of the batch in turn. LDS holds the
-// batch's 5 hot columns as [col][P][128] u64; a lane's ds_read_b64 at stride 8 B is conflict-free.
-// ------------------------------------------------------------------------------------------------
-#define RG_LDS_WAVES 1
-#define RG_LDS_BATCH 128
-
-template <int P, bool GC>
-__global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMsgs ms) {
-    __shared__ u64 lds[RG_LDS_WAVES][5][P][RG_LDS_BATCH];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u64 b0 = ((u64)blockIdx.x * RG_LDS_WAVES + wave) * RG_LDS_BATCH;
-    if (b0 >= st.G) return; // whole wave out of range (stride is a multiple of 256, so loads below stay in bounds)
-    // LDS operations of one wave execute in issue order, so a wave-level fence (a compiler ordering
-    // point; no s_barrier needed for a single-wave batch) is all the staging needs.
-    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-    u64(*L)[P][RG_LDS_BATCH] = lds[wave];
-    const u64 *cols[5] = {st.match, st.next, st.prc, ms.mi, ms.mc};
-    // stage in: 5*P coalesced 16-B loads per lane, all issued before the first LDS write
-    u64x2 tmp[5][P];
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-#pragma unroll
-        for (int p = 0; p < P; p++)
-            tmp[c][p] = *reinterpret_cast<const u64x2 *>(cols[c] + (u64)p * st.stride + b0 + 2 * lane);
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-#pragma unroll
-        for (int p = 0; p < P; p++)
-            *reinterpret_cast<u64x2 *>(&L[c][p][2 * lane]) = tmp[c][p];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int li = lane + 64 * half;
-        const u64 g = b0 + li;
-        if (g < st.G) {
-            RgGroup<P> r;
-            r.mf = ms.mflags[g];
-            r.pf = st.pflags[g];
-            r.cfg = st.cfg[g];
-            r.commit = st.commit[g];
-            r.lo = st.lo[g];
-            r.hi = st.hi[g];
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                r.mt[p] = L[0][p][li];
-                r.nx[p] = L[1][p][li];
-                r.pc[p] = L[2][p][li];
-                r.mi[p] = L[3][p][li];
-                r.mc[p] = L[4][p][li];
-            }
-            rg_group_tick<P, GC>(r, st, ms, g);
-            const u32 d = r.dirty;
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                if (d & (1u << p)) L[0][p][li] = r.mt[p];
-                if (d & (1u << (8 + p))) L[1][p][li] = r.nx[p];
-                if (d & (1u << (16 + p))) L[2][p][li] = r.pc[p];
-            }
-            if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
-            if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
-            if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
-            st.out[g] = r.out;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // stage out: the three state columns, 16-B stores (whole rows; unchanged cells rewrite their value)
-    u64 *ocols[3] = {st.match, st.next, st.prc};
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const u64x2 v = *reinterpret_cast<const u64x2 *>(&L[c][p][2 * lane]);
-            if (b0 + 2 * lane < st.G) // never write padding past G (keeps padding zero)
-                *reinterpret_cast<u64x2 *>(ocols[c] + (u64)p * st.stride + b0 + 2 * lane) = v;
-        }
-}
 
 // ------------------------------------------------------------------------------------------------
 // kernels: Raft::maybe_commit for all groups without messages, and maximal_committed_index
@@ -332,11 +203,18 @@ __global__ __launch_bounds__(RG_BLOCK) void k_msg_stats(const u64 *mflags, const
         s += __shfl_down(s, off, 64);
         e += __shfl_down(e, off, 64);
     }
+    __shared__ u64 part[4][RG_BLOCK / 64];
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long *)&counts[0], (unsigned long long)a);
-        atomicAdd((unsigned long long *)&counts[1], (unsigned long long)r);
-        atomicAdd((unsigned long long *)&counts[2], (unsigned long long)s);
-        atomicAdd((unsigned long long *)&counts[3], (unsigned long long)e);
+        part[0][threadIdx.x >> 6] = a;
+        part[1][threadIdx.x >> 6] = r;
+        part[2][threadIdx.x >> 6] = s;
+        part[3][threadIdx.x >> 6] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u64 t = 0;
+        for (int w = 0; w < RG_BLOCK / 64; w++) t += part[threadIdx.x][w];
+        atomicAdd((unsigned long long *)&counts[threadIdx.x], (unsigned long long)t);
     }
 }
 
@@ -394,7 +272,9 @@ static size_t rg_col_elem(int c) {
 }
 static bool rg_col_per_slot(int c) { return c <= RG_COL_GID; }
 
-extern "C" const char *rg_version(void) { return "raftgroups 0.1 (gfx950)"; }
+#define RG_STR2(x) #x
+#define RG_STR(x) RG_STR2(x)
+extern "C" const char *rg_version(void) { return "raftgroups 0.1 (gfx950, opt " RG_STR(RG_OPT) ")"; }
 extern "C" const char *rg_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int rg_device_count(void) {
@@ -571,31 +451,19 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
 // ------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------
-template <int P, bool GC> static void rg_launch_tick2(rg_engine *h, const RgMsgs &ms) {
-    const u32 variant = h->cfg.variant == RG_VARIANT_DEFAULT ? RG_VARIANT_LANE : h->cfg.variant;
-    if (variant == RG_VARIANT_LDS) {
-        hipLaunchKernelGGL((k_tick_lds<P, GC>), dim3(rg_grid(h->G, RG_LDS_BATCH * RG_LDS_WAVES)),
-                           dim3(64 * RG_LDS_WAVES), 0, h->stream, h->st, ms);
-    } else {
-        hipLaunchKernelGGL((k_tick_lane<P, GC>), dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms);
-    }
-}
-template <int P> static void rg_launch_tick(rg_engine *h, const RgMsgs &ms) {
-    // the group-commit kernel is only needed when some group has ProgressTracker.group_commit set
-    if (h->any_group_commit) rg_launch_tick2<P, true>(h, ms);
-    else rg_launch_tick2<P, false>(h, ms);
-}
-
 static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
+    // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
+    // needed when some group has ProgressTracker.group_commit set
+    const u32 variant = h->cfg.variant == RG_VARIANT_DEFAULT ? RG_VARIANT_LANE : h->cfg.variant;
     switch (h->P) {
-    case 1: rg_launch_tick<1>(h, ms); break;
-    case 2: rg_launch_tick<2>(h, ms); break;
-    case 3: rg_launch_tick<3>(h, ms); break;
-    case 4: rg_launch_tick<4>(h, ms); break;
-    case 5: rg_launch_tick<5>(h, ms); break;
-    case 6: rg_launch_tick<6>(h, ms); break;
-    case 7: rg_launch_tick<7>(h, ms); break;
-    default: rg_launch_tick<8>(h, ms); break;
+    case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 3: rg_launch_tick_t<3>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 4: rg_launch_tick_t<4>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 5: rg_launch_tick_t<5>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 6: rg_launch_tick_t<6>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 7: rg_launch_tick_t<7>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    default: rg_launch_tick_t<8>(h->stream, h->st, ms, variant, h->any_group_commit); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
@@ -726,7 +594,7 @@ extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t cou
     if (!h || !d_m_flags || !counts) return rg_fail(RG_ERR_INVALID_ARG, "rg_msg_stats: bad argument");
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
-    const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
+    const unsigned grid = rg_grid(h->G, RG_BLOCK) < 1024 ? rg_grid(h->G, RG_BLOCK) : 1024;
     hipLaunchKernelGGL(k_msg_stats, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u64 *)d_m_flags,
                        (const u32 *)h->st.cfg, h->G, h->d_counts);
     RG_HIP(hipMemcpyAsync(counts, h->d_counts, 32, hipMemcpyDeviceToHost, h->stream));

@@ -143,8 +143,9 @@ RG_D u64 rg_majority_ci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 M, boo
 }
 
 // ProgressTracker::maximal_committed_index with group commit on (tracker.rs:294-298, joint.rs:47-51).
+// (not inlined: it is called after every accepted ack and only the rare group-commit kernels carry it)
 template <int P>
-RG_D u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
+__device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
     bool fi, fo;
     const u64 a = rg_majority_ci_group<P>(v, gid, incoming, fi);
     const u64 b = rg_majority_ci_group<P>(v, gid, outgoing, fo);

@@ -1,0 +1,200 @@
+// rg_tick_kernels.h -- the tick kernels (one lane per raft group; LDS-staged variant) and their
+// launcher. Instantiated once per slot count in tick_inst.hip (-DRG_P=n) so the eight
+// specialisations compile in parallel; engine.hip only sees the extern template declarations.
+#pragma once
+
+#include "rg_group.h"
+
+// Build-time tuning knobs (python -m raft_rs_amd.build --opt N); the default is what measured best
+// on MI355X (profiles/).  bit0: non-temporal loads of the read-once message columns;
+// bit1: unconditional stores of match/next/pr_commit for slots that have a Progress (full 128-B
+// lines instead of lane-masked partial lines); bit2: 64-thread workgroups.
+#ifndef RG_OPT
+#define RG_OPT 0
+#endif
+#define RG_OPT_NT_MSG (RG_OPT & 1)
+#define RG_OPT_UNCOND_ST (RG_OPT & 2)
+#if RG_OPT & 4
+#define RG_BLOCK 64
+#else
+#define RG_BLOCK 256
+#endif
+
+static inline unsigned rg_grid_for(u64 n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick (RG_VARIANT_LANE)
+// ------------------------------------------------------------------------------------------------
+template <typename T> RG_D T rg_ld_stream(const T *p) { // read-once data: keep it out of L2/MALL
+#if RG_OPT_NT_MSG
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
+template <int P> RG_D void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
+    r.mf = rg_ld_stream(ms.mflags + g);
+    r.pf = st.pflags[g];
+    r.cfg = st.cfg[g];
+    r.commit = st.commit[g];
+    r.lo = st.lo[g];
+    r.hi = st.hi[g];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        r.mt[p] = st.match[o];
+        r.nx[p] = st.next[o];
+        r.pc[p] = st.prc[o];
+        r.mi[p] = rg_ld_stream(ms.mi + o);
+        r.mc[p] = rg_ld_stream(ms.mc + o);
+    }
+}
+
+template <int P> RG_D void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
+    u32 d = r.dirty;
+#if RG_OPT_UNCOND_ST
+    {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
+        const u32 present = RG_CFG_PRESENT(r.cfg);
+        u32 ev = 0;
+#pragma unroll
+        for (int p = 0; p < P; p++) ev |= ((r.mf >> (8 * p)) & 0xffULL) ? (1u << p) : 0u;
+        ev &= present;
+        d |= ev | (ev << 8) | (ev << 16);
+    }
+#endif
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        if (d & (1u << p)) st.match[o] = r.mt[p];
+        if (d & (1u << (8 + p))) st.next[o] = r.nx[p];
+        if (d & (1u << (16 + p))) st.prc[o] = r.pc[p];
+    }
+    if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
+    if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
+    if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
+    st.out[g] = r.out;
+}
+
+template <int P, bool GC> __global__ __launch_bounds__(RG_BLOCK) void k_tick_lane(RgState st, RgMsgs ms) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    RgGroup<P> r;
+    rg_load_group<P>(r, st, ms, g);
+    rg_group_tick<P, GC>(r, st, ms, g);
+    rg_store_group<P>(r, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick (RG_VARIANT_LDS) -- one wave per 128-group batch, columns staged through LDS.
+// Global side: lane l moves groups {2l, 2l+1} of the batch with 16-B loads/stores (1 KiB per wave
+// instruction). Compute side: lane l owns groups l and l+64 of the batch in turn. LDS holds the
+// batch's 5 hot columns as [col][P][128] u64; a lane's ds_read_b64 at stride 8 B is conflict-free.
+// ------------------------------------------------------------------------------------------------
+#define RG_LDS_WAVES 1
+#define RG_LDS_BATCH 128
+
+template <int P, bool GC>
+__global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMsgs ms) {
+    __shared__ u64 lds[RG_LDS_WAVES][5][P][RG_LDS_BATCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 b0 = ((u64)blockIdx.x * RG_LDS_WAVES + wave) * RG_LDS_BATCH;
+    if (b0 >= st.G) return; // whole wave out of range (stride is a multiple of 256, so loads below stay in bounds)
+    // LDS operations of one wave execute in issue order, so a wave-level fence (a compiler ordering
+    // point; no s_barrier needed for a single-wave batch) is all the staging needs.
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    u64(*L)[P][RG_LDS_BATCH] = lds[wave];
+    const u64 *cols[5] = {st.match, st.next, st.prc, ms.mi, ms.mc};
+    // stage in: 5*P coalesced 16-B loads per lane, all issued before the first LDS write
+    u64x2 tmp[5][P];
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            tmp[c][p] = *reinterpret_cast<const u64x2 *>(cols[c] + (u64)p * st.stride + b0 + 2 * lane);
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            *reinterpret_cast<u64x2 *>(&L[c][p][2 * lane]) = tmp[c][p];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int li = lane + 64 * half;
+        const u64 g = b0 + li;
+        if (g < st.G) {
+            RgGroup<P> r;
+            r.mf = ms.mflags[g];
+            r.pf = st.pflags[g];
+            r.cfg = st.cfg[g];
+            r.commit = st.commit[g];
+            r.lo = st.lo[g];
+            r.hi = st.hi[g];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                r.mt[p] = L[0][p][li];
+                r.nx[p] = L[1][p][li];
+                r.pc[p] = L[2][p][li];
+                r.mi[p] = L[3][p][li];
+                r.mc[p] = L[4][p][li];
+            }
+            rg_group_tick<P, GC>(r, st, ms, g);
+            const u32 d = r.dirty;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if (d & (1u << p)) L[0][p][li] = r.mt[p];
+                if (d & (1u << (8 + p))) L[1][p][li] = r.nx[p];
+                if (d & (1u << (16 + p))) L[2][p][li] = r.pc[p];
+            }
+            if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
+            if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
+            if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
+            st.out[g] = r.out;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // stage out: the three state columns, 16-B stores (whole rows; unchanged cells rewrite their value)
+    u64 *ocols[3] = {st.match, st.next, st.prc};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(&L[c][p][2 * lane]);
+            if (b0 + 2 * lane < st.G) // never write padding past G (keeps padding zero)
+                *reinterpret_cast<u64x2 *>(ocols[c] + (u64)p * st.stride + b0 + 2 * lane) = v;
+        }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------------
+template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
+
+#ifdef RG_TICK_INSTANTIATE
+template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
+    if (variant == RG_VARIANT_LDS) {
+        hipLaunchKernelGGL((k_tick_lds<P, GC>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
+                           dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
+    } else {
+        hipLaunchKernelGGL((k_tick_lane<P, GC>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
+    }
+}
+template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc) {
+    if (gc) rg_launch_tick_gc<P, true>(stream, st, ms, variant);
+    else rg_launch_tick_gc<P, false>(stream, st, ms, variant);
+}
+#else
+extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+#endif

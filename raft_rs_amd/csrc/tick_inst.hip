@@ -1,0 +1,8 @@
+// tick_inst.hip -- instantiates the tick kernels for ONE slot count (compile with -DRG_P=1..8).
+#ifndef RG_P
+#error "compile with -DRG_P=<slots>"
+#endif
+#define RG_TICK_INSTANTIATE
+#include "rg_tick_kernels.h"
+
+template void rg_launch_tick_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libraftgroups.so")
+LIB_PATH = os.environ.get("RG_LIB_PATH") or os.path.join(PKG, "libraftgroups.so")  # RG_LIB_PATH: tuning builds
 
 
 class EngineError(RuntimeError):
@@ -148,6 +148,12 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m raft_rs_amd.build` "
                           "(hipcc, gfx950). The engine has no CPU fallback.")
+    try:
+        # torch ships its own HIP runtime; load it FIRST so the engine binds to the same runtime
+        # instance (streams handed over with rg_set_stream must belong to it).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -246,7 +252,7 @@ class Engine:
         return self.L.rg_column_ptr(self.h, col)
 
     def load_state(self, st):
-        """st: dict with the column names of COL.NAMES[:11] (tests/oracle_lib.alloc_state layout)."""
+        """st: dict with the column names of COL.NAMES[:11] (numpy arrays shaped as column_shape_dtype says)."""
         for col in range(COL.CFG + 1):
             self.load_column(col, st[COL.NAMES[col]])
 

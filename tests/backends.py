@@ -1,0 +1,184 @@
+"""Two interchangeable single-group "leader" backends for scenario tests that read like the
+reference's own tests (harness/tests/integration_cases/*.rs): the CPU oracle and the HIP engine.
+
+Peer id i lives in slot i-1. Test infrastructure.
+"""
+import numpy as np
+
+import oracle_lib as O
+
+PROBE, REPLICATE, SNAPSHOT = 0, 1, 2
+
+
+class OracleLeader:
+    name = "oracle"
+
+    def __init__(self, self_id, term, voters, outgoing=(), learners=(), log=(), committed=0, dummy=(0, 0),
+                 next_idx=1):
+        self.cl = O.Cluster(1).config(0, self_id, term, voters, outgoing, learners, next_idx=next_idx)
+        self.cl.set_log(0, list(log), committed=committed, dummy=dummy)
+        self.term = term
+
+    def set_progress(self, pid, **kw):
+        p = self.cl.pr(0, pid)
+        for k, v in kw.items():
+            setattr(p, {"match": "matched", "next": "next_idx", "commit_group_id": "commit_group_id"}.get(k, k), v)
+
+    def progress(self, pid):
+        p = self.cl.pr(0, pid)
+        return {"match": p.matched, "next": p.next_idx, "state": p.state, "paused": bool(p.paused),
+                "pending_snapshot": p.pending_snapshot, "pending_request_snapshot": p.pending_request_snapshot,
+                "recent_active": bool(p.recent_active), "committed_index": p.committed_index}
+
+    def committed(self):
+        return self.cl.committed(0)
+
+    def enable_group_commit(self, on):
+        O.lib().ro_group_set_group_commit(self.cl.h, 0, on)
+
+    def set_transferee(self, pid):
+        O.lib().ro_group_set_transferee(self.cl.h, 0, pid)
+
+    def maybe_commit(self):
+        return self.cl.maybe_commit(0)
+
+    def mci(self):
+        return self.cl.mci(0)
+
+    def append(self, n):
+        O.lib().ro_group_append(self.cl.h, 0, n)
+
+    def persisted(self, index):
+        return O.lib().ro_on_persist_entries(self.cl.h, 0, index)
+
+    def sent(self, pid):
+        return O.lib().ro_progress_update_state(self.cl.pr(0, pid), self.cl.last_index(0))
+
+    def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False):
+        o = self.cl.step(0, from_, index, commit, reject, reject_hint, request_snapshot, 1 if ins_full else 0)
+        return {"send_append": bool(o.send_append), "send_more": bool(o.send_more),
+                "changed": bool(o.commit_changed), "free_to": bool(o.free_to), "timeout_now": bool(o.timeout_now)}
+
+
+class EngineLeader:
+    """Same surface over the HIP engine: one group, one message per tick through the C ABI."""
+    name = "engine"
+
+    def __init__(self, self_id, term, voters, outgoing=(), learners=(), log=(), committed=0, dummy=(0, 0),
+                 next_idx=1, n_slots=None):
+        import raft_rs_amd as rg
+        self.rg = rg
+        ids = sorted(set(voters) | set(outgoing) | set(learners))
+        self.P = n_slots or max(ids)
+        self.eng = rg.Engine(1, self.P)
+        self.term = term
+        self.self_id = self_id
+        mask = lambda s: sum(1 << (i - 1) for i in s)
+        self.cfg = dict(incoming=mask(voters), outgoing=mask(outgoing), self_slot=self_id - 1,
+                        group_commit=False, transferee_plus1=0, present=mask(ids))
+        st = O.alloc_state(1, self.P, stride=self.eng.stride)
+        for i in ids:
+            st["next"][i - 1, 0] = next_idx
+        # current-term range from the log (entries of `term` are the contiguous tail)
+        log = list(log)
+        last = log[-1][1] if log else dummy[0]
+        cur = [idx for (t, idx) in log if t == term]
+        # For a real leader the entries of its term are the log tail and term_hi == last_index. A few
+        # reference tests (test_commit) build logs whose tail has a HIGHER term than the leader's; the
+        # gate term(mci) == term is then still the contiguous range [cur[0], cur[-1]].
+        lo, hi = (cur[0], cur[-1]) if cur else (last + 1, last)
+        st["term_lo"][0], st["term_hi"][0], st["commit"][0] = lo, hi, committed
+        st["cfg"][0] = rg.cfg_make(**self.cfg)
+        self.eng.load_state(st)
+        self.msgs = rg.MsgBuffers(1, self.P, self.eng.stride)
+
+    def _push_cfg(self):
+        self.eng.load_column(self.rg.COL.CFG, np.array([self.rg.cfg_make(**self.cfg)], dtype=np.uint32))
+
+    def set_progress(self, pid, **kw):
+        cell = {"group": 0, "slot": pid - 1}
+        names = {"match": "match", "next": "next", "pending_snapshot": "pend_snap",
+                 "pending_request_snapshot": "pend_rs", "commit_group_id": "gid", "committed_index": "pr_commit"}
+        flags = None
+        for k, v in kw.items():
+            if k in names:
+                cell[names[k]] = v
+            elif k in ("state", "paused", "recent_active"):
+                if flags is None:
+                    flags = int(self.eng.read_column(self.rg.COL.PFLAGS)[0, pid - 1])
+                if k == "state":
+                    flags = (flags & ~3) | v
+                elif k == "paused":
+                    flags = (flags & ~4) | (4 if v else 0)
+                else:
+                    flags = (flags & ~8) | (8 if v else 0)
+            else:
+                raise KeyError(k)
+        if flags is not None:
+            cell["pflags"] = flags
+        self.eng.write_cells([cell])
+
+    def progress(self, pid):
+        st = self.eng.read_state()
+        f = int(st["pflags"][0, pid - 1])
+        s = pid - 1
+        return {"match": int(st["match"][s, 0]), "next": int(st["next"][s, 0]), "state": f & 3,
+                "paused": bool(f & 4), "pending_snapshot": int(st["pend_snap"][s, 0]),
+                "pending_request_snapshot": int(st["pend_rs"][s, 0]), "recent_active": bool(f & 8),
+                "committed_index": int(st["pr_commit"][s, 0])}
+
+    def committed(self):
+        return int(self.eng.read_column(self.rg.COL.COMMIT)[0])
+
+    def enable_group_commit(self, on):
+        self.cfg["group_commit"] = on
+        self._push_cfg()
+
+    def set_transferee(self, pid):
+        self.cfg["transferee_plus1"] = pid
+        self._push_cfg()
+
+    def maybe_commit(self):
+        self.eng.recompute()
+        _, out = self.eng.results()
+        return bool(out[0] & 1)
+
+    def mci(self):
+        m, f = self.eng.maximal_committed_index(with_flag=True)
+        return int(m[0]), bool(f[0])
+
+    def _tick(self):
+        self.eng.tick(self.msgs)
+        self.msgs.clear()
+        _, out = self.eng.results()
+        return int(out[0])
+
+    def append(self, n):
+        hi = int(self.eng.read_column(self.rg.COL.TERM_HI)[0])
+        s = self.self_id - 1
+        self.msgs.m_commit[s, 0] = hi + n
+        self.msgs.m_flags[0, s] = self.rg.MF.APPEND
+        self._tick()
+
+    def persisted(self, index):
+        s = self.self_id - 1
+        self.msgs.m_index[s, 0] = index
+        self.msgs.m_flags[0, s] = self.rg.MF.VALID
+        return bool(self._tick() & 1)
+
+    def sent(self, pid):
+        self.msgs.m_flags[0, pid - 1] = self.rg.MF.SENT
+        return -1 if (self._tick() & 2) else 0
+
+    def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False):
+        MF = self.rg.MF
+        s = from_ - 1
+        self.msgs.m_index[s, 0] = index
+        self.msgs.m_commit[s, 0] = commit
+        self.msgs.m_hint[s, 0] = reject_hint
+        self.msgs.m_rs[s, 0] = request_snapshot
+        self.msgs.m_flags[0, s] = (MF.VALID | (MF.REJECT if reject else 0) | (MF.HAS_RS if request_snapshot else 0) |
+                                   (MF.INS_FULL if ins_full else 0))
+        out = self._tick()
+        return {"send_append": bool((out >> (8 + s)) & 1), "send_more": bool((out >> (16 + s)) & 1),
+                "changed": bool(out & 1), "free_to": bool((out >> (24 + s)) & 1), "timeout_now": bool(out & 4)}

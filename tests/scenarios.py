@@ -1,0 +1,206 @@
+"""Scenario tests shared by the oracle (CPU) and the engine (GPU): each function takes a backend
+class from tests/backends.py and replays one of the reference's integration tests
+(harness/tests/integration_cases/*.rs, cited per function) at the boundary of the hot path."""
+from golden import reference_tables as T
+
+PROBE, REPLICATE, SNAPSHOT = 0, 1, 2
+
+
+def scenario_test_commit(B):
+    """test_raft.rs:1145-1240 test_commit."""
+    for i, (matches, log, sm_term, want) in enumerate(T.TEST_COMMIT):
+        n = len(matches)
+        ld = B(1, sm_term, list(range(1, n + 1)), log=log)
+        for j, m in enumerate(matches):
+            ld.set_progress(j + 1, match=m, next=m + 1)
+        ld.maybe_commit()
+        assert ld.committed() == want, f"#{i}: committed = {ld.committed()}, want {want}"
+
+
+def scenario_test_group_commit(B):
+    """test_raft.rs:5092-5163 test_group_commit."""
+    for i, (matches, gids, g_w, q_w) in enumerate(T.TEST_GROUP_COMMIT):
+        n = len(matches)
+        log = [(1, k) for k in range(min(matches), max(matches) + 1)]
+        ld = B(1, 1, list(range(1, n + 1)), log=log, dummy=(min(matches) - 1, 0))
+        for j, (m, g) in enumerate(zip(matches, gids)):
+            ld.set_progress(j + 1, match=m, next=m + 1, commit_group_id=g)
+        ld.enable_group_commit(True)
+        ld.maybe_commit()  # assign_commit_groups as leader (src/raft.rs:541-543)
+        assert ld.committed() == g_w, f"#{i}: leader group committed {ld.committed()}, want {g_w}"
+        ld.enable_group_commit(False)
+        ld.maybe_commit()  # enable_group_commit(false) re-evaluates (src/raft.rs:513-518)
+        assert ld.committed() == q_w, f"#{i}: quorum committed {ld.committed()}, want {q_w}"
+
+
+def scenario_test_group_commit_consistent(B):
+    """test_raft.rs:5166-5287 (leader rows): check_group_commit_consistent, src/raft.rs:557-576."""
+    log = [(1, k) for k in range(1, 6)] + [(2, k) for k in range(6, 9)]
+    for i, (matches, gids, committed, applied, want) in enumerate(T.TEST_GROUP_COMMIT_CONSISTENT):
+        n = len(matches)
+        ld = B(1, 2, list(range(1, n + 1)), log=log, committed=committed)
+        for j, (m, g) in enumerate(zip(matches, gids)):
+            ld.set_progress(j + 1, match=m, next=m + 1, commit_group_id=g)
+        ld.enable_group_commit(True)
+        apply_to_current_term = applied >= 6  # term(applied) == self.term (src/raft.rs:580-586)
+        if not apply_to_current_term:
+            got = None
+        else:
+            idx, used = ld.mci()
+            got = used and idx == ld.committed()
+        assert got == want, f"#{i}: consistency = {got}, want {want}"
+
+
+def scenario_test_leader_append_response(B):
+    """test_raft.rs:2611-2675 test_leader_append_response (setup derivation in reference_tables.py)."""
+    for i, (index, reject, wmatch, wnext, wmsg_num, windex, wcommitted) in enumerate(T.TEST_LEADER_APPEND_RESPONSE):
+        ld = B(1, 1, [1, 2, 3], log=[(0, 1), (1, 2), (1, 3)], committed=0, next_idx=3)
+        ld.set_progress(1, match=2, next=3, state=REPLICATE)
+        out = ld.step(2, index, reject=reject, reject_hint=index)
+        # the send path the hot path asked for, modelled as the reference's test observes it
+        msgs = []
+        if out["changed"]:  # bcast_append to 2 and 3 (should_bcast_commit: skip_bcast_commit = false)
+            targets = [2, 3]
+        elif out["send_append"] or out["send_more"]:
+            targets = [2]
+        else:
+            targets = []
+        for to in targets:
+            pr = ld.progress(to)
+            if pr["state"] == PROBE and pr["paused"]:
+                continue
+            has_entries = pr["next"] <= 3
+            if not has_entries and not (out["changed"] or out["send_append"]):
+                continue  # maybe_send_append(.., allow_empty=false) sends nothing (raft.rs:797-800)
+            msgs.append((pr["next"] - 1, ld.committed()))
+            if has_entries:
+                ld.sent(to)
+        pr2 = ld.progress(2)
+        assert pr2["match"] == wmatch, f"#{i}: match = {pr2['match']}, want {wmatch}"
+        assert pr2["next"] == wnext, f"#{i}: next = {pr2['next']}, want {wnext}"
+        assert len(msgs) == wmsg_num, f"#{i}: msg_num = {len(msgs)}, want {wmsg_num}"
+        for j, (mi, mc) in enumerate(msgs):
+            assert mi == windex, f"#{i}.{j}: index = {mi}, want {windex}"
+            assert mc == wcommitted, f"#{i}.{j}: commit = {mc}, want {wcommitted}"
+
+
+def scenario_leader_only_commits_log_from_current_term(B):
+    """test_raft_paper.rs:1012-1052."""
+    for i, (index, wcommit) in enumerate(T.TEST_LEADER_ONLY_COMMITS_CURRENT_TERM):
+        ld = B(1, 3, [1, 2], log=[(1, 1), (2, 2), (3, 3), (3, 4)], committed=0, next_idx=3)
+        ld.set_progress(1, match=4, next=5, state=REPLICATE)
+        ld.step(2, index)
+        assert ld.committed() == wcommit, f"#{i}: commit = {ld.committed()}, want {wcommit}"
+
+
+def scenario_leader_acknowledge_commit(B):
+    """test_raft_paper.rs:499-534."""
+    for i, (size, acceptors, wack) in enumerate(T.TEST_LEADER_ACKNOWLEDGE_COMMIT):
+        ld = B(1, 1, list(range(1, size + 1)), log=[(1, 1), (1, 2)], committed=1, next_idx=2)
+        for pid in range(1, size + 1):
+            ld.set_progress(pid, match=1, next=2, state=REPLICATE)
+        ld.persisted(2)
+        for pid in acceptors:
+            ld.step(pid, 2)
+        assert (ld.committed() > 1) == wack, f"#{i}: ack commit = {ld.committed() > 1}, want {wack}"
+
+
+def scenario_snapshot_abort(B):
+    """test_raft_snap.rs:112-131 test_snapshot_abort: snapshot (index 11, term 11) restored, leader at
+    term 1 with an unpersisted noop at 12; peer 2 in Snapshot(pending 11), next 1."""
+    ld = B(1, 1, [1, 2], log=[(1, 12)], committed=11, dummy=(11, 11), next_idx=12)
+    ld.set_progress(1, match=11, next=12, state=REPLICATE)
+    ld.set_progress(2, next=1, state=SNAPSHOT, pending_snapshot=11)
+    ld.step(2, 11)
+    pr = ld.progress(2)
+    assert pr["pending_snapshot"] == 0 and pr["next"] == 12 and pr["state"] == PROBE
+
+
+def scenario_request_snapshot(B):
+    """test_raft_snap.rs:155-233 test_request_snapshot, the handle_append_response parts."""
+    ld = B(1, 1, [1, 2], log=[(1, 12)], committed=11, dummy=(11, 11), next_idx=12)
+    ld.set_progress(1, match=11, next=12, state=REPLICATE)
+    ld.step(2, 11)  # advance matched: Probe -> Replicate
+    assert ld.progress(2)["state"] == REPLICATE
+    rs = ld.committed()
+    # out-of-order request snapshot (index 9 < matched 11) is ignored
+    out = ld.step(2, 9, reject=True, reject_hint=0, request_snapshot=rs)
+    assert ld.progress(2)["state"] == REPLICATE and not out["send_append"]
+    # in-order one: maybe_decr_to accepts, Replicate -> Probe, send_append (the send path then turns
+    # pending_request_snapshot into become_snapshot, raft.rs:791-795 -- host side)
+    out = ld.step(2, 11, reject=True, reject_hint=0, request_snapshot=rs)
+    pr = ld.progress(2)
+    assert out["send_append"] and pr["state"] == PROBE and pr["pending_request_snapshot"] == rs and pr["next"] == 12
+    ld.set_progress(2, state=SNAPSHOT, pending_snapshot=11, paused=False)  # become_snapshot(11) by the send path
+    # a repeated ack at the same index does not leave Snapshot: maybe_update returns false first (:217-224)
+    ld.step(2, 11)
+    pr = ld.progress(2)
+    assert pr["state"] == SNAPSHOT and pr["pending_snapshot"] == 11 and pr["next"] == 12
+
+
+def scenario_unconditional_next_bump(B):
+    """progress.rs:145-147: next_idx is raised even when the ack is stale (SURVEY.md 8d known-answer cell)."""
+    ld = B(1, 1, [1, 2, 3], log=[(1, k) for k in range(1, 10)], committed=0)
+    ld.set_progress(1, match=9, next=10, state=REPLICATE)
+    ld.set_progress(2, match=5, next=3, state=REPLICATE)
+    out = ld.step(2, 4, commit=3)
+    pr = ld.progress(2)
+    assert pr["match"] == 5 and pr["next"] == 5 and not out["send_more"]
+    assert pr["recent_active"] and pr["committed_index"] == 3, "stale acks still mark activity (raft.rs:1674-1677)"
+
+
+def scenario_old_paused_resend_and_transfer(B):
+    """raft.rs:1749-1751 (old_paused -> send_append when commit did not move) and :1764-1774
+    (transferee caught up -> timeout_now); cf. test_msg_append_response_wait_reset test_raft.rs:1484-1529."""
+    ld = B(1, 1, [1, 2, 3], log=[(1, k) for k in range(1, 6)], committed=5)
+    for pid in (1, 2, 3):
+        ld.set_progress(pid, match=5 if pid == 1 else 3, next=6 if pid == 1 else 4, state=REPLICATE)
+    ld.set_progress(2, match=5)
+    out = ld.step(3, 4, ins_full=True)  # commit already 5: no change; window was full -> resend
+    assert out["send_append"] and out["send_more"] and out["free_to"] and not out["changed"]
+    ld.set_transferee(3)
+    out = ld.step(3, 5)
+    assert out["timeout_now"]
+    # paused probe gets resumed by an accepting ack (Probe -> Replicate)
+    ld.set_progress(2, match=1, next=2, state=PROBE, paused=True)
+    out = ld.step(2, 2)
+    pr = ld.progress(2)
+    assert pr["state"] == REPLICATE and not pr["paused"] and pr["next"] == 3 and out["send_append"]
+
+
+def scenario_learners_never_count(B):
+    """test_raft.rs:3891-3943 test_learner_log_replication: a learner's acks update its Progress but
+    never move the commit index (tracker.rs:43-49)."""
+    ld = B(1, 1, [1, 2, 3], learners=[4], log=[(1, k) for k in range(1, 6)], committed=1)
+    ld.set_progress(1, match=5, next=6, state=REPLICATE)
+    for pid in (2, 3, 4):
+        ld.set_progress(pid, match=1, next=2, state=REPLICATE)
+    out = ld.step(4, 5)
+    assert ld.progress(4)["match"] == 5 and ld.committed() == 1 and not out["changed"]
+    out = ld.step(2, 4)
+    assert ld.committed() == 4 and out["changed"]
+    assert ld.progress(1)["committed_index"] == 4, "leader's own Progress.committed_index follows (raft.rs:896-900)"
+
+
+def scenario_joint_needs_both_majorities(B):
+    """joint.rs:47-51 through maybe_commit: incoming {1,2,3} && outgoing {3,4,5} (cf. joint_commit.txt)."""
+    ld = B(1, 1, [1, 2, 3], outgoing=[3, 4, 5], log=[(1, k) for k in range(1, 11)], committed=0)
+    ld.set_progress(1, match=10, next=11, state=REPLICATE)
+    for pid in (2, 3, 4, 5):
+        ld.set_progress(pid, match=0, next=1, state=REPLICATE)
+    ld.step(2, 8)
+    assert ld.committed() == 0, "incoming {10,8,0} -> 8 but outgoing {0,0,0} -> 0"
+    ld.step(4, 6)
+    assert ld.committed() == 0, "outgoing {0,6,0} -> 0"
+    out = ld.step(5, 7)
+    assert ld.committed() == 6 and out["changed"], "outgoing {0,6,7} -> 6, incoming -> 8, min = 6"
+    assert ld.mci() == (6, False)
+    ld.step(3, 9)
+    assert ld.committed() == 7, "incoming {10,8,9} -> 9, outgoing {9,6,7} -> 7"
+
+
+ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
+       scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
+       scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,
+       scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
+       scenario_learners_never_count, scenario_joint_needs_both_majorities]

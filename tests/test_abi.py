@@ -1,0 +1,70 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/raftgroups.h declares; the bit
+layouts the oracle's SoA adapter uses are the header's; without a GPU the engine fails loudly."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "raftgroups.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|uint64_t|char)\s*\*?\s*(rg_\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def header_defines():
+    src = open(HEADER).read()
+    return {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(RG_\w+)\s+(0x[0-9a-fA-F]+u?|\d+u?)\s", src)}
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    assert len(names) >= 30
+    for must in ("rg_create", "rg_tick", "rg_tick_device", "rg_recompute", "rg_results", "rg_step", "rg_flush",
+                 "rg_vote_result", "rg_workload_gen"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(rg):
+    lib = ctypes.CDLL(rg.LIB_PATH)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+    from raft_rs_amd import engine as E
+    unbound = [n for n in declared_functions() if n not in E.SYMBOLS]
+    assert not unbound, f"python binding lacks {unbound}"
+
+
+def test_oracle_adapter_uses_the_header_bit_layouts():
+    d = header_defines()
+    osrc = open(os.path.join(ROOT, "oracle", "raft_oracle.c")).read()
+    odef = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(RO_\w+)\s+(0x[0-9a-fA-F]+u?)\s", osrc)}
+    for name in ("PF_STATE_MASK", "PF_PAUSED", "PF_RECENT_ACTIVE", "MF_VALID", "MF_REJECT", "MF_HAS_RS",
+                 "MF_INS_FULL", "MF_SENT", "MF_APPEND", "OUT_CHANGED", "OUT_FAULT", "OUT_TIMEOUT_NOW"):
+        assert d["RG_" + name] == odef["RO_" + name], name
+    from raft_rs_amd import engine as E
+    assert (E.MF.VALID, E.MF.REJECT, E.MF.HAS_RS, E.MF.INS_FULL, E.MF.SENT, E.MF.APPEND) == tuple(
+        d["RG_MF_" + k] for k in ("VALID", "REJECT", "HAS_RS", "INS_FULL", "SENT", "APPEND"))
+    assert E.cfg_make(0x07, 0x0e, 2, True, 3, 0x1f) == (0x07 | (0x0e << 8) | (2 << 16) | 0x80000 | (3 << 20) | (0x1f << 24))
+
+
+def test_engine_fails_loudly_without_a_gpu(rg):
+    lib = rg.load_library()
+    if lib.rg_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(rg.EngineError) as ei:
+        rg.Engine(16, 3)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "raft_rs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
