@@ -22,7 +22,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -58,17 +57,12 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
     msgs = E.MsgBuffers(n_groups, n_slots, st["stride"])
     gout = np.zeros(n_groups, dtype=np.uint32)
     md = msgs.as_dict()
-    bounds = [(i * n_groups // threads, (i + 1) * n_groups // threads) for i in range(threads)]
 
     def run_tick(nthreads):
         if nthreads == 1:
             cl.tick_soa(md, gout, 0, n_groups)
-            return
-        ts = [threading.Thread(target=cl.tick_soa, args=(md, gout, a, b)) for a, b in bounds]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        else:
+            cl.tick_soa_mt(md, gout, nthreads)  # pthreads inside the oracle, contiguous group ranges
 
     elapsed = {1: 0.0, threads: 0.0}
     evals = {1: 0, threads: 0}
@@ -101,8 +95,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-groups", type=int, default=500_000)
-    ap.add_argument("--cpu-sample-ticks", type=int, default=12)
+    ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
 
     import torch
@@ -206,6 +200,15 @@ def main():
     A = float(np.mean([c["valid"] for c in census[W:]])) / G
     R = float(np.mean([c["rejects"] for c in census[W:]])) / G
 
+    # HBM traffic per launch: PMC-measured in separate rocprofv3 passes of this same command
+    # (tools/summarize_prof.py -> profiles/traffic.json); null for configurations not profiled.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f).get(f"{args.workload}:{G}:{P}", {}).get("bytes")
+    except (OSError, ValueError):
+        pass
+
     result = {
         "metric": "raft-group progress+commit evaluations/sec (commit-index recomputes/sec at 1M groups x 5 peers)",
         "value": value, "unit": "group-evals/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -220,7 +223,7 @@ def main():
                    "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
                    "sharding": f"{world} disjoint group ranges" + (", commit_idx all-gather per tick (RCCL)" if distributed else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_tick_lane" if args.variant != 2 else "k_tick_lds",
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6},
@@ -228,7 +231,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_groups, G), P, args.workload,
-                                              args.cpu_sample_ticks, args.seed, os.cpu_count() or 1)
+                                              args.cpu_sample_ticks, args.seed, min(os.cpu_count() or 1, 128))
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

@@ -7,6 +7,7 @@
  */
 #include "raft_oracle.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -790,4 +791,44 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
         if (gout) gout[g] = out;
     }
     return stepped;
+}
+
+/* Groups are independent, so the CPU baseline may split a tick over threads by group range. */
+typedef struct {
+    ro_cluster *c;
+    const ro_soa_msgs *m;
+    uint32_t *gout;
+    size_t a, b;
+    uint64_t stepped;
+} ro_mt_job;
+
+static void *ro_mt_worker(void *arg) {
+    ro_mt_job *j = (ro_mt_job *)arg;
+    j->stepped = ro_tick_soa(j->c, j->m, j->gout, j->a, j->b);
+    return NULL;
+}
+
+uint64_t ro_tick_soa_mt(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t n_threads) {
+    size_t n = m->n_groups < c->n ? m->n_groups : c->n;
+    if (n_threads <= 1) return ro_tick_soa(c, m, gout, 0, n);
+    if (n_threads > 1024) n_threads = 1024;
+    pthread_t *th = (pthread_t *)malloc(n_threads * sizeof(pthread_t));
+    ro_mt_job *jobs = (ro_mt_job *)malloc(n_threads * sizeof(ro_mt_job));
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_threads; i++) {
+        jobs[i].c = c;
+        jobs[i].m = m;
+        jobs[i].gout = gout;
+        jobs[i].a = i * n / n_threads;
+        jobs[i].b = (i + 1) * n / n_threads;
+        jobs[i].stepped = 0;
+        pthread_create(&th[i], NULL, ro_mt_worker, &jobs[i]);
+    }
+    for (size_t i = 0; i < n_threads; i++) {
+        pthread_join(th[i], NULL);
+        total += jobs[i].stepped;
+    }
+    free(th);
+    free(jobs);
+    return total;
 }

@@ -10,7 +10,7 @@
 // bit1: unconditional stores of match/next/pr_commit for slots that have a Progress (full 128-B
 // lines instead of lane-masked partial lines); bit2: 64-thread workgroups.
 #ifndef RG_OPT
-#define RG_OPT 0
+#define RG_OPT 6 /* measured best on MI355X: gpurun sweep in profiles/r01_tuning_sweep.txt */
 #endif
 #define RG_OPT_NT_MSG (RG_OPT & 1)
 #define RG_OPT_UNCOND_ST (RG_OPT & 2)

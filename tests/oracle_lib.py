@@ -120,6 +120,7 @@ def lib():
         "ro_load_soa": (C.c_int, [vp, C.POINTER(SoaState), u64, sz]),
         "ro_store_soa": (C.c_int, [vp, C.POINTER(SoaState)]),
         "ro_tick_soa": (u64, [vp, C.POINTER(SoaMsgs), vp, sz, sz]),
+        "ro_tick_soa_mt": (u64, [vp, C.POINTER(SoaMsgs), vp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -216,6 +217,11 @@ class Cluster:
                     *[msgs[k].ctypes.data for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")])
         return self.L.ro_tick_soa(self.h, C.byref(m), gout.ctypes.data, g_begin,
                                   self.n if g_end is None else g_end)
+
+    def tick_soa_mt(self, msgs, gout, n_threads):
+        m = SoaMsgs(msgs["n_groups"], msgs["n_slots"], msgs["stride"],
+                    *[msgs[k].ctypes.data for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")])
+        return self.L.ro_tick_soa_mt(self.h, C.byref(m), gout.ctypes.data, n_threads)
 
 
 STATE_COLS = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",

@@ -4,9 +4,13 @@ import re
 import subprocess
 import sys
 
-SRC = "raft_rs_amd/csrc/engine.hip"
+# usage: tools/kernel_resources.py [-DRG_P=5] [-DRG_OPT=6] ...   (default: the P=5 tick kernels)
+SRC = "raft_rs_amd/csrc/tick_inst.hip"
+defs = [a for a in sys.argv[1:] if a.startswith("-")]
+if not any(d.startswith("-DRG_P=") for d in defs):
+    defs.append("-DRG_P=5")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", SRC, "-o", "/dev/null",
-       "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
+       "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage"] + defs
 out = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
