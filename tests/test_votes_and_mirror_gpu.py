@@ -1,0 +1,136 @@
+"""GPU: vote / liveness kernels against the reference's golden vote vectors and the oracle, and the
+message-at-a-time host mirror (rg_step / rg_flush) against the oracle stepped one message at a time."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+VEC = json.load(open(os.path.join(HERE, "golden", "quorum_vectors.json"), encoding="utf-8"))
+NAMES = {"VotePending": 0, "VoteLost": 1, "VoteWon": 2}
+
+
+def vote_cases():
+    from test_oracle_golden import build_case
+    cases = []
+    for fname in ("majority_vote.txt", "joint_vote.txt"):
+        for case in VEC[fname]:
+            ids, idsj, joint, look = build_case(case["args"], key="votes")
+            cases.append((f"{fname}:{case['line']}", ids, idsj, look, NAMES[case["result"]]))
+    return cases
+
+
+def test_vote_result_golden_vectors(rg):
+    cases = vote_cases()
+    assert len(cases) == 61
+    G = len(cases)
+    eng = rg.Engine(G, 8)
+    cfg = np.zeros(G, dtype=np.uint32)
+    yes = np.zeros(G, dtype=np.uint8)
+    no = np.zeros(G, dtype=np.uint8)
+    for g, (_, ids, idsj, look, _) in enumerate(cases):
+        m = lambda s: sum(1 << (i - 1) for i in s)
+        cfg[g] = rg.cfg_make(m(ids), m(idsj), 0)
+        yes[g] = m([i for i, v in look.items() if v == 2])
+        no[g] = m([i for i, v in look.items() if v == 1])
+    eng.load_column(rg.COL.CFG, cfg)
+    res = eng.vote_result(yes, no)
+    for g, (name, *_rest, want) in enumerate(cases):
+        assert res[g] == want, name
+    # joint symmetry (datadriven_test.rs:296-301): swap the majorities
+    cfg2 = ((cfg & 0xff) << 8) | ((cfg >> 8) & 0xff) | (cfg & 0xffff0000)
+    eng.load_column(rg.COL.CFG, cfg2.astype(np.uint32))
+    assert (eng.vote_result(yes, no) == res).all()
+    eng.close()
+
+
+def test_quorum_recently_active_matches_oracle(rg):
+    import fuzz
+    rng = np.random.default_rng(11)
+    G, P = 4000, 7
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st)
+    eng = rg.Engine(G, P)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=3)
+    got = eng.quorum_recently_active()
+    want = np.array([O.lib().ro_quorum_recently_active(cl.h, g, int((st["cfg"][g] >> 16) & 7) + 1) for g in range(G)])
+    assert (got.astype(bool) == want).all()
+    cl.store_soa(st)
+    pf = eng.read_column(rg.COL.PFLAGS)
+    present = (st["cfg"] >> 24) & 0xff
+    for p in range(P):
+        sel = ((present >> p) & 1) == 1
+        assert (pf[sel, p] == st["pflags"][sel, p]).all(), "recent_active bits after the sweep (tracker.rs:349-358)"
+    # second sweep: only the leader is still active
+    got2 = eng.quorum_recently_active()
+    want2 = np.array([O.lib().ro_quorum_recently_active(cl.h, g, int((st["cfg"][g] >> 16) & 7) + 1) for g in range(G)])
+    assert (got2.astype(bool) == want2).all()
+    eng.close()
+
+
+def test_host_mirror_steps_like_raw_node(rg):
+    """rg_step mirrors RawNode::step + Raft::step's term gate for MsgAppendResponse."""
+    G, P, TERM = 64, 3, 5
+    eng = rg.Engine(G, P)
+    eng.workload_init(rg.WL_MAJORITY)
+    st = eng.read_state()
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    for g in range(G):
+        eng.set_peers(g, [101, 102, 103], TERM)  # arbitrary peer ids -> slots 0,1,2
+    # error behaviour (src/raw_node.rs:404-410, src/raft.rs:1284-1411)
+    with pytest.raises(rg.EngineError) as e:
+        eng.step(0, 999, TERM, 5)
+    assert e.value.code == -5  # StepPeerNotFound
+    with pytest.raises(rg.EngineError) as e:
+        eng.step(0, 102, 0, 5)
+    assert e.value.code == -4  # StepLocalMsg (term 0 = local message)
+    with pytest.raises(rg.EngineError) as e:
+        eng.step(0, 102, TERM + 1, 5)
+    assert e.value.code == -7  # higher term: the host must step down
+    eng.step(0, 102, TERM - 1, 10 ** 9)  # lower term: silently ignored
+    rng = np.random.default_rng(3)
+    for rnd in range(4):
+        expect_out = {}
+        for g in range(G):
+            hi = cl.last_index(g)
+            new_last = hi + int(rng.integers(0, 4))
+            eng.local_append(g, new_last)
+            eng.local_persisted(g, new_last)
+            O.lib().ro_group_append(cl.h, g, new_last - hi)
+            changed = O.lib().ro_on_persist_entries(cl.h, g, new_last)
+            outw = 1 if changed else 0
+            for pid, oid in ((102, 2), (103, 3)):
+                if rng.random() < 0.8:
+                    pr = cl.pr(g, oid)
+                    idx = min(new_last, pr.matched + int(rng.integers(0, 6)))
+                    eng.step(g, pid, TERM, idx, commit=min(idx, cl.committed(g)))
+                    o = cl.step(g, oid, idx, commit=min(idx, cl.committed(g)), ins_full=0)
+                    s = oid - 1
+                    outw |= (1 if o.commit_changed else 0) | (int(o.send_append) << (8 + s)) | \
+                            (int(o.send_more) << (16 + s)) | (int(o.free_to) << (24 + s))
+            expect_out[g] = outw
+        with pytest.raises(rg.EngineError) as e:
+            eng.local_persisted(0, 1)
+        assert e.value.code == -6  # a second event for the same slot before the flush
+        eng.flush()
+        commit, out = eng.results()
+        for g in range(G):
+            assert commit[g] == cl.committed(g), (rnd, g)
+            assert out[g] == expect_out[g], (rnd, g, hex(out[g]), hex(expect_out[g]))
+    got = eng.read_state()
+    ref = O.alloc_state(G, P)
+    for k in ("cfg", "term_lo"):
+        ref[k][...] = st[k]
+    cl.store_soa(ref)
+    for k in ("match", "next", "pr_commit"):
+        assert (got[k][:, :G] == ref[k][:, :G]).all(), k
+    assert (got["pflags"] == ref["pflags"]).all()
+    eng.close()
