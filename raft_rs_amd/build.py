@@ -69,6 +69,11 @@ def build_opt(opt, verbose=False):
     return _build(os.path.join(PKG, f"libraftgroups_opt{opt}.so"), f"_opt{opt}", [f"-DRG_OPT={opt}"], verbose)
 
 
+def build_exp(name, defs, verbose=False):
+    """Experiment build with arbitrary -D flags: libraftgroups_<name>.so."""
+    return _build(os.path.join(PKG, f"libraftgroups_{name}.so"), "_" + name, list(defs), verbose)
+
+
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
@@ -76,7 +81,10 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    if "--opt" in sys.argv:
+    if "--exp" in sys.argv:  # --exp name -DFOO=1 -DBAR=2
+        i = sys.argv.index("--exp")
+        print(build_exp(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--opt" in sys.argv:
         for o in sys.argv[sys.argv.index("--opt") + 1:]:
             print(build_opt(int(o), verbose=False))
     else:

@@ -190,10 +190,10 @@ template <int P, bool GC> struct RgTick {
     const RgState &st;
     const RgMsgs &ms;
     const u64 g;
-    RgQuorum<P> qm;
     u64 last0; // last_index the send path saw before this tick
     u32 incoming, outgoing, self, present, xfer, out;
-    bool any_commit;
+    u32 acc;      // slots whose maybe_update returned true this tick (each is followed by a maybe_commit)
+    u32 acc_oldp; // ... of those, the ones that were paused before the ack (raft.rs:1724,1749-1751)
 
     RG_D RgTick(RgGroup<P> &r_, const RgState &st_, const RgMsgs &ms_, u64 g_)
         : r(r_), st(st_), ms(ms_), g(g_) {
@@ -205,31 +205,25 @@ template <int P, bool GC> struct RgTick {
         xfer = RG_CFG_TRANSFEREE(cfg);
         last0 = r.hi;
         out = 0;
-        any_commit = false;
+        acc = 0;
+        acc_oldp = 0;
         r.dirty = 0;
 #pragma unroll
         for (int i = 0; i < P; i++) // slots without a Progress ack 0 and are never written back
             if (!((present >> i) & 1u)) r.mt[i] = 0;
-        qm.init(r.mt);
     }
 
-    // Raft::maybe_commit (src/raft.rs:893-904) on the current matches. The leader's own
-    // update_committed (:896-900) is applied once at the end (commit only grows within a tick).
-    RG_D bool maybe_commit() {
-        u64 mci;
+    // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v`.
+    RG_D u64 mci_of(const RgQuorum<P> &qm, const u64 (&v)[P]) {
         if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
             u64 gidv[P];
 #pragma unroll
             for (int i = 0; i < P; i++)
                 gidv[i] = ((present >> i) & 1u) ? st.gid[(u64)i * st.stride + g] : 0ULL;
             bool used;
-            mci = rg_mci_group<P>(r.mt, gidv, incoming, outgoing, used);
-        } else {
-            mci = qm.mci(r.mt, incoming, outgoing);
+            return rg_mci_group<P>(v, gidv, incoming, outgoing, used);
         }
-        const bool ch = rg_log_maybe_commit(mci, r.commit, r.lo, r.hi);
-        any_commit |= ch;
-        return ch;
+        return qm.mci(v, incoming, outgoing);
     }
 
     // Progress::reset_state (progress.rs:75-80): paused=false, pending_snapshot=0, state; the
@@ -253,7 +247,7 @@ template <int P, bool GC> struct RgTick {
             r.mt[S] = idx;
             r.dirty |= 1u << S;
             pb &= ~RG_PF_PAUSED; // resume()
-            qm.template update<S>(r.mt);
+            acc |= 1u << S;      // the reference now calls maybe_commit(): evaluated in commit_phase()
         }
         if (r.nx[S] < idx + 1) set_next<S>(idx + 1);
         return upd;
@@ -277,7 +271,7 @@ template <int P, bool GC> struct RgTick {
             if (f & RG_MF_VALID) { // on_persist_entries (raft.rs:994-1016)
                 const u64 idx = r.mi[S];
                 if ((idx >> 63) || idx > r.hi) out |= RG_OUT_FAULT;
-                if (maybe_update<S>(idx, pb) && maybe_commit()) out |= RG_OUT_CHANGED;
+                maybe_update<S>(idx, pb); // && self.maybe_commit() -> commit_phase()
             }
         } else {
             const u32 state = pb & RG_PF_STATE_MASK;
@@ -347,8 +341,9 @@ template <int P, bool GC> struct RgTick {
                         } else {
                             out |= 1u << (24 + S); // ins.free_to(m.index), raft.rs:1742
                         }
-                        if (maybe_commit()) out |= RG_OUT_CHANGED;  // raft.rs:1745-1748
-                        else if (old_paused) out |= 1u << (8 + S);  // raft.rs:1749-1751
+                        // `if self.maybe_commit() {bcast} else if old_paused {send_append}` (raft.rs:1745-1751)
+                        // is resolved in commit_phase(), which knows whether THIS ack moved the commit index
+                        if (old_paused) acc_oldp |= 1u << S;
                         out |= 1u << (16 + S);                      // raft.rs:1761
                         if (xfer == (u32)S + 1u && r.mt[S] == r.hi) // raft.rs:1764-1774
                             out |= RG_OUT_TIMEOUT_NOW;
@@ -369,12 +364,51 @@ template <int P, bool GC> struct RgTick {
         }
     }
 
-    template <int... S> RG_D void run(rg_seq<S...>) {
-        (slot<S>(), ...);
-        if (any_commit) {
+    // One step of the sequential replay: slot S's accepted ack lands, Raft::maybe_commit runs.
+    template <int S> RG_D void replay_slot(RgQuorum<P> &qm, u64 (&cur)[P], u64 &commit) {
+        if (!((acc >> S) & 1u)) return;
+        cur[S] = r.mt[S];
+        qm.template update<S>(cur);
+        // last_index as it was when this message was processed: the leader's APPEND lands at its own slot
+        const u64 hi_then = (u32)S < self ? last0 : r.hi;
+        if (rg_log_maybe_commit(mci_of(qm, cur), commit, r.lo, hi_then)) out |= RG_OUT_CHANGED;
+        else if ((acc_oldp >> S) & 1u) out |= 1u << (8 + S); // raft.rs:1749-1751
+    }
+
+    // Raft::maybe_commit (src/raft.rs:893-904) after every accepted ack of the tick, in slot order.
+    //
+    // Matches only grow within a tick, so the quorum index is non-decreasing over the message
+    // sequence and, for well-formed acks (index <= last_index at that moment), the final commit
+    // index is decided by the LAST evaluation alone and "some maybe_commit returned true" == "the
+    // final commit index moved". The per-message results are observable only through
+    // `else if old_paused { send_append }` (raft.rs:1749-1751) and through malformed acks (flagged
+    // RG_OUT_FAULT). So: one evaluation on the final matches when neither occurs in this group,
+    // otherwise an exact replay of the sequence (old matches re-read from memory: nothing has been
+    // stored yet). Both paths are bit-identical to the message-at-a-time reference.
+    template <int... S> RG_D void commit_phase(rg_seq<S...>) {
+        if (acc == 0) return;
+        const u64 commit0 = r.commit;
+        RgQuorum<P> qm;
+        if (acc_oldp == 0 && !(out & RG_OUT_FAULT)) {
+            qm.init(r.mt);
+            if (rg_log_maybe_commit(mci_of(qm, r.mt), r.commit, r.lo, r.hi)) out |= RG_OUT_CHANGED;
+        } else {
+            u64 cur[P];
+            ((cur[S] = ((acc >> S) & 1u) ? st.match[(u64)S * st.stride + g] : r.mt[S]), ...);
+            qm.init(cur);
+            u64 commit = commit0;
+            (replay_slot<S>(qm, cur, commit), ...);
+            r.commit = commit;
+        }
+        if (r.commit != commit0) {
             r.dirty |= RG_DIRTY_COMMIT;
             (self_committed<S>(), ...);
         }
+    }
+
+    template <int... S> RG_D void run(rg_seq<S...> seq) {
+        (slot<S>(), ...);
+        commit_phase(seq);
         r.out = out;
     }
 };

@@ -14,10 +14,17 @@
 #endif
 #define RG_OPT_NT_MSG (RG_OPT & 1)
 #define RG_OPT_UNCOND_ST (RG_OPT & 2)
-#if RG_OPT & 4
+#ifdef RG_BLOCK_SIZE /* experiment override */
+#define RG_BLOCK RG_BLOCK_SIZE
+#elif RG_OPT & 4
 #define RG_BLOCK 64
 #else
 #define RG_BLOCK 256
+#endif
+#ifdef RG_MIN_WAVES /* experiment: minimum waves per SIMD the register allocator must leave room for */
+#define RG_TICK_BOUNDS __launch_bounds__(RG_BLOCK, RG_MIN_WAVES)
+#else
+#define RG_TICK_BOUNDS __launch_bounds__(RG_BLOCK)
 #endif
 
 static inline unsigned rg_grid_for(u64 n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -76,7 +83,7 @@ template <int P> RG_D void rg_store_group(const RgGroup<P> &r, const RgState &st
     st.out[g] = r.out;
 }
 
-template <int P, bool GC> __global__ __launch_bounds__(RG_BLOCK) void k_tick_lane(RgState st, RgMsgs ms) {
+template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
     RgGroup<P> r;

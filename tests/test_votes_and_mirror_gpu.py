@@ -33,7 +33,8 @@ def test_vote_result_golden_vectors(rg):
     yes = np.zeros(G, dtype=np.uint8)
     no = np.zeros(G, dtype=np.uint8)
     for g, (_, ids, idsj, look, _) in enumerate(cases):
-        m = lambda s: sum(1 << (i - 1) for i in s)
+        slot = {pid: k for k, pid in enumerate(sorted(set(ids) | set(idsj)))}  # peer id -> slot
+        m = lambda s: sum(1 << slot[i] for i in s)
         cfg[g] = rg.cfg_make(m(ids), m(idsj), 0)
         yes[g] = m([i for i, v in look.items() if v == 2])
         no[g] = m([i for i, v in look.items() if v == 1])
