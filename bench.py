@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--publish-every", type=int, default=8,
+                    help="N>1: all-gather the commit column every E ticks (and after the last tick)")
+    ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
@@ -120,58 +123,134 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
-    first_group = rank * G  # disjoint group ranges per rank (sharding.weak_shard)
-    eng = rg.Engine(G, P, device=local_rank, variant=args.variant)
+    T = W + K
     stream = torch.cuda.current_stream()
-    eng.set_stream(stream.cuda_stream)
-    stride = eng.stride
+
+    # A rank's shard is one engine per replica-set size class. Configs 2-4 have one size; config 5
+    # (mixed 3/5/7) places its groups by size class -- three engines of G/3 groups, three launches per
+    # tick -- instead of streaming the absent peers' cells of a single 7-slot engine.
+    # --one-engine keeps the mixed population interleaved in one P-slot engine for comparison.
+    if args.workload == 5 and not args.one_engine:
+        sizes = [(3, G // 3), (5, G // 3), (7, G - 2 * (G // 3))]
+    else:
+        sizes = [(P, G)]
+
+    class Part:
+        pass
+
+    parts, first = [], rank * G  # disjoint global group ids per rank (sharding.weak_shard)
+    for slots, n in sizes:
+        pt = Part()
+        pt.n, pt.slots, pt.first = n, slots, first
+        pt.fixed = slots if len(sizes) > 1 else 0
+        pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant)
+        pt.eng.set_stream(stream.cuda_stream)
+        pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed)
+        pt.eng.checkpoint()
+        pt.cols = [torch.empty((T, slots, pt.eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+        pt.flags = torch.empty((T, n, 8), dtype=torch.uint8, device="cuda")
+        first += n
+        parts.append(pt)
+
+    def tick_ptrs(pt, t):
+        return [c[t].data_ptr() for c in pt.cols] + [pt.flags[t].data_ptr()]
 
     # ---- untimed pass: generate + apply W+K ticks, recording the message columns on the device ----
-    eng.workload_init(args.workload, seed=args.seed, first_group=first_group)
-    eng.checkpoint()
-    T = W + K
-    cols = [torch.empty((T, P, stride), dtype=torch.int64, device="cuda") for _ in range(4)]
-    flags = torch.empty((T, G, 8), dtype=torch.uint8, device="cuda")
-    alg_bytes = []
-    census = []
+    alg_bytes = [0] * T
+    census = [dict(valid=0, rejects=0, slots=0) for _ in range(T)]
     for t in range(T):
-        ptrs = [c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]
-        eng.workload_gen(args.workload, t, *ptrs, seed=args.seed, first_group=first_group)
-        s = eng.msg_stats(flags[t].data_ptr())
-        census.append(s)
-        alg_bytes.append(algorithmic_bytes(G, s["slots"], s["valid"], s["rejects"]))
-        eng.tick_device(*ptrs)
-    eng.sync()
-    ref_commit, ref_out = eng.results()
-    n_changed, n_fault = eng.result_counts()
-    if n_fault:
-        raise SystemExit(f"stream raised {n_fault} faults: malformed workload")
+        for pt in parts:
+            pt.eng.workload_gen(args.workload, t, *tick_ptrs(pt, t), seed=args.seed, first_group=pt.first,
+                                fixed_peers=pt.fixed)
+            s = pt.eng.msg_stats(pt.flags[t].data_ptr())
+            for k in census[t]:
+                census[t][k] += s[k]
+            alg_bytes[t] += algorithmic_bytes(pt.n, s["slots"], s["valid"], s["rejects"])
+            pt.eng.tick_device(*tick_ptrs(pt, t))
+    n_changed = 0
+    for pt in parts:
+        pt.eng.sync()
+        pt.ref_commit, pt.ref_out = pt.eng.results()
+        ch, n_fault = pt.eng.result_counts()
+        n_changed += ch
+        if n_fault:
+            raise SystemExit(f"stream raised {n_fault} faults: malformed workload")
 
     # ---- commit publication (N>1): double-buffered snapshot of commit_idx, all-gather on a side stream ----
-    if distributed:
+    def make_publishers():
         from raft_rs_amd import sharding
-        commit_view = torch.as_tensor(DevCommitView(eng.column_ptr(rg.COL.COMMIT), G), device="cuda")
-        pub = sharding.CommitPublisher(dist, G, world, "cuda")
+        return [sharding.CommitPublisher(dist, pt.n, world, "cuda") for pt in parts]
 
-    def run_ticks(t0, n):
+    pubs = None
+    if distributed:
+        for pt in parts:
+            pt.commit_view = torch.as_tensor(DevCommitView(pt.eng.column_ptr(rg.COL.COMMIT), pt.n), device="cuda")
+        pubs = make_publishers()
+
+    # Publishing all commit indices EVERY tick is not physically possible at this tick rate: 8 ranks x
+    # 8 MB gathered per ~60 us tick would be ~1 TB/s of xGMI ingress per GPU (7 links x ~64 GB/s each
+    # way). The exchange therefore runs every E ticks (default 8: ~64 MB per ~0.5 ms), always including
+    # the last tick of the region so the gathered result can be verified.
+    E = max(1, args.publish_every)
+    n_pub = [0]
+
+    def run_ticks(t0, n, publishers):
         for i in range(n):
-            t = t0 + i
-            eng.tick_device(cols[0][t].data_ptr(), cols[1][t].data_ptr(), cols[2][t].data_ptr(),
-                            cols[3][t].data_ptr(), flags[t].data_ptr())
-            if distributed:
-                pub.publish(i, commit_view)
+            for j, pt in enumerate(parts):
+                pt.eng.tick_device(*tick_ptrs(pt, t0 + i))
+                if publishers is not None and ((i + 1) % E == 0 or i == n - 1):
+                    publishers[j].publish(n_pub[0], pt.commit_view)
+            if publishers is not None and ((i + 1) % E == 0 or i == n - 1):
+                n_pub[0] += 1
+
+    def join(publishers):
+        if publishers is not None:
+            for pb in publishers:
+                pb.join()
+
+    def set_streams(handle):
+        for pt in parts:
+            pt.eng.set_stream(handle)
 
     # ---- timed region ----
-    eng.restore()
-    run_ticks(0, W)
+    for pt in parts:
+        pt.eng.restore()
+    run_ticks(0, W, pubs)
+    join(pubs)
     torch.cuda.synchronize()
+    # BENCH_GRAPH=1: capture the K ticks + their all-gathers into ONE HIP graph. Measured at world size 1
+    # (profiles/r01_dist_path_ws1.txt): with the exchange every 8 ticks eager launches are faster (66 vs
+    # 68 us/step; the host stays >4 ticks ahead of the GPU), the graph only wins when every tick publishes
+    # (90 vs 98 us/step), so eager is the default.
+    graph = None
+    launch_mode = "eager"
+    if distributed and os.environ.get("BENCH_GRAPH") == "1":
+        try:
+            gpubs = make_publishers()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                set_streams(torch.cuda.current_stream().cuda_stream)
+                run_ticks(W, K, gpubs)
+                join(gpubs)
+            set_streams(stream.cuda_stream)
+            pubs = gpubs
+            launch_mode = "hipGraph"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
+            graph = None
+            set_streams(stream.cuda_stream)
+            torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wall0 = time.perf_counter()
     e0.record(stream)
-    run_ticks(W, K)
+    if graph is not None:
+        graph.replay()
+    else:
+        run_ticks(W, K, pubs)
+        join(pubs)
     e1.record(stream)
     torch.cuda.synchronize()
     if distributed:
@@ -181,13 +260,15 @@ def main():
     kernel_ms = e0.elapsed_time(e1)  # HIP events on the stream the tick kernels run on
 
     # replay determinism: the timed replay must land on the state the recorded pass produced
-    commit, out = eng.results()
-    if not (np.array_equal(commit, ref_commit) and np.array_equal(out, ref_out)):
-        raise SystemExit("timed replay diverged from the recorded pass")
+    for j, pt in enumerate(parts):
+        commit, out = pt.eng.results()
+        if not (np.array_equal(commit, pt.ref_commit) and np.array_equal(out, pt.ref_out)):
+            raise SystemExit("timed replay diverged from the recorded pass")
+        if distributed:
+            got = pubs[j].result((n_pub[0] - 1) & 1)[rank].cpu().numpy().view(np.uint64)
+            if not np.array_equal(got, commit):
+                raise SystemExit("all-gathered commit indices do not match this rank's shard")
     if distributed:
-        got = pub.result((K - 1) & 1)[rank].cpu().numpy().view(np.uint64)
-        if not np.array_equal(got, commit):
-            raise SystemExit("all-gathered commit indices do not match this rank's shard")
         tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
@@ -195,7 +276,7 @@ def main():
     evals = world * G * K
     value = evals / wall
     timed_bytes = float(np.mean(alg_bytes[W:]))
-    per_launch_s = kernel_ms / 1e3 / K
+    per_launch_s = kernel_ms / 1e3 / K  # one step = one launch per size class (1 except config 5)
     achieved = timed_bytes / per_launch_s / 1e9
     A = float(np.mean([c["valid"] for c in census[W:]])) / G
     R = float(np.mean([c["rejects"] for c in census[W:]])) / G
@@ -205,7 +286,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f).get(f"{args.workload}:{G}:{P}", {}).get("bytes")
+            traffic = json.load(f).get(f"{args.workload}:{G}:{P}", {}).get("bytes") if len(parts) == 1 else None
     except (OSError, ValueError):
         pass
 
@@ -221,7 +302,9 @@ def main():
                    "groups_per_gpu": G, "peer_slots": P, "workload_id": args.workload, "seed": hex(args.seed),
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
                    "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
-                   "sharding": f"{world} disjoint group ranges" + (", commit_idx all-gather per tick (RCCL)" if distributed else "")},
+                   "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
+                   "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks (RCCL)" if distributed else ""),
+                   "launch": launch_mode},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_tick_lane" if args.variant != 2 else "k_tick_lds",
@@ -234,11 +317,18 @@ def main():
                                               args.cpu_sample_ticks, args.seed, min(os.cpu_count() or 1, 128))
     elif rank == 0:
         result["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    eng.close()
+    for pt in parts:
+        pt.eng.close()
     if distributed:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio; drain it so the JSON is the LAST line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

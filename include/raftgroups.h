@@ -222,7 +222,7 @@ int rg_flush(rg_engine *h);
 typedef struct {
     uint64_t seed;
     uint32_t workload; /* RG_WL_* */
-    uint32_t reserved;
+    uint32_t reserved; /* RG_WL_MIXED only: fixed replica-set size (3/5/7) of a size-class shard, 0 = by group id % 3 */
 } rg_workload;
 #define RG_WL_MAJORITY 2u /* BASELINE config 2 (and 1, 4): majority quorum over all P slots */
 #define RG_WL_JOINT 3u    /* config 3: incoming {0,1,2} && outgoing {1,2,3}, slot 4.. learners */

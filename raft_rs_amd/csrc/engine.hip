@@ -759,9 +759,10 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
     if (!h || !w) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: bad argument");
     if (w->workload != RG_WL_MAJORITY && w->workload != RG_WL_JOINT && w->workload != RG_WL_MIXED)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: unknown workload %u", w->workload);
+    if (w->reserved > 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: fixed replica-set size %u", w->reserved);
     RG_HIP(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_wl_init, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
-                       w->workload, h->P, (u64)first);
+                       w->workload | (w->reserved << 8), h->P, (u64)first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_init: %s", hipGetErrorString(e));
     return RG_OK;
@@ -772,7 +773,7 @@ extern "C" int rg_workload_gen(rg_engine *h, const rg_workload *w, uint64_t firs
     if (!h || !w || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen: bad argument");
     RG_HIP(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_wl_gen, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
-                       w->workload, h->P, (u64)first, (u64)tick, (u64 *)mi, (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
+                       w->workload | (w->reserved << 8), h->P, (u64)first, (u64)tick, (u64 *)mi, (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_gen: %s", hipGetErrorString(e));
     return RG_OK;
@@ -781,7 +782,7 @@ extern "C" int rg_workload_gen(rg_engine *h, const rg_workload *w, uint64_t firs
 extern "C" int rg_workload_init_host(const rg_workload *w, uint64_t first, rg_host_state *s) {
     if (!w || !s || s->n_slots == 0 || s->n_slots > 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init_host: bad argument");
     for (u64 g = 0; g < s->n_groups; g++)
-        rg_wl_init_group(w->seed, w->workload, s->n_slots, s->stride, g, first + g, (u64 *)s->match, (u64 *)s->next,
+        rg_wl_init_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g, first + g, (u64 *)s->match, (u64 *)s->next,
                          (u64 *)s->pr_commit, (u64 *)s->pend_snap, (u64 *)s->pend_rs, (u64 *)s->gid, s->pflags,
                          (u64 *)s->commit, (u64 *)s->term_lo, (u64 *)s->term_hi, s->cfg);
     return RG_OK;
@@ -791,7 +792,7 @@ extern "C" int rg_workload_gen_host(const rg_workload *w, uint64_t first, uint64
                                     uint64_t *mi, uint64_t *mc, uint64_t *mh, uint64_t *mrs, uint8_t *mf) {
     if (!w || !s || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen_host: bad argument");
     for (u64 g = 0; g < s->n_groups; g++)
-        rg_wl_gen_group(w->seed, w->workload, s->n_slots, s->stride, g, first + g, tick, (const u64 *)s->match,
+        rg_wl_gen_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g, first + g, tick, (const u64 *)s->match,
                         (const u64 *)s->next, s->pflags, (const u64 *)s->commit, (const u64 *)s->term_hi, (u64 *)mi,
                         (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
     return RG_OK;

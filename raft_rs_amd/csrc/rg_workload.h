@@ -28,13 +28,16 @@ struct RgWlGroup { // static (tick-independent) facts of a group
     bool post_election;
 };
 
-RG_HD RgWlGroup rg_wl_group(u64 seed, u32 workload, u32 n_slots, u64 gg) {
+RG_HD RgWlGroup rg_wl_group(u64 seed, u32 workload_word, u32 n_slots, u64 gg) {
+    // workload_word: low 8 bits = RG_WL_*, bits 8-11 = fixed replica-set size for RG_WL_MIXED (0 = by gg % 3):
+    // a size-class shard holds only groups of one size
+    const u32 workload = workload_word & 0xffu, fixed_peers = (workload_word >> 8) & 0xfu;
     RgWlGroup w;
     const u64 h = rg_hash(seed, 0, gg, 0);
     w.n_peers = n_slots;
     if (workload == RG_WL_MIXED) {
         const u32 k = (u32)(gg % 3);
-        w.n_peers = k == 0 ? 3u : (k == 1 ? 5u : 7u);
+        w.n_peers = fixed_peers ? fixed_peers : (k == 0 ? 3u : (k == 1 ? 5u : 7u));
         if (w.n_peers > n_slots) w.n_peers = n_slots;
     }
     const u32 all = (1u << w.n_peers) - 1u;
@@ -133,7 +136,7 @@ RG_HD void rg_wl_gen_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64 
                            u8 *m_flags) {
     const RgWlGroup w = rg_wl_group(seed, workload, n_slots, gg);
     const u64 last = hi[g], cm = commit[g];
-    const bool mixed = workload == RG_WL_MIXED; // rejects / snapshot requests / full windows: config 5 only
+    const bool mixed = (workload & 0xffu) == RG_WL_MIXED; // rejects / snapshot requests / full windows: config 5 only
     for (u32 p = 0; p < 8; p++) {
         u8 f = 0;
         u64 idx = 0, mcm = 0, hint = 0, rs = 0;

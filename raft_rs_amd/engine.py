@@ -353,12 +353,13 @@ class Engine:
         self._check(self.L.rg_flush(self.h))
 
     # ---- synthetic stream --------------------------------------------------------------------
-    def workload_init(self, workload, seed=0x5EED5EED, first_group=0):
-        w = _Workload(seed, workload, 0)
+    def workload_init(self, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0):
+        w = _Workload(seed, workload, fixed_peers)
         self._check(self.L.rg_workload_init(self.h, C.byref(w), first_group))
 
-    def workload_gen(self, workload, tick, m_index, m_commit, m_hint, m_rs, m_flags, seed=0x5EED5EED, first_group=0):
-        w = _Workload(seed, workload, 0)
+    def workload_gen(self, workload, tick, m_index, m_commit, m_hint, m_rs, m_flags, seed=0x5EED5EED, first_group=0,
+                     fixed_peers=0):
+        w = _Workload(seed, workload, fixed_peers)
         self._check(self.L.rg_workload_gen(self.h, C.byref(w), first_group, tick, _ptr(m_index), _ptr(m_commit),
                                            _ptr(m_hint), _ptr(m_rs), _ptr(m_flags)))
 
@@ -368,20 +369,20 @@ def _host_state_struct(st):
                       *[st[k].ctypes.data for k in COL.NAMES[:11]])
 
 
-def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0):
+def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0):
     """Host twin of Engine.workload_init over numpy columns (no GPU)."""
     L = load_library()
-    w = _Workload(seed, workload, 0)
+    w = _Workload(seed, workload, fixed_peers)
     s = _host_state_struct(st)
     rc = L.rg_workload_init_host(C.byref(w), first_group, C.byref(s))
     if rc:
         raise EngineError(rc, L.rg_last_error().decode())
 
 
-def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0):
+def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, fixed_peers=0):
     """Host twin of Engine.workload_gen: messages of `tick` from the numpy state columns."""
     L = load_library()
-    w = _Workload(seed, workload, 0)
+    w = _Workload(seed, workload, fixed_peers)
     s = _host_state_struct(st)
     rc = L.rg_workload_gen_host(C.byref(w), first_group, tick, C.byref(s), msgs.m_index.ctypes.data,
                                 msgs.m_commit.ctypes.data, msgs.m_hint.ctypes.data, msgs.m_rs.ctypes.data,

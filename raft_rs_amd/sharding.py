@@ -48,6 +48,7 @@ class CommitPublisher:
             self.side = torch.cuda.Stream()
             self.ready = [torch.cuda.Event() for _ in range(2)]
             self.done = [torch.cuda.Event() for _ in range(2)]
+            self.pending = [False, False]  # done[b] recorded and not yet waited for
 
     def publish(self, i, commit):
         b = i & 1
@@ -57,14 +58,27 @@ class CommitPublisher:
             return b
         torch = self.torch
         main = torch.cuda.current_stream()
-        main.wait_event(self.done[b])  # the previous gather out of this staging buffer has finished
+        if self.pending[b]:
+            main.wait_event(self.done[b])  # the previous gather out of this staging buffer has finished
         self.stage[b].copy_(commit, non_blocking=True)
         self.ready[b].record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ready[b])
             self.dist.all_gather_into_tensor(self.gathered[b], self.stage[b])
             self.done[b].record(self.side)
+        self.pending[b] = True
         return b
+
+    def join(self):
+        """Make the current stream wait for every outstanding gather (needed before the end of a
+        HIP-graph capture, and before reading `result`)."""
+        if not self.cuda:
+            return
+        main = self.torch.cuda.current_stream()
+        for b in range(2):
+            if self.pending[b]:
+                main.wait_event(self.done[b])
+                self.pending[b] = False
 
     def result(self, b):
         """[world, n_groups] view of the gathered commit indices of buffer b (sync first on CUDA)."""
