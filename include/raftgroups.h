@@ -67,6 +67,10 @@ typedef enum {
                                 apply Progress::update_state(last) first (progress.rs:231-243, src/raft.rs:726-729) */
 #define RG_MF_APPEND 0x20u   /* self slot only: leader appended entries, new last_index in m_commit
                                 (Raft::append_entry, src/raft.rs:976-991) */
+#define RG_MF_HEARTBEAT 0x40u /* a MsgHeartbeatResponse from this peer (m_commit = Message.commit), handled as
+                                Raft::handle_heartbeat_response (src/raft.rs:1777-1803); exclusive with RG_MF_VALID.
+                                Result bits: RG_OUT_SEND_APPEND(slot) = send_append (matched < last_index or a
+                                pending snapshot request), RG_OUT_FREE_TO(slot) = ins.free_first_one() */
 
 /* ---- per-group configuration word ---- */
 #define RG_CFG_INCOMING(c) ((uint32_t)(c) & 0xffu)        /* voters.incoming as a slot bitmask (tracker.rs:37-40) */
@@ -176,6 +180,11 @@ int rg_recompute(rg_engine *h);
 /* ProgressTracker::maximal_committed_index for every group -> device/host u64[G] (no gate, no
  * state change); used_gc (u8[G], may be NULL) receives the group-commit flag. Host destination. */
 int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint8_t *host_used_gc);
+/* Raft::bcast_heartbeat (src/raft.rs:885-891 -> send_heartbeat :822-844): the commit index each
+ * MsgHeartbeat carries, min(pr.matched, raft_log.committed), for every slot -> u64 [P][stride] in DEVICE
+ * memory (`dev_hb_commit`) or, when `host_hb_commit` is not NULL, copied to the host. Slots without a
+ * Progress get 0. Asynchronous unless a host destination is given. */
+int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb_commit, uint64_t *host_hb_commit);
 /* Results of the last tick: commit[G] and out[G] to host memory (either may be NULL). Synchronises. */
 int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out);
 /* Sum of RG_OUT_CHANGED / RG_OUT_FAULT bits over all groups for the last tick (device reduction). */
@@ -211,12 +220,38 @@ typedef struct {
 int rg_set_peers(rg_engine *h, uint64_t group, const uint64_t *peer_ids, uint32_t n, uint64_t term);
 /* Queue one MsgAppendResponse for the next rg_flush. Errors mirror RawNode::step / Raft::step. */
 int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m);
+/* Queue one MsgHeartbeatResponse (src/raft.rs:2099-2101 -> handle_heartbeat_response :1777-1803). */
+int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t from, uint64_t term, uint64_t commit,
+                               uint8_t ins_full);
 /* Leader-local events, queued the same way (src/raft.rs:976-1016). */
 int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index);
 int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index);
 int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id);
 /* Run one tick over everything queued since the last flush and clear the queue. */
 int rg_flush(rg_engine *h);
+
+/* ---- sparse path: wire-order records -> slot matrix -> tick over the touched groups only ----
+ * For realistic traffic (a small fraction of the groups has events in a tick) the dense sweep of rg_tick
+ * wastes bandwidth. rg_ingest scatters array-of-structs records (what a transport thread produces from
+ * eraftpb::Message, proto/proto/eraftpb.proto:71-92) into the engine-owned message columns on the device
+ * (LDS-staged AoS->SoA transpose) and collects the set of touched groups; rg_tick_ingested runs the same
+ * per-group arithmetic as rg_tick over exactly those groups and consumes the events. At most ONE record per
+ * (group, slot) between two rg_tick_ingested calls: a second one is dropped and counted in n_duplicates (the
+ * caller re-submits it after the tick, which preserves per-peer order). rg_flush uses this path. */
+typedef struct {
+    uint64_t group;  /* engine-local group index */
+    uint64_t index;  /* Message.index (self slot: persisted index) */
+    uint64_t commit; /* Message.commit (self slot with RG_MF_APPEND: new last_index) */
+    uint64_t hint;   /* Message.reject_hint (after find_conflict_by_term) */
+    uint64_t rs;     /* Message.request_snapshot */
+    uint32_t slot;   /* peer slot 0..P-1 */
+    uint32_t flags;  /* RG_MF_* */
+} rg_wire_msg;
+int rg_ingest(rg_engine *h, const rg_wire_msg *host_records, uint64_t n, uint64_t *n_duplicates);
+int rg_tick_ingested(rg_engine *h, uint64_t *n_groups);
+/* Groups touched by the last rg_tick_ingested with their commit index and result word (host arrays of
+ * capacity `cap`; *n receives the number of groups, which may exceed cap: then only cap are written). */
+int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *commit, uint32_t *out, uint64_t cap, uint64_t *n);
 
 /* ---- synthetic AppendResponse stream; same code on host and device ---- */
 typedef struct {

@@ -589,6 +589,32 @@ void ro_handle_append_response(ro_cluster *c, size_t g, const ro_msg *m, ro_out 
     }
 }
 
+void ro_handle_heartbeat_response(ro_cluster *c, size_t g, uint64_t from, uint64_t commit, int8_t ins_full,
+                                  ro_out *out) { /* raft.rs:1777-1803 (the read-index part is host-side) */
+    ro_group *gr = &c->g[g];
+    memset(out, 0, sizeof(*out));
+    ro_progress *pr = pmap_get(&gr->progress, from);
+    if (!pr) return;
+    out->handled = true;
+    ro_progress_update_committed(pr, commit); /* :1791 */
+    pr->recent_active = true;                 /* :1792 */
+    pr->paused = false;                       /* :1793 resume() */
+    bool full = ins_full < 0 ? ro_ins_full(&pr->ins) : (ins_full != 0);
+    if (pr->state == RO_REPLICATE && full) { /* :1796-1798 */
+        if (ins_full < 0) ro_ins_free_first_one(&pr->ins);
+        out->free_to = true;
+    }
+    if (pr->matched < gr->last_index || pr->pending_request_snapshot != RO_INVALID_INDEX) /* :1800-1803 */
+        out->send_append = true;
+}
+
+uint64_t ro_heartbeat_commit(ro_cluster *c, size_t g, uint64_t to) { /* raft.rs:830-838 */
+    ro_group *gr = &c->g[g];
+    ro_progress *pr = pmap_get(&gr->progress, to);
+    if (!pr) return 0;
+    return pr->matched < gr->committed ? pr->matched : gr->committed;
+}
+
 bool ro_on_persist_entries(ro_cluster *c, size_t g, uint64_t index) { /* raft.rs:994-1016 */
     ro_group *gr = &c->g[g];
     ro_progress *pr = pmap_get(&gr->progress, gr->id);
@@ -649,6 +675,7 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_MF_INS_FULL 0x08u
 #define RO_MF_SENT 0x10u
 #define RO_MF_APPEND 0x20u
+#define RO_MF_HEARTBEAT 0x40u
 #define RO_OUT_CHANGED 0x1u
 #define RO_OUT_FAULT 0x2u
 #define RO_OUT_TIMEOUT_NOW 0x4u
@@ -748,7 +775,7 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
         uint32_t self_slot = (uint32_t)(gr->id - 1);
         for (uint32_t p = 0; p < m->n_slots; p++) {
             uint8_t f = m->m_flags[g * 8 + p];
-            if (!(f & (RO_MF_VALID | RO_MF_SENT | RO_MF_APPEND))) continue;
+            if (!(f & (RO_MF_VALID | RO_MF_SENT | RO_MF_APPEND | RO_MF_HEARTBEAT))) continue;
             size_t o = (size_t)p * m->stride + g;
             ro_progress *pr = pmap_get(&gr->progress, p + 1);
             if (!pr) continue; /* "no progress available" raft.rs:1663-1673 */
@@ -767,6 +794,14 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
             }
             if (f & RO_MF_SENT) { /* prepare_send_entries -> update_state(last), raft.rs:726-729 */
                 if (ro_progress_update_state(pr, last0) != 0) out |= RO_OUT_FAULT;
+            }
+            if (f & RO_MF_HEARTBEAT) { /* MsgHeartbeatResponse, raft.rs:1777-1803 */
+                ro_out ho;
+                ro_handle_heartbeat_response(c, g, p + 1, m->m_commit[o], (f & RO_MF_INS_FULL) ? 1 : 0, &ho);
+                stepped++;
+                if (ho.send_append) out |= 1u << (8 + p);
+                if (ho.free_to) out |= 1u << (24 + p);
+                continue;
             }
             if (!(f & RO_MF_VALID)) continue;
             ro_msg msg;

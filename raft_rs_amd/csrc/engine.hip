@@ -152,6 +152,82 @@ __global__ __launch_bounds__(RG_BLOCK) void k_quorum_active(RgState st, u8 *res)
                            rg_vote_majority(RG_CFG_OUTGOING(cfg), active, 0)) == 2u;
 }
 
+// send_heartbeat's commit = min(pr.matched, raft_log.committed) (src/raft.rs:830-838) for every slot
+__global__ __launch_bounds__(RG_BLOCK) void k_heartbeat_commits(RgState st, u32 P, u64 *hb) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    const u64 commit = st.commit[g];
+    const u32 present = RG_CFG_PRESENT(st.cfg[g]);
+    for (u32 p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        const u64 m = st.match[o];
+        hb[o] = ((present >> p) & 1u) ? (m < commit ? m : commit) : 0ULL;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: ingest (wire-order AoS records -> the slot matrix) and helpers of the sparse path
+// ------------------------------------------------------------------------------------------------
+#define RG_INGEST_BLOCK 256
+// A workgroup stages 256 records (12 KiB) through LDS with fully coalesced 16-B loads, then lane t
+// decodes record t and scatters its fields to the peer-major message columns. The event byte of the
+// cell is claimed with a CAS on its 32-bit word; a second record for the same cell is dropped and
+// counted. The first record that touches a group appends it to the tick list.
+__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(const rg_wire_msg *rec, u64 n, u64 G, u64 stride, u32 P,
+                                                            u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u32 *mflags32,
+                                                            u32 *gmark, u32 epoch, u64 *list, u32 *counters) {
+    __shared__ uint4 stage[RG_INGEST_BLOCK * 3];
+    const u64 base = (u64)blockIdx.x * RG_INGEST_BLOCK;
+    const u32 nrec = (u32)((n - base) < RG_INGEST_BLOCK ? (n - base) : RG_INGEST_BLOCK);
+    const uint4 *src = reinterpret_cast<const uint4 *>(rec + base);
+    for (u32 k = threadIdx.x; k < 3 * nrec; k += RG_INGEST_BLOCK) stage[k] = src[k];
+    __syncthreads();
+    const u32 t = threadIdx.x;
+    if (t >= nrec) return;
+    const uint4 a = stage[3 * t], b = stage[3 * t + 1], c = stage[3 * t + 2];
+    const u64 group = (u64)a.x | ((u64)a.y << 32), index = (u64)a.z | ((u64)a.w << 32);
+    const u64 commit = (u64)b.x | ((u64)b.y << 32), hint = (u64)b.z | ((u64)b.w << 32);
+    const u64 rs = (u64)c.x | ((u64)c.y << 32);
+    const u32 slot = c.z, flags = c.w & 0xffu;
+    if (group >= G || slot >= P || flags == 0) { // malformed record: counted with the duplicates
+        atomicAdd(&counters[1], 1u);
+        return;
+    }
+    u32 *word = mflags32 + group * 2 + (slot >> 2);
+    const u32 shift = 8u * (slot & 3u);
+    u32 old = *word;
+    for (;;) {
+        if ((old >> shift) & 0xffu) { // the cell already holds an event of this tick
+            atomicAdd(&counters[1], 1u);
+            return;
+        }
+        const u32 seen = atomicCAS(word, old, old | (flags << shift));
+        if (seen == old) break;
+        old = seen;
+    }
+    const u64 o = (u64)slot * stride + group;
+    mi[o] = index;
+    mc[o] = commit;
+    if (flags & RG_MF_REJECT) mh[o] = hint;
+    if (flags & RG_MF_HAS_RS) mrs[o] = rs;
+    if (atomicExch(&gmark[group], epoch) != epoch) list[atomicAdd(&counters[0], 1u)] = group;
+}
+
+__global__ void k_gather_results(const u64 *list, const u32 *n_ptr, const u64 *commit, const u32 *out, u64 *rl, u64 *rc,
+                                 u32 *ro) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const u64 g = list[i];
+    rl[i] = g;
+    rc[i] = commit[g];
+    ro[i] = out[g];
+}
+
+__global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[list[i]] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels: sparse cell writes, counters, workload
 // ------------------------------------------------------------------------------------------------
@@ -253,6 +329,16 @@ struct rg_engine {
     RgState st;
     RgMsgs staged;    // views into msg_arena
     bool ticked;
+    // sparse path (rg_ingest / rg_tick_ingested)
+    char *sparse_arena;       // gmark | list | res_list | res_commit | res_out | counters
+    u32 *gmark, *counters, *res_out;
+    u64 *list, *res_list, *res_commit;
+    rg_wire_msg *d_records;   // device staging for records
+    u64 d_records_cap;
+    u32 epoch;
+    u64 ingested_upper;       // records accepted for upload since the last sparse tick (>= touched groups)
+    u64 last_sparse_n;        // groups of the last rg_tick_ingested (result arrays are valid for them)
+    bool out_is_dense;        // RG_COL_OUT was last written by a dense tick
     bool any_group_commit; // some group's cfg word has RG_CFG_GROUP_COMMIT (tracked on cfg loads)
     // host mirror of RawNode::step (rg_set_peers / rg_step / rg_flush)
     std::vector<u64> peer_ids; // [G][8], 0 = unused
@@ -260,6 +346,7 @@ struct rg_engine {
     std::vector<u64> q_mi, q_mc, q_mh, q_mrs; // [P][stride] host queues
     std::vector<u8> q_mf;                      // [G][8]
     std::vector<u64> q_dirty;                  // groups touched since the last flush
+    std::vector<rg_wire_msg> q_records;        // flush staging (wire-order records of the dirty groups)
     bool host_mirror;
 };
 
@@ -313,6 +400,13 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->ckpt = nullptr;
     h->msg_arena = nullptr;
     h->ticked = false;
+    h->sparse_arena = nullptr;
+    h->d_records = nullptr;
+    h->d_records_cap = 0;
+    h->epoch = 1;
+    h->ingested_upper = 0;
+    h->last_sparse_n = 0;
+    h->out_is_dense = true;
     h->any_group_commit = false;
     h->host_mirror = false;
     size_t off = 0;
@@ -363,6 +457,8 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->ckpt) (void)hipFree(h->ckpt);
     if (h->msg_arena) (void)hipFree(h->msg_arena);
+    if (h->sparse_arena) (void)hipFree(h->sparse_arena);
+    if (h->d_records) (void)hipFree(h->d_records);
     delete h;
 }
 
@@ -468,6 +564,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
     h->ticked = true;
+    h->out_is_dense = true;
     return RG_OK;
 }
 
@@ -514,7 +611,122 @@ extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
     RG_HIP(hipMemcpyAsync((void *)h->staged.mflags, m->m_flags, h->G * 8, hipMemcpyHostToDevice, h->stream));
     rc = rg_tick_impl(h, ms);
     if (rc) return rc;
+    // the engine-owned message columns must read "no events" outside a tick (sparse-path invariant)
+    RG_HIP(hipMemsetAsync((void *)h->staged.mflags, 0, h->stride * 8, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // caller-owned host buffers may be reused after return
+    return RG_OK;
+}
+
+static int rg_ensure_sparse(rg_engine *h) {
+    if (h->sparse_arena) return RG_OK;
+    int rc = rg_ensure_msg_arena(h);
+    if (rc) return rc;
+    const size_t G = h->stride;
+    const size_t o_gmark = 0, o_list = rg_align(G * 4), o_rl = o_list + rg_align(G * 8), o_rc = o_rl + rg_align(G * 8);
+    const size_t o_ro = o_rc + rg_align(G * 8), o_cnt = o_ro + rg_align(G * 4), total = o_cnt + 256;
+    RG_HIP(hipMalloc(&h->sparse_arena, total));
+    RG_HIP(hipMemsetAsync(h->sparse_arena, 0, total, h->stream));
+    h->gmark = (u32 *)(h->sparse_arena + o_gmark);
+    h->list = (u64 *)(h->sparse_arena + o_list);
+    h->res_list = (u64 *)(h->sparse_arena + o_rl);
+    h->res_commit = (u64 *)(h->sparse_arena + o_rc);
+    h->res_out = (u32 *)(h->sparse_arena + o_ro);
+    h->counters = (u32 *)(h->sparse_arena + o_cnt);
+    return RG_OK;
+}
+
+extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, uint64_t *n_duplicates) {
+    if (!h || (!records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest: bad argument");
+    if (n_duplicates) *n_duplicates = 0;
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_ensure_sparse(h);
+    if (rc) return rc;
+    if (n > h->d_records_cap) {
+        if (h->d_records) {
+            RG_HIP(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_records);
+            h->d_records = nullptr;
+        }
+        u64 cap = h->d_records_cap ? h->d_records_cap : 4096;
+        while (cap < n) cap *= 2;
+        RG_HIP(hipMalloc(&h->d_records, (cap + RG_INGEST_BLOCK) * sizeof(rg_wire_msg)));
+        h->d_records_cap = cap;
+    }
+    RG_HIP(hipMemsetAsync(h->counters + 1, 0, 4, h->stream));
+    RG_HIP(hipMemcpyAsync(h->d_records, records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
+                       h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
+                       (u64 *)h->staged.mrs, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list, h->counters);
+    u32 dup = 0;
+    RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream)); // the caller's record array may be reused after return
+    if (n_duplicates) *n_duplicates = dup;
+    h->ingested_upper += n;
+    return RG_OK;
+}
+
+extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_ingested: null engine");
+    if (n_groups) *n_groups = 0;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_ensure_sparse(h);
+    if (rc) return rc;
+    // RG_COL_OUT must hold zeros for every group this tick does not touch
+    if (h->out_is_dense) {
+        RG_HIP(hipMemsetAsync(h->st.out, 0, h->stride * 4, h->stream));
+    } else if (h->last_sparse_n) {
+        hipLaunchKernelGGL(k_clear_out, dim3(rg_grid(h->last_sparse_n, 256)), dim3(256), 0, h->stream, h->res_list,
+                           h->last_sparse_n, h->st.out);
+    }
+    h->out_is_dense = false;
+    h->last_sparse_n = 0;
+    u64 upper = h->ingested_upper < h->G ? h->ingested_upper : h->G;
+    if (upper) {
+        const RgMsgs ms = h->staged;
+        u64 *mf = (u64 *)h->staged.mflags;
+        switch (h->P) {
+        case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        case 2: rg_launch_tick_list_t<2>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        case 3: rg_launch_tick_list_t<3>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        case 4: rg_launch_tick_list_t<4>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        case 5: rg_launch_tick_list_t<5>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        case 6: rg_launch_tick_list_t<6>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        case 7: rg_launch_tick_list_t<7>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        default: rg_launch_tick_list_t<8>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+        }
+        hipLaunchKernelGGL(k_gather_results, dim3(rg_grid(upper, 256)), dim3(256), 0, h->stream, h->list, h->counters,
+                           (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_tick_ingested: launch failed: %s", hipGetErrorString(e));
+        u32 n = 0;
+        RG_HIP(hipMemcpyAsync(&n, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipMemsetAsync(h->counters, 0, 4, h->stream));
+        RG_HIP(hipStreamSynchronize(h->stream));
+        h->last_sparse_n = n;
+    }
+    h->ingested_upper = 0;
+    h->epoch++;
+    if (h->epoch == 0) { // epoch wrapped: the marks are ambiguous, reset them
+        RG_HIP(hipMemsetAsync(h->gmark, 0, h->stride * 4, h->stream));
+        h->epoch = 1;
+    }
+    h->ticked = true;
+    if (n_groups) *n_groups = h->last_sparse_n;
+    return RG_OK;
+}
+
+extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *commit, uint32_t *out, uint64_t cap,
+                                   uint64_t *n) {
+    if (!h || !n) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingested_results: bad argument");
+    *n = h->last_sparse_n;
+    const u64 k = h->last_sparse_n < cap ? h->last_sparse_n : cap;
+    if (k == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    if (groups) RG_HIP(hipMemcpyAsync(groups, h->res_list, k * 8, hipMemcpyDeviceToHost, h->stream));
+    if (commit) RG_HIP(hipMemcpyAsync(commit, h->res_commit, k * 8, hipMemcpyDeviceToHost, h->stream));
+    if (out) RG_HIP(hipMemcpyAsync(out, h->res_out, k * 4, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }
 
@@ -562,6 +774,30 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
     if (d_gc) (void)hipFree(d_gc);
     if (rc) return rc;
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_maximal_committed_index: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb, uint64_t *host_hb) {
+    if (!h || (!dev_hb && !host_hb)) return rg_fail(RG_ERR_INVALID_ARG, "rg_heartbeat_commits: no destination");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u64 *tmp = nullptr;
+    u64 *dst = (u64 *)dev_hb;
+    const size_t bytes = (size_t)h->P * h->stride * 8;
+    if (!dst) {
+        RG_HIP(hipMalloc(&tmp, bytes));
+        dst = tmp;
+    }
+    hipLaunchKernelGGL(k_heartbeat_commits, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, h->P, dst);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && host_hb) {
+        e = hipMemcpyAsync(host_hb, dst, bytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    if (tmp) {
+        if (!host_hb) (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(tmp);
+    }
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_heartbeat_commits: %s", hipGetErrorString(e));
     return RG_OK;
 }
 
@@ -678,7 +914,7 @@ extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m
     if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_step: peer %llu not in group %llu (raw_node.rs:407-410)",
                                  (unsigned long long)m->from, (unsigned long long)group);
     u8 &f = h->q_mf[group * 8 + slot];
-    if (f & RG_MF_VALID) return rg_fail(RG_ERR_SLOT_BUSY, "rg_step: peer %llu already has a message queued; rg_flush first",
+    if (f & (RG_MF_VALID | RG_MF_HEARTBEAT)) return rg_fail(RG_ERR_SLOT_BUSY, "rg_step: peer %llu already has a message queued; rg_flush first",
                                         (unsigned long long)m->from);
     rg_touch(h, group);
     const size_t o = (size_t)slot * h->stride + group;
@@ -688,6 +924,25 @@ extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m
     h->q_mrs[o] = m->request_snapshot;
     f |= RG_MF_VALID | (m->reject ? RG_MF_REJECT : 0) | (m->request_snapshot ? RG_MF_HAS_RS : 0) |
          (m->ins_full ? RG_MF_INS_FULL : 0);
+    return RG_OK;
+}
+
+extern "C" int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t from, uint64_t term, uint64_t commit,
+                                          uint8_t ins_full) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_heartbeat_response: bad argument");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step_heartbeat_response: rg_set_peers was never called");
+    if (term == 0) return rg_fail(RG_ERR_STEP_LOCAL_MSG, "rg_step_heartbeat_response: term 0 marks a local message");
+    if (term > h->terms[group]) return rg_fail(RG_ERR_HIGHER_TERM, "rg_step_heartbeat_response: higher term: step down");
+    if (term < h->terms[group]) return RG_OK;
+    const int slot = rg_find_slot(h, group, from);
+    if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_step_heartbeat_response: peer %llu not in group %llu",
+                                 (unsigned long long)from, (unsigned long long)group);
+    u8 &f = h->q_mf[group * 8 + slot];
+    if (f & (RG_MF_VALID | RG_MF_HEARTBEAT))
+        return rg_fail(RG_ERR_SLOT_BUSY, "rg_step_heartbeat_response: peer %llu already has a message queued", (unsigned long long)from);
+    rg_touch(h, group);
+    h->q_mc[(size_t)slot * h->stride + group] = commit;
+    f |= RG_MF_HEARTBEAT | (ins_full ? RG_MF_INS_FULL : 0);
     return RG_OK;
 }
 
@@ -740,13 +995,41 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
 extern "C" int rg_flush(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
-    rg_msgs m;
-    m.m_index = h->q_mi.data();
-    m.m_commit = h->q_mc.data();
-    m.m_hint = h->q_mh.data();
-    m.m_rs = h->q_mrs.data();
-    m.m_flags = h->q_mf.data();
-    int rc = rg_tick(h, &m);
+    int rc;
+    if (h->q_dirty.size() * 4 >= h->G) {
+        // most groups have events: stream the whole columns through the dense tick
+        rg_msgs m;
+        m.m_index = h->q_mi.data();
+        m.m_commit = h->q_mc.data();
+        m.m_hint = h->q_mh.data();
+        m.m_rs = h->q_mrs.data();
+        m.m_flags = h->q_mf.data();
+        rc = rg_tick(h, &m);
+    } else {
+        // few groups have events: ship only their records and tick only them
+        std::vector<rg_wire_msg> &recs = h->q_records;
+        recs.clear();
+        for (u64 g : h->q_dirty) {
+            for (u32 p = 0; p < h->P; p++) {
+                const u8 f = h->q_mf[g * 8 + p];
+                if (!f) continue;
+                const size_t o = (size_t)p * h->stride + g;
+                rg_wire_msg r;
+                r.group = g;
+                r.index = h->q_mi[o];
+                r.commit = h->q_mc[o];
+                r.hint = h->q_mh[o];
+                r.rs = h->q_mrs[o];
+                r.slot = p;
+                r.flags = f;
+                recs.push_back(r);
+            }
+        }
+        uint64_t dup = 0, ng = 0;
+        rc = rg_ingest(h, recs.data(), recs.size(), &dup);
+        if (rc == RG_OK && dup) rc = rg_fail(RG_ERR_STATE, "rg_flush: %llu duplicate cells (internal error)", (unsigned long long)dup);
+        if (rc == RG_OK) rc = rg_tick_ingested(h, &ng);
+    }
     for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
     h->q_dirty.clear();
     return rc;

@@ -280,7 +280,15 @@ template <int P, bool GC> struct RgTick {
                 else if (state == RG_STATE_PROBE) pb |= RG_PF_PAUSED;
                 else out |= RG_OUT_FAULT; // the reference panics
             }
-            if (f & RG_MF_VALID) {
+            if (f & RG_MF_HEARTBEAT) { // Raft::handle_heartbeat_response (raft.rs:1777-1803)
+                if (r.mc[S] > r.pc[S]) { // update_committed(m.commit)
+                    r.pc[S] = r.mc[S];
+                    r.dirty |= 1u << (16 + S);
+                }
+                pb = (pb | RG_PF_RECENT_ACTIVE) & ~RG_PF_PAUSED; // recent_active = true; resume()
+                if (state == RG_STATE_REPLICATE && (f & RG_MF_INS_FULL)) out |= 1u << (24 + S); // ins.free_first_one()
+                if (r.mt[S] < r.hi || st.prs[o] != 0) out |= 1u << (8 + S); // send_append(m.from)
+            } else if (f & RG_MF_VALID) {
                 const u64 idx = r.mi[S];
                 const bool reject = (f & RG_MF_REJECT) != 0;
                 if ((idx >> 63) || (!reject && idx > r.hi)) out |= RG_OUT_FAULT;

@@ -92,6 +92,21 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st,
     rg_store_group<P>(r, st, g);
 }
 
+// Sparse variant: lane i owns group list[i] (the groups an ingest touched). Same arithmetic; accesses
+// are gathers instead of streams, and the consumed event row is cleared so the message columns are
+// all-zero again outside the touched set.
+template <int P, bool GC>
+__global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw) {
+    const u64 i = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const u64 g = list[i];
+    RgGroup<P> r;
+    rg_load_group<P>(r, st, ms, g);
+    rg_group_tick<P, GC>(r, st, ms, g);
+    rg_store_group<P>(r, st, g);
+    mflags_rw[g] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels: the tick (RG_VARIANT_LDS) -- one wave per 128-group batch, columns staged through LDS.
 // Global side: lane l moves groups {2l, 2l+1} of the batch with 16-B loads/stores (1 KiB per wave
@@ -181,6 +196,9 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
 // launcher
 // ------------------------------------------------------------------------------------------------
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
+template <int P>
+void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
+                           const u32 *n_ptr, u64 n_upper, u64 *mflags_rw);
 
 #ifdef RG_TICK_INSTANTIATE
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
@@ -195,13 +213,28 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
     if (gc) rg_launch_tick_gc<P, true>(stream, st, ms, variant);
     else rg_launch_tick_gc<P, false>(stream, st, ms, variant);
 }
+template <int P>
+void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
+                           const u32 *n_ptr, u64 n_upper, u64 *mflags_rw) {
+    const dim3 grid(rg_grid_for(n_upper, RG_BLOCK)), block(RG_BLOCK);
+    if (gc) hipLaunchKernelGGL((k_tick_list<P, true>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw);
+    else hipLaunchKernelGGL((k_tick_list<P, false>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw);
+}
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
 #endif

@@ -6,3 +6,5 @@
 #include "rg_tick_kernels.h"
 
 template void rg_launch_tick_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+template void rg_launch_tick_list_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64,
+                                          u64 *);

@@ -30,7 +30,7 @@ class PF:
 
 
 class MF:
-    VALID, REJECT, HAS_RS, INS_FULL, SENT, APPEND = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20
+    VALID, REJECT, HAS_RS, INS_FULL, SENT, APPEND, HEARTBEAT = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
 
 
 class OUT:
@@ -91,6 +91,15 @@ class AppendResponse(C.Structure):
                 ("ins_full", C.c_uint8), ("pad", C.c_uint8 * 6)]
 
 
+class WireMsg(C.Structure):
+    _fields_ = [("group", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64), ("hint", C.c_uint64),
+                ("rs", C.c_uint64), ("slot", C.c_uint32), ("flags", C.c_uint32)]
+
+
+WIRE_DTYPE = np.dtype([("group", "<u8"), ("index", "<u8"), ("commit", "<u8"), ("hint", "<u8"), ("rs", "<u8"),
+                       ("slot", "<u4"), ("flags", "<u4")])
+
+
 class CellWrite(C.Structure):
     _fields_ = [("group", C.c_uint64), ("slot", C.c_uint32), ("field_mask", C.c_uint32),
                 ("match", C.c_uint64), ("next", C.c_uint64), ("pr_commit", C.c_uint64),
@@ -121,8 +130,13 @@ SYMBOLS = {
     "rg_recompute": (_i, [_vp]),
     "rg_maximal_committed_index": (_i, [_vp, _vp, _vp]),
     "rg_results": (_i, [_vp, _vp, _vp]),
+    "rg_heartbeat_commits": (_i, [_vp, _vp, _vp]),
+    "rg_step_heartbeat_response": (_i, [_vp, _u64, _u64, _u64, _u64, C.c_uint8]),
     "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 4)]),
+    "rg_ingest": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "rg_tick_ingested": (_i, [_vp, C.POINTER(_u64)]),
+    "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_vote_result": (_i, [_vp, _vp, _vp, _vp]),
     "rg_quorum_recently_active": (_i, [_vp, _vp]),
     "rg_set_peers": (_i, [_vp, _u64, C.POINTER(_u64), C.c_uint32, _u64]),
@@ -293,6 +307,31 @@ class Engine:
         m = _Msgs(_ptr(m_index), _ptr(m_commit), _ptr(m_hint), _ptr(m_rs), _ptr(m_flags))
         self._check(self.L.rg_tick_device(self.h, C.byref(m)))
 
+    def ingest(self, records):
+        """records: numpy structured array of WIRE_DTYPE (wire-order AppendResponse records). Returns the
+        number of dropped duplicate / malformed records."""
+        rec = np.ascontiguousarray(records, dtype=WIRE_DTYPE)
+        dup = _u64(0)
+        self._check(self.L.rg_ingest(self.h, rec.ctypes.data, len(rec), C.byref(dup)))
+        return dup.value
+
+    def tick_ingested(self):
+        n = _u64(0)
+        self._check(self.L.rg_tick_ingested(self.h, C.byref(n)))
+        return n.value
+
+    def ingested_results(self):
+        n = _u64(0)
+        self._check(self.L.rg_ingested_results(self.h, None, None, None, 0, C.byref(n)))
+        k = n.value
+        groups = np.empty(k, dtype=np.uint64)
+        commit = np.empty(k, dtype=np.uint64)
+        out = np.empty(k, dtype=np.uint32)
+        if k:
+            self._check(self.L.rg_ingested_results(self.h, groups.ctypes.data, commit.ctypes.data, out.ctypes.data, k,
+                                                   C.byref(n)))
+        return groups, commit, out
+
     def recompute(self):
         self._check(self.L.rg_recompute(self.h))
 
@@ -301,6 +340,15 @@ class Engine:
         gc = np.empty(self.n_groups, dtype=np.uint8) if with_flag else None
         self._check(self.L.rg_maximal_committed_index(self.h, mci.ctypes.data, _ptr(gc)))
         return (mci, gc) if with_flag else mci
+
+    def heartbeat_commits(self):
+        """bcast_heartbeat: min(matched, committed) per slot -> [P][stride] u64 (host copy)."""
+        hb = np.empty((self.n_slots, self.stride), dtype=np.uint64)
+        self._check(self.L.rg_heartbeat_commits(self.h, None, hb.ctypes.data))
+        return hb
+
+    def step_heartbeat_response(self, group, from_, term, commit=0, ins_full=False):
+        self._check(self.L.rg_step_heartbeat_response(self.h, group, from_, term, commit, int(ins_full)))
 
     def results(self):
         commit = np.empty(self.n_groups, dtype=np.uint64)

@@ -54,6 +54,14 @@ class OracleLeader:
     def sent(self, pid):
         return O.lib().ro_progress_update_state(self.cl.pr(0, pid), self.cl.last_index(0))
 
+    def heartbeat_commit(self, to):
+        return O.lib().ro_heartbeat_commit(self.cl.h, 0, to)
+
+    def step_heartbeat_response(self, from_, commit=0, ins_full=False):
+        o = O.Out()
+        O.lib().ro_handle_heartbeat_response(self.cl.h, 0, from_, commit, 1 if ins_full else 0, o)
+        return {"send_append": bool(o.send_append), "free_first_one": bool(o.free_to)}
+
     def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False):
         o = self.cl.step(0, from_, index, commit, reject, reject_hint, request_snapshot, 1 if ins_full else 0)
         return {"send_append": bool(o.send_append), "send_more": bool(o.send_more),
@@ -169,6 +177,17 @@ class EngineLeader:
     def sent(self, pid):
         self.msgs.m_flags[0, pid - 1] = self.rg.MF.SENT
         return -1 if (self._tick() & 2) else 0
+
+    def heartbeat_commit(self, to):
+        return int(self.eng.heartbeat_commits()[to - 1, 0])
+
+    def step_heartbeat_response(self, from_, commit=0, ins_full=False):
+        MF = self.rg.MF
+        s = from_ - 1
+        self.msgs.m_commit[s, 0] = commit
+        self.msgs.m_flags[0, s] = MF.HEARTBEAT | (MF.INS_FULL if ins_full else 0)
+        out = self._tick()
+        return {"send_append": bool((out >> (8 + s)) & 1), "free_first_one": bool((out >> (24 + s)) & 1)}
 
     def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False):
         MF = self.rg.MF

@@ -4,7 +4,7 @@ Test infrastructure: plain numpy, no dependency on the oracle or the engine.
 """
 import numpy as np
 
-MF_VALID, MF_REJECT, MF_HAS_RS, MF_INS_FULL, MF_SENT, MF_APPEND = 1, 2, 4, 8, 16, 32
+MF_VALID, MF_REJECT, MF_HAS_RS, MF_INS_FULL, MF_SENT, MF_APPEND, MF_HEARTBEAT = 1, 2, 4, 8, 16, 32, 64
 
 
 def random_cfg(rng, n_groups, n_slots, joint_frac=0.3, learner_frac=0.2, group_commit_frac=0.0,
@@ -69,7 +69,7 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
     return st
 
 
-def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p=0.0, sent_p=0.5):
+def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p=0.0, sent_p=0.5, heartbeat_p=0.1):
     """One tick of random messages against state `st` (fills an alloc_msgs() dict in place)."""
     G, P = st["n_groups"], st["n_slots"]
     self_slot = ((st["cfg"] >> 16) & 7).astype(np.int64)
@@ -77,7 +77,8 @@ def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p
     for p in range(P):
         m, nx, hi = st["match"][p, :G], st["next"][p, :G], st["term_hi"]
         is_self = self_slot == p
-        valid = rng.random(G) < valid_p
+        hb = (rng.random(G) < heartbeat_p) & ~is_self  # a MsgHeartbeatResponse instead of an AppendResponse
+        valid = (rng.random(G) < valid_p) & ~hb
         reject = valid & (rng.random(G) < reject_p) & ~is_self
         has_rs = reject & (rng.random(G) < rs_p)
         sent = (rng.random(G) < sent_p) & ~is_self
@@ -105,7 +106,7 @@ def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p
         msgs["m_hint"][p, :G] = hint
         msgs["m_rs"][p, :G] = np.where(has_rs, rng.integers(1, 100, size=G), 0).astype(np.uint64)
         f = (valid * MF_VALID) | (reject * MF_REJECT) | (has_rs * MF_HAS_RS) | (ins_full * MF_INS_FULL) | \
-            (sent * MF_SENT) | (append * MF_APPEND)
+            (sent * MF_SENT) | (append * MF_APPEND) | (hb * MF_HEARTBEAT)
         msgs["m_flags"][:, p] = f.astype(np.uint8)
     return msgs
 

@@ -115,6 +115,8 @@ def lib():
         "ro_maybe_commit": (C.c_bool, [vp, sz]),
         "ro_handle_append_response": (None, [vp, sz, C.POINTER(Msg), C.POINTER(Out)]),
         "ro_on_persist_entries": (C.c_bool, [vp, sz, u64]),
+        "ro_handle_heartbeat_response": (None, [vp, sz, u64, u64, C.c_int8, C.POINTER(Out)]),
+        "ro_heartbeat_commit": (u64, [vp, sz, u64]),
         "ro_group_vote_result": (C.c_int, [vp, sz, C.POINTER(u64), C.POINTER(C.c_uint8), sz]),
         "ro_quorum_recently_active": (C.c_bool, [vp, sz, u64]),
         "ro_load_soa": (C.c_int, [vp, C.POINTER(SoaState), u64, sz]),

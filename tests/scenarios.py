@@ -199,8 +199,38 @@ def scenario_joint_needs_both_majorities(B):
     assert ld.committed() == 7, "incoming {10,8,9} -> 9, outgoing {9,6,7} -> 7"
 
 
+def scenario_handle_heartbeat_resp(B):
+    """test_raft.rs:1398-1440 test_handle_heartbeat_resp: a heartbeat response from a peer that is behind
+    re-sends MsgAppend until an MsgAppResp catches it up; + test_progress_resume_by_heartbeat_resp
+    (test_raft.rs:331-346) and the heartbeat commit rule min(matched, committed) (raft.rs:830-838)."""
+    ld = B(1, 1, [1, 2], log=[(1, 1), (2, 2), (3, 3), (1, 4)], committed=4, next_idx=4)
+    # (log terms are irrelevant here; leader at last_index 4, peer 2 just reset to Probe/match 0)
+    ld.set_progress(1, match=4, next=5, state=REPLICATE)
+    assert ld.heartbeat_commit(2) == 0, "MUST NOT forward the follower's commit to an unmatched index"
+    out = ld.step_heartbeat_response(2)
+    assert out["send_append"]
+    out = ld.step_heartbeat_response(2)
+    assert out["send_append"], "a second heartbeat response generates another MsgApp re-send"
+    ld.step(2, 4)  # MsgAppResp catches the peer up
+    assert ld.heartbeat_commit(2) == 4
+    out = ld.step_heartbeat_response(2, commit=4)
+    assert not out["send_append"], "once caught up, heartbeats no longer send MsgApp"
+    assert ld.progress(2)["committed_index"] == 4 and ld.progress(2)["recent_active"]
+    # resume by heartbeat response
+    ld.set_progress(2, paused=True, state=PROBE)
+    ld.step_heartbeat_response(2)
+    assert not ld.progress(2)["paused"]
+    # a full inflight window gets one slot freed (raft.rs:1796-1798)
+    ld.set_progress(2, state=REPLICATE)
+    assert ld.step_heartbeat_response(2, ins_full=True)["free_first_one"]
+    assert not ld.step_heartbeat_response(2, ins_full=False)["free_first_one"]
+    # a pending snapshot request also triggers send_append (raft.rs:1800)
+    ld.set_progress(2, pending_request_snapshot=3)
+    assert ld.step_heartbeat_response(2)["send_append"]
+
+
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
        scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
-       scenario_learners_never_count, scenario_joint_needs_both_majorities]
+       scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp]

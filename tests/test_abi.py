@@ -44,7 +44,7 @@ def test_oracle_adapter_uses_the_header_bit_layouts():
     osrc = open(os.path.join(ROOT, "oracle", "raft_oracle.c")).read()
     odef = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(RO_\w+)\s+(0x[0-9a-fA-F]+u?)\s", osrc)}
     for name in ("PF_STATE_MASK", "PF_PAUSED", "PF_RECENT_ACTIVE", "MF_VALID", "MF_REJECT", "MF_HAS_RS",
-                 "MF_INS_FULL", "MF_SENT", "MF_APPEND", "OUT_CHANGED", "OUT_FAULT", "OUT_TIMEOUT_NOW"):
+                 "MF_INS_FULL", "MF_SENT", "MF_APPEND", "MF_HEARTBEAT", "OUT_CHANGED", "OUT_FAULT", "OUT_TIMEOUT_NOW"):
         assert d["RG_" + name] == odef["RO_" + name], name
     from raft_rs_amd import engine as E
     assert (E.MF.VALID, E.MF.REJECT, E.MF.HAS_RS, E.MF.INS_FULL, E.MF.SENT, E.MF.APPEND) == tuple(

@@ -1,0 +1,130 @@
+"""GPU: the sparse path (rg_ingest -> rg_tick_ingested) against the oracle: wire-order records for a
+small random subset of the groups, bit-exact state afterwards, results only for the touched groups."""
+import numpy as np
+import pytest
+
+import fuzz
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def records_from_msgs(rg, msgs, groups, rng, n_slots):
+    from raft_rs_amd.engine import WIRE_DTYPE
+    recs = []
+    for g in groups:
+        for p in range(n_slots):
+            f = int(msgs["m_flags"][g, p])
+            if f:
+                recs.append((g, msgs["m_index"][p, g], msgs["m_commit"][p, g], msgs["m_hint"][p, g],
+                             msgs["m_rs"][p, g], p, f))
+    arr = np.array(recs, dtype=WIRE_DTYPE)
+    rng.shuffle(arr)  # wire order is arbitrary across cells
+    return arr
+
+
+@pytest.mark.parametrize("n_slots", [3, 5, 7])
+def test_sparse_ticks_match_oracle(rg, n_slots):
+    rng = np.random.default_rng(500 + n_slots)
+    G = 20000
+    st = O.alloc_state(G, n_slots)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots)
+    fuzz.random_state(rng, st)
+    eng = rg.Engine(G, n_slots)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=4)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    mb = rg.MsgBuffers(G, n_slots, eng.stride)
+    for t in range(6):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs)
+        if t == 3:  # a dense tick in between (RG_COL_OUT then holds dense results)
+            for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+                getattr(mb, k)[...] = msgs[k]
+            eng.tick(mb)
+            cl.tick_soa(msgs, gout)
+        else:
+            touched = np.sort(rng.choice(G, size=G // 40, replace=False))
+            keep = np.zeros(G, dtype=bool)
+            keep[touched] = True
+            msgs["m_flags"][~keep] = 0
+            recs = records_from_msgs(rg, msgs, touched, rng, n_slots)
+            # split the batch in two ingests to exercise accumulation
+            half = len(recs) // 2
+            assert eng.ingest(recs[:half]) == 0
+            assert eng.ingest(recs[half:]) == 0
+            n = eng.tick_ingested()
+            with_events = np.nonzero(msgs["m_flags"].any(axis=1))[0]
+            assert n == len(with_events)
+            cl.tick_soa(msgs, gout)
+            groups, commit, out = eng.ingested_results()
+            order = np.argsort(groups)
+            assert (groups[order] == with_events).all()
+            cl.store_soa(st)
+            assert (commit[order] == st["commit"][with_events]).all()
+            assert (out[order] == gout[with_events]).all()
+        got = eng.read_state()
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, got, G, n_slots)
+        assert not diffs, (t, diffs[:5])
+        assert (got["out"] == gout).all(), f"tick {t}: RG_COL_OUT must be zero for untouched groups"
+    eng.close()
+
+
+def test_duplicate_and_malformed_records_are_dropped_and_counted(rg):
+    from raft_rs_amd.engine import WIRE_DTYPE
+    G, P = 1000, 3
+    eng = rg.Engine(G, P)
+    eng.workload_init(rg.WL_MAJORITY)
+    st = eng.read_state()
+    hi = int(st["term_hi"][7])
+    recs = np.array([(7, hi, 0, 0, 0, 1, rg.MF.VALID), (7, hi - 1, 0, 0, 0, 1, rg.MF.VALID),  # same cell twice
+                     (G + 5, 1, 0, 0, 0, 0, rg.MF.VALID), (3, 1, 0, 0, 0, 9, rg.MF.VALID),   # bad group / slot
+                     (9, 1, 0, 0, 0, 2, 0)], dtype=WIRE_DTYPE)                                # no event bits
+    assert eng.ingest(recs) == 4
+    assert eng.tick_ingested() == 1
+    groups, commit, out = eng.ingested_results()
+    assert list(groups) == [7]
+    got = eng.read_state()
+    assert got["match"][1, 7] in (hi, max(hi - 1, st["match"][1, 7]))
+    assert eng.tick_ingested() == 0  # nothing pending
+    eng.close()
+
+
+def test_flush_uses_the_sparse_path_for_few_groups(rg):
+    G, P, TERM = 4096, 3, 5
+    eng = rg.Engine(G, P)
+    eng.workload_init(rg.WL_MAJORITY)
+    st = eng.read_state()
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    for g in range(G):
+        eng.set_peers(g, [11, 12, 13], TERM)
+    rng = np.random.default_rng(9)
+    for rnd in range(3):
+        touched = rng.choice(G, size=50, replace=False)
+        want = {}
+        for g in touched:
+            g = int(g)
+            pr = cl.pr(g, 2)
+            idx = min(cl.last_index(g), pr.matched + int(rng.integers(1, 5)))
+            eng.mark_sent(g, 12)
+            eng.step(g, 12, TERM, idx, commit=min(idx, cl.committed(g)))
+            O.lib().ro_progress_update_state(pr, cl.last_index(g))
+            o = cl.step(g, 2, idx, commit=min(idx, cl.committed(g)), ins_full=0)
+            want[g] = (cl.committed(g), (1 if o.commit_changed else 0) | (int(o.send_append) << 9) |
+                       (int(o.send_more) << 17) | (int(o.free_to) << 25))
+        eng.flush()
+        groups, commit, out = eng.ingested_results()
+        assert sorted(groups.tolist()) == sorted(want)
+        for g, c, o in zip(groups, commit, out):
+            assert (int(c), int(o)) == want[int(g)], (rnd, g)
+    got = eng.read_state()
+    ref = O.alloc_state(G, P)
+    for k in ("cfg", "term_lo"):
+        ref[k][...] = st[k]
+    cl.store_soa(ref)
+    assert not fuzz.diff_states(ref, got, G, P, keys=("match", "next", "pr_commit", "pflags", "commit"))
+    eng.close()

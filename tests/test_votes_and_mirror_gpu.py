@@ -135,3 +135,24 @@ def test_host_mirror_steps_like_raw_node(rg):
         assert (got[k][:, :G] == ref[k][:, :G]).all(), k
     assert (got["pflags"] == ref["pflags"]).all()
     eng.close()
+
+
+def test_heartbeat_commits_match_oracle(rg):
+    import fuzz
+    rng = np.random.default_rng(21)
+    G, P = 3000, 5
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st)
+    eng = rg.Engine(G, P)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=3)
+    hb = eng.heartbeat_commits()
+    present = (st["cfg"] >> 24) & 0xff
+    for p in range(P):
+        want = np.array([O.lib().ro_heartbeat_commit(cl.h, g, p + 1) for g in range(G)], dtype=np.uint64)
+        sel = ((present >> p) & 1) == 1
+        assert (hb[p, :G][sel] == want[sel]).all()
+        assert (hb[p, :G][~sel] == 0).all()
+    eng.close()
