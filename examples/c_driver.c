@@ -1,0 +1,87 @@
+/* c_driver.c -- the C ABI used directly from plain C (no Python, no torch): a 3-peer group commits an
+ * entry once a majority has acknowledged it. Build + run (on an MI355X):
+ *   gcc -std=c99 -Iinclude examples/c_driver.c -o examples/c_driver -Lraft_rs_amd -lraftgroups \
+ *       -Wl,-rpath,$PWD/raft_rs_amd && ./examples/c_driver
+ * Mirrors harness/tests/integration_cases/test_raft_paper.rs:499-534 (test_leader_acknowledge_commit). */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "raftgroups.h"
+
+#define CHECK(call)                                                                  \
+    do {                                                                             \
+        int rc__ = (call);                                                           \
+        if (rc__ != RG_OK) {                                                         \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc__, rg_last_error());         \
+            return 2;                                                                \
+        }                                                                            \
+    } while (0)
+
+int main(void) {
+    enum { G = 4, P = 3 };
+    rg_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_groups = G;
+    cfg.n_slots = P;
+    rg_engine *h = NULL;
+    CHECK(rg_create(&cfg, &h));
+    const uint64_t stride = rg_stride(h);
+
+    /* every group: leader = slot 0 with entries 1..2 of its term persisted; followers at match 1; commit 1 */
+    uint64_t *col = calloc(P * stride, 8);
+    uint64_t per_group[G];
+    uint32_t cfgw[G];
+    uint8_t pflags[G][8];
+    memset(pflags, 0, sizeof pflags);
+    for (int g = 0; g < G; g++) {
+        for (int p = 0; p < P; p++) {
+            col[p * stride + g] = p == 0 ? 2 : 1;
+            pflags[g][p] = RG_STATE_REPLICATE;
+        }
+        cfgw[g] = RG_CFG_MAKE(0x7, 0, 0, 0, 0, 0x7);
+    }
+    CHECK(rg_load_column(h, RG_COL_MATCH, col, rg_column_bytes(h, RG_COL_MATCH)));
+    for (int g = 0; g < G; g++)
+        for (int p = 0; p < P; p++) col[p * stride + g] = (p == 0 ? 2 : 1) + 1;
+    CHECK(rg_load_column(h, RG_COL_NEXT, col, rg_column_bytes(h, RG_COL_NEXT)));
+    CHECK(rg_load_column(h, RG_COL_PFLAGS, pflags, rg_column_bytes(h, RG_COL_PFLAGS)));
+    CHECK(rg_load_column(h, RG_COL_CFG, cfgw, rg_column_bytes(h, RG_COL_CFG)));
+    for (int g = 0; g < G; g++) per_group[g] = 1;
+    CHECK(rg_load_column(h, RG_COL_COMMIT, per_group, rg_column_bytes(h, RG_COL_COMMIT)));
+    CHECK(rg_load_column(h, RG_COL_TERM_LO, per_group, rg_column_bytes(h, RG_COL_TERM_LO)));
+    for (int g = 0; g < G; g++) per_group[g] = 2;
+    CHECK(rg_load_column(h, RG_COL_TERM_HI, per_group, rg_column_bytes(h, RG_COL_TERM_HI)));
+
+    /* group g receives acks for index 2 from g followers (0, 1 or 2 of them) */
+    rg_wire_msg recs[2 * G];
+    uint64_t n = 0, dup = 0, touched = 0;
+    for (int g = 0; g < G; g++) {
+        for (int k = 0; k < (g < 3 ? g : 2); k++) {
+            memset(&recs[n], 0, sizeof recs[n]);
+            recs[n].group = (uint64_t)g;
+            recs[n].slot = 1u + (uint32_t)k;
+            recs[n].index = 2;
+            recs[n].commit = 1;
+            recs[n].flags = RG_MF_VALID;
+            n++;
+        }
+    }
+    CHECK(rg_ingest(h, recs, n, &dup));
+    CHECK(rg_tick_ingested(h, &touched));
+    uint64_t commit[G];
+    uint32_t out[G];
+    CHECK(rg_results(h, commit, out));
+    int ok = dup == 0 && touched == 3;
+    for (int g = 0; g < G; g++) {
+        const int acks = g < 3 ? g : 2;
+        const uint64_t want = acks >= 1 ? 2 : 1; /* leader + one follower = majority of 3 */
+        printf("group %d: %d acks -> commit %llu (want %llu) out %#x\n", g, acks, (unsigned long long)commit[g],
+               (unsigned long long)want, out[g]);
+        ok = ok && commit[g] == want && ((out[g] & RG_OUT_CHANGED) != 0) == (want == 2);
+    }
+    rg_destroy(h);
+    free(col);
+    puts(ok ? "C_DRIVER_OK" : "C_DRIVER_FAILED");
+    return ok ? 0 : 1;
+}

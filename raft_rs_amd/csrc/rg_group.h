@@ -1,5 +1,9 @@
 // rg_group.h -- per-group arithmetic of the hot path, written for one lane = one raft group.
 //
+// The functions are __host__ __device__ only so that tests/host_check/ can compile this very header
+// for the host and diff it against the CPU restatement of the reference without a GPU; the product library never runs
+// them on the host.
+//
 // All loops are over compile-time slot counts so every array lives in VGPRs (no dynamic register
 // indexing, no scratch). Citations are file:line in the pingcap/raft-rs v0.6.0 tree.
 #pragma once
@@ -25,7 +29,7 @@ template <int P> struct RgQuorum {
     // (a voter without a Progress acks 0: unwrap_or_default, majority.rs:80-82)
     u32 ge[P]; // bit j of ge[i] = (v[j] >= v[i])
 
-    RG_D void init(const u64 (&v)[P]) {
+    RG_HD void init(const u64 (&v)[P]) {
 #pragma unroll
         for (int i = 0; i < P; i++) ge[i] = 1u << i;
 #pragma unroll
@@ -41,7 +45,7 @@ template <int P> struct RgQuorum {
     }
 
     // slot S's value was raised to nv = v[S]: refresh row S and column S.
-    template <int S> RG_D void update(const u64 (&v)[P]) {
+    template <int S> RG_HD void update(const u64 (&v)[P]) {
         const u64 nv = v[S];
         u32 row = 1u << S;
 #pragma unroll
@@ -56,15 +60,15 @@ template <int P> struct RgQuorum {
     }
 
     // q-th largest over the voter mask M (majority.rs:95-101); empty config => u64::MAX (:71-75).
-    RG_D u64 kth(const u64 (&v)[P], u32 M) const {
-        const u32 n = (u32)__popc(M);
+    RG_HD u64 kth(const u64 (&v)[P], u32 M) const {
+        const u32 n = (u32)__builtin_popcount(M);
         if (n == 0) return ~0ULL;
         const u32 q = n / 2u + 1u;
         u64 t = 0;
 #pragma unroll
         for (int i = 0; i < P; i++) {
             const bool in = (M >> i) & 1u;
-            const bool ok = in && ((u32)__popc(ge[i] & M) >= q);
+            const bool ok = in && ((u32)__builtin_popcount(ge[i] & M) >= q);
             const u64 c = ok ? v[i] : 0ULL;
             t = c > t ? c : t;
         }
@@ -72,7 +76,7 @@ template <int P> struct RgQuorum {
     }
 
     // JointConfig::committed_index (src/quorum/joint.rs:47-51): min of both majorities.
-    RG_D u64 mci(const u64 (&v)[P], u32 incoming, u32 outgoing) const {
+    RG_HD u64 mci(const u64 (&v)[P], u32 incoming, u32 outgoing) const {
         const u64 a = kth(v, incoming);
         const u64 b = kth(v, outgoing);
         return a < b ? a : b;
@@ -85,8 +89,8 @@ template <int P> struct RgQuorum {
 // the sort so that all indexing stays static. Rare path (ProgressTracker.group_commit, tracker.rs:207).
 // ---------------------------------------------------------------------------------------------
 template <int P>
-RG_D u64 rg_majority_ci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 M, bool &flag) {
-    const u32 n = (u32)__popc(M);
+RG_HD u64 rg_majority_ci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 M, bool &flag) {
+    const u32 n = (u32)__builtin_popcount(M);
     if (n == 0) {
         flag = true;
         return ~0ULL;
@@ -145,7 +149,7 @@ RG_D u64 rg_majority_ci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 M, boo
 // ProgressTracker::maximal_committed_index with group commit on (tracker.rs:294-298, joint.rs:47-51).
 // (not inlined: it is called after every accepted ack and only the rare group-commit kernels carry it)
 template <int P>
-__device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
+__host__ __device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
     bool fi, fo;
     const u64 a = rg_majority_ci_group<P>(v, gid, incoming, fi);
     const u64 b = rg_majority_ci_group<P>(v, gid, outgoing, fo);
@@ -171,7 +175,7 @@ template <int P> struct RgGroup {
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
 // (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
 // ends at last_index); commit_to (:286-300) can then never exceed last_index.
-RG_D bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
+RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
     if (mci > commit && mci >= lo && mci <= hi) {
         commit = mci;
         return true;
@@ -195,7 +199,7 @@ template <int P, bool GC> struct RgTick {
     u32 acc;      // slots whose maybe_update returned true this tick (each is followed by a maybe_commit)
     u32 acc_oldp; // ... of those, the ones that were paused before the ack (raft.rs:1724,1749-1751)
 
-    RG_D RgTick(RgGroup<P> &r_, const RgState &st_, const RgMsgs &ms_, u64 g_)
+    RG_HD RgTick(RgGroup<P> &r_, const RgState &st_, const RgMsgs &ms_, u64 g_)
         : r(r_), st(st_), ms(ms_), g(g_) {
         const u32 cfg = r.cfg;
         incoming = RG_CFG_INCOMING(cfg);
@@ -214,7 +218,7 @@ template <int P, bool GC> struct RgTick {
     }
 
     // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v`.
-    RG_D u64 mci_of(const RgQuorum<P> &qm, const u64 (&v)[P]) {
+    RG_HD u64 mci_of(const RgQuorum<P> &qm, const u64 (&v)[P]) {
         if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
             u64 gidv[P];
 #pragma unroll
@@ -228,12 +232,12 @@ template <int P, bool GC> struct RgTick {
 
     // Progress::reset_state (progress.rs:75-80): paused=false, pending_snapshot=0, state; the
     // Inflights reset is the host's (it sees the transition through the state column).
-    RG_D void reset_state(u32 &pb, u32 new_state, u64 o) {
+    RG_HD void reset_state(u32 &pb, u32 new_state, u64 o) {
         pb = (pb & ~(RG_PF_PAUSED | RG_PF_STATE_MASK)) | new_state;
         st.psnap[o] = 0;
     }
 
-    template <int S> RG_D void set_next(u64 n) {
+    template <int S> RG_HD void set_next(u64 n) {
         if (r.nx[S] != n) {
             r.nx[S] = n;
             r.dirty |= 1u << (8 + S);
@@ -241,7 +245,7 @@ template <int P, bool GC> struct RgTick {
     }
 
     // Progress::maybe_update (progress.rs:138-150); returns need_update
-    template <int S> RG_D bool maybe_update(u64 idx, u32 &pb) {
+    template <int S> RG_HD bool maybe_update(u64 idx, u32 &pb) {
         const bool upd = r.mt[S] < idx;
         if (upd) {
             r.mt[S] = idx;
@@ -253,7 +257,7 @@ template <int P, bool GC> struct RgTick {
         return upd;
     }
 
-    template <int S> RG_D void slot() {
+    template <int S> RG_HD void slot() {
         const u32 f = (u32)(r.mf >> (8 * S)) & 0xffu;
         if (f == 0 || !((present >> S) & 1u)) return; // no event / no Progress (raft.rs:1663-1673)
         const u32 pb0 = (u32)(r.pf >> (8 * S)) & 0xffu;
@@ -365,7 +369,7 @@ template <int P, bool GC> struct RgTick {
         }
     }
 
-    template <int S> RG_D void self_committed() { // prs[self].update_committed(committed), raft.rs:896-900
+    template <int S> RG_HD void self_committed() { // prs[self].update_committed(committed), raft.rs:896-900
         if ((u32)S == self && ((present >> S) & 1u) && r.pc[S] < r.commit) {
             r.pc[S] = r.commit;
             r.dirty |= 1u << (16 + S);
@@ -373,7 +377,7 @@ template <int P, bool GC> struct RgTick {
     }
 
     // One step of the sequential replay: slot S's accepted ack lands, Raft::maybe_commit runs.
-    template <int S> RG_D void replay_slot(RgQuorum<P> &qm, u64 (&cur)[P], u64 &commit) {
+    template <int S> RG_HD void replay_slot(RgQuorum<P> &qm, u64 (&cur)[P], u64 &commit) {
         if (!((acc >> S) & 1u)) return;
         cur[S] = r.mt[S];
         qm.template update<S>(cur);
@@ -385,22 +389,34 @@ template <int P, bool GC> struct RgTick {
 
     // Raft::maybe_commit (src/raft.rs:893-904) after every accepted ack of the tick, in slot order.
     //
-    // Matches only grow within a tick, so the quorum index is non-decreasing over the message
-    // sequence and, for well-formed acks (index <= last_index at that moment), the final commit
-    // index is decided by the LAST evaluation alone and "some maybe_commit returned true" == "the
-    // final commit index moved". The per-message results are observable only through
-    // `else if old_paused { send_append }` (raft.rs:1749-1751) and through malformed acks (flagged
-    // RG_OUT_FAULT). So: one evaluation on the final matches when neither occurs in this group,
-    // otherwise an exact replay of the sequence (old matches re-read from memory: nothing has been
-    // stored yet). Both paths are bit-identical to the message-at-a-time reference.
-    template <int... S> RG_D void commit_phase(rg_seq<S...>) {
+    // Matches only grow within a tick, so the quorum index mci_k is non-decreasing over the message
+    // sequence. Let k* be the last accepted ack and hi* the last_index at that moment. If
+    // mci_final <= hi*, the final commit index is decided by the evaluation at k* alone (an earlier
+    // evaluation can only have committed some mci_k <= mci_final, and if the last one fails the gate
+    // because mci_final < term_lo or <= commit, every earlier one failed too), and "some maybe_commit
+    // returned true" == "the commit index moved". The per-message results are otherwise observable only
+    // through `else if old_paused { send_append }` (raft.rs:1749-1751). So: ONE evaluation on the final
+    // matches unless an accepted ack came from a paused peer or mci_final > hi* (possible only with
+    // acks beyond last_index), else an exact replay of the sequence (old matches are re-read from
+    // memory: nothing has been stored yet). Both paths are bit-identical to the message-at-a-time
+    // reference for ANY state and input.
+    template <int... S> RG_HD void commit_phase(rg_seq<S...>) {
         if (acc == 0) return;
         const u64 commit0 = r.commit;
         RgQuorum<P> qm;
-        if (acc_oldp == 0 && !(out & RG_OUT_FAULT)) {
+        bool replay = acc_oldp != 0;
+        if (!replay) {
+            const u32 last_acc = 31u - (u32)__builtin_clz(acc);
+            const u64 hi_last = last_acc < self ? last0 : r.hi;
             qm.init(r.mt);
-            if (rg_log_maybe_commit(mci_of(qm, r.mt), r.commit, r.lo, r.hi)) out |= RG_OUT_CHANGED;
-        } else {
+            const u64 mci = mci_of(qm, r.mt);
+            if (mci <= hi_last) {
+                if (rg_log_maybe_commit(mci, r.commit, r.lo, hi_last)) out |= RG_OUT_CHANGED;
+            } else {
+                replay = true;
+            }
+        }
+        if (replay) {
             u64 cur[P];
             ((cur[S] = ((acc >> S) & 1u) ? st.match[(u64)S * st.stride + g] : r.mt[S]), ...);
             qm.init(cur);
@@ -414,7 +430,7 @@ template <int P, bool GC> struct RgTick {
         }
     }
 
-    template <int... S> RG_D void run(rg_seq<S...> seq) {
+    template <int... S> RG_HD void run(rg_seq<S...> seq) {
         (slot<S>(), ...);
         commit_phase(seq);
         r.out = out;
@@ -422,7 +438,7 @@ template <int P, bool GC> struct RgTick {
 };
 
 template <int P, bool GC>
-RG_D void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
+RG_HD void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
     RgTick<P, GC> t(r, st, ms, g);
     t.run(typename rg_make_seq<P>::type{});
 }

@@ -32,7 +32,7 @@ static inline unsigned rg_grid_for(u64 n, unsigned per_block) { return (unsigned
 // ------------------------------------------------------------------------------------------------
 // kernels: the tick (RG_VARIANT_LANE)
 // ------------------------------------------------------------------------------------------------
-template <typename T> RG_D T rg_ld_stream(const T *p) { // read-once data: keep it out of L2/MALL
+template <typename T> RG_HD T rg_ld_stream(const T *p) { // read-once data: keep it out of L2/MALL
 #if RG_OPT_NT_MSG
     return __builtin_nontemporal_load(p);
 #else
@@ -40,7 +40,7 @@ template <typename T> RG_D T rg_ld_stream(const T *p) { // read-once data: keep 
 #endif
 }
 
-template <int P> RG_D void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
+template <int P> RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
     r.mf = rg_ld_stream(ms.mflags + g);
     r.pf = st.pflags[g];
     r.cfg = st.cfg[g];
@@ -58,7 +58,7 @@ template <int P> RG_D void rg_load_group(RgGroup<P> &r, const RgState &st, const
     }
 }
 
-template <int P> RG_D void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
+template <int P> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines

@@ -47,6 +47,9 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
         lag = rng.integers(0, 10, size=G).astype(np.uint64)
         m = (last - np.minimum(lag, last)).astype(np.uint64)
         m = np.where(rng.random(G) < 0.1, 0, m).astype(np.uint64)
+        # ill-formed leftovers (matched beyond last_index, as after a malformed ack): the engine must
+        # still follow the reference arithmetic exactly
+        m = np.where(rng.random(G) < 0.02, last + rng.integers(1, 4, size=G).astype(np.uint64), m).astype(np.uint64)
         st["match"][p, :G] = m
         nxt = m + 1 + rng.integers(0, 4, size=G).astype(np.uint64)
         nxt = np.where(rng.random(G) < 0.03, m, nxt)  # next <= matched corner (progress.rs:145-147)
@@ -60,7 +63,7 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
         st["pflags"][:, p] = state | (paused << 2) | (ra << 3)
         ps = np.where(state == 2, m + rng.integers(0, 5, size=G).astype(np.uint64) - 2, 0)
         ps = np.where(rng.random(G) < 0.02, rng.integers(0, 50, size=G), ps)  # stale pending_snapshot on non-Snapshot
-        st["pend_snap"][p, :G] = np.maximum(ps, 0).astype(np.uint64)
+        st["pend_snap"][p, :G] = np.maximum(ps.astype(np.int64), 0).astype(np.uint64)
         st["pend_rs"][p, :G] = np.where(rng.random(G) < 0.05, rng.integers(1, 30, size=G), 0).astype(np.uint64)
         if with_gids:
             st["gid"][p, :G] = rng.integers(0, 4, size=G).astype(np.uint64)

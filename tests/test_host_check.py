@@ -1,0 +1,91 @@
+"""CPU-only differential test of the ENGINE'S OWN per-group arithmetic: tests/host_check/ compiles
+raft_rs_amd/csrc/rg_group.h (the header the HIP kernels inline) for the host and this file diffs it
+against the oracle on seeded random streams. It catches arithmetic regressions without a GPU; the GPU
+parity tests (-m gpu) remain the gate for the kernels themselves. Nothing here is product code."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import fuzz
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_check", "host_tick.hip")
+LIB = os.path.join(HERE, "host_check", "libhost_tick.so")
+CSRC = os.path.join(os.path.dirname(HERE), "raft_rs_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def host_tick():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
+                               "-Wno-pass-failed", SRC, "-o", LIB])
+    fn = C.CDLL(LIB).rg_host_check_tick
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 17 + [C.c_int]
+
+    def tick(st, msgs, out, gc):
+        cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
+                                "term_lo", "term_hi", "cfg")] + [out] + \
+               [msgs[k] for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")]
+        rc = fn(st["n_slots"], st["n_groups"], st["stride"], *[c.ctypes.data for c in cols], int(gc))
+        assert rc == 0
+    return tick
+
+
+def copy_state(st):
+    return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("gc", [False, True])
+@pytest.mark.parametrize("n_slots", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_device_arithmetic_on_host_matches_oracle(host_tick, n_slots, gc):
+    rng = np.random.default_rng(4000 + n_slots + (100 if gc else 0))
+    G = 3000
+    st = O.alloc_state(G, n_slots)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05, group_commit_frac=0.5 if gc else 0.0)
+    fuzz.random_state(rng, st, small_values=True, with_gids=gc)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    for t in range(6):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, malformed_p=0.03 if t == 4 else 0.0)
+        host_tick(eng_st, msgs, out, gc)
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+
+
+@pytest.mark.parametrize("workload,n_slots", [(2, 5), (3, 5), (5, 7)])
+def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slots):
+    from raft_rs_amd import engine as E
+    G = 4000
+    st = O.alloc_state(G, n_slots)
+    E.workload_init_host(st, workload)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    mb = E.MsgBuffers(G, n_slots, st["stride"])
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    for t in range(6):
+        E.workload_gen_host(st, mb, workload, t)
+        host_tick(eng_st, mb.as_dict(), out, False)
+        cl.tick_soa(mb.as_dict(), gout)
+        cl.store_soa(st)
+        assert not fuzz.diff_states(st, eng_st, G, n_slots)
+        assert (out == gout).all()
