@@ -74,6 +74,7 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
         elapsed[nthreads] += time.perf_counter() - t0
         evals[nthreads] += n_groups
         cl.store_soa(st)
+    soa = soa_cpu_line(n_groups, n_slots, workload, seed, threads)
     out = {"value": evals[threads] / elapsed[threads] if elapsed[threads] else None, "unit": "group-evals/s",
            "cores": threads, "kind": "port",
            "sample": f"{n_groups} groups x {n_slots} peers, {sample_ticks} ticks of the same stream "
@@ -81,7 +82,54 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
                      f"(message-at-a-time, per-group hash map like the reference)",
            "value_1core": evals[1] / elapsed[1] if elapsed[1] else None,
            "host_cores": os.cpu_count()}
+    out.update(soa)
     return out
+
+
+def soa_cpu_line(n_groups, n_slots, workload, seed, threads):
+    """Second CPU line: the engine's own struct-of-arrays arithmetic compiled for the host
+    (tests/host_check/, test infrastructure) -- a best-effort CPU implementation of the same algorithm,
+    next to the reference-shaped (hash-map, message-at-a-time) port above."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        import test_host_check as H
+        import oracle_lib as O
+        from raft_rs_amd import engine as E
+        if H.build_lib() is None:
+            return {}
+        fn = C.CDLL(H.LIB).rg_host_check_tick
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 17 + [C.c_int, C.c_ulong, C.c_ulong]
+        st = O.alloc_state(n_groups, n_slots)
+        E.workload_init_host(st, workload, seed=seed)
+        msgs = E.MsgBuffers(n_groups, n_slots, st["stride"])
+        out = np.zeros(n_groups, dtype=np.uint32)
+        cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
+                                "term_lo", "term_hi", "cfg")] + [out] + \
+               [msgs.m_index, msgs.m_commit, msgs.m_hint, msgs.m_rs, msgs.m_flags]
+        ptrs = [c.ctypes.data for c in cols]
+
+        def run(a, b):
+            fn(n_slots, n_groups, st["stride"], *ptrs, 0, a, b)
+
+        res = {}
+        pool = ThreadPoolExecutor(max_workers=threads)
+        for nthreads in (1, threads):
+            total, el = 0, 0.0
+            for t in range(6):
+                E.workload_gen_host(st, msgs, workload, t if nthreads == 1 else t + 6, seed=seed)
+                bounds = [(i * n_groups // nthreads, (i + 1) * n_groups // nthreads) for i in range(nthreads)]
+                t0 = time.perf_counter()
+                list(pool.map(lambda ab: run(*ab), bounds))
+                el += time.perf_counter() - t0
+                total += n_groups
+            res[nthreads] = total / el
+        pool.shutdown()
+        return {"soa_value_1core": res[1], "soa_value": res[threads], "soa_cores": threads,
+                "soa_note": "engine arithmetic (rg_group.h) compiled for the host over the same SoA columns"}
+    except Exception as e:  # noqa: BLE001
+        return {"soa_note": f"unavailable: {type(e).__name__}: {e}"}
 
 
 def main():
@@ -194,19 +242,38 @@ def main():
     E = max(1, args.publish_every)
     n_pub = [0]
 
+    # Size-class engines are independent, so each runs on its own HIP stream (forked from / joined to the
+    # main stream around the region): the tail of one engine's launch overlaps the next engine's head.
+    multi = len(parts) > 1 and os.environ.get("BENCH_GRAPH") != "1"
+    for pt in parts:
+        pt.stream = torch.cuda.Stream() if multi else stream
+        pt.eng.set_stream(pt.stream.cuda_stream)
+
     def run_ticks(t0, n, publishers):
+        if multi:
+            fork = torch.cuda.Event()
+            fork.record(stream)
+            for pt in parts:
+                pt.stream.wait_event(fork)
         for i in range(n):
+            pub_now = publishers is not None and ((i + 1) % E == 0 or i == n - 1)
             for j, pt in enumerate(parts):
                 pt.eng.tick_device(*tick_ptrs(pt, t0 + i))
-                if publishers is not None and ((i + 1) % E == 0 or i == n - 1):
-                    publishers[j].publish(n_pub[0], pt.commit_view)
-            if publishers is not None and ((i + 1) % E == 0 or i == n - 1):
+                if pub_now:
+                    publishers[j].publish(n_pub[0], pt.commit_view, pt.stream)
+            if pub_now:
                 n_pub[0] += 1
+        if publishers is not None:
+            for j, pt in enumerate(parts):
+                publishers[j].join(pt.stream)
+        if multi:
+            for pt in parts:
+                ev = torch.cuda.Event()
+                ev.record(pt.stream)
+                stream.wait_event(ev)
 
     def join(publishers):
-        if publishers is not None:
-            for pb in publishers:
-                pb.join()
+        pass  # run_ticks joins its publishers itself
 
     def set_streams(handle):
         for pt in parts:
@@ -229,15 +296,21 @@ def main():
             gpubs = make_publishers()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                set_streams(torch.cuda.current_stream().cuda_stream)
+                cap = torch.cuda.current_stream()
+                for pt in parts:
+                    pt.stream = cap
+                set_streams(cap.cuda_stream)
                 run_ticks(W, K, gpubs)
-                join(gpubs)
+            for pt in parts:
+                pt.stream = stream
             set_streams(stream.cuda_stream)
             pubs = gpubs
             launch_mode = "hipGraph"
         except Exception as e:  # noqa: BLE001
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
             graph = None
+            for pt in parts:
+                pt.stream = stream
             set_streams(stream.cuda_stream)
             torch.cuda.synchronize()
     if distributed:

@@ -50,17 +50,19 @@ class CommitPublisher:
             self.done = [torch.cuda.Event() for _ in range(2)]
             self.pending = [False, False]  # done[b] recorded and not yet waited for
 
-    def publish(self, i, commit):
+    def publish(self, i, commit, stream=None):
+        """`stream`: the stream the tick kernels of this shard run on (default: torch's current stream)."""
         b = i & 1
         if not self.cuda:
             self.stage[b].copy_(commit)
             self.dist.all_gather_into_tensor(self.gathered[b], self.stage[b])
             return b
         torch = self.torch
-        main = torch.cuda.current_stream()
+        main = stream if stream is not None else torch.cuda.current_stream()
         if self.pending[b]:
             main.wait_event(self.done[b])  # the previous gather out of this staging buffer has finished
-        self.stage[b].copy_(commit, non_blocking=True)
+        with torch.cuda.stream(main):
+            self.stage[b].copy_(commit, non_blocking=True)
         self.ready[b].record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ready[b])
@@ -69,12 +71,12 @@ class CommitPublisher:
         self.pending[b] = True
         return b
 
-    def join(self):
-        """Make the current stream wait for every outstanding gather (needed before the end of a
-        HIP-graph capture, and before reading `result`)."""
+    def join(self, stream=None):
+        """Make `stream` (default: the current stream) wait for every outstanding gather (needed before
+        the end of a HIP-graph capture, and before reading `result`)."""
         if not self.cuda:
             return
-        main = self.torch.cuda.current_stream()
+        main = stream if stream is not None else self.torch.cuda.current_stream()
         for b in range(2):
             if self.pending[b]:
                 main.wait_event(self.done[b])

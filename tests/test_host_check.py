@@ -19,24 +19,31 @@ LIB = os.path.join(HERE, "host_check", "libhost_tick.so")
 CSRC = os.path.join(os.path.dirname(HERE), "raft_rs_amd", "csrc")
 
 
-@pytest.fixture(scope="module")
-def host_tick():
+def build_lib():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
+        return None
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call([hipcc, "-O2", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
+        subprocess.check_call([hipcc, "-O3", "-march=native", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
                                "-Wno-pass-failed", SRC, "-o", LIB])
+    return LIB
+
+
+@pytest.fixture(scope="module")
+def host_tick():
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
     fn = C.CDLL(LIB).rg_host_check_tick
     fn.restype = C.c_int
-    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 17 + [C.c_int]
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 17 + [C.c_int, C.c_ulong, C.c_ulong]
 
     def tick(st, msgs, out, gc):
         cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
                                 "term_lo", "term_hi", "cfg")] + [out] + \
                [msgs[k] for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")]
-        rc = fn(st["n_slots"], st["n_groups"], st["stride"], *[c.ctypes.data for c in cols], int(gc))
+        rc = fn(st["n_slots"], st["n_groups"], st["stride"], *[c.ctypes.data for c in cols], int(gc), 0,
+                st["n_groups"])
         assert rc == 0
     return tick
 
