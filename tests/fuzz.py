@@ -31,11 +31,12 @@ def random_cfg(rng, n_groups, n_slots, joint_frac=0.3, learner_frac=0.2, group_c
     return cfg
 
 
-def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False, with_gids=False):
-    """Fill an oracle_lib.alloc_state() dict in place (cfg must already be set)."""
+def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False, with_gids=False, base=0):
+    """Fill an oracle_lib.alloc_state() dict in place (cfg must already be set). `base` shifts every
+    log index (e.g. 2**62: arithmetic near the top of the u64 range the reference allows)."""
     G, P, stride = st["n_groups"], st["n_slots"], st["stride"]
     hi_max = 40 if small_values else 1 << 20
-    last = rng.integers(5, hi_max, size=G).astype(np.uint64)
+    last = (rng.integers(5, hi_max, size=G).astype(np.uint64) + np.uint64(base)).astype(np.uint64)
     span = rng.integers(0, 8, size=G).astype(np.uint64)
     lo = np.maximum(last - np.minimum(span, last - 1), 1).astype(np.uint64)
     empty = rng.random(G) < 0.05  # no entry of the current term yet: lo == hi + 1
@@ -46,7 +47,7 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
     for p in range(P):
         lag = rng.integers(0, 10, size=G).astype(np.uint64)
         m = (last - np.minimum(lag, last)).astype(np.uint64)
-        m = np.where(rng.random(G) < 0.1, 0, m).astype(np.uint64)
+        m = np.where(rng.random(G) < 0.1, 0, m).astype(np.uint64)  # a peer that never acked
         # ill-formed leftovers (matched beyond last_index, as after a malformed ack): the engine must
         # still follow the reference arithmetic exactly
         m = np.where(rng.random(G) < 0.02, last + rng.integers(1, 4, size=G).astype(np.uint64), m).astype(np.uint64)

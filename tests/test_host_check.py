@@ -77,6 +77,30 @@ def test_device_arithmetic_on_host_matches_oracle(host_tick, n_slots, gc):
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
 
 
+def test_device_arithmetic_near_the_top_of_the_index_range(host_tick):
+    """All indices shifted by 2**62 (the reference computes n + 1 on u64: indices < 2**63)."""
+    rng = np.random.default_rng(99)
+    G, P = 3000, 5
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st, small_values=True, base=2 ** 62)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    msgs = O.alloc_msgs(G, P)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    for t in range(5):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs)
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        assert not fuzz.diff_states(st, eng_st, G, P), t
+        assert (out == gout).all()
+    assert (st["commit"] >= 2 ** 62).mean() > 0.5
+
+
 @pytest.mark.parametrize("workload,n_slots", [(2, 5), (3, 5), (5, 7)])
 def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slots):
     from raft_rs_amd import engine as E

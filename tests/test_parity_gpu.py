@@ -105,6 +105,45 @@ def test_random_streams_match_oracle(rg, variant, n_slots):
     eng.close()
 
 
+@pytest.mark.parametrize("n_groups,n_slots", [(1, 3), (63, 5), (64, 5), (65, 7), (257, 8)])
+def test_tiny_and_ragged_group_counts(rg, n_groups, n_slots):
+    """Edge sizes: a single group, one short of / exactly / one past a wave, one past a 256 tile; indices
+    near the top of the u64 range."""
+    rng = np.random.default_rng(n_groups * 10 + n_slots)
+    for variant in (1, 2):
+        st = O.alloc_state(n_groups, n_slots)
+        st["cfg"][:] = fuzz.random_cfg(rng, n_groups, n_slots)
+        fuzz.random_state(rng, st, small_values=True, base=2 ** 62)
+        eng = rg.Engine(n_groups, n_slots, variant=variant)
+        eng.load_state(st)
+        cl = oracle_from_state(st)
+        msgs = O.alloc_msgs(n_groups, n_slots)
+        gout = np.zeros(n_groups, dtype=np.uint32)
+        mb = rg.MsgBuffers(n_groups, n_slots, eng.stride)
+        for t in range(4):
+            cl.store_soa(st)
+            fuzz.random_msgs(rng, st, msgs)
+            for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+                getattr(mb, k)[...] = msgs[k]
+            eng.tick(mb)
+            cl.tick_soa(msgs, gout)
+            assert_same(eng, cl, st, gout, f"G={n_groups} P={n_slots} variant={variant} tick {t}")
+        eng.close()
+
+
+def test_empty_tick_changes_nothing(rg):
+    G, P = 5000, 5
+    eng = rg.Engine(G, P)
+    eng.workload_init(2)
+    before = eng.read_state()
+    eng.tick(rg.MsgBuffers(G, P, eng.stride))  # no events at all
+    after = eng.read_state()
+    for k in fuzz.STATE_KEYS:
+        assert (before[k] == after[k]).all(), k
+    assert (after["out"] == 0).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("n_slots", [3, 5, 7])
 def test_group_commit_streams_match_oracle(rg, n_slots):
     rng = np.random.default_rng(77 + n_slots)
