@@ -1005,6 +1005,21 @@ extern "C" int rg_flush(rg_engine *h) {
         m.m_rs = h->q_mrs.data();
         m.m_flags = h->q_mf.data();
         rc = rg_tick(h, &m);
+        // rg_ingested_results must work after ANY flush: gather the dirty groups' results compactly
+        if (rc == RG_OK) rc = rg_ensure_sparse(h);
+        if (rc == RG_OK) {
+            const u32 n = (u32)h->q_dirty.size();
+            hipError_t e = hipMemcpyAsync(h->list, h->q_dirty.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->counters, &n, 4, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_gather_results, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->list, h->counters,
+                                   (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out);
+                e = hipMemsetAsync(h->counters, 0, 4, h->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = rg_fail(RG_ERR_NO_DEVICE, "rg_flush: %s", hipGetErrorString(e));
+            else h->last_sparse_n = n;
+        }
     } else {
         // few groups have events: ship only their records and tick only them
         std::vector<rg_wire_msg> &recs = h->q_records;

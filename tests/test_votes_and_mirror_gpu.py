@@ -126,6 +126,10 @@ def test_host_mirror_steps_like_raw_node(rg):
         for g in range(G):
             assert commit[g] == cl.committed(g), (rnd, g)
             assert out[g] == expect_out[g], (rnd, g, hex(out[g]), hex(expect_out[g]))
+        # the compact results are available after a dense flush too
+        groups, c2, o2 = eng.ingested_results()
+        assert sorted(groups.tolist()) == list(range(G))
+        assert (c2 == commit[groups]).all() and (o2 == out[groups]).all()
     got = eng.read_state()
     ref = O.alloc_state(G, P)
     for k in ("cfg", "term_lo"):
