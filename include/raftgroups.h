@@ -167,6 +167,12 @@ typedef struct {
 } rg_cell_write;
 int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n);
 
+/* Membership of ONE group (ProgressTracker::apply_conf, src/tracker.rs:380-397, after
+ * Changer::{simple,enter_joint,leave_joint}, src/confchange/changer.rs:66-157): rewrite the group's
+ * configuration word (RG_CFG_MAKE). New peers' Progress cells (Progress::new(last_index+1), recent_active)
+ * are written with rg_write_cells; follow with rg_recompute for post_conf_change's maybe_commit (raft.rs:2630). */
+int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word);
+
 /* ---- the hot path ---- */
 /* One tick: for every group, apply its <=1 message per slot in slot order exactly as
  * handle_append_response would (commit re-evaluated after every accepted ack), update state in

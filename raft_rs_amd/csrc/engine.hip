@@ -544,6 +544,18 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
     return RG_OK;
 }
 
+extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_config: bad argument");
+    if (RG_CFG_SELF(cfg_word) >= h->P || (RG_CFG_PRESENT(cfg_word) >> h->P) || (RG_CFG_INCOMING(cfg_word) >> h->P) ||
+        (RG_CFG_OUTGOING(cfg_word) >> h->P) || RG_CFG_TRANSFEREE(cfg_word) > h->P)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_set_config: cfg word %#x names a slot >= %u", cfg_word, h->P);
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemcpyAsync(h->st.cfg + group, &cfg_word, 4, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    if (cfg_word & RG_CFG_GROUP_COMMIT) h->any_group_commit = true; // (stays set: the GC kernel is a superset)
+    return RG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------

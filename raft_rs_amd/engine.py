@@ -125,6 +125,7 @@ SYMBOLS = {
     "rg_checkpoint": (_i, [_vp]),
     "rg_restore": (_i, [_vp]),
     "rg_write_cells": (_i, [_vp, C.POINTER(CellWrite), _u64]),
+    "rg_set_config": (_i, [_vp, _u64, C.c_uint32]),
     "rg_tick": (_i, [_vp, C.POINTER(_Msgs)]),
     "rg_tick_device": (_i, [_vp, C.POINTER(_Msgs)]),
     "rg_recompute": (_i, [_vp]),
@@ -295,6 +296,10 @@ class Engine:
                     setattr(arr[i], name, int(c[name]))
             arr[i].field_mask = mask
         self._check(self.L.rg_write_cells(self.h, arr, len(cells)))
+
+    def set_config(self, group, cfg_word):
+        """apply_conf for one group: rewrite its RG_CFG_* word."""
+        self._check(self.L.rg_set_config(self.h, group, int(cfg_word)))
 
     # ---- hot path --------------------------------------------------------------------------
     def tick(self, msgs):

@@ -18,11 +18,12 @@ class OracleLeader:
         self.cl = O.Cluster(1).config(0, self_id, term, voters, outgoing, learners, next_idx=next_idx)
         self.cl.set_log(0, list(log), committed=committed, dummy=dummy)
         self.term = term
+        self._voters, self._self_id = list(voters), self_id
 
     def set_progress(self, pid, **kw):
         p = self.cl.pr(0, pid)
         for k, v in kw.items():
-            setattr(p, {"match": "matched", "next": "next_idx", "commit_group_id": "commit_group_id"}.get(k, k), v)
+            setattr(p, {"match": "matched", "next": "next_idx"}.get(k, k), v)
 
     def progress(self, pid):
         p = self.cl.pr(0, pid)
@@ -32,6 +33,21 @@ class OracleLeader:
 
     def committed(self):
         return self.cl.committed(0)
+
+    def remove_node(self, pid):
+        # rebuild the group without `pid`, keeping every other Progress and the log (apply_conf Remove)
+        L = O.lib()
+        g = self.cl
+        keep = [i for i in self._voters if i != pid]
+        saved = {i: self.progress(i) for i in keep}
+        committed, last = g.committed(0), g.last_index(0)
+        entries = [(L.ro_log_term(g.h, 0, i), i) for i in range(1, last + 1)]
+        g.config(0, self._self_id, self.term, keep)
+        g.set_log(0, entries, committed=committed)
+        for i, pr in saved.items():
+            self.set_progress(i, match=pr["match"], next=pr["next"], state=pr["state"], paused=pr["paused"],
+                              committed_index=pr["committed_index"], recent_active=pr["recent_active"])
+        self._voters = keep
 
     def enable_group_commit(self, on):
         O.lib().ro_group_set_group_commit(self.cl.h, 0, on)
@@ -101,7 +117,14 @@ class EngineLeader:
         self.msgs = rg.MsgBuffers(1, self.P, self.eng.stride)
 
     def _push_cfg(self):
-        self.eng.load_column(self.rg.COL.CFG, np.array([self.rg.cfg_make(**self.cfg)], dtype=np.uint32))
+        self.eng.set_config(0, self.rg.cfg_make(**self.cfg))
+
+    def remove_node(self, pid):
+        """apply_conf_change(RemoveNode) for a simple (non-joint) config: tracker.rs:380-397."""
+        bit = 1 << (pid - 1)
+        self.cfg["incoming"] &= ~bit
+        self.cfg["present"] &= ~bit
+        self._push_cfg()
 
     def set_progress(self, pid, **kw):
         cell = {"group": 0, "slot": pid - 1}

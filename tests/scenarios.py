@@ -229,8 +229,22 @@ def scenario_handle_heartbeat_resp(B):
     assert ld.step_heartbeat_response(2)["send_append"]
 
 
+def scenario_commit_after_remove_node(B):
+    """test_raft.rs:3291-3340 test_commit_after_remove_node: a pending entry becomes committed when a conf
+    change reduces the quorum (apply_conf + post_conf_change's maybe_commit, raft.rs:2630)."""
+    # leader 1 of {1,2} at term 1: noop 1, conf-change entry 2, "hello" 3 -- all persisted by the leader
+    ld = B(1, 1, [1, 2], log=[(1, 1), (1, 2), (1, 3)], committed=0, next_idx=1)
+    ld.set_progress(1, match=3, next=4, state=REPLICATE)
+    out = ld.step(2, 2)  # node 2 acknowledges the config change, committing entries 1..2
+    assert ld.committed() == 2 and out["changed"]
+    ld.remove_node(2)     # applying it leaves {1}
+    assert ld.maybe_commit(), "post_conf_change: the pending command can now commit"
+    assert ld.committed() == 3
+
+
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
        scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
-       scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp]
+       scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
+       scenario_commit_after_remove_node]
