@@ -189,7 +189,7 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 // request_snapshot) are touched through `st`/`ms` only on the rare paths that need them.
 // GC = false compiles the group-commit path out (the engine launches the GC = true kernel only
 // when some group has ProgressTracker.group_commit set).
-template <int P, bool GC> struct RgTick {
+template <int P, bool GC, bool LAZY_NX> struct RgTick {
     RgGroup<P> &r;
     const RgState &st;
     const RgMsgs &ms;
@@ -215,6 +215,19 @@ template <int P, bool GC> struct RgTick {
 #pragma unroll
         for (int i = 0; i < P; i++) // slots without a Progress ack 0 and are never written back
             if (!((present >> i) & 1u)) r.mt[i] = 0;
+        if (LAZY_NX) {
+            // next_idx is read only where its old value can matter: a slot with an event, unless the event
+            // set starts with SENT on a Replicate peer, which overwrites it (optimistic_update,
+            // progress.rs:161) before anything reads it. In steady state that is every follower, so the
+            // `next` column is written but (except for the leader's own slot) never read.
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const u32 f = (u32)(r.mf >> (8 * i)) & 0xffu, pb = (u32)(r.pf >> (8 * i)) & 0xffu;
+                const bool overwritten = (u32)i != self && (f & RG_MF_SENT) && (pb & RG_PF_STATE_MASK) == RG_STATE_REPLICATE;
+                const bool need = ((present >> i) & 1u) && f != 0 && !overwritten;
+                r.nx[i] = need ? st.next[(u64)i * st.stride + g] : 0ULL;
+            }
+        }
     }
 
     // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v`.
@@ -238,10 +251,8 @@ template <int P, bool GC> struct RgTick {
     }
 
     template <int S> RG_HD void set_next(u64 n) {
-        if (r.nx[S] != n) {
-            r.nx[S] = n;
-            r.dirty |= 1u << (8 + S);
-        }
+        r.nx[S] = n;
+        r.dirty |= 1u << (8 + S);
     }
 
     // Progress::maybe_update (progress.rs:138-150); returns need_update
@@ -437,8 +448,9 @@ template <int P, bool GC> struct RgTick {
     }
 };
 
-template <int P, bool GC>
+// LAZY_NX: r.nx is NOT pre-loaded by the caller; the tick fetches the cells it needs (lane/list kernels).
+template <int P, bool GC, bool LAZY_NX>
 RG_HD void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
-    RgTick<P, GC> t(r, st, ms, g);
+    RgTick<P, GC, LAZY_NX> t(r, st, ms, g);
     t.run(typename rg_make_seq<P>::type{});
 }

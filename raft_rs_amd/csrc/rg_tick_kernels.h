@@ -13,6 +13,9 @@
 #define RG_OPT 6 /* measured best on MI355X: gpurun sweep in profiles/r01_tuning_sweep.txt */
 #endif
 #define RG_OPT_NT_MSG (RG_OPT & 1)
+#ifndef RG_LAZY_NEXT /* 1: the lane kernels fetch `next` only where its old value can matter (rg_group.h) */
+#define RG_LAZY_NEXT 1
+#endif
 #define RG_OPT_UNCOND_ST (RG_OPT & 2)
 #ifdef RG_BLOCK_SIZE /* experiment override */
 #define RG_BLOCK RG_BLOCK_SIZE
@@ -40,7 +43,8 @@ template <typename T> RG_HD T rg_ld_stream(const T *p) { // read-once data: keep
 #endif
 }
 
-template <int P> RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
+template <int P, bool LOAD_NX>
+RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
     r.mf = rg_ld_stream(ms.mflags + g);
     r.pf = st.pflags[g];
     r.cfg = st.cfg[g];
@@ -51,7 +55,7 @@ template <int P> RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, cons
     for (int p = 0; p < P; p++) {
         const u64 o = (u64)p * st.stride + g;
         r.mt[p] = st.match[o];
-        r.nx[p] = st.next[o];
+        if (LOAD_NX) r.nx[p] = st.next[o];
         r.pc[p] = st.prc[o];
         r.mi[p] = rg_ld_stream(ms.mi + o);
         r.mc[p] = rg_ld_stream(ms.mc + o);
@@ -87,8 +91,8 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st,
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
     RgGroup<P> r;
-    rg_load_group<P>(r, st, ms, g);
-    rg_group_tick<P, GC>(r, st, ms, g);
+    rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
+    rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
     rg_store_group<P>(r, st, g);
 }
 
@@ -101,8 +105,8 @@ __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *lis
     if (i >= *n_ptr) return;
     const u64 g = list[i];
     RgGroup<P> r;
-    rg_load_group<P>(r, st, ms, g);
-    rg_group_tick<P, GC>(r, st, ms, g);
+    rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
+    rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
     rg_store_group<P>(r, st, g);
     mflags_rw[g] = 0;
 }
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
                 r.mi[p] = L[3][p][li];
                 r.mc[p] = L[4][p][li];
             }
-            rg_group_tick<P, GC>(r, st, ms, g);
+            rg_group_tick<P, GC, false>(r, st, ms, g);
             const u32 d = r.dirty;
 #pragma unroll
             for (int p = 0; p < P; p++) {

@@ -7,9 +7,9 @@
 template <int P> static void host_tick(const RgState &st, const RgMsgs &ms, bool gc, u64 g0, u64 g1) {
     for (u64 g = g0; g < g1; g++) {
         RgGroup<P> r;
-        rg_load_group<P>(r, st, ms, g);
-        if (gc) rg_group_tick<P, true>(r, st, ms, g);
-        else rg_group_tick<P, false>(r, st, ms, g);
+        rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
+        if (gc) rg_group_tick<P, true, RG_LAZY_NEXT>(r, st, ms, g);
+        else rg_group_tick<P, false, RG_LAZY_NEXT>(r, st, ms, g);
         rg_store_group<P>(r, st, g);
     }
 }
