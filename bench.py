@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--publish-every", type=int, default=8,
                     help="N>1: all-gather the commit column every E ticks (and after the last tick)")
+    ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
@@ -182,6 +183,10 @@ def main():
         sizes = [(3, G // 3), (5, G // 3), (7, G - 2 * (G // 3))]
     else:
         sizes = [(P, G)]
+    if args.split > 1:
+        # Independent sub-shards on separate HIP streams: ticks of one sub-shard are ordered, the
+        # sub-shards are not, so one chain's launch tail / kernel boundary overlaps the other's body.
+        sizes = [(sl, n // args.split + (1 if k < n % args.split else 0)) for sl, n in sizes for k in range(args.split)]
 
     class Part:
         pass
@@ -190,7 +195,7 @@ def main():
     for slots, n in sizes:
         pt = Part()
         pt.n, pt.slots, pt.first = n, slots, first
-        pt.fixed = slots if len(sizes) > 1 else 0
+        pt.fixed = slots if (args.workload == 5 and not args.one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant)
         pt.eng.set_stream(stream.cuda_stream)
         pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed)
