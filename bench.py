@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--publish-every", type=int, default=8,
                     help="N>1: all-gather the commit column every E ticks (and after the last tick)")
+    ap.add_argument("--fuse", type=int, default=1,
+                    help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
@@ -260,6 +262,17 @@ def main():
             fork.record(stream)
             for pt in parts:
                 pt.stream.wait_event(fork)
+        F = max(1, min(8, args.fuse))
+        if F > 1 and publishers is None:
+            # temporal fusion: F consecutive recorded ticks per launch (state stays in registers between them)
+            for pt in parts:
+                if not hasattr(pt, "out_t"):
+                    pt.out_t = torch.empty((F, pt.n), dtype=torch.int32, device="cuda")
+            for i in range(0, n, F):
+                k = min(F, n - i)
+                for pt in parts:
+                    pt.eng.tick_device_fused([tick_ptrs(pt, t0 + i + q) for q in range(k)], pt.out_t.data_ptr())
+            n = 0  # nothing left for the per-tick loop below
         for i in range(n):
             pub_now = publishers is not None and ((i + 1) % E == 0 or i == n - 1)
             for j, pt in enumerate(parts):
@@ -382,12 +395,15 @@ def main():
                    "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
                    "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks (RCCL)" if distributed else ""),
-                   "launch": launch_mode},
+                   "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not distributed else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_tick_lane" if args.variant != 2 else "k_tick_lds",
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
-                     "avg_launch_us": per_launch_s * 1e6},
+                     "avg_launch_us": per_launch_s * 1e6,
+                     **({"note": "temporal fusion: state stays in registers across the fused ticks, so fewer bytes "
+                                 "move than the per-tick algorithmic model counts; frac is not a per-tick HBM "
+                                 "efficiency in this mode"} if args.fuse > 1 and not distributed else {})},
         "commit_changed_last_tick": int(n_changed),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -180,6 +180,16 @@ int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word);
 int rg_tick(rg_engine *h, const rg_msgs *host_msgs);
 /* Same, message columns already in device memory (layout identical). Asynchronous. */
 int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
+/* Temporal fusion: n_ticks (1..8) consecutive ticks in ONE launch. `dev_msgs` is a HOST array of n_ticks
+ * rg_msgs whose pointers are DEVICE memory, in tick order. Each group's state stays in registers across the
+ * ticks and is written back once, so per tick only the message columns plus 1/n of the state traffic move.
+ * Results are bit-identical to n_ticks calls of rg_tick_device. `dev_out_t` (u32 [n_ticks][G], device,
+ * required) receives every tick's RG_OUT_* word, `dev_commit_t` (u64 [n_ticks][G], device, may be NULL) the
+ * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. Asynchronous. Use it to
+ * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
+#define RG_MAX_FUSE 8
+int rg_tick_device_fused(rg_engine *h, const rg_msgs *dev_msgs, uint32_t n_ticks, uint32_t *dev_out_t,
+                         uint64_t *dev_commit_t);
 /* Raft::maybe_commit() for every group with no messages (post_conf_change src/raft.rs:2630,
  * enable_group_commit :513-518, assign_commit_groups :531-544). Asynchronous. */
 int rg_recompute(rg_engine *h);

@@ -593,6 +593,42 @@ extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
     return rg_tick_impl(h, ms);
 }
 
+extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_ticks, uint32_t *dev_out_t,
+                                    uint64_t *dev_commit_t) {
+    if (!h || !m || !dev_out_t || n_ticks == 0 || n_ticks > RG_MAX_FUSE)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: need 1..%d ticks and an out buffer", RG_MAX_FUSE);
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RgFused fm;
+    memset(&fm, 0, sizeof(fm));
+    for (u32 t = 0; t < n_ticks; t++) {
+        if (!m[t].m_index || !m[t].m_commit || !m[t].m_flags)
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: tick %u lacks m_index/m_commit/m_flags", t);
+        fm.m[t].mi = (const u64 *)m[t].m_index;
+        fm.m[t].mc = (const u64 *)m[t].m_commit;
+        fm.m[t].mh = m[t].m_hint ? (const u64 *)m[t].m_hint : h->zero_col;
+        fm.m[t].mrs = m[t].m_rs ? (const u64 *)m[t].m_rs : h->zero_col;
+        fm.m[t].mflags = (const u64 *)m[t].m_flags;
+    }
+    fm.out_t = dev_out_t;
+    fm.commit_t = (u64 *)dev_commit_t;
+    fm.n_ticks = n_ticks;
+    switch (h->P) {
+    case 1: rg_launch_tick_fused_t<1>(h->stream, h->st, fm, h->any_group_commit); break;
+    case 2: rg_launch_tick_fused_t<2>(h->stream, h->st, fm, h->any_group_commit); break;
+    case 3: rg_launch_tick_fused_t<3>(h->stream, h->st, fm, h->any_group_commit); break;
+    case 4: rg_launch_tick_fused_t<4>(h->stream, h->st, fm, h->any_group_commit); break;
+    case 5: rg_launch_tick_fused_t<5>(h->stream, h->st, fm, h->any_group_commit); break;
+    case 6: rg_launch_tick_fused_t<6>(h->stream, h->st, fm, h->any_group_commit); break;
+    case 7: rg_launch_tick_fused_t<7>(h->stream, h->st, fm, h->any_group_commit); break;
+    default: rg_launch_tick_fused_t<8>(h->stream, h->st, fm, h->any_group_commit); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "fused tick launch failed: %s", hipGetErrorString(e));
+    h->ticked = true;
+    h->out_is_dense = true;
+    return RG_OK;
+}
+
 static int rg_ensure_msg_arena(rg_engine *h) {
     if (h->msg_arena) return RG_OK;
     const size_t col = rg_align((size_t)h->P * h->stride * 8);

@@ -167,6 +167,7 @@ template <int P> struct RgGroup {
     u64 commit, lo, hi;      // RaftLog.committed, current-term index range [lo, hi], hi = last_index
     u32 cfg, out;
     u32 dirty;               // bit s: mt[s] changed, bit 8+s: nx[s], bit 16+s: pc[s], bit 24: pf, 25: commit, 26: hi
+    u32 evm;                 // slots (with a Progress) that had any event since the state was loaded
 };
 #define RG_DIRTY_PF (1u << 24)
 #define RG_DIRTY_COMMIT (1u << 25)
@@ -189,13 +190,17 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 // request_snapshot) are touched through `st`/`ms` only on the rare paths that need them.
 // GC = false compiles the group-commit path out (the engine launches the GC = true kernel only
 // when some group has ProgressTracker.group_commit set).
-template <int P, bool GC, bool LAZY_NX> struct RgTick {
+// FUSED: the group's state stays in registers across several ticks (k_tick_fused): `dirty`/`evm`
+// accumulate, `next` cells already fetched or written are not fetched again, and the replay path takes
+// the matches of the tick's start from a register snapshot instead of re-reading memory.
+template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
     RgGroup<P> &r;
     const RgState &st;
     const RgMsgs &ms;
     const u64 g;
     u64 last0; // last_index the send path saw before this tick
     u32 incoming, outgoing, self, present, xfer, out;
+    u64 mt_start[FUSED ? P : 1]; // FUSED: matches at the start of this tick (memory still holds older ones)
     u32 acc;      // slots whose maybe_update returned true this tick (each is followed by a maybe_commit)
     u32 acc_oldp; // ... of those, the ones that were paused before the ack (raft.rs:1724,1749-1751)
 
@@ -211,10 +216,20 @@ template <int P, bool GC, bool LAZY_NX> struct RgTick {
         out = 0;
         acc = 0;
         acc_oldp = 0;
-        r.dirty = 0;
+        if (!FUSED) {
+            r.dirty = 0;
+            r.evm = 0;
+        }
 #pragma unroll
         for (int i = 0; i < P; i++) // slots without a Progress ack 0 and are never written back
             if (!((present >> i) & 1u)) r.mt[i] = 0;
+        if (FUSED) {
+#pragma unroll
+            for (int i = 0; i < P; i++) mt_start[i] = r.mt[i];
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if (((r.mf >> (8 * i)) & 0xffULL) && ((present >> i) & 1u)) r.evm |= 1u << i;
         if (LAZY_NX) {
             // next_idx is read only where its old value can matter: a slot with an event, unless the event
             // set starts with SENT on a Replicate peer, which overwrites it (optimistic_update,
@@ -224,8 +239,17 @@ template <int P, bool GC, bool LAZY_NX> struct RgTick {
             for (int i = 0; i < P; i++) {
                 const u32 f = (u32)(r.mf >> (8 * i)) & 0xffu, pb = (u32)(r.pf >> (8 * i)) & 0xffu;
                 const bool overwritten = (u32)i != self && (f & RG_MF_SENT) && (pb & RG_PF_STATE_MASK) == RG_STATE_REPLICATE;
-                const bool need = ((present >> i) & 1u) && f != 0 && !overwritten;
-                r.nx[i] = need ? st.next[(u64)i * st.stride + g] : 0ULL;
+                // FUSED: a cell fetched or written by an earlier tick of this launch is already current
+                // (bit 8+i of dirty doubles as "r.nx[i] is valid": fetched cells are marked too -- rewriting
+                // an unchanged value is harmless)
+                const bool have = FUSED && ((r.dirty >> (8 + i)) & 1u);
+                const bool need = ((present >> i) & 1u) && f != 0 && !overwritten && !have;
+                if (need) {
+                    r.nx[i] = st.next[(u64)i * st.stride + g];
+                    if (FUSED) r.dirty |= 1u << (8 + i);
+                } else if (!have) {
+                    r.nx[i] = 0ULL;
+                }
             }
         }
     }
@@ -429,7 +453,8 @@ template <int P, bool GC, bool LAZY_NX> struct RgTick {
         }
         if (replay) {
             u64 cur[P];
-            ((cur[S] = ((acc >> S) & 1u) ? st.match[(u64)S * st.stride + g] : r.mt[S]), ...);
+            if (FUSED) ((cur[S] = mt_start[S]), ...);
+            else ((cur[S] = ((acc >> S) & 1u) ? st.match[(u64)S * st.stride + g] : r.mt[S]), ...);
             qm.init(cur);
             u64 commit = commit0;
             (replay_slot<S>(qm, cur, commit), ...);
@@ -449,8 +474,8 @@ template <int P, bool GC, bool LAZY_NX> struct RgTick {
 };
 
 // LAZY_NX: r.nx is NOT pre-loaded by the caller; the tick fetches the cells it needs (lane/list kernels).
-template <int P, bool GC, bool LAZY_NX>
+template <int P, bool GC, bool LAZY_NX, bool FUSED = false>
 RG_HD void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
-    RgTick<P, GC, LAZY_NX> t(r, st, ms, g);
+    RgTick<P, GC, LAZY_NX, FUSED> t(r, st, ms, g);
     t.run(typename rg_make_seq<P>::type{});
 }

@@ -66,11 +66,7 @@ template <int P> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &s
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
-        const u32 present = RG_CFG_PRESENT(r.cfg);
-        u32 ev = 0;
-#pragma unroll
-        for (int p = 0; p < P; p++) ev |= ((r.mf >> (8 * p)) & 0xffULL) ? (1u << p) : 0u;
-        ev &= present;
+        const u32 ev = r.evm; // slots with a Progress that had an event (RgTick)
         d |= ev | (ev << 8) | (ev << 16);
     }
 #endif
@@ -109,6 +105,54 @@ __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *lis
     rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
     rg_store_group<P>(r, st, g);
     mflags_rw[g] = 0;
+}
+
+// Temporal fusion: T consecutive ticks of a group in ONE launch. A group's tick t+1 depends only on
+// its own tick t, so a lane keeps its group's Progress/commit state in registers, streams the T
+// message sets through, and writes the state back once: per tick the traffic is the message columns
+// plus 1/T of the state read+write. Every tick's result word (and, optionally, commit index) is still
+// produced. Bit-identical to T launches of k_tick_lane (tests). For backlogs / replay, not for latency.
+#define RG_MAX_FUSE 8
+struct RgFused {
+    RgMsgs m[RG_MAX_FUSE];
+    u32 *out_t;    // [T][G] result word of every tick
+    u64 *commit_t; // [T][G] commit index after every tick, or nullptr
+    u32 n_ticks;
+};
+
+template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st, RgFused fm) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    RgGroup<P> r;
+    r.pf = st.pflags[g];
+    r.cfg = st.cfg[g];
+    r.commit = st.commit[g];
+    r.lo = st.lo[g];
+    r.hi = st.hi[g];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        r.mt[p] = st.match[o];
+        r.pc[p] = st.prc[o];
+        r.nx[p] = 0;
+    }
+    r.dirty = 0;
+    r.evm = 0;
+    for (u32 t = 0; t < fm.n_ticks; t++) {
+        const RgMsgs &ms = fm.m[t];
+        r.mf = rg_ld_stream(ms.mflags + g);
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const u64 o = (u64)p * st.stride + g;
+            r.mi[p] = rg_ld_stream(ms.mi + o);
+            r.mc[p] = rg_ld_stream(ms.mc + o);
+        }
+        rg_group_tick<P, GC, true, true>(r, st, ms, g);
+        fm.out_t[(u64)t * st.G + g] = r.out;
+        if (fm.commit_t) fm.commit_t[(u64)t * st.G + g] = r.commit;
+    }
+    // `next` cells that were only fetched (never needed a write) are harmlessly rewritten with their value
+    rg_store_group<P>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,6 +247,7 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw);
+template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc);
 
 #ifdef RG_TICK_INSTANTIATE
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
@@ -224,21 +269,34 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
     if (gc) hipLaunchKernelGGL((k_tick_list<P, true>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw);
     else hipLaunchKernelGGL((k_tick_list<P, false>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw);
 }
+template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
+    const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
+    if (gc) hipLaunchKernelGGL((k_tick_fused<P, true>), grid, block, 0, stream, st, fm);
+    else hipLaunchKernelGGL((k_tick_fused<P, false>), grid, block, 0, stream, st, fm);
+}
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 #endif

@@ -128,6 +128,7 @@ SYMBOLS = {
     "rg_set_config": (_i, [_vp, _u64, C.c_uint32]),
     "rg_tick": (_i, [_vp, C.POINTER(_Msgs)]),
     "rg_tick_device": (_i, [_vp, C.POINTER(_Msgs)]),
+    "rg_tick_device_fused": (_i, [_vp, C.POINTER(_Msgs), C.c_uint32, _vp, _vp]),
     "rg_recompute": (_i, [_vp]),
     "rg_maximal_committed_index": (_i, [_vp, _vp, _vp]),
     "rg_results": (_i, [_vp, _vp, _vp]),
@@ -336,6 +337,14 @@ class Engine:
             self._check(self.L.rg_ingested_results(self.h, groups.ctypes.data, commit.ctypes.data, out.ctypes.data, k,
                                                    C.byref(n)))
         return groups, commit, out
+
+    def tick_device_fused(self, ticks, dev_out_t, dev_commit_t=None):
+        """ticks: list (1..8) of (m_index, m_commit, m_hint, m_rs, m_flags) DEVICE pointers in tick order;
+        dev_out_t: device u32 [T][G]; dev_commit_t: optional device u64 [T][G]. Asynchronous."""
+        arr = (_Msgs * len(ticks))()
+        for i, t in enumerate(ticks):
+            arr[i] = _Msgs(*[_ptr(x) for x in t])
+        self._check(self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t)))
 
     def recompute(self):
         self._check(self.L.rg_recompute(self.h))

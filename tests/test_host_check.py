@@ -48,6 +48,28 @@ def host_tick():
     return tick
 
 
+@pytest.fixture(scope="module")
+def host_fused():
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_fused
+    fn.restype = C.c_int
+    PP = C.POINTER(C.c_void_p)
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 12 + [C.c_uint, PP, PP, PP, PP, PP,
+                                                                            C.c_void_p, C.c_void_p, C.c_int]
+
+    def fused(st, ticks, out_last, out_t, commit_t, gc):
+        cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
+                                "term_lo", "term_hi", "cfg")] + [out_last]
+        arrs = []
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+            arrs.append((C.c_void_p * len(ticks))(*[t[k].ctypes.data for t in ticks]))
+        rc = fn(st["n_slots"], st["n_groups"], st["stride"], *[c.ctypes.data for c in cols], len(ticks), *arrs,
+                out_t.ctypes.data, commit_t.ctypes.data, int(gc))
+        assert rc == 0
+    return fused
+
+
 def copy_state(st):
     return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
 
@@ -120,3 +142,41 @@ def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slo
         cl.store_soa(st)
         assert not fuzz.diff_states(st, eng_st, G, n_slots)
         assert (out == gout).all()
+
+
+@pytest.mark.parametrize("gc", [False, True])
+@pytest.mark.parametrize("n_slots,T", [(1, 2), (3, 8), (5, 4), (7, 3), (8, 5)])
+def test_fused_ticks_equal_sequential_ticks(host_fused, n_slots, T, gc):
+    """k_tick_fused's per-lane sequence (state in registers across T ticks, one write-back) against the
+    oracle stepping the same T ticks one at a time: final state, every tick's result word and commit."""
+    rng = np.random.default_rng(7000 + n_slots * 10 + T + (100 if gc else 0))
+    G = 2500
+    st = O.alloc_state(G, n_slots)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05, group_commit_frac=0.5 if gc else 0.0)
+    fuzz.random_state(rng, st, small_values=True, with_gids=gc)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    for rnd in range(2):
+        ticks, want_out, want_commit = [], [], []
+        gout = np.zeros(G, dtype=np.uint32)
+        for t in range(T):
+            cl.store_soa(st)
+            msgs = O.alloc_msgs(G, n_slots)
+            fuzz.random_msgs(rng, st, msgs, malformed_p=0.02 if t == 1 else 0.0)
+            cl.tick_soa(msgs, gout)
+            cl.store_soa(st)
+            ticks.append(msgs)
+            want_out.append(gout.copy())
+            want_commit.append(st["commit"].copy())
+        out_t = np.zeros((T, G), dtype=np.uint32)
+        commit_t = np.zeros((T, G), dtype=np.uint64)
+        out_last = np.zeros(G, dtype=np.uint32)
+        host_fused(eng_st, ticks, out_last, out_t, commit_t, gc)
+        for t in range(T):
+            bad = np.nonzero(out_t[t] != want_out[t])[0]
+            assert bad.size == 0, (rnd, t, bad[:5], [hex(x) for x in out_t[t][bad[:5]]], [hex(x) for x in want_out[t][bad[:5]]])
+            assert (commit_t[t] == want_commit[t]).all(), (rnd, t)
+        assert (out_last == want_out[-1]).all()
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (rnd, diffs[:6])

@@ -268,3 +268,51 @@ def test_full_size_properties_1m_groups(rg):
         assert (gout == s0["out"][:n_or]).all()
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("workload,n_slots,T", [(2, 5, 4), (5, 7, 8), (3, 5, 3)])
+def test_fused_launch_equals_sequential_ticks(rg, workload, n_slots, T):
+    """rg_tick_device_fused(T ticks) == T x rg_tick_device: final state, every tick's result word and commit
+    index; and both equal the oracle."""
+    import torch
+    from raft_rs_amd import engine as E
+    G = 30000 + 11
+    seq = rg.Engine(G, n_slots)
+    fus = rg.Engine(G, n_slots)
+    for e in (seq, fus):
+        e.workload_init(workload)
+    st = seq.read_state()
+    cl = oracle_from_state(st)
+    gout = np.zeros(G, dtype=np.uint32)
+    host = rg.MsgBuffers(G, n_slots, seq.stride)
+    for rnd in range(2):
+        dev_ticks, want_out, want_commit = [], [], []
+        for t in range(T):
+            cl.store_soa(st)
+            E.workload_gen_host(st, host, workload, rnd * T + t)
+            cols = [torch.from_numpy(getattr(host, k).view(np.int64).copy()).cuda()
+                    for k in ("m_index", "m_commit", "m_hint", "m_rs")]
+            flags = torch.from_numpy(host.m_flags.copy()).cuda()
+            dev_ticks.append((cols, flags))
+            seq.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+            cl.tick_soa(host.as_dict(), gout)
+            cl.store_soa(st)
+            c, o = seq.results()
+            assert (o == gout).all() and (c == st["commit"]).all()
+            want_out.append(o)
+            want_commit.append(c)
+        out_t = torch.zeros((T, G), dtype=torch.int32, device="cuda")
+        commit_t = torch.zeros((T, G), dtype=torch.int64, device="cuda")
+        fus.tick_device_fused([[c.data_ptr() for c in cols] + [flags.data_ptr()] for cols, flags in dev_ticks],
+                              out_t.data_ptr(), commit_t.data_ptr())
+        fus.sync()
+        ot = out_t.cpu().numpy().view(np.uint32)
+        ct = commit_t.cpu().numpy().view(np.uint64)
+        for t in range(T):
+            assert (ot[t] == want_out[t]).all(), (rnd, t)
+            assert (ct[t] == want_commit[t]).all(), (rnd, t)
+        a, b = seq.read_state(), fus.read_state()
+        for k in fuzz.STATE_KEYS + ("out",):
+            assert (a[k] == b[k]).all(), (rnd, k)
+    seq.close()
+    fus.close()
