@@ -264,6 +264,11 @@ typedef struct {
     uint32_t flags;  /* RG_MF_* */
 } rg_wire_msg;
 int rg_ingest(rg_engine *h, const rg_wire_msg *host_records, uint64_t n, uint64_t *n_duplicates);
+/* Same, records already in DEVICE memory (a device-side transport / decoder); the array must hold
+ * n records (any alignment of 16 B). Asynchronous: duplicates are accumulated and reported by the next
+ * rg_ingest (host) call or readable through rg_ingested_duplicates after rg_sync. */
+int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, uint64_t n);
+int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates);
 int rg_tick_ingested(rg_engine *h, uint64_t *n_groups);
 /* Groups touched by the last rg_tick_ingested with their commit index and result word (host arrays of
  * capacity `cap`; *n receives the number of groups, which may exceed cap: then only cap are written). */

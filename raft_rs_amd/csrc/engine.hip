@@ -701,7 +701,8 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
         RG_HIP(hipMalloc(&h->d_records, (cap + RG_INGEST_BLOCK) * sizeof(rg_wire_msg)));
         h->d_records_cap = cap;
     }
-    RG_HIP(hipMemsetAsync(h->counters + 1, 0, 4, h->stream));
+    u32 dup0 = 0; // duplicates so far in this tick window (device ingests included)
+    RG_HIP(hipMemcpyAsync(&dup0, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipMemcpyAsync(h->d_records, records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
                        h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
@@ -709,8 +710,35 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     u32 dup = 0;
     RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // the caller's record array may be reused after return
-    if (n_duplicates) *n_duplicates = dup;
+    if (n_duplicates) *n_duplicates = dup - dup0; // dup0 was read before the kernel ran (stream order)
     h->ingested_upper += n;
+    return RG_OK;
+}
+
+extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, uint64_t n) {
+    if (!h || (!dev_records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest_device: bad argument");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_ensure_sparse(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, dev_records, (u64)n,
+                       h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
+                       (u64 *)h->staged.mrs, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list, h->counters);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_ingest_device: %s", hipGetErrorString(e));
+    h->ingested_upper += n;
+    return RG_OK;
+}
+
+extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
+    if (!h || !n_duplicates) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingested_duplicates: bad argument");
+    *n_duplicates = 0;
+    if (!h->sparse_arena) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u32 dup = 0;
+    RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    *n_duplicates = dup;
     return RG_OK;
 }
 
@@ -749,7 +777,7 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_tick_ingested: launch failed: %s", hipGetErrorString(e));
         u32 n = 0;
         RG_HIP(hipMemcpyAsync(&n, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
-        RG_HIP(hipMemsetAsync(h->counters, 0, 4, h->stream));
+        RG_HIP(hipMemsetAsync(h->counters, 0, 8, h->stream)); // group count and duplicate count of the window
         RG_HIP(hipStreamSynchronize(h->stream));
         h->last_sparse_n = n;
     }

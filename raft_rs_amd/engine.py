@@ -137,6 +137,8 @@ SYMBOLS = {
     "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 4)]),
     "rg_ingest": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "rg_ingest_device": (_i, [_vp, _vp, _u64]),
+    "rg_ingested_duplicates": (_i, [_vp, C.POINTER(_u64)]),
     "rg_tick_ingested": (_i, [_vp, C.POINTER(_u64)]),
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_vote_result": (_i, [_vp, _vp, _vp, _vp]),
@@ -320,6 +322,14 @@ class Engine:
         dup = _u64(0)
         self._check(self.L.rg_ingest(self.h, rec.ctypes.data, len(rec), C.byref(dup)))
         return dup.value
+
+    def ingest_device(self, dev_records_ptr, n):
+        self._check(self.L.rg_ingest_device(self.h, _ptr(dev_records_ptr), n))
+
+    def ingested_duplicates(self):
+        d = _u64(0)
+        self._check(self.L.rg_ingested_duplicates(self.h, C.byref(d)))
+        return d.value
 
     def tick_ingested(self):
         n = _u64(0)

@@ -128,3 +128,31 @@ def test_flush_uses_the_sparse_path_for_few_groups(rg):
     cl.store_soa(ref)
     assert not fuzz.diff_states(ref, got, G, P, keys=("match", "next", "pr_commit", "pflags", "commit"))
     eng.close()
+
+
+def test_device_resident_records(rg):
+    """rg_ingest_device: the same records from device memory give the same result as from host memory."""
+    import torch
+    rng = np.random.default_rng(31)
+    G, P = 10000, 5
+    engs = [rg.Engine(G, P) for _ in range(2)]
+    for e in engs:
+        e.workload_init(rg.WL_MAJORITY)
+    st = engs[0].read_state()
+    msgs = O.alloc_msgs(G, P)
+    fuzz.random_msgs(rng, st, msgs)
+    touched = np.sort(rng.choice(G, size=500, replace=False))
+    recs = records_from_msgs(rg, msgs, touched, rng, P)
+    assert engs[0].ingest(recs) == 0
+    dev = torch.from_numpy(recs.view(np.uint8).copy()).cuda()
+    engs[1].ingest_device(dev.data_ptr(), len(recs))
+    engs[1].ingest_device(dev.data_ptr(), 3)  # the first three records again: duplicates
+    engs[1].sync()
+    assert engs[1].ingested_duplicates() == 3
+    n0, n1 = engs[0].tick_ingested(), engs[1].tick_ingested()
+    assert n0 == n1 > 0
+    a, b = engs[0].read_state(), engs[1].read_state()
+    for k in fuzz.STATE_KEYS + ("out",):
+        assert (a[k] == b[k]).all(), k
+    for e in engs:
+        e.close()
