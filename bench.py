@@ -100,18 +100,15 @@ def soa_cpu_line(n_groups, n_slots, workload, seed, threads):
             return {}
         fn = C.CDLL(H.LIB).rg_host_check_tick
         fn.restype = C.c_int
-        fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 17 + [C.c_int, C.c_ulong, C.c_ulong]
+        fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_int, C.c_ulong, C.c_ulong]
         st = O.alloc_state(n_groups, n_slots)
         E.workload_init_host(st, workload, seed=seed)
         msgs = E.MsgBuffers(n_groups, n_slots, st["stride"])
         out = np.zeros(n_groups, dtype=np.uint32)
-        cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
-                                "term_lo", "term_hi", "cfg")] + [out] + \
-               [msgs.m_index, msgs.m_commit, msgs.m_hint, msgs.m_rs, msgs.m_flags]
-        ptrs = [c.ctypes.data for c in cols]
+        sp, mp = H.state_ptrs(st, out), H.msg_ptrs(msgs.as_dict())
 
         def run(a, b):
-            fn(n_slots, n_groups, st["stride"], *ptrs, 0, a, b)
+            fn(n_slots, n_groups, st["stride"], sp, mp, 0, a, b)
 
         res = {}
         pool = ThreadPoolExecutor(max_workers=threads)

@@ -67,6 +67,9 @@ typedef enum {
                                 apply Progress::update_state(last) first (progress.rs:231-243, src/raft.rs:726-729) */
 #define RG_MF_APPEND 0x20u   /* self slot only: leader appended entries, new last_index in m_commit
                                 (Raft::append_entry, src/raft.rs:976-991) */
+#define RG_MF_HAS_LOGTERM 0x80u /* a reject with Message.log_term > 0 (value in m_logterm): the engine runs
+                                RaftLog::find_conflict_by_term(reject_hint, log_term) (src/raft_log.rs:209-235,
+                                src/raft.rs:1562,1657-1660) against the group's term-run table (RG_COL_RUN_*) */
 #define RG_MF_HEARTBEAT 0x40u /* a MsgHeartbeatResponse from this peer (m_commit = Message.commit), handled as
                                 Raft::handle_heartbeat_response (src/raft.rs:1777-1803); exclusive with RG_MF_VALID.
                                 Result bits: RG_OUT_SEND_APPEND(slot) = send_append (matched < last_index or a
@@ -106,8 +109,19 @@ typedef enum {
     RG_COL_TERM_HI = 9,   /* u64 [G]          last_index (last index whose term == current term) */
     RG_COL_CFG = 10,      /* u32 [G]          RG_CFG_* */
     RG_COL_OUT = 11,      /* u32 [G]          RG_OUT_* of the last tick */
-    RG_COL_COUNT = 12
+    /* compact log-term table for find_conflict_by_term: the leader's log is a dummy entry
+     * (index, term) = (first_index - 1, snapshot term), then up to RG_TERM_RUNS runs of equal-term entries of
+     * OLDER terms (run k covers [run_first[k], run_first[k+1]), the last one up to term_lo - 1; unused runs have
+     * run_first = 0), then the entries [term_lo, term_hi] of the leader's own term RG_COL_CUR_TERM (this last run
+     * grows with every RG_MF_APPEND without touching the table). Only read for rejects with RG_MF_HAS_LOGTERM. */
+    RG_COL_RUN_FIRST = 12,   /* u64 [RG_TERM_RUNS][stride] */
+    RG_COL_RUN_TERM = 13,    /* u64 [RG_TERM_RUNS][stride] */
+    RG_COL_DUMMY_INDEX = 14, /* u64 [G] */
+    RG_COL_DUMMY_TERM = 15,  /* u64 [G] */
+    RG_COL_CUR_TERM = 16,    /* u64 [G] the leader's term (Raft.term) */
+    RG_COL_COUNT = 17
 } rg_column;
+#define RG_TERM_RUNS 4
 
 /* ---- a tick's messages, struct-of-arrays, HOST or DEVICE memory (see rg_tick / rg_tick_device) ---- */
 typedef struct {
@@ -116,6 +130,7 @@ typedef struct {
     const uint64_t *m_hint;   /* [P][stride] Message.reject_hint, after find_conflict_by_term when log_term>0 (raft.rs:1562,1657-1660); read only for rejects; may be NULL if no rejects */
     const uint64_t *m_rs;     /* [P][stride] Message.request_snapshot; read only when RG_MF_HAS_RS; may be NULL */
     const uint8_t *m_flags;   /* [G][8] RG_MF_* */
+    const uint64_t *m_logterm; /* [P][stride] Message.log_term; read only when RG_MF_HAS_LOGTERM; may be NULL */
 } rg_msgs;
 
 typedef struct rg_engine rg_engine;
@@ -231,6 +246,8 @@ typedef struct {
     uint8_t reject;            /* Message.reject */
     uint8_t ins_full;          /* caller's Inflights::full() for `from` */
     uint8_t pad[6];
+    uint64_t log_term;         /* Message.log_term: if > 0 on a reject, reject_hint is passed through
+                                  find_conflict_by_term ON THE DEVICE (needs RG_COL_RUN_*); 0 = reject_hint is final */
 } rg_append_response;
 /* Register peer ids and the leader term of a group so rg_step can map Message.from to a slot. */
 int rg_set_peers(rg_engine *h, uint64_t group, const uint64_t *peer_ids, uint32_t n, uint64_t term);
@@ -260,8 +277,10 @@ typedef struct {
     uint64_t commit; /* Message.commit (self slot with RG_MF_APPEND: new last_index) */
     uint64_t hint;   /* Message.reject_hint (after find_conflict_by_term) */
     uint64_t rs;     /* Message.request_snapshot */
+    uint64_t log_term; /* Message.log_term (with RG_MF_HAS_LOGTERM) */
     uint32_t slot;   /* peer slot 0..P-1 */
     uint32_t flags;  /* RG_MF_* */
+    uint64_t pad;    /* 64-byte records */
 } rg_wire_msg;
 int rg_ingest(rg_engine *h, const rg_wire_msg *host_records, uint64_t n, uint64_t *n_duplicates);
 /* Same, records already in DEVICE memory (a device-side transport / decoder); the array must hold

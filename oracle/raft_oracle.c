@@ -543,9 +543,12 @@ bool ro_maybe_commit(ro_cluster *c, size_t g) { /* raft.rs:893-904 */
 }
 
 void ro_handle_append_response(ro_cluster *c, size_t g, const ro_msg *m, ro_out *out) {
-    /* raft.rs:1559-1775. find_conflict_by_term (:1562,:1657-1660) is resolved by the caller. */
+    /* raft.rs:1559-1775 */
     ro_group *gr = &c->g[g];
     memset(out, 0, sizeof(*out));
+    uint64_t next_probe_index = m->reject_hint; /* :1560 */
+    if (m->reject && m->log_term > 0)           /* :1562, :1657-1660 */
+        next_probe_index = ro_log_find_conflict_by_term(c, g, m->reject_hint, m->log_term);
     ro_progress *pr = pmap_get(&gr->progress, m->from); /* :1663-1673 */
     if (!pr) return;
     out->handled = true;
@@ -553,7 +556,7 @@ void ro_handle_append_response(ro_cluster *c, size_t g, const ro_msg *m, ro_out 
     ro_progress_update_committed(pr, m->commit);   /* :1677 */
 
     if (m->reject) { /* :1679-1722 */
-        if (ro_progress_maybe_decr_to(pr, m->index, m->reject_hint, m->request_snapshot)) {
+        if (ro_progress_maybe_decr_to(pr, m->index, next_probe_index, m->request_snapshot)) {
             if (pr->state == RO_REPLICATE) ro_progress_become_probe(pr);
             out->send_append = true; /* self.send_append(m.from) */
         }
@@ -676,6 +679,7 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_MF_SENT 0x10u
 #define RO_MF_APPEND 0x20u
 #define RO_MF_HEARTBEAT 0x40u
+#define RO_MF_HAS_LOGTERM 0x80u
 #define RO_OUT_CHANGED 0x1u
 #define RO_OUT_FAULT 0x2u
 #define RO_OUT_TIMEOUT_NOW 0x4u
@@ -728,7 +732,24 @@ int ro_load_soa(ro_cluster *c, const ro_soa_state *s, uint64_t term, size_t max_
          * older one (dummy at term_lo-1 with term-1, or an older-term run when term_lo > 1). An
          * empty range (term_lo > term_hi) = no entry of the current term yet. */
         uint64_t lo = s->term_lo[g], hi = s->term_hi[g];
-        if (lo <= hi) {
+        if (s->run_first) { /* explicit table: dummy entry + older runs + the leader's own run [lo, hi] */
+            uint64_t rf[5], rt[5];
+            size_t nr = 0;
+            for (int k = 0; k < 4; k++) {
+                uint64_t f = s->run_first[(size_t)k * s->stride + g];
+                if (f == 0) continue;
+                rf[nr] = f;
+                rt[nr] = s->run_term[(size_t)k * s->stride + g];
+                nr++;
+            }
+            gr->term = s->cur_term[g];
+            if (lo <= hi) {
+                rf[nr] = lo;
+                rt[nr] = gr->term;
+                nr++;
+            }
+            ro_group_set_log(c, g, s->dummy_index[g], s->dummy_term[g], rf, rt, nr, hi, s->commit[g]);
+        } else if (lo <= hi) {
             uint64_t rf[1] = {lo}, rt[1] = {term};
             ro_group_set_log(c, g, lo - 1, term - 1, rf, rt, 1, hi, s->commit[g]);
         } else {
@@ -811,6 +832,7 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
             msg.reject = (f & RO_MF_REJECT) != 0;
             msg.reject_hint = msg.reject ? m->m_hint[o] : 0;
             msg.request_snapshot = (f & RO_MF_HAS_RS) ? m->m_rs[o] : 0;
+            msg.log_term = (msg.reject && (f & RO_MF_HAS_LOGTERM) && m->m_logterm) ? m->m_logterm[o] : 0;
             msg.ins_full = (f & RO_MF_INS_FULL) ? 1 : 0;
             if ((msg.index >> 63) || (!msg.reject && msg.index > gr->last_index))
                 out |= RO_OUT_FAULT;

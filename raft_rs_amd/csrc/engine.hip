@@ -169,26 +169,28 @@ __global__ __launch_bounds__(RG_BLOCK) void k_heartbeat_commits(RgState st, u32 
 // kernels: ingest (wire-order AoS records -> the slot matrix) and helpers of the sparse path
 // ------------------------------------------------------------------------------------------------
 #define RG_INGEST_BLOCK 256
-// A workgroup stages 256 records (12 KiB) through LDS with fully coalesced 16-B loads, then lane t
+// A workgroup stages 256 records (16 KiB) through LDS with fully coalesced 16-B loads, then lane t
 // decodes record t and scatters its fields to the peer-major message columns. The event byte of the
 // cell is claimed with a CAS on its 32-bit word; a second record for the same cell is dropped and
 // counted. The first record that touches a group appends it to the tick list.
 __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(const rg_wire_msg *rec, u64 n, u64 G, u64 stride, u32 P,
-                                                            u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u32 *mflags32,
-                                                            u32 *gmark, u32 epoch, u64 *list, u32 *counters) {
-    __shared__ uint4 stage[RG_INGEST_BLOCK * 3];
+                                                            u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u64 *mlt,
+                                                            u32 *mflags32, u32 *gmark, u32 epoch, u64 *list,
+                                                            u32 *counters) {
+    __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
     const u64 base = (u64)blockIdx.x * RG_INGEST_BLOCK;
     const u32 nrec = (u32)((n - base) < RG_INGEST_BLOCK ? (n - base) : RG_INGEST_BLOCK);
     const uint4 *src = reinterpret_cast<const uint4 *>(rec + base);
-    for (u32 k = threadIdx.x; k < 3 * nrec; k += RG_INGEST_BLOCK) stage[k] = src[k];
+    for (u32 k = threadIdx.x; k < 4 * nrec; k += RG_INGEST_BLOCK) stage[k] = src[k];
     __syncthreads();
     const u32 t = threadIdx.x;
     if (t >= nrec) return;
-    const uint4 a = stage[3 * t], b = stage[3 * t + 1], c = stage[3 * t + 2];
+    // record t occupies 4 x 16 B of the staged block
+    const uint4 a = stage[4 * t], b = stage[4 * t + 1], c = stage[4 * t + 2], d = stage[4 * t + 3];
     const u64 group = (u64)a.x | ((u64)a.y << 32), index = (u64)a.z | ((u64)a.w << 32);
     const u64 commit = (u64)b.x | ((u64)b.y << 32), hint = (u64)b.z | ((u64)b.w << 32);
-    const u64 rs = (u64)c.x | ((u64)c.y << 32);
-    const u32 slot = c.z, flags = c.w & 0xffu;
+    const u64 rs = (u64)c.x | ((u64)c.y << 32), log_term = (u64)c.z | ((u64)c.w << 32);
+    const u32 slot = d.x, flags = d.y & 0xffu;
     if (group >= G || slot >= P || flags == 0) { // malformed record: counted with the duplicates
         atomicAdd(&counters[1], 1u);
         return;
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(const rg_wire_msg *r
     mc[o] = commit;
     if (flags & RG_MF_REJECT) mh[o] = hint;
     if (flags & RG_MF_HAS_RS) mrs[o] = rs;
+    if (flags & RG_MF_HAS_LOGTERM) mlt[o] = log_term;
     if (atomicExch(&gmark[group], epoch) != epoch) list[atomicAdd(&counters[0], 1u)] = group;
 }
 
@@ -343,7 +346,7 @@ struct rg_engine {
     // host mirror of RawNode::step (rg_set_peers / rg_step / rg_flush)
     std::vector<u64> peer_ids; // [G][8], 0 = unused
     std::vector<u64> terms;    // [G]
-    std::vector<u64> q_mi, q_mc, q_mh, q_mrs; // [P][stride] host queues
+    std::vector<u64> q_mi, q_mc, q_mh, q_mrs, q_mlt; // [P][stride] host queues
     std::vector<u8> q_mf;                      // [G][8]
     std::vector<u64> q_dirty;                  // groups touched since the last flush
     std::vector<rg_wire_msg> q_records;        // flush staging (wire-order records of the dirty groups)
@@ -358,6 +361,7 @@ static size_t rg_col_elem(int c) {
     return 8;
 }
 static bool rg_col_per_slot(int c) { return c <= RG_COL_GID; }
+static bool rg_col_per_run(int c) { return c == RG_COL_RUN_FIRST || c == RG_COL_RUN_TERM; }
 
 #define RG_STR2(x) #x
 #define RG_STR(x) RG_STR2(x)
@@ -373,6 +377,7 @@ extern "C" int rg_device_count(void) {
 extern "C" uint64_t rg_column_bytes(const rg_engine *h, int c) {
     if (!h || c < 0 || c >= RG_COL_COUNT) return 0;
     if (rg_col_per_slot(c)) return (uint64_t)h->P * h->stride * 8;
+    if (rg_col_per_run(c)) return (uint64_t)RG_TERM_RUNS * h->stride * 8;
     return (uint64_t)h->G * rg_col_elem(c);
 }
 
@@ -412,7 +417,9 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     size_t off = 0;
     for (int c = 0; c < RG_COL_COUNT; c++) {
         h->col_off[c] = off;
-        const size_t bytes = rg_col_per_slot(c) ? (size_t)h->P * h->stride * 8 : (size_t)h->stride * rg_col_elem(c);
+        const size_t bytes = rg_col_per_slot(c)  ? (size_t)h->P * h->stride * 8
+                             : rg_col_per_run(c) ? (size_t)RG_TERM_RUNS * h->stride * 8
+                                                 : (size_t)h->stride * rg_col_elem(c);
         off += rg_align(bytes);
     }
     h->state_bytes = off;
@@ -444,6 +451,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.hi = (u64 *)rg_col(h, RG_COL_TERM_HI);
     s.cfg = (u32 *)rg_col(h, RG_COL_CFG);
     s.out = (u32 *)rg_col(h, RG_COL_OUT);
+    s.run_first = (u64 *)rg_col(h, RG_COL_RUN_FIRST);
+    s.run_term = (u64 *)rg_col(h, RG_COL_RUN_TERM);
+    s.dummy_idx = (u64 *)rg_col(h, RG_COL_DUMMY_INDEX);
+    s.dummy_term = (u64 *)rg_col(h, RG_COL_DUMMY_TERM);
+    s.cur_term = (u64 *)rg_col(h, RG_COL_CUR_TERM);
     s.G = h->G;
     s.stride = h->stride;
     *out = h;
@@ -589,6 +601,7 @@ extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
     ms.mc = (const u64 *)m->m_commit;
     ms.mh = m->m_hint ? (const u64 *)m->m_hint : h->zero_col;
     ms.mrs = m->m_rs ? (const u64 *)m->m_rs : h->zero_col;
+    ms.mlt = m->m_logterm ? (const u64 *)m->m_logterm : h->zero_col;
     ms.mflags = (const u64 *)m->m_flags;
     return rg_tick_impl(h, ms);
 }
@@ -607,6 +620,7 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
         fm.m[t].mc = (const u64 *)m[t].m_commit;
         fm.m[t].mh = m[t].m_hint ? (const u64 *)m[t].m_hint : h->zero_col;
         fm.m[t].mrs = m[t].m_rs ? (const u64 *)m[t].m_rs : h->zero_col;
+        fm.m[t].mlt = m[t].m_logterm ? (const u64 *)m[t].m_logterm : h->zero_col;
         fm.m[t].mflags = (const u64 *)m[t].m_flags;
     }
     fm.out_t = dev_out_t;
@@ -632,13 +646,14 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
 static int rg_ensure_msg_arena(rg_engine *h) {
     if (h->msg_arena) return RG_OK;
     const size_t col = rg_align((size_t)h->P * h->stride * 8);
-    RG_HIP(hipMalloc(&h->msg_arena, 4 * col + rg_align(h->stride * 8)));
-    RG_HIP(hipMemsetAsync(h->msg_arena, 0, 4 * col + rg_align(h->stride * 8), h->stream));
+    RG_HIP(hipMalloc(&h->msg_arena, 5 * col + rg_align(h->stride * 8)));
+    RG_HIP(hipMemsetAsync(h->msg_arena, 0, 5 * col + rg_align(h->stride * 8), h->stream));
     h->staged.mi = (u64 *)(h->msg_arena);
     h->staged.mc = (u64 *)(h->msg_arena + col);
     h->staged.mh = (u64 *)(h->msg_arena + 2 * col);
     h->staged.mrs = (u64 *)(h->msg_arena + 3 * col);
-    h->staged.mflags = (u64 *)(h->msg_arena + 4 * col);
+    h->staged.mlt = (u64 *)(h->msg_arena + 4 * col);
+    h->staged.mflags = (u64 *)(h->msg_arena + 5 * col);
     return RG_OK;
 }
 
@@ -656,6 +671,8 @@ extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
     else ms.mh = h->zero_col;
     if (m->m_rs) RG_HIP(hipMemcpyAsync((void *)h->staged.mrs, m->m_rs, colb, hipMemcpyHostToDevice, h->stream));
     else ms.mrs = h->zero_col;
+    if (m->m_logterm) RG_HIP(hipMemcpyAsync((void *)h->staged.mlt, m->m_logterm, colb, hipMemcpyHostToDevice, h->stream));
+    else ms.mlt = h->zero_col;
     RG_HIP(hipMemcpyAsync((void *)h->staged.mflags, m->m_flags, h->G * 8, hipMemcpyHostToDevice, h->stream));
     rc = rg_tick_impl(h, ms);
     if (rc) return rc;
@@ -706,7 +723,8 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     RG_HIP(hipMemcpyAsync(h->d_records, records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
                        h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
-                       (u64 *)h->staged.mrs, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list, h->counters);
+                       (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
+                       h->counters);
     u32 dup = 0;
     RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // the caller's record array may be reused after return
@@ -723,7 +741,8 @@ extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, ui
     if (rc) return rc;
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, dev_records, (u64)n,
                        h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
-                       (u64 *)h->staged.mrs, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list, h->counters);
+                       (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
+                       h->counters);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_ingest_device: %s", hipGetErrorString(e));
     h->ingested_upper += n;
@@ -952,6 +971,7 @@ static void rg_mirror_init(rg_engine *h) {
     h->q_mc.assign(n, 0);
     h->q_mh.assign(n, 0);
     h->q_mrs.assign(n, 0);
+    h->q_mlt.assign(n, 0);
     h->q_mf.assign(h->G * 8, 0);
     h->host_mirror = true;
 }
@@ -998,8 +1018,9 @@ extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m
     h->q_mc[o] = m->commit;
     h->q_mh[o] = m->reject_hint;
     h->q_mrs[o] = m->request_snapshot;
+    h->q_mlt[o] = m->log_term;
     f |= RG_MF_VALID | (m->reject ? RG_MF_REJECT : 0) | (m->request_snapshot ? RG_MF_HAS_RS : 0) |
-         (m->ins_full ? RG_MF_INS_FULL : 0);
+         (m->ins_full ? RG_MF_INS_FULL : 0) | ((m->reject && m->log_term) ? RG_MF_HAS_LOGTERM : 0);
     return RG_OK;
 }
 
@@ -1079,6 +1100,7 @@ extern "C" int rg_flush(rg_engine *h) {
         m.m_commit = h->q_mc.data();
         m.m_hint = h->q_mh.data();
         m.m_rs = h->q_mrs.data();
+        m.m_logterm = h->q_mlt.data();
         m.m_flags = h->q_mf.data();
         rc = rg_tick(h, &m);
         // rg_ingested_results must work after ANY flush: gather the dirty groups' results compactly
@@ -1111,8 +1133,10 @@ extern "C" int rg_flush(rg_engine *h) {
                 r.commit = h->q_mc[o];
                 r.hint = h->q_mh[o];
                 r.rs = h->q_mrs[o];
+                r.log_term = h->q_mlt[o];
                 r.slot = p;
                 r.flags = f;
+                r.pad = 0;
                 recs.push_back(r);
             }
         }

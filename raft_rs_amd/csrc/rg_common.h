@@ -22,12 +22,15 @@ struct RgState {
     u64 *pflags;                                 // [G] one byte per slot
     u64 *commit, *lo, *hi;                       // [G]
     u32 *cfg, *out;                              // [G]
+    u64 *run_first, *run_term;                   // [RG_TERM_RUNS][stride] term-run table (cold)
+    u64 *dummy_idx, *dummy_term, *cur_term;      // [G] (cold)
     u64 G, stride;
 };
 
 struct RgMsgs {
     const u64 *mi, *mc, *mh, *mrs; // [P][stride]
     const u64 *mflags;             // [G] one byte per slot
+    const u64 *mlt;                // [P][stride] Message.log_term (cold)
 };
 
 RG_HD u64 rg_min(u64 a, u64 b) { return a < b ? a : b; }

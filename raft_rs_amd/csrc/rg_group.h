@@ -158,6 +158,46 @@ __host__ __device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (
 }
 
 // ---------------------------------------------------------------------------------------------
+// RaftLog::term (src/raft_log.rs:122-140) and RaftLog::find_conflict_by_term (:209-235) over the group's
+// compact term-run table: dummy entry + up to RG_TERM_RUNS runs of older terms (ascending) + the implicit
+// run [term_lo, last_index] of the leader's own term. Rare path (rejects with log_term > 0), so the
+// table is read straight from its cold columns.
+// ---------------------------------------------------------------------------------------------
+RG_HD u64 rg_log_term(const RgState &st, u64 g, u64 lo, u64 last_index, u64 idx) {
+    const u64 dummy = st.dummy_idx[g];
+    if (idx < dummy || idx > last_index) return 0; // outside [dummy, last_index]
+    if (idx >= lo) return st.cur_term[g];          // the leader's own entries (lo <= idx <= last_index)
+    if (idx == dummy) return st.dummy_term[g];
+    u64 t = 0;
+    for (int k = 0; k < RG_TERM_RUNS; k++) {
+        const u64 first = st.run_first[(u64)k * st.stride + g];
+        if (first != 0 && first <= idx) t = st.run_term[(u64)k * st.stride + g];
+    }
+    return t;
+}
+
+RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, u64 lo, u64 last_index, u64 index, u64 term) {
+    if (index > last_index) return index; // "out of range": returned as is (raft_log.rs:214-223)
+    u64 ci = index;
+    for (;;) { // every iteration leaves a whole run (or the dummy entry) behind: <= RG_TERM_RUNS + 3 rounds
+        const u64 t = rg_log_term(st, g, lo, last_index, ci);
+        if (t <= term) return ci;
+        // t > term: the reference steps ci -= 1 until the term changes; skip to just below this run
+        u64 run_start;
+        if (ci >= lo) {
+            run_start = lo; // inside the leader's own run
+        } else {
+            run_start = st.dummy_idx[g]; // ci == dummy: step below it
+            for (int k = 0; k < RG_TERM_RUNS; k++) {
+                const u64 first = st.run_first[(u64)k * st.stride + g];
+                if (first != 0 && first <= ci) run_start = first;
+            }
+        }
+        ci = run_start - 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One group's registers for a tick.
 // ---------------------------------------------------------------------------------------------
 template <int P> struct RgGroup {
@@ -351,7 +391,10 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                         const bool stale = (r.nx[S] == 0 || r.nx[S] - 1 != idx) && rs == 0;
                         if (!stale) {
                             if (rs == 0) {
-                                const u64 h = ms.mh[o] + 1;
+                                u64 hint = ms.mh[o];
+                                if (f & RG_MF_HAS_LOGTERM) // raft.rs:1562,1657-1660
+                                    hint = rg_find_conflict_by_term(st, g, r.lo, r.hi, hint, ms.mlt[o]);
+                                const u64 h = hint + 1;
                                 u64 n = idx < h ? idx : h;
                                 if (n < 1) n = 1;
                                 set_next<S>(n);

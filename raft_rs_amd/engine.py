@@ -19,10 +19,15 @@ class EngineError(RuntimeError):
 
 
 class COL:
-    MATCH, NEXT, PR_COMMIT, PEND_SNAP, PEND_RS, GID, PFLAGS, COMMIT, TERM_LO, TERM_HI, CFG, OUT = range(12)
+    (MATCH, NEXT, PR_COMMIT, PEND_SNAP, PEND_RS, GID, PFLAGS, COMMIT, TERM_LO, TERM_HI, CFG, OUT, RUN_FIRST,
+     RUN_TERM, DUMMY_INDEX, DUMMY_TERM, CUR_TERM) = range(17)
     PER_SLOT = (0, 1, 2, 3, 4, 5)
+    PER_RUN = (12, 13)
     NAMES = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
-             "term_lo", "term_hi", "cfg", "out")
+             "term_lo", "term_hi", "cfg", "out", "run_first", "run_term", "dummy_index", "dummy_term", "cur_term")
+
+
+TERM_RUNS = 4
 
 
 class PF:
@@ -30,7 +35,7 @@ class PF:
 
 
 class MF:
-    VALID, REJECT, HAS_RS, INS_FULL, SENT, APPEND, HEARTBEAT = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
+    VALID, REJECT, HAS_RS, INS_FULL, SENT, APPEND, HEARTBEAT, HAS_LOGTERM = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80
 
 
 class OUT:
@@ -71,7 +76,7 @@ class _Config(C.Structure):
 
 class _Msgs(C.Structure):
     _fields_ = [("m_index", C.c_void_p), ("m_commit", C.c_void_p), ("m_hint", C.c_void_p),
-                ("m_rs", C.c_void_p), ("m_flags", C.c_void_p)]
+                ("m_rs", C.c_void_p), ("m_flags", C.c_void_p), ("m_logterm", C.c_void_p)]
 
 
 class _Workload(C.Structure):
@@ -88,16 +93,18 @@ class _HostState(C.Structure):
 class AppendResponse(C.Structure):
     _fields_ = [("from_", C.c_uint64), ("term", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
                 ("reject_hint", C.c_uint64), ("request_snapshot", C.c_uint64), ("reject", C.c_uint8),
-                ("ins_full", C.c_uint8), ("pad", C.c_uint8 * 6)]
+                ("ins_full", C.c_uint8), ("pad", C.c_uint8 * 6), ("log_term", C.c_uint64)]
 
 
 class WireMsg(C.Structure):
     _fields_ = [("group", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64), ("hint", C.c_uint64),
-                ("rs", C.c_uint64), ("slot", C.c_uint32), ("flags", C.c_uint32)]
+                ("rs", C.c_uint64), ("log_term", C.c_uint64), ("slot", C.c_uint32), ("flags", C.c_uint32),
+                ("pad", C.c_uint64)]
 
 
 WIRE_DTYPE = np.dtype([("group", "<u8"), ("index", "<u8"), ("commit", "<u8"), ("hint", "<u8"), ("rs", "<u8"),
-                       ("slot", "<u4"), ("flags", "<u4")])
+                       ("log_term", "<u8"), ("slot", "<u4"), ("flags", "<u4"), ("pad", "<u8")])
+assert WIRE_DTYPE.itemsize == 64
 
 
 class CellWrite(C.Structure):
@@ -199,16 +206,17 @@ class MsgBuffers:
         self.m_commit = np.zeros((n_slots, stride), dtype=np.uint64)
         self.m_hint = np.zeros((n_slots, stride), dtype=np.uint64)
         self.m_rs = np.zeros((n_slots, stride), dtype=np.uint64)
+        self.m_logterm = np.zeros((n_slots, stride), dtype=np.uint64)
         self.m_flags = np.zeros((n_groups, 8), dtype=np.uint8)
 
     def clear(self):
-        for a in (self.m_index, self.m_commit, self.m_hint, self.m_rs, self.m_flags):
+        for a in (self.m_index, self.m_commit, self.m_hint, self.m_rs, self.m_logterm, self.m_flags):
             a[...] = 0
 
     def as_dict(self):
         return {"n_groups": self.n_groups, "n_slots": self.n_slots, "stride": self.stride,
                 "m_index": self.m_index, "m_commit": self.m_commit, "m_hint": self.m_hint,
-                "m_rs": self.m_rs, "m_flags": self.m_flags}
+                "m_rs": self.m_rs, "m_logterm": self.m_logterm, "m_flags": self.m_flags}
 
 
 class Engine:
@@ -248,6 +256,8 @@ class Engine:
     def column_shape_dtype(self, col):
         if col in COL.PER_SLOT:
             return (self.n_slots, self.stride), np.uint64
+        if col in COL.PER_RUN:
+            return (TERM_RUNS, self.stride), np.uint64
         if col == COL.PFLAGS:
             return (self.n_groups, 8), np.uint8
         if col in (COL.CFG, COL.OUT):
@@ -273,6 +283,9 @@ class Engine:
         """st: dict with the column names of COL.NAMES[:11] (numpy arrays shaped as column_shape_dtype says)."""
         for col in range(COL.CFG + 1):
             self.load_column(col, st[COL.NAMES[col]])
+        for col in (COL.RUN_FIRST, COL.RUN_TERM, COL.DUMMY_INDEX, COL.DUMMY_TERM, COL.CUR_TERM):  # optional term-run table
+            if COL.NAMES[col] in st:
+                self.load_column(col, st[COL.NAMES[col]])
 
     def read_state(self):
         st = {"n_groups": self.n_groups, "n_slots": self.n_slots, "stride": self.stride}
@@ -307,12 +320,13 @@ class Engine:
     # ---- hot path --------------------------------------------------------------------------
     def tick(self, msgs):
         """Host-buffer tick (H2D copy + kernel + sync)."""
-        m = _Msgs(_ptr(msgs.m_index), _ptr(msgs.m_commit), _ptr(msgs.m_hint), _ptr(msgs.m_rs), _ptr(msgs.m_flags))
+        m = _Msgs(_ptr(msgs.m_index), _ptr(msgs.m_commit), _ptr(msgs.m_hint), _ptr(msgs.m_rs), _ptr(msgs.m_flags),
+                  _ptr(getattr(msgs, "m_logterm", None)))
         self._check(self.L.rg_tick(self.h, C.byref(m)))
 
-    def tick_device(self, m_index, m_commit, m_hint, m_rs, m_flags):
+    def tick_device(self, m_index, m_commit, m_hint, m_rs, m_flags, m_logterm=None):
         """Device-pointer tick (asynchronous on the engine's stream)."""
-        m = _Msgs(_ptr(m_index), _ptr(m_commit), _ptr(m_hint), _ptr(m_rs), _ptr(m_flags))
+        m = _Msgs(_ptr(m_index), _ptr(m_commit), _ptr(m_hint), _ptr(m_rs), _ptr(m_flags), _ptr(m_logterm))
         self._check(self.L.rg_tick_device(self.h, C.byref(m)))
 
     def ingest(self, records):
@@ -353,7 +367,7 @@ class Engine:
         dev_out_t: device u32 [T][G]; dev_commit_t: optional device u64 [T][G]. Asynchronous."""
         arr = (_Msgs * len(ticks))()
         for i, t in enumerate(ticks):
-            arr[i] = _Msgs(*[_ptr(x) for x in t])
+            arr[i] = _Msgs(*([_ptr(x) for x in t] + [None] * (6 - len(t))))
         self._check(self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t)))
 
     def recompute(self):
@@ -408,8 +422,9 @@ class Engine:
         self._check(self.L.rg_set_peers(self.h, group, arr, len(peer_ids), term))
 
     def step(self, group, from_, term, index, commit=0, reject=False, reject_hint=0, request_snapshot=0,
-             ins_full=False):
-        m = AppendResponse(from_, term, index, commit, reject_hint, request_snapshot, int(reject), int(ins_full))
+             ins_full=False, log_term=0):
+        m = AppendResponse(from_, term, index, commit, reject_hint, request_snapshot, int(reject), int(ins_full),
+                           (C.c_uint8 * 6)(), log_term)
         self._check(self.L.rg_step(self.h, group, C.byref(m)))
 
     def local_append(self, group, new_last_index):

@@ -73,7 +73,36 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
     return st
 
 
-def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p=0.0, sent_p=0.5, heartbeat_p=0.1):
+def random_term_table(rng, st, term):
+    """Fill st's term-run table (oracle_lib.add_term_table): 0..4 runs of terms OLDER than the leader's `term`
+    right below term_lo (the leader's own entries [term_lo, term_hi] are implicit), the dummy entry below them."""
+    G = st["n_groups"]
+    st["cur_term"][:] = term
+    for g in range(G):
+        lo, hi = int(st["term_lo"][g]), int(st["term_hi"][g])
+        top = lo if lo <= hi else hi + 1  # first index that is NOT an older entry
+        runs, first, t = [], top, term
+        for _ in range(int(rng.integers(0, 5))):
+            if first <= 1 or t <= 1:
+                break
+            first = max(1, first - int(rng.integers(1, 6)))
+            t = max(1, t - int(rng.integers(1, 3)))
+            runs.insert(0, (first, t))
+        d_idx = (runs[0][0] - 1) if runs else top - 1
+        # the dummy (snapshot) entry is older than the leader's term: a snapshot index is always committed,
+        # so "term(dummy) == current term" can never gate a commit in a real log
+        d_term = int(rng.integers(0, min(runs[0][1] if runs else term - 1, term - 1) + 1))
+        for k in range(4):
+            st["run_first"][k, g] = runs[k][0] if k < len(runs) else 0
+            st["run_term"][k, g] = runs[k][1] if k < len(runs) else 0
+        st["dummy_index"][g] = d_idx
+        st["dummy_term"][g] = d_term
+    return st
+
+
+def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p=0.0, sent_p=0.5, heartbeat_p=0.1,
+                logterm_max=0):
+    """logterm_max > 0: 60% of the rejects carry Message.log_term in [1, logterm_max + 1] (needs a term table)."""
     """One tick of random messages against state `st` (fills an alloc_msgs() dict in place)."""
     G, P = st["n_groups"], st["n_slots"]
     self_slot = ((st["cfg"] >> 16) & 7).astype(np.int64)
@@ -109,8 +138,14 @@ def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p
         msgs["m_commit"][p, :G] = mc.astype(np.uint64)
         msgs["m_hint"][p, :G] = hint
         msgs["m_rs"][p, :G] = np.where(has_rs, rng.integers(1, 100, size=G), 0).astype(np.uint64)
+        # rejects that carry the follower's log term: the hint goes through find_conflict_by_term
+        has_lt = reject & (rng.random(G) < 0.6) & bool(logterm_max)
+        if "m_logterm" in msgs:
+            msgs["m_logterm"][p, :G] = np.where(has_lt, rng.integers(1, max(2, logterm_max + 2), size=G), 0).astype(np.uint64)
+            hint_lt = np.clip(hi.astype(np.int64) - rng.integers(-2, 14, size=G), 0, None).astype(np.uint64)
+            msgs["m_hint"][p, :G] = np.where(has_lt, hint_lt, msgs["m_hint"][p, :G])
         f = (valid * MF_VALID) | (reject * MF_REJECT) | (has_rs * MF_HAS_RS) | (ins_full * MF_INS_FULL) | \
-            (sent * MF_SENT) | (append * MF_APPEND) | (hb * MF_HEARTBEAT)
+            (sent * MF_SENT) | (append * MF_APPEND) | (hb * MF_HEARTBEAT) | (has_lt * 0x80)
         msgs["m_flags"][:, p] = f.astype(np.uint8)
     return msgs
 

@@ -1,8 +1,28 @@
 // host_tick.hip -- TEST INFRASTRUCTURE. Compiles the engine's per-group arithmetic header
 // (raft_rs_amd/csrc/rg_group.h, the exact code the HIP kernels inline) for the HOST, so CPU-only
 // tests can diff it against the oracle. This file is never part of libraftgroups.so: the product has
-// no CPU path. Build: hipcc -O2 -shared -fPIC --offload-arch=gfx950 host_tick.hip -o libhost_tick.so
+// no CPU path. Build: hipcc -O3 -shared -fPIC --offload-arch=gfx950 host_tick.hip -o libhost_tick.so
 #include "../../raft_rs_amd/csrc/rg_tick_kernels.h"
+
+// state[]: match next pr_commit pend_snap pend_rs gid pflags commit term_lo term_hi cfg out
+//          run_first run_term dummy_index dummy_term cur_term   (17 pointers)
+// msg[]:   m_index m_commit m_hint m_rs m_flags m_logterm       (6 pointers)
+static RgState make_state(void *const *p, u64 G, u64 stride) {
+    RgState st;
+    st.match = (u64 *)p[0]; st.next = (u64 *)p[1]; st.prc = (u64 *)p[2]; st.psnap = (u64 *)p[3];
+    st.prs = (u64 *)p[4]; st.gid = (u64 *)p[5]; st.pflags = (u64 *)p[6]; st.commit = (u64 *)p[7];
+    st.lo = (u64 *)p[8]; st.hi = (u64 *)p[9]; st.cfg = (u32 *)p[10]; st.out = (u32 *)p[11];
+    st.run_first = (u64 *)p[12]; st.run_term = (u64 *)p[13]; st.dummy_idx = (u64 *)p[14]; st.dummy_term = (u64 *)p[15];
+    st.cur_term = (u64 *)p[16];
+    st.G = G; st.stride = stride;
+    return st;
+}
+static RgMsgs make_msgs(const void *const *p) {
+    RgMsgs ms;
+    ms.mi = (const u64 *)p[0]; ms.mc = (const u64 *)p[1]; ms.mh = (const u64 *)p[2]; ms.mrs = (const u64 *)p[3];
+    ms.mflags = (const u64 *)p[4]; ms.mlt = (const u64 *)p[5];
+    return ms;
+}
 
 template <int P> static void host_tick(const RgState &st, const RgMsgs &ms, bool gc, u64 g0, u64 g1) {
     for (u64 g = g0; g < g1; g++) {
@@ -12,33 +32,6 @@ template <int P> static void host_tick(const RgState &st, const RgMsgs &ms, bool
         else rg_group_tick<P, false, RG_LAZY_NEXT>(r, st, ms, g);
         rg_store_group<P>(r, st, g);
     }
-}
-
-extern "C" int rg_host_check_tick(unsigned P, unsigned long G, unsigned long stride, u64 *match, u64 *next, u64 *prc,
-                                  u64 *psnap, u64 *prs, u64 *gid, u64 *pflags, u64 *commit, u64 *lo, u64 *hi, u32 *cfg,
-                                  u32 *out, const u64 *mi, const u64 *mc, const u64 *mh, const u64 *mrs,
-                                  const u64 *mflags, int group_commit_kernel, unsigned long g_begin,
-                                  unsigned long g_end) {
-    RgState st;
-    st.match = match; st.next = next; st.prc = prc; st.psnap = psnap; st.prs = prs; st.gid = gid;
-    st.pflags = pflags; st.commit = commit; st.lo = lo; st.hi = hi; st.cfg = cfg; st.out = out;
-    st.G = G; st.stride = stride;
-    RgMsgs ms;
-    ms.mi = mi; ms.mc = mc; ms.mh = mh; ms.mrs = mrs; ms.mflags = mflags;
-    const bool gc = group_commit_kernel != 0;
-    const u64 g0 = g_begin, g1 = g_end < G ? g_end : G;
-    switch (P) {
-    case 1: host_tick<1>(st, ms, gc, g0, g1); break;
-    case 2: host_tick<2>(st, ms, gc, g0, g1); break;
-    case 3: host_tick<3>(st, ms, gc, g0, g1); break;
-    case 4: host_tick<4>(st, ms, gc, g0, g1); break;
-    case 5: host_tick<5>(st, ms, gc, g0, g1); break;
-    case 6: host_tick<6>(st, ms, gc, g0, g1); break;
-    case 7: host_tick<7>(st, ms, gc, g0, g1); break;
-    case 8: host_tick<8>(st, ms, gc, g0, g1); break;
-    default: return -1;
-    }
-    return 0;
 }
 
 // Fused replay on the host: the same sequence k_tick_fused runs per lane (state in "registers" across ticks).
@@ -66,31 +59,37 @@ template <int P> static void host_fused(const RgState &st, const RgMsgs *ms, u32
     }
 }
 
-extern "C" int rg_host_check_fused(unsigned P, unsigned long G, unsigned long stride, u64 *match, u64 *next, u64 *prc,
-                                   u64 *psnap, u64 *prs, u64 *gid, u64 *pflags, u64 *commit, u64 *lo, u64 *hi, u32 *cfg,
-                                   u32 *out, unsigned T, const u64 *const *mi, const u64 *const *mc, const u64 *const *mh,
-                                   const u64 *const *mrs, const u64 *const *mflags, u32 *out_t, u64 *commit_t,
-                                   int group_commit_kernel) {
-    RgState st;
-    st.match = match; st.next = next; st.prc = prc; st.psnap = psnap; st.prs = prs; st.gid = gid;
-    st.pflags = pflags; st.commit = commit; st.lo = lo; st.hi = hi; st.cfg = cfg; st.out = out;
-    st.G = G; st.stride = stride;
+#define RG_DISPATCH_P(P, CALL)                                                                    \
+    switch (P) {                                                                                  \
+    case 1: { constexpr int N = 1; CALL; } break;                                                 \
+    case 2: { constexpr int N = 2; CALL; } break;                                                 \
+    case 3: { constexpr int N = 3; CALL; } break;                                                 \
+    case 4: { constexpr int N = 4; CALL; } break;                                                 \
+    case 5: { constexpr int N = 5; CALL; } break;                                                 \
+    case 6: { constexpr int N = 6; CALL; } break;                                                 \
+    case 7: { constexpr int N = 7; CALL; } break;                                                 \
+    case 8: { constexpr int N = 8; CALL; } break;                                                 \
+    default: return -1;                                                                           \
+    }
+
+extern "C" int rg_host_check_tick(unsigned P, unsigned long G, unsigned long stride, void *const *state,
+                                  const void *const *msg, int group_commit_kernel, unsigned long g_begin,
+                                  unsigned long g_end) {
+    const RgState st = make_state(state, G, stride);
+    const RgMsgs ms = make_msgs(msg);
+    const bool gc = group_commit_kernel != 0;
+    const u64 g0 = g_begin, g1 = g_end < G ? g_end : G;
+    RG_DISPATCH_P(P, host_tick<N>(st, ms, gc, g0, g1));
+    return 0;
+}
+
+extern "C" int rg_host_check_fused(unsigned P, unsigned long G, unsigned long stride, void *const *state, unsigned T,
+                                   const void *const *const *msgs, u32 *out_t, u64 *commit_t, int group_commit_kernel) {
+    const RgState st = make_state(state, G, stride);
     RgMsgs ms[RG_MAX_FUSE];
     if (T == 0 || T > RG_MAX_FUSE) return -1;
-    for (unsigned t = 0; t < T; t++) {
-        ms[t].mi = mi[t]; ms[t].mc = mc[t]; ms[t].mh = mh[t]; ms[t].mrs = mrs[t]; ms[t].mflags = mflags[t];
-    }
+    for (unsigned t = 0; t < T; t++) ms[t] = make_msgs(msgs[t]);
     const bool gc = group_commit_kernel != 0;
-    switch (P) {
-    case 1: host_fused<1>(st, ms, T, out_t, commit_t, gc); break;
-    case 2: host_fused<2>(st, ms, T, out_t, commit_t, gc); break;
-    case 3: host_fused<3>(st, ms, T, out_t, commit_t, gc); break;
-    case 4: host_fused<4>(st, ms, T, out_t, commit_t, gc); break;
-    case 5: host_fused<5>(st, ms, T, out_t, commit_t, gc); break;
-    case 6: host_fused<6>(st, ms, T, out_t, commit_t, gc); break;
-    case 7: host_fused<7>(st, ms, T, out_t, commit_t, gc); break;
-    case 8: host_fused<8>(st, ms, T, out_t, commit_t, gc); break;
-    default: return -1;
-    }
+    RG_DISPATCH_P(P, host_fused<N>(st, ms, T, out_t, commit_t, gc));
     return 0;
 }

@@ -50,7 +50,7 @@ class Index(C.Structure):
 class Msg(C.Structure):
     _fields_ = [("from_", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
                 ("reject_hint", C.c_uint64), ("request_snapshot", C.c_uint64),
-                ("reject", C.c_bool), ("ins_full", C.c_int8)]
+                ("reject", C.c_bool), ("ins_full", C.c_int8), ("log_term", C.c_uint64)]
 
 
 class Out(C.Structure):
@@ -61,12 +61,13 @@ class Out(C.Structure):
 class SoaState(C.Structure):
     _fields_ = [("n_groups", C.c_size_t), ("n_slots", C.c_size_t), ("stride", C.c_size_t)] + \
                [(n, C.c_void_p) for n in ("match", "next", "pr_commit", "pend_snap", "pend_rs",
-                                          "gid", "pflags", "commit", "term_lo", "term_hi", "cfg")]
+                                          "gid", "pflags", "commit", "term_lo", "term_hi", "cfg",
+                                          "run_first", "run_term", "dummy_index", "dummy_term", "cur_term")]
 
 
 class SoaMsgs(C.Structure):
     _fields_ = [("n_groups", C.c_size_t), ("n_slots", C.c_size_t), ("stride", C.c_size_t)] + \
-               [(n, C.c_void_p) for n in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")]
+               [(n, C.c_void_p) for n in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags", "m_logterm")]
 
 
 _lib = None
@@ -197,8 +198,9 @@ class Cluster:
         v = self.L.ro_maximal_committed_index(self.h, g, C.byref(flag))
         return v, bool(flag.value)
 
-    def step(self, g, from_, index, commit=0, reject=False, reject_hint=0, request_snapshot=0, ins_full=-1):
-        m = Msg(from_, index, commit, reject_hint, request_snapshot, reject, ins_full)
+    def step(self, g, from_, index, commit=0, reject=False, reject_hint=0, request_snapshot=0, ins_full=-1,
+             log_term=0):
+        m = Msg(from_, index, commit, reject_hint, request_snapshot, reject, ins_full, log_term)
         o = Out()
         self.L.ro_handle_append_response(self.h, g, C.byref(m), C.byref(o))
         return o
@@ -215,14 +217,12 @@ class Cluster:
         assert r == 0, r
 
     def tick_soa(self, msgs, gout, g_begin=0, g_end=None):
-        m = SoaMsgs(msgs["n_groups"], msgs["n_slots"], msgs["stride"],
-                    *[msgs[k].ctypes.data for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")])
+        m = _soa_msgs_struct(msgs)
         return self.L.ro_tick_soa(self.h, C.byref(m), gout.ctypes.data, g_begin,
                                   self.n if g_end is None else g_end)
 
     def tick_soa_mt(self, msgs, gout, n_threads):
-        m = SoaMsgs(msgs["n_groups"], msgs["n_slots"], msgs["stride"],
-                    *[msgs[k].ctypes.data for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")])
+        m = _soa_msgs_struct(msgs)
         return self.L.ro_tick_soa_mt(self.h, C.byref(m), gout.ctypes.data, n_threads)
 
 
@@ -230,8 +230,21 @@ STATE_COLS = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pfla
               "term_lo", "term_hi", "cfg")
 
 
+TERM_TABLE_COLS = ("run_first", "run_term", "dummy_index", "dummy_term", "cur_term")
+
+
 def _soa_state_struct(st):
-    return SoaState(st["n_groups"], st["n_slots"], st["stride"], *[st[k].ctypes.data for k in STATE_COLS])
+    table = [st[k].ctypes.data if k in st else None for k in TERM_TABLE_COLS]
+    if any(t is None for t in table):
+        table = [None] * 5
+    return SoaState(st["n_groups"], st["n_slots"], st["stride"], *[st[k].ctypes.data for k in STATE_COLS], *table)
+
+
+def _soa_msgs_struct(msgs):
+    lt = msgs.get("m_logterm")
+    return SoaMsgs(msgs["n_groups"], msgs["n_slots"], msgs["stride"],
+                   *[msgs[k].ctypes.data for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")],
+                   lt.ctypes.data if lt is not None else None)
 
 
 def alloc_state(n_groups, n_slots, stride=None):
@@ -249,7 +262,17 @@ def alloc_state(n_groups, n_slots, stride=None):
 def alloc_msgs(n_groups, n_slots, stride=None):
     stride = stride or ((n_groups + 255) // 256) * 256
     m = {"n_groups": n_groups, "n_slots": n_slots, "stride": stride}
-    for k in ("m_index", "m_commit", "m_hint", "m_rs"):
+    for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_logterm"):
         m[k] = np.zeros((n_slots, stride), dtype=np.uint64)
     m["m_flags"] = np.zeros((n_groups, 8), dtype=np.uint8)
     return m
+
+
+def add_term_table(st):
+    """Attach an (empty) term-run table to a state dict: run_first/run_term [4][stride], dummy [G]."""
+    st["run_first"] = np.zeros((4, st["stride"]), dtype=np.uint64)
+    st["run_term"] = np.zeros((4, st["stride"]), dtype=np.uint64)
+    st["dummy_index"] = np.zeros(st["n_groups"], dtype=np.uint64)
+    st["dummy_term"] = np.zeros(st["n_groups"], dtype=np.uint64)
+    st["cur_term"] = np.zeros(st["n_groups"], dtype=np.uint64)
+    return st

@@ -30,19 +30,44 @@ def build_lib():
     return LIB
 
 
+STATE_ORDER = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit", "term_lo", "term_hi",
+               "cfg")
+TABLE_ORDER = ("run_first", "run_term", "dummy_index", "dummy_term")
+MSG_ORDER = ("m_index", "m_commit", "m_hint", "m_rs", "m_flags", "m_logterm")
+_ZERO = {}
+
+
+def state_ptrs(st, out):
+    """17 pointers in the order host_tick.hip expects; a zero table when the state has no term-run table."""
+    key = (st["n_groups"], st["stride"])
+    if key not in _ZERO:
+        _ZERO[key] = (np.zeros((4, st["stride"]), dtype=np.uint64), np.zeros(st["n_groups"], dtype=np.uint64))
+    z4, zg = _ZERO[key]
+    table = [st.get("run_first", z4), st.get("run_term", z4), st.get("dummy_index", zg), st.get("dummy_term", zg),
+             st.get("cur_term", zg)]
+    cols = [st[k] for k in STATE_ORDER] + [out] + table
+    return (C.c_void_p * 17)(*[c.ctypes.data for c in cols])
+
+
+def msg_ptrs(msgs):
+    key = ("m", msgs["m_index"].shape)
+    if key not in _ZERO:
+        _ZERO[key] = np.zeros(msgs["m_index"].shape, dtype=np.uint64)
+    cols = [msgs[k] for k in MSG_ORDER[:5]] + [msgs.get("m_logterm", _ZERO[key]) if isinstance(msgs, dict)
+                                                 else msgs["m_logterm"]]
+    return (C.c_void_p * 6)(*[c.ctypes.data for c in cols])
+
+
 @pytest.fixture(scope="module")
 def host_tick():
     if build_lib() is None:
         pytest.skip("hipcc not available")
     fn = C.CDLL(LIB).rg_host_check_tick
     fn.restype = C.c_int
-    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 17 + [C.c_int, C.c_ulong, C.c_ulong]
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_int, C.c_ulong, C.c_ulong]
 
     def tick(st, msgs, out, gc):
-        cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
-                                "term_lo", "term_hi", "cfg")] + [out] + \
-               [msgs[k] for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags")]
-        rc = fn(st["n_slots"], st["n_groups"], st["stride"], *[c.ctypes.data for c in cols], int(gc), 0,
+        rc = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), msg_ptrs(msgs), int(gc), 0,
                 st["n_groups"])
         assert rc == 0
     return tick
@@ -54,17 +79,12 @@ def host_fused():
         pytest.skip("hipcc not available")
     fn = C.CDLL(LIB).rg_host_check_fused
     fn.restype = C.c_int
-    PP = C.POINTER(C.c_void_p)
-    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong] + [C.c_void_p] * 12 + [C.c_uint, PP, PP, PP, PP, PP,
-                                                                            C.c_void_p, C.c_void_p, C.c_int]
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
     def fused(st, ticks, out_last, out_t, commit_t, gc):
-        cols = [st[k] for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
-                                "term_lo", "term_hi", "cfg")] + [out_last]
-        arrs = []
-        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
-            arrs.append((C.c_void_p * len(ticks))(*[t[k].ctypes.data for t in ticks]))
-        rc = fn(st["n_slots"], st["n_groups"], st["stride"], *[c.ctypes.data for c in cols], len(ticks), *arrs,
+        per_tick = [msg_ptrs(t) for t in ticks]
+        arr = (C.c_void_p * len(ticks))(*[C.addressof(p) for p in per_tick])
+        rc = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out_last), len(ticks), arr,
                 out_t.ctypes.data, commit_t.ctypes.data, int(gc))
         assert rc == 0
     return fused
@@ -180,3 +200,49 @@ def test_fused_ticks_equal_sequential_ticks(host_fused, n_slots, T, gc):
         assert (out_last == want_out[-1]).all()
         diffs = fuzz.diff_states(st, eng_st, G, n_slots)
         assert not diffs, (rnd, diffs[:6])
+
+
+@pytest.mark.parametrize("n_slots", [3, 5, 7])
+def test_find_conflict_by_term_on_the_device_table(host_tick, n_slots):
+    """Rejects carrying Message.log_term: the engine resolves the hint with find_conflict_by_term over its
+    compact term-run table (raft_log.rs:209-235 via raft.rs:1562,1657-1660); the oracle walks its own log."""
+    rng = np.random.default_rng(9100 + n_slots)
+    G, TERM = 3000, 9
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots)
+    fuzz.random_state(rng, st, small_values=True, probe_frac=0.5)
+    fuzz.random_term_table(rng, st, TERM)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    # the table and the oracle's log agree on every term
+    L = O.lib()
+    for g in range(0, G, 37):
+        for idx in range(max(0, int(st["dummy_index"][g]) - 1), int(st["term_hi"][g]) + 2):
+            want = L.ro_log_term(cl.h, g, idx)
+            runs = [(int(st["run_first"][k, g]), int(st["run_term"][k, g])) for k in range(4) if st["run_first"][k, g]]
+            d = int(st["dummy_index"][g])
+            if idx < d or idx > int(st["term_hi"][g]):
+                got = 0
+            elif idx >= int(st["term_lo"][g]):
+                got = TERM
+            elif idx == d:
+                got = int(st["dummy_term"][g])
+            else:
+                got = ([t for f, t in runs if f <= idx] or [0])[-1]
+            assert got == want, (g, idx, got, want)
+    eng_st = copy_state(st)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    n_lt = 0
+    for t in range(5):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, reject_p=0.4, logterm_max=TERM)
+        n_lt += int(((msgs["m_flags"] & 0x80) != 0).sum())
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        assert (out == gout).all()
+    assert n_lt > 500

@@ -316,3 +316,49 @@ def test_fused_launch_equals_sequential_ticks(rg, workload, n_slots, T):
             assert (a[k] == b[k]).all(), (rnd, k)
     seq.close()
     fus.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("n_slots", [3, 7])
+def test_find_conflict_by_term_on_device(rg, n_slots, variant):
+    """Rejects that carry Message.log_term: hint resolved on the device against the term-run table
+    (raft_log.rs:209-235 via raft.rs:1562,1657-1660); dense tick and the wire-record path."""
+    from raft_rs_amd.engine import WIRE_DTYPE
+    rng = np.random.default_rng(600 + n_slots)
+    G, TERM = 6000, 9
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots)
+    fuzz.random_state(rng, st, small_values=True, probe_frac=0.5)
+    fuzz.random_term_table(rng, st, TERM)
+    eng = rg.Engine(G, n_slots, variant=variant)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    mb = rg.MsgBuffers(G, n_slots, eng.stride)
+    n_lt = 0
+    for t in range(5):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, reject_p=0.4, logterm_max=TERM)
+        n_lt += int(((msgs["m_flags"] & 0x80) != 0).sum())
+        if t % 2 == 0:
+            for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_logterm", "m_flags"):
+                getattr(mb, k)[...] = msgs[k]
+            eng.tick(mb)
+        else:  # the same messages as wire-order records through the sparse path
+            recs = []
+            for g in range(G):
+                for p in range(n_slots):
+                    f = int(msgs["m_flags"][g, p])
+                    if f:
+                        recs.append((g, msgs["m_index"][p, g], msgs["m_commit"][p, g], msgs["m_hint"][p, g],
+                                     msgs["m_rs"][p, g], msgs["m_logterm"][p, g], p, f, 0))
+            arr = np.array(recs, dtype=WIRE_DTYPE)
+            rng.shuffle(arr)
+            assert eng.ingest(arr) == 0
+            eng.tick_ingested()
+        cl.tick_soa(msgs, gout)
+        assert_same(eng, cl, st, gout, f"log_term rejects P={n_slots} variant={variant} tick {t}")
+    assert n_lt > 1000
+    eng.close()

@@ -17,7 +17,7 @@ def records_from_msgs(rg, msgs, groups, rng, n_slots):
             f = int(msgs["m_flags"][g, p])
             if f:
                 recs.append((g, msgs["m_index"][p, g], msgs["m_commit"][p, g], msgs["m_hint"][p, g],
-                             msgs["m_rs"][p, g], p, f))
+                             msgs["m_rs"][p, g], 0, p, f, 0))
     arr = np.array(recs, dtype=WIRE_DTYPE)
     rng.shuffle(arr)  # wire order is arbitrary across cells
     return arr
@@ -80,9 +80,10 @@ def test_duplicate_and_malformed_records_are_dropped_and_counted(rg):
     eng.workload_init(rg.WL_MAJORITY)
     st = eng.read_state()
     hi = int(st["term_hi"][7])
-    recs = np.array([(7, hi, 0, 0, 0, 1, rg.MF.VALID), (7, hi - 1, 0, 0, 0, 1, rg.MF.VALID),  # same cell twice
-                     (G + 5, 1, 0, 0, 0, 0, rg.MF.VALID), (3, 1, 0, 0, 0, 9, rg.MF.VALID),   # bad group / slot
-                     (9, 1, 0, 0, 0, 2, 0)], dtype=WIRE_DTYPE)                                # no event bits
+    V = rg.MF.VALID
+    recs = np.array([(7, hi, 0, 0, 0, 0, 1, V, 0), (7, hi - 1, 0, 0, 0, 0, 1, V, 0),  # same cell twice
+                     (G + 5, 1, 0, 0, 0, 0, 0, V, 0), (3, 1, 0, 0, 0, 0, 9, V, 0),    # bad group / slot
+                     (9, 1, 0, 0, 0, 0, 2, 0, 0)], dtype=WIRE_DTYPE)                    # no event bits
     assert eng.ingest(recs) == 4
     assert eng.tick_ingested() == 1
     groups, commit, out = eng.ingested_results()
