@@ -100,6 +100,61 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out
     }
 }
 
+// Wave-cooperative recompute (RG_VARIANT_COOP): 8 lanes per group, lane s holds slot s's matched index;
+// the q-th largest is found by a cross-lane rank select: every lane counts, with 7 xor-shuffles inside
+// its 8-lane group, how many voters are >= its own value, and a 3-step butterfly max picks the largest
+// value whose count reaches the quorum. No group commit here (the caller falls back to the lane kernel).
+template <bool COMMIT>
+__global__ __launch_bounds__(256) void k_recompute_coop(RgState st, u32 P, u64 *mci_out, u8 *gc_out) {
+    const u32 s = threadIdx.x & 7u;
+    const u64 g = (u64)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = g < st.G;
+    const u64 gc = live ? g : st.G - 1; // keep every lane in the shuffles
+    const u32 cfg = st.cfg[gc];
+    const u32 present = RG_CFG_PRESENT(cfg), incoming = RG_CFG_INCOMING(cfg), outgoing = RG_CFG_OUTGOING(cfg);
+    const u64 v = (s < P && ((present >> s) & 1u)) ? st.match[(u64)s * st.stride + gc] : 0ULL;
+    u64 result[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const u32 M = c == 0 ? incoming : outgoing;
+        const u32 n = (u32)__builtin_popcount(M);
+        const bool mine = (M >> s) & 1u;
+        u32 cnt = mine ? 1u : 0u;
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+            const u64 pv = __shfl_xor(v, k, 8);
+            const bool theirs = (M >> (s ^ (u32)k)) & 1u;
+            cnt += (theirs && pv >= v) ? 1u : 0u;
+        }
+        u64 cand = (mine && cnt >= n / 2u + 1u) ? v : 0ULL;
+#pragma unroll
+        for (int k = 1; k < 8; k <<= 1) {
+            const u64 o = __shfl_xor(cand, k, 8);
+            cand = o > cand ? o : cand;
+        }
+        result[c] = n == 0 ? ~0ULL : cand;
+    }
+    if (!live || s != 0) return;
+    const u64 mci = result[0] < result[1] ? result[0] : result[1];
+    if (COMMIT) {
+        u64 commit = st.commit[g];
+        u32 out = 0;
+        if (rg_log_maybe_commit(mci, commit, st.lo[g], st.hi[g])) {
+            st.commit[g] = commit;
+            const u32 self = RG_CFG_SELF(cfg);
+            if ((present >> self) & 1u) {
+                const u64 o = (u64)self * st.stride + g;
+                if (st.prc[o] < commit) st.prc[o] = commit;
+            }
+            out = RG_OUT_CHANGED;
+        }
+        st.out[g] = out;
+    } else {
+        mci_out[g] = mci;
+        if (gc_out) gc_out[g] = (incoming == 0 && outgoing == 0) ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels: votes and quorum liveness (src/quorum/majority.rs:130-154, joint.rs:56-67, tracker.rs:346-372)
 // ------------------------------------------------------------------------------------------------
@@ -388,7 +443,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: n_groups=%llu n_slots=%u out of range",
                        (unsigned long long)cfg->n_groups, cfg->n_slots);
-    if (cfg->variant > RG_VARIANT_LDS) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
+    if (cfg->variant > RG_VARIANT_COOP) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return rg_fail(RG_ERR_NO_DEVICE, "rg_create: no HIP device visible (this engine has no CPU fallback)");
@@ -574,7 +629,7 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
 static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
-    const u32 variant = h->cfg.variant == RG_VARIANT_DEFAULT ? RG_VARIANT_LANE : h->cfg.variant;
+    const u32 variant = h->cfg.variant == RG_VARIANT_LDS ? RG_VARIANT_LDS : RG_VARIANT_LANE;
     switch (h->P) {
     case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
     case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;
@@ -826,6 +881,12 @@ extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *com
 }
 
 template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *gc) {
+    if (h->cfg.variant == RG_VARIANT_COOP && !h->any_group_commit) {
+        hipLaunchKernelGGL((k_recompute_coop<COMMIT>), dim3(rg_grid(h->G, 32)), dim3(256), 0, h->stream, h->st, h->P, mci, gc);
+        hipError_t ce = hipGetLastError();
+        if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(ce));
+        return RG_OK;
+    }
     const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
     switch (h->P) {
     case 1: hipLaunchKernelGGL((k_recompute<1, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;

@@ -173,16 +173,19 @@ def test_group_commit_streams_match_oracle(rg, n_slots):
     eng.close()
 
 
-def test_recompute_matches_oracle_maybe_commit(rg):
+@pytest.mark.parametrize("variant,P", [(1, 5), (3, 5), (3, 8), (3, 3)])
+def test_recompute_matches_oracle_maybe_commit(rg, variant, P):
     rng = np.random.default_rng(5)
-    G, P = 5000, 5
+    G = 5000 + 7
     st = O.alloc_state(G, P)
     st["cfg"][:] = fuzz.random_cfg(rng, G, P)
     fuzz.random_state(rng, st)
     st["commit"][:] = st["commit"] // 2  # leave room to commit
-    eng = rg.Engine(G, P)
+    eng = rg.Engine(G, P, variant=variant)  # 3 = wave-cooperative rank select (8 lanes per group)
     eng.load_state(st)
+    mci = eng.maximal_committed_index()
     cl = oracle_from_state(st)
+    assert (mci == np.array([cl.mci(g)[0] for g in range(G)], dtype=np.uint64)).all()
     eng.recompute()
     gout = np.array([1 if cl.maybe_commit(g) else 0 for g in range(G)], dtype=np.uint32)
     assert_same(eng, cl, st, gout, "recompute")

@@ -47,6 +47,8 @@ for frac in (0.001, 0.01, 0.05, 0.2):
           f"tick {tt*1e6:7.1f} us  -> {len(recs)/(ti+tt)/1e6:7.1f} M msgs/s, {n_g/(ti+tt)/1e6:6.2f} M group-evals/s")
 
 # recompute-only (Raft::maybe_commit for every group, no messages): B0 = 8P+37 bytes per group
+coop = rg.Engine(G, P, variant=rg.VARIANT_COOP)
+coop.workload_init(rg.WL_MAJORITY)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -62,4 +64,16 @@ us = e0.elapsed_time(e1) * 1e3 / K
 b0 = (8 * P + 37) * G
 print(f"recompute-only k_recompute<{P}>: {us:.1f} us per sweep, {G/us/1e3:.2f} G recomputes/s, "
       f"algorithmic {b0/us/1e3:.0f} GB/s ({b0/us/1e3/8000*100:.1f}% of 8 TB/s; B0 = {8*P+37} B/group)")
+coop.set_stream(torch.cuda.current_stream().cuda_stream)
+for _ in range(5):
+    coop.recompute()
+e0.record()
+for _ in range(K):
+    coop.recompute()
+e1.record()
+torch.cuda.synchronize()
+usc = e0.elapsed_time(e1) * 1e3 / K
+print(f"recompute-only, wave-cooperative variant (8 lanes/group, shuffle rank-select): {usc:.1f} us per sweep, "
+      f"{G/usc/1e3:.2f} G recomputes/s ({b0/usc/1e3/8000*100:.1f}% of 8 TB/s)")
+coop.close()
 eng.close()
