@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--publish-every", type=int, default=8,
+    ap.add_argument("--publish-every", type=int, default=16,
                     help="N>1: all-gather the commit column every E ticks (and after the last tick)")
     ap.add_argument("--fuse", type=int, default=1,
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
@@ -241,7 +241,7 @@ def main():
 
     # Publishing all commit indices EVERY tick is not physically possible at this tick rate: 8 ranks x
     # 8 MB gathered per ~60 us tick would be ~1 TB/s of xGMI ingress per GPU (7 links x ~64 GB/s each
-    # way). The exchange therefore runs every E ticks (default 8: ~64 MB per ~0.5 ms), always including
+    # way). The exchange therefore runs every E ticks (default 16: ~64 MB per ~1 ms), always including
     # the last tick of the region so the gathered result can be verified.
     E = max(1, args.publish_every)
     n_pub = [0]
