@@ -78,8 +78,13 @@ class OracleLeader:
         O.lib().ro_handle_heartbeat_response(self.cl.h, 0, from_, commit, 1 if ins_full else 0, o)
         return {"send_append": bool(o.send_append), "free_first_one": bool(o.free_to)}
 
-    def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False):
-        o = self.cl.step(0, from_, index, commit, reject, reject_hint, request_snapshot, 1 if ins_full else 0)
+    def log_term(self, idx):
+        return O.lib().ro_log_term(self.cl.h, 0, idx)
+
+    def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False,
+             log_term=0):
+        o = self.cl.step(0, from_, index, commit, reject, reject_hint, request_snapshot, 1 if ins_full else 0,
+                         log_term)
         return {"send_append": bool(o.send_append), "send_more": bool(o.send_more),
                 "changed": bool(o.commit_changed), "free_to": bool(o.free_to), "timeout_now": bool(o.timeout_now)}
 
@@ -106,12 +111,34 @@ class EngineLeader:
         # current-term range from the log (entries of `term` are the contiguous tail)
         log = list(log)
         last = log[-1][1] if log else dummy[0]
-        cur = [idx for (t, idx) in log if t == term]
+        # the leader's own run = the contiguous TAIL of entries at `term` (some reference tests build logs whose
+        # older entries reuse the leader's term number; only the tail run is "the leader's entries")
+        cur = []
+        for t, idx in reversed(log):
+            if t != term:
+                break
+            cur.insert(0, idx)
+        if not cur:  # test_commit-style logs: entries of `term` that are not the tail
+            cur = [idx for (t, idx) in log if t == term]
         # For a real leader the entries of its term are the log tail and term_hi == last_index. A few
         # reference tests (test_commit) build logs whose tail has a HIGHER term than the leader's; the
         # gate term(mci) == term is then still the contiguous range [cur[0], cur[-1]].
         lo, hi = (cur[0], cur[-1]) if cur else (last + 1, last)
         st["term_lo"][0], st["term_hi"][0], st["commit"][0] = lo, hi, committed
+        # compact term-run table of the entries below the leader's own run (find_conflict_by_term on device)
+        O.add_term_table(st)
+        self.log = {idx: t for t, idx in log}
+        self.dummy = dummy
+        older = [(t, idx) for t, idx in log if idx < lo]
+        runs = []
+        for t, idx in older:
+            if not runs or runs[-1][1] != t:
+                runs.append((idx, t))
+        self.table_ok = len(runs) <= 4 and (not cur or cur[-1] == last)
+        if self.table_ok:
+            for k, (f, t) in enumerate(runs):
+                st["run_first"][k, 0], st["run_term"][k, 0] = f, t
+        st["dummy_index"][0], st["dummy_term"][0], st["cur_term"][0] = dummy[0], dummy[1], term
         st["cfg"][0] = rg.cfg_make(**self.cfg)
         self.eng.load_state(st)
         self.msgs = rg.MsgBuffers(1, self.P, self.eng.stride)
@@ -212,15 +239,37 @@ class EngineLeader:
         out = self._tick()
         return {"send_append": bool((out >> (8 + s)) & 1), "free_first_one": bool((out >> (24 + s)) & 1)}
 
-    def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False):
+    def log_term(self, idx):
+        if idx == self.dummy[0]:
+            return self.dummy[1]
+        return self.log.get(idx, 0)
+
+    def _find_conflict_on_host(self, index, term):
+        """What a host whose log has more term runs than the device table does itself (raft_log.rs:209-235)."""
+        last = max(self.log) if self.log else self.dummy[0]
+        if index > last:
+            return index
+        ci = index
+        while True:
+            t = 0 if (ci < self.dummy[0] or ci > last) else self.log_term(ci)
+            if t > term:
+                ci -= 1
+            else:
+                return ci
+
+    def step(self, from_, index, reject=False, reject_hint=0, commit=0, request_snapshot=0, ins_full=False,
+             log_term=0):
         MF = self.rg.MF
         s = from_ - 1
+        if reject and log_term and not self.table_ok:
+            reject_hint, log_term = self._find_conflict_on_host(reject_hint, log_term), 0
         self.msgs.m_index[s, 0] = index
         self.msgs.m_commit[s, 0] = commit
         self.msgs.m_hint[s, 0] = reject_hint
         self.msgs.m_rs[s, 0] = request_snapshot
+        self.msgs.m_logterm[s, 0] = log_term
         self.msgs.m_flags[0, s] = (MF.VALID | (MF.REJECT if reject else 0) | (MF.HAS_RS if request_snapshot else 0) |
-                                   (MF.INS_FULL if ins_full else 0))
+                                   (MF.INS_FULL if ins_full else 0) | (MF.HAS_LOGTERM if (reject and log_term) else 0))
         out = self._tick()
         return {"send_append": bool((out >> (8 + s)) & 1), "send_more": bool((out >> (16 + s)) & 1),
                 "changed": bool(out & 1), "free_to": bool((out >> (24 + s)) & 1), "timeout_now": bool(out & 4)}

@@ -64,7 +64,32 @@ def parse_file(path):
     return cases
 
 
+def extract_fast_log_rejection():
+    """harness/tests/integration_cases/test_raft.rs:5573-5775 test_fast_log_rejection: 8 rows of
+    (leader_log, follower_log, reject_hint_term, reject_hint_index, next_append_term, next_append_index);
+    logs are lists of empty_entry(term, index). Extracted as data (no test code is copied)."""
+    path = "/root/reference/harness/tests/integration_cases/test_raft.rs"
+    src = open(path, encoding="utf-8").read()
+    a = src.index("fn test_fast_log_rejection()")
+    b = src.index("for (", a)
+    body = src[a:b]
+    rows = []
+    # each row: "(" vec![..], vec![..], n, n, n, n ")"
+    for m in re.finditer(r"\(\s*vec!\[(.*?)\],\s*vec!\[(.*?)\],\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*\)", body, flags=re.S):
+        logs = []
+        for k in (1, 2):
+            logs.append([[int(t), int(i)] for t, i in re.findall(r"empty_entry\((\d+),\s*(\d+)\)", m.group(k))])
+        rows.append({"leader_log": logs[0], "follower_log": logs[1], "reject_hint_term": int(m.group(3)),
+                     "reject_hint_index": int(m.group(4)), "next_append_term": int(m.group(5)),
+                     "next_append_index": int(m.group(6))})
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fast_log_rejection.json")
+    with open(dst, "w", encoding="utf-8") as f:
+        json.dump({"source": "harness/tests/integration_cases/test_raft.rs:5573-5775", "rows": rows}, f, indent=1)
+    print(len(rows), "rows ->", dst)
+
+
 def main():
+    extract_fast_log_rejection()
     out = {}
     for name in FILES:
         out[name] = parse_file(os.path.join(REF, name))

@@ -242,9 +242,31 @@ def scenario_commit_after_remove_node(B):
     assert ld.committed() == 3
 
 
+def scenario_fast_log_rejection(B):
+    """test_raft.rs:5573-5839 test_fast_log_rejection, leader side: the follower's rejection carries
+    (reject_hint, log_term); find_conflict_by_term (raft_log.rs:209-235) turns it into the next probe."""
+    import json
+    import os
+    rows = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                       "fast_log_rejection.json")))["rows"]
+    assert len(rows) == 8
+    for i, r in enumerate(rows):
+        leader_log = [(t, idx) for t, idx in r["leader_log"]]
+        last = len(leader_log)
+        # become_candidate from term 0 -> term 1; become_leader appends its noop at last+1 (raft.rs:1163-1194)
+        ld = B(1, 1, [1, 2, 3], log=leader_log + [(1, last + 1)], committed=0, next_idx=last + 1)
+        ld.set_progress(1, match=last, next=last + 1, state=REPLICATE)
+        ld.sent(2)  # the probe MsgAppend(index = next - 1 = last) went out: Probe is now paused
+        out = ld.step(2, last, reject=True, reject_hint=r["reject_hint_index"], log_term=r["reject_hint_term"])
+        assert out["send_append"], i
+        nxt = ld.progress(2)["next"]
+        assert nxt - 1 == r["next_append_index"], f"#{i}: next append index {nxt - 1}, want {r['next_append_index']}"
+        assert ld.log_term(nxt - 1) == r["next_append_term"], f"#{i}: next append term"
+
+
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
        scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
        scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
-       scenario_commit_after_remove_node]
+       scenario_commit_after_remove_node, scenario_fast_log_rejection]
