@@ -264,9 +264,47 @@ def scenario_fast_log_rejection(B):
         assert ld.log_term(nxt - 1) == r["next_append_term"], f"#{i}: next append term"
 
 
+def scenario_progress_committed_index(B):
+    """test_raft.rs:116-299 test_progress_committed_index, the leader-side steps whose messages the test
+    spells out: #3 rejections carry commit 4 and must not move Progress.committed_index; the re-sent append
+    is acknowledged at 7; #4 delayed responses with a smaller commit must not lower it (progress.rs:153-157)."""
+    def committed_indexes(ld):
+        return tuple(ld.progress(i)["committed_index"] for i in (1, 2, 3))
+    # --- #3: leader 2, term 2, log 1..7 (4 = its noop; 5,6 proposed while isolated, 7 after), commit 4
+    ld = B(2, 2, [1, 2, 3], log=[(1, 1), (1, 2), (1, 3), (2, 4), (2, 5), (2, 6), (2, 7)], committed=4)
+    ld.set_progress(2, match=7, next=8, state=REPLICATE, committed_index=4)
+    for pid in (1, 3):  # followers acked the noop (match 4); the leader optimistically streamed up to 7
+        ld.set_progress(pid, match=4, next=7, state=REPLICATE, committed_index=4)
+    for pid in (1, 3):  # MsgAppendResponse index: 6 commit: 4 reject: true reject_hint: 4
+        out = ld.step(pid, 6, reject=True, reject_hint=4, commit=4)
+        pr = ld.progress(pid)
+        assert out["send_append"] and pr["state"] == PROBE and pr["next"] == 5, pid  # MsgAppend index 4, entries 5..7
+    assert committed_indexes(ld) == (4, 4, 4) and ld.committed() == 4
+    for pid in (3, 1):  # the re-sent append is accepted: index 7, the follower's commit is still 4
+        ld.sent(pid)
+        ld.step(pid, 7, commit=4)
+    assert ld.committed() == 7
+    assert committed_indexes(ld) == (4, 7, 4), "the leader's own entry follows commit; followers report theirs later"
+    for pid in (1, 3):  # the next round of responses carries commit 7
+        ld.step(pid, 7, commit=7)
+    assert committed_indexes(ld) == (7, 7, 7)
+    # --- #4: leader 1, term 3, log up to 10, everything at 8; responses for 9/10 arrive out of order
+    ld = B(1, 3, [1, 2, 3], log=[(1, k) for k in range(1, 8)] + [(3, 8), (3, 9), (3, 10)], committed=8)
+    ld.set_progress(1, match=10, next=11, state=REPLICATE, committed_index=8)
+    for pid in (2, 3):
+        ld.set_progress(pid, match=8, next=11, state=REPLICATE, committed_index=8)
+    for pid in (3, 2):  # m1, m2: index 10 commit 10 (the newer responses overtake)
+        ld.step(pid, 10, commit=10)
+    assert ld.committed() == 10 and committed_indexes(ld) == (10, 10, 10)
+    for pid in (2, 3):  # the delayed ones: index 10 commit 9
+        out = ld.step(pid, 10, commit=9)
+        assert not out["changed"] and not out["send_more"], "stale ack: maybe_update returns false"
+    assert committed_indexes(ld) == (10, 10, 10)
+
+
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
        scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
        scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
-       scenario_commit_after_remove_node, scenario_fast_log_rejection]
+       scenario_commit_after_remove_node, scenario_fast_log_rejection, scenario_progress_committed_index]
