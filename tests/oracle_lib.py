@@ -77,7 +77,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    L = C.CDLL(build())
+    L = C.CDLL(os.environ.get("RO_LIB_PATH") or build())  # RO_LIB_PATH: e.g. the ASan/UBSan build (make -C oracle asan)
     u64, sz, vp = C.c_uint64, C.c_size_t, C.c_void_p
     PP, PI = C.POINTER(Progress), C.POINTER(Inflights)
     sig = {
