@@ -405,6 +405,8 @@ struct rg_engine {
     std::vector<u8> q_mf;                      // [G][8]
     std::vector<u64> q_dirty;                  // groups touched since the last flush
     std::vector<rg_wire_msg> q_records;        // flush staging (wire-order records of the dirty groups)
+    std::vector<u32> host_cfg;                 // host copy of RG_COL_CFG for the mirror (self slots)
+    bool host_cfg_valid;
     bool host_mirror;
 };
 
@@ -469,6 +471,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->out_is_dense = true;
     h->any_group_commit = false;
     h->host_mirror = false;
+    h->host_cfg_valid = false;
     size_t off = 0;
     for (int c = 0; c < RG_COL_COUNT; c++) {
         h->col_off[c] = off;
@@ -553,6 +556,7 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
     RG_HIP(hipMemcpyAsync(rg_col(h, c), src, bytes, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     if (c == RG_COL_CFG) {
+        h->host_cfg_valid = false;
         const u32 *w = static_cast<const u32 *>(src);
         bool any = false;
         for (u64 g = 0; g < h->G && !any; g++) any = (w[g] & RG_CFG_GROUP_COMMIT) != 0;
@@ -620,6 +624,7 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
     RG_HIP(hipMemcpyAsync(h->st.cfg + group, &cfg_word, 4, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     if (cfg_word & RG_CFG_GROUP_COMMIT) h->any_group_commit = true; // (stays set: the GC kernel is a superset)
+    if (h->host_cfg_valid) h->host_cfg[group] = cfg_word;
     return RG_OK;
 }
 
@@ -1105,11 +1110,15 @@ extern "C" int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t
 }
 
 static int rg_self_slot(rg_engine *h, u64 group, u32 *slot) {
-    // the self slot lives in the device cfg word; mirror keeps no copy, so read the one word
-    u32 cfg = 0;
-    RG_HIP(hipMemcpyAsync(&cfg, h->st.cfg + group, 4, hipMemcpyDeviceToHost, h->stream));
-    RG_HIP(hipStreamSynchronize(h->stream));
-    *slot = RG_CFG_SELF(cfg);
+    // the self slot lives in the device cfg word; the mirror keeps a host copy of the column, refreshed
+    // whenever the column may have changed (rg_load_column / rg_set_config / rg_workload_init)
+    if (!h->host_cfg_valid) {
+        h->host_cfg.resize(h->G);
+        RG_HIP(hipMemcpyAsync(h->host_cfg.data(), h->st.cfg, h->G * 4, hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipStreamSynchronize(h->stream));
+        h->host_cfg_valid = true;
+    }
+    *slot = RG_CFG_SELF(h->host_cfg[group]);
     return RG_OK;
 }
 
@@ -1224,6 +1233,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
                        w->workload | (w->reserved << 8), h->P, (u64)first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_init: %s", hipGetErrorString(e));
+    h->host_cfg_valid = false;
     return RG_OK;
 }
 
