@@ -552,6 +552,16 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
     if (bytes != rg_column_bytes(h, c))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column(%d): %llu bytes given, %llu expected", c,
                        (unsigned long long)bytes, (unsigned long long)rg_column_bytes(h, c));
+    if (c == RG_COL_CFG) { // a configuration word may only name slots the engine has
+        const u32 *w = static_cast<const u32 *>(src);
+        for (u64 g = 0; g < h->G; g++) {
+            const u32 x = w[g];
+            if (RG_CFG_SELF(x) >= h->P || (RG_CFG_PRESENT(x) >> h->P) || (RG_CFG_INCOMING(x) >> h->P) ||
+                (RG_CFG_OUTGOING(x) >> h->P) || RG_CFG_TRANSFEREE(x) > h->P)
+                return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column(CFG): group %llu: word %#x names a slot >= %u",
+                               (unsigned long long)g, x, h->P);
+        }
+    }
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(rg_col(h, c), src, bytes, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));

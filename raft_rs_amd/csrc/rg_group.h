@@ -392,8 +392,10 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                         if (!stale) {
                             if (rs == 0) {
                                 u64 hint = ms.mh[o];
-                                if (f & RG_MF_HAS_LOGTERM) // raft.rs:1562,1657-1660
-                                    hint = rg_find_conflict_by_term(st, g, r.lo, r.hi, hint, ms.mlt[o]);
+                                if (f & RG_MF_HAS_LOGTERM) { // `if m.reject && m.log_term > 0` raft.rs:1562,1657-1660
+                                    const u64 lt = ms.mlt[o];
+                                    if (lt > 0) hint = rg_find_conflict_by_term(st, g, r.lo, r.hi, hint, lt);
+                                }
                                 const u64 h = hint + 1;
                                 u64 n = idx < h ? idx : h;
                                 if (n < 1) n = 1;

@@ -179,3 +179,21 @@ def diff_states(a, b, n_groups, n_slots, keys=STATE_KEYS, present_only=True):
         if len(diffs) > 20:
             break
     return diffs
+
+
+def garbage_msgs(rng, st, msgs):
+    """Arbitrary event bytes (all 256 combinations, also meaningless ones such as REJECT without VALID or
+    VALID|HEARTBEAT) and arbitrary values: the engine must still follow the reference arithmetic exactly."""
+    G, P = st["n_groups"], st["n_slots"]
+    hi = st["term_hi"]
+    msgs["m_flags"][...] = 0
+    msgs["m_flags"][:, :P] = rng.integers(0, 256, size=(G, P), dtype=np.uint8)
+    for k in ("m_index", "m_commit", "m_hint", "m_rs"):
+        near = np.clip(hi.astype(np.int64)[None, :] + rng.integers(-12, 6, size=(P, G)), 0, None).astype(np.uint64)
+        # "wild" stays small: the reference's find_conflict_by_term walks the log index by index (and so does
+        # the oracle), so astronomically large garbage indices would only test patience
+        wild = rng.integers(0, 3000, size=(P, G), dtype=np.uint64)
+        msgs[k][:, :G] = np.where(rng.random((P, G)) < 0.9, near, wild)
+    if "m_logterm" in msgs:
+        msgs["m_logterm"][:, :G] = rng.integers(0, 12, size=(P, G), dtype=np.uint64)
+    return msgs

@@ -246,3 +246,53 @@ def test_find_conflict_by_term_on_the_device_table(host_tick, n_slots):
         assert not diffs, (t, diffs[:6])
         assert (out == gout).all()
     assert n_lt > 500
+
+
+@pytest.mark.parametrize("n_slots", [2, 5, 8])
+def test_garbage_events_still_follow_the_reference(host_tick, n_slots):
+    rng = np.random.default_rng(1234 + n_slots)
+    G, TERM = 3000, 9
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.1)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, TERM)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    eng_st = copy_state(st)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    for t in range(6):
+        cl.store_soa(st)
+        fuzz.garbage_msgs(rng, st, msgs)
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+
+
+@pytest.mark.parametrize("workload,n_slots", [(5, 7), (2, 5)])
+def test_soak_many_ticks(host_tick, workload, n_slots):
+    """120 ticks of the synthetic stream: long-horizon paths (Probe -> Replicate cycles, snapshot requests,
+    full windows) keep matching the oracle."""
+    from raft_rs_amd import engine as E
+    G = 1500
+    st = O.alloc_state(G, n_slots)
+    E.workload_init_host(st, workload)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    mb = E.MsgBuffers(G, n_slots, st["stride"])
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    for t in range(120):
+        E.workload_gen_host(st, mb, workload, t)
+        host_tick(eng_st, mb.as_dict(), out, False)
+        cl.tick_soa(mb.as_dict(), gout)
+        cl.store_soa(st)
+        assert (out == gout).all(), t
+        if t % 10 == 9:
+            assert not fuzz.diff_states(st, eng_st, G, n_slots), t
+    assert (st["commit"] > 1000).all()

@@ -365,3 +365,62 @@ def test_find_conflict_by_term_on_device(rg, n_slots, variant):
         assert_same(eng, cl, st, gout, f"log_term rejects P={n_slots} variant={variant} tick {t}")
     assert n_lt > 1000
     eng.close()
+
+
+@pytest.mark.parametrize("n_slots", [3, 8])
+def test_garbage_events_on_gpu(rg, n_slots):
+    rng = np.random.default_rng(4321 + n_slots)
+    G, TERM = 5000, 9
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.1)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, TERM)
+    for variant in (1, 2):
+        eng = rg.Engine(G, n_slots, variant=variant)
+        eng.load_state(st)
+        cl = O.Cluster(G)
+        cl.load_soa(st, term=TERM)
+        ref = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+        msgs = O.alloc_msgs(G, n_slots)
+        gout = np.zeros(G, dtype=np.uint32)
+        mb = rg.MsgBuffers(G, n_slots, eng.stride)
+        for t in range(4):
+            cl.store_soa(ref)
+            fuzz.garbage_msgs(rng, ref, msgs)
+            for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_logterm", "m_flags"):
+                getattr(mb, k)[...] = msgs[k]
+            eng.tick(mb)
+            cl.tick_soa(msgs, gout)
+            assert_same(eng, cl, ref, gout, f"garbage events P={n_slots} variant={variant} tick {t}")
+        eng.close()
+
+
+def test_soak_on_gpu(rg):
+    """100 ticks of the mixed workload on the GPU against the oracle (compared every 10 ticks)."""
+    from raft_rs_amd import engine as E
+    G, P, WL = 6000, 7, 5
+    eng = rg.Engine(G, P)
+    eng.workload_init(WL)
+    st = eng.read_state()
+    cl = oracle_from_state(st)
+    mb = rg.MsgBuffers(G, P, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    for t in range(100):
+        E.workload_gen_host(st, mb, WL, t)
+        eng.tick(mb)
+        cl.tick_soa(mb.as_dict(), gout)
+        cl.store_soa(st)
+        if t % 10 == 9:
+            assert_same(eng, cl, st, gout, f"soak tick {t}")
+    eng.close()
+
+
+def test_cfg_words_are_validated(rg):
+    eng = rg.Engine(16, 3)
+    bad = np.full(16, rg.cfg_make(0x0f, 0, 0), dtype=np.uint32)  # names slot 3 of a 3-slot engine
+    with pytest.raises(rg.EngineError) as e:
+        eng.load_column(rg.COL.CFG, bad)
+    assert e.value.code == -1
+    with pytest.raises(rg.EngineError):
+        eng.set_config(0, rg.cfg_make(0x07, 0, 5))  # self slot 5
+    eng.close()
