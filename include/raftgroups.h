@@ -203,7 +203,8 @@ int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
  * ticks and is written back once, so per tick only the message columns plus 1/n of the state traffic move.
  * Results are bit-identical to n_ticks calls of rg_tick_device. `dev_out_t` (u32 [n_ticks][G], device,
  * required) receives every tick's RG_OUT_* word, `dev_commit_t` (u64 [n_ticks][G], device, may be NULL) the
- * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. Asynchronous. Use it to
+ * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. m_logterm must be NULL (hints
+ * are not passed through find_conflict_by_term in fused launches: resolve them on the host). Asynchronous. Use it to
  * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
 #define RG_MAX_FUSE 8
 int rg_tick_device_fused(rg_engine *h, const rg_msgs *dev_msgs, uint32_t n_ticks, uint32_t *dev_out_t,

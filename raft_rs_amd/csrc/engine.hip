@@ -221,6 +221,21 @@ __global__ __launch_bounds__(RG_BLOCK) void k_heartbeat_commits(RgState st, u32 
 }
 
 // ------------------------------------------------------------------------------------------------
+// kernels: find_conflict_by_term pre-pass (only launched when a tick carries Message.log_term values)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RG_BLOCK) void k_resolve_hints(RgState st, RgMsgs ms, u32 P, u64 *rh) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    rg_resolve_hints(st, ms, g, P, rh);
+}
+__global__ __launch_bounds__(RG_BLOCK) void k_resolve_hints_list(RgState st, RgMsgs ms, u32 P, u64 *rh, const u64 *list,
+                                                                 const u32 *n_ptr) {
+    const u64 i = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (i >= *n_ptr) return;
+    rg_resolve_hints(st, ms, list[i], P, rh);
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernels: ingest (wire-order AoS records -> the slot matrix) and helpers of the sparse path
 // ------------------------------------------------------------------------------------------------
 #define RG_INGEST_BLOCK 256
@@ -381,6 +396,7 @@ struct rg_engine {
     char *ckpt;       // checkpoint copy of the state columns (lazy)
     char *msg_arena;  // device staging for rg_tick(host msgs) / rg_flush (lazy)
     u64 *zero_col;    // [P][stride] zeros, substituted for NULL m_hint / m_rs
+    u64 *rhint;       // [P][stride] reject hints after find_conflict_by_term (pre-pass output)
     u64 *d_counts;    // 4 x u64 scratch for reductions
     void *d_scratch;  // G x 8 B scratch for host<->device result shuttles
     size_t col_off[RG_COL_COUNT];
@@ -405,6 +421,7 @@ struct rg_engine {
     std::vector<u8> q_mf;                      // [G][8]
     std::vector<u64> q_dirty;                  // groups touched since the last flush
     std::vector<rg_wire_msg> q_records;        // flush staging (wire-order records of the dirty groups)
+    bool q_any_logterm;                        // some queued message carries Message.log_term
     std::vector<u32> host_cfg;                 // host copy of RG_COL_CFG for the mirror (self slots)
     bool host_cfg_valid;
     bool host_mirror;
@@ -472,6 +489,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->any_group_commit = false;
     h->host_mirror = false;
     h->host_cfg_valid = false;
+    h->q_any_logterm = false;
     size_t off = 0;
     for (int c = 0; c < RG_COL_COUNT; c++) {
         h->col_off[c] = off;
@@ -482,12 +500,12 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     }
     h->state_bytes = off;
     const size_t zero_bytes = rg_align((size_t)h->P * h->stride * 8);
-    hipError_t e = hipMalloc(&h->arena, off + zero_bytes + 256 + rg_align(h->stride * 8));
+    hipError_t e = hipMalloc(&h->arena, off + 2 * zero_bytes + 256 + rg_align(h->stride * 8));
     if (e != hipSuccess) {
         delete h;
         return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
     }
-    e = hipMemset(h->arena, 0, off + zero_bytes + 256 + rg_align(h->stride * 8));
+    e = hipMemset(h->arena, 0, off + 2 * zero_bytes + 256 + rg_align(h->stride * 8));
     if (e != hipSuccess) {
         (void)hipFree(h->arena);
         delete h;
@@ -496,6 +514,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->zero_col = reinterpret_cast<u64 *>(h->arena + off);
     h->d_counts = reinterpret_cast<u64 *>(h->arena + off + zero_bytes);
     h->d_scratch = h->arena + off + zero_bytes + 256;
+    h->rhint = reinterpret_cast<u64 *>(h->arena + off + zero_bytes + 256 + rg_align(h->stride * 8));
     RgState &s = h->st;
     s.match = (u64 *)rg_col(h, RG_COL_MATCH);
     s.next = (u64 *)rg_col(h, RG_COL_NEXT);
@@ -673,6 +692,12 @@ extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
     ms.mrs = m->m_rs ? (const u64 *)m->m_rs : h->zero_col;
     ms.mlt = m->m_logterm ? (const u64 *)m->m_logterm : h->zero_col;
     ms.mflags = (const u64 *)m->m_flags;
+    ms.mhr = ms.mh;
+    if (m->m_logterm) { // this tick may carry log terms: resolve the flagged hints first
+        hipLaunchKernelGGL(k_resolve_hints, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms, h->P,
+                           h->rhint);
+        ms.mhr = h->rhint;
+    }
     return rg_tick_impl(h, ms);
 }
 
@@ -690,7 +715,11 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
         fm.m[t].mc = (const u64 *)m[t].m_commit;
         fm.m[t].mh = m[t].m_hint ? (const u64 *)m[t].m_hint : h->zero_col;
         fm.m[t].mrs = m[t].m_rs ? (const u64 *)m[t].m_rs : h->zero_col;
-        fm.m[t].mlt = m[t].m_logterm ? (const u64 *)m[t].m_logterm : h->zero_col;
+        if (m[t].m_logterm)
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: Message.log_term is not resolved in fused launches "
+                                               "(last_index changes between the fused ticks); resolve hints on the host");
+        fm.m[t].mlt = h->zero_col;
+        fm.m[t].mhr = fm.m[t].mh;
         fm.m[t].mflags = (const u64 *)m[t].m_flags;
     }
     fm.out_t = dev_out_t;
@@ -741,9 +770,15 @@ extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
     else ms.mh = h->zero_col;
     if (m->m_rs) RG_HIP(hipMemcpyAsync((void *)h->staged.mrs, m->m_rs, colb, hipMemcpyHostToDevice, h->stream));
     else ms.mrs = h->zero_col;
+    ms.mhr = ms.mh;
     if (m->m_logterm) RG_HIP(hipMemcpyAsync((void *)h->staged.mlt, m->m_logterm, colb, hipMemcpyHostToDevice, h->stream));
     else ms.mlt = h->zero_col;
     RG_HIP(hipMemcpyAsync((void *)h->staged.mflags, m->m_flags, h->G * 8, hipMemcpyHostToDevice, h->stream));
+    if (m->m_logterm) { // pre-pass (after ALL message columns are on the device): find_conflict_by_term
+        hipLaunchKernelGGL(k_resolve_hints, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms, h->P,
+                           h->rhint);
+        ms.mhr = h->rhint;
+    }
     rc = rg_tick_impl(h, ms);
     if (rc) return rc;
     // the engine-owned message columns must read "no events" outside a tick (sparse-path invariant)
@@ -848,7 +883,10 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     h->last_sparse_n = 0;
     u64 upper = h->ingested_upper < h->G ? h->ingested_upper : h->G;
     if (upper) {
-        const RgMsgs ms = h->staged;
+        RgMsgs ms = h->staged;
+        ms.mhr = h->rhint; // records may carry log terms: resolve the touched groups' flagged hints first
+        hipLaunchKernelGGL(k_resolve_hints_list, dim3(rg_grid(upper, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms, h->P,
+                           h->rhint, (const u64 *)h->list, (const u32 *)h->counters);
         u64 *mf = (u64 *)h->staged.mflags;
         switch (h->P) {
         case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
@@ -1095,6 +1133,7 @@ extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m
     h->q_mh[o] = m->reject_hint;
     h->q_mrs[o] = m->request_snapshot;
     h->q_mlt[o] = m->log_term;
+    if (m->reject && m->log_term) h->q_any_logterm = true;
     f |= RG_MF_VALID | (m->reject ? RG_MF_REJECT : 0) | (m->request_snapshot ? RG_MF_HAS_RS : 0) |
          (m->ins_full ? RG_MF_INS_FULL : 0) | ((m->reject && m->log_term) ? RG_MF_HAS_LOGTERM : 0);
     return RG_OK;
@@ -1180,7 +1219,7 @@ extern "C" int rg_flush(rg_engine *h) {
         m.m_commit = h->q_mc.data();
         m.m_hint = h->q_mh.data();
         m.m_rs = h->q_mrs.data();
-        m.m_logterm = h->q_mlt.data();
+        m.m_logterm = h->q_any_logterm ? h->q_mlt.data() : nullptr;
         m.m_flags = h->q_mf.data();
         rc = rg_tick(h, &m);
         // rg_ingested_results must work after ANY flush: gather the dirty groups' results compactly
@@ -1227,6 +1266,7 @@ extern "C" int rg_flush(rg_engine *h) {
     }
     for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
     h->q_dirty.clear();
+    h->q_any_logterm = false;
     return rc;
 }
 

@@ -31,6 +31,8 @@ struct RgMsgs {
     const u64 *mi, *mc, *mh, *mrs; // [P][stride]
     const u64 *mflags;             // [G] one byte per slot
     const u64 *mlt;                // [P][stride] Message.log_term (cold)
+    const u64 *mhr;                // [P][stride] hints after find_conflict_by_term (written by the pre-pass;
+                                   // == mh when no message of the tick carries a log term)
 };
 
 RG_HD u64 rg_min(u64 a, u64 b) { return a < b ? a : b; }

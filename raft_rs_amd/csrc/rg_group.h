@@ -197,6 +197,40 @@ RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, u64 lo, u64 last_in
     }
 }
 
+// Pre-pass of a tick for ONE group: for every slot whose event is a reject with RG_MF_HAS_LOGTERM, store
+// find_conflict_by_term(reject_hint, log_term) (or the hint itself when log_term == 0) into `rh`.
+// last_index "at message time" is reproduced exactly: the leader's APPEND lands at its own slot, so slots
+// after it see the grown log (RgTick::slot).
+RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u64 *rh) {
+    const u64 mf = ms.mflags[g];
+    bool any = false;
+    for (u32 p = 0; p < n_slots; p++) {
+        const u32 f = (u32)(mf >> (8 * p)) & 0xffu;
+        any |= (f & (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) == (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM);
+    }
+    if (!any) return;
+    const u32 cfg = st.cfg[g];
+    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
+    const u64 lo = st.lo[g], hi0 = st.hi[g];
+    u64 hi_after = hi0; // last_index once the leader's own slot has been processed
+    if (self < n_slots && ((present >> self) & 1u)) {
+        const u32 fs = (u32)(mf >> (8 * self)) & 0xffu;
+        if (fs & RG_MF_APPEND) {
+            const u64 nl = ms.mc[(u64)self * st.stride + g];
+            if (nl > hi0) hi_after = nl;
+        }
+    }
+    for (u32 p = 0; p < n_slots; p++) {
+        const u32 f = (u32)(mf >> (8 * p)) & 0xffu;
+        if ((f & (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) != (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) continue;
+        const u64 o = (u64)p * st.stride + g;
+        const u64 lt = ms.mlt[o];
+        u64 hint = ms.mh[o];
+        if (lt > 0) hint = rg_find_conflict_by_term(st, g, lo, p > self ? hi_after : hi0, hint, lt);
+        rh[o] = hint;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One group's registers for a tick.
 // ---------------------------------------------------------------------------------------------
@@ -391,11 +425,10 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                         const bool stale = (r.nx[S] == 0 || r.nx[S] - 1 != idx) && rs == 0;
                         if (!stale) {
                             if (rs == 0) {
-                                u64 hint = ms.mh[o];
-                                if (f & RG_MF_HAS_LOGTERM) { // `if m.reject && m.log_term > 0` raft.rs:1562,1657-1660
-                                    const u64 lt = ms.mlt[o];
-                                    if (lt > 0) hint = rg_find_conflict_by_term(st, g, r.lo, r.hi, hint, lt);
-                                }
+                                // rejects that carry log_term > 0 read their hint AFTER find_conflict_by_term
+                                // (raft.rs:1562,1657-1660): resolved by rg_resolve_hints in a pre-pass so that
+                                // the walk over the term table costs this kernel no registers
+                                const u64 hint = (f & RG_MF_HAS_LOGTERM) ? ms.mhr[o] : ms.mh[o];
                                 const u64 h = hint + 1;
                                 u64 n = idx < h ? idx : h;
                                 if (n < 1) n = 1;

@@ -21,10 +21,22 @@ static RgMsgs make_msgs(const void *const *p) {
     RgMsgs ms;
     ms.mi = (const u64 *)p[0]; ms.mc = (const u64 *)p[1]; ms.mh = (const u64 *)p[2]; ms.mrs = (const u64 *)p[3];
     ms.mflags = (const u64 *)p[4]; ms.mlt = (const u64 *)p[5];
+    ms.mhr = ms.mh;
     return ms;
 }
 
-template <int P> static void host_tick(const RgState &st, const RgMsgs &ms, bool gc, u64 g0, u64 g1) {
+#include <vector>
+template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, bool gc, u64 g0, u64 g1) {
+    // the engine's pre-pass (k_resolve_hints) followed by the tick, group by group
+    std::vector<u64> rh;
+    RgMsgs ms = ms_in;
+    bool any = false;
+    for (u64 g = g0; g < g1 && !any; g++) any = (ms_in.mflags[g] & 0x8080808080808080ULL) != 0;
+    if (any) { // like the engine: the pre-pass only runs when the tick carries log terms
+        rh.assign((size_t)P * st.stride, 0);
+        for (u64 g = g0; g < g1; g++) rg_resolve_hints(st, ms_in, g, P, rh.data());
+        ms.mhr = rh.data();
+    }
     for (u64 g = g0; g < g1; g++) {
         RgGroup<P> r;
         rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
