@@ -302,9 +302,27 @@ def scenario_progress_committed_index(B):
     assert committed_indexes(ld) == (10, 10, 10)
 
 
+def scenario_send_path_update_state(B):
+    """Progress::update_state through the SENT event (progress.rs:231-243; test_raft.rs:2793-2910
+    test_leader_increase_next / test_send_append_for_progress_{probe,replicate,snapshot}): Replicate =>
+    optimistic next = last + 1; Probe => one send, then paused; Snapshot => the reference panics (fault)."""
+    ld = B(1, 1, [1, 2, 3], log=[(1, k) for k in range(1, 7)], committed=0)
+    ld.set_progress(1, match=6, next=7, state=REPLICATE)
+    ld.set_progress(2, match=2, next=3, state=REPLICATE)
+    assert ld.sent(2) == 0
+    assert ld.progress(2)["next"] == 7, "Replicate: optimistically increase next to last_index + 1"
+    ld.set_progress(3, match=0, next=4, state=PROBE, paused=False)
+    assert ld.sent(3) == 0
+    pr = ld.progress(3)
+    assert pr["paused"] and pr["next"] == 4, "Probe: pause after one message, next unchanged"
+    ld.set_progress(3, state=SNAPSHOT, pending_snapshot=5)
+    assert ld.sent(3) != 0, "Snapshot: update_state panics in the reference -> reported as a fault"
+
+
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
        scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
        scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
-       scenario_commit_after_remove_node, scenario_fast_log_rejection, scenario_progress_committed_index]
+       scenario_commit_after_remove_node, scenario_fast_log_rejection, scenario_progress_committed_index,
+       scenario_send_path_update_state]
