@@ -1212,8 +1212,9 @@ extern "C" int rg_flush(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
     int rc;
-    if (h->q_dirty.size() * 4 >= h->G) {
-        // most groups have events: stream the whole columns through the dense tick
+    if (h->q_dirty.size() * 2 >= h->G) {
+        // most groups have events: stream the whole columns through the dense tick (measured crossover with the
+        // 64-B-record path is around 60 % of the groups: profiles/r01_sparse_path_and_recompute.txt, mirror_bench)
         rg_msgs m;
         m.m_index = h->q_mi.data();
         m.m_commit = h->q_mc.data();
