@@ -162,13 +162,21 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # BENCH_SHARE_GPU=1 (test hook): every rank uses GPU 0 and the collective backend is gloo, so the N>1
+    # code path (sharding offsets, publication, max-over-ranks timing) can run on a single-GPU box
+    share_gpu = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # BENCH_FORCE_DIST=1 runs the N>1 code path (process group + commit all-gather) at world size 1
     distributed = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
     T = W + K
@@ -391,7 +399,7 @@ def main():
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
                    "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
-                   "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks (RCCL)" if distributed else ""),
+                   "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks ({'gloo, shared GPU test hook' if share_gpu else 'RCCL'})" if distributed else ""),
                    "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not distributed else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

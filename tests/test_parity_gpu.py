@@ -424,3 +424,23 @@ def test_cfg_words_are_validated(rg):
     with pytest.raises(rg.EngineError):
         eng.set_config(0, rg.cfg_make(0x07, 0, 5))  # self slot 5
     eng.close()
+
+
+def test_bench_two_ranks_sharing_the_gpu(rg, tmp_path):
+    """The N>1 path of bench.py (rank offsets, commit publication + verification, max-over-ranks timing) with two
+    ranks on this box's single GPU (BENCH_SHARE_GPU=1 switches the collective backend to gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12",
+           "--warmup", "2", "--groups", "60000", "--publish-every", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
+    assert d["config"]["groups_per_gpu"] == 60000 and "all-gather every 4 ticks" in d["config"]["sharding"]
