@@ -2,6 +2,7 @@
 """bench.py -- raft-group progress+commit evaluations per second on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--groups G] [--slots P] [--workload 2|3|5]
+                    [--fuse T] [--split S] [--variant 0|2] [--publish-every E] [--one-engine] [--no-cpu-baseline]
 
 One "step" = one tick of the hot path over every raft group of the shard: apply each group's
 AppendResponse slots (Raft::handle_append_response semantics) and re-evaluate + gate the commit
@@ -74,7 +75,7 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
         elapsed[nthreads] += time.perf_counter() - t0
         evals[nthreads] += n_groups
         cl.store_soa(st)
-    soa = soa_cpu_line(n_groups, n_slots, workload, seed, threads)
+    soa = soa_cpu_line(n_groups, n_slots, workload, seed, min(threads, 128))  # Python thread pool: 128 is its sweet spot
     out = {"value": evals[threads] / elapsed[threads] if elapsed[threads] else None, "unit": "group-evals/s",
            "cores": threads, "kind": "port",
            "sample": f"{n_groups} groups x {n_slots} peers, {sample_ticks} ticks of the same stream "
@@ -413,7 +414,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_groups, G), P, args.workload,
-                                              args.cpu_sample_ticks, args.seed, min(os.cpu_count() or 1, 128))
+                                              args.cpu_sample_ticks, args.seed, os.cpu_count() or 1)
     elif rank == 0:
         result["cpu_baseline"] = None
     for pt in parts:
