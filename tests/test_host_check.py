@@ -25,7 +25,8 @@ def build_lib():
         return None
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call([hipcc, "-O3", "-march=native", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
+        # no -march=native: the built .so travels with gpurun snapshots to hosts with other CPUs
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
                                "-Wno-pass-failed", SRC, "-o", LIB])
     return LIB
 
