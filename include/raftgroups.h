@@ -57,12 +57,15 @@ typedef enum {
 #define RG_STATE_SNAPSHOT 2u
 #define RG_PF_PAUSED 0x04u        /* Progress.paused */
 #define RG_PF_RECENT_ACTIVE 0x08u /* Progress.recent_active */
+#define RG_PF_INS_FULL 0x10u      /* engine-owned, only with rg_config.max_inflight > 0: Inflights::full() of the
+                                     device-side ring (rg_send_appends maintains it; OR-ed with RG_MF_INS_FULL) */
 
 /* ---- message flag byte (one per slot per tick) ---- */
 #define RG_MF_VALID 0x01u    /* an AppendResponse from this peer (on the self slot: on_persist_entries(m_index), src/raft.rs:994-1016) */
 #define RG_MF_REJECT 0x02u   /* Message.reject */
 #define RG_MF_HAS_RS 0x04u   /* Message.request_snapshot != 0 (value in m_rs) */
-#define RG_MF_INS_FULL 0x08u /* host's Inflights::full() for this peer (Progress::is_paused, progress.rs:210-216) */
+#define RG_MF_INS_FULL 0x08u /* host's Inflights::full() for this peer (Progress::is_paused, progress.rs:210-216);
+                                not needed when the engine holds the Inflights (rg_config.max_inflight > 0) */
 #define RG_MF_SENT 0x10u     /* the host sent a MsgAppend up to last_index since the previous tick:
                                 apply Progress::update_state(last) first (progress.rs:231-243, src/raft.rs:726-729) */
 #define RG_MF_APPEND 0x20u   /* self slot only: leader appended entries, new last_index in m_commit
@@ -91,6 +94,7 @@ typedef enum {
 #define RG_OUT_CHANGED 0x1u     /* some maybe_commit() returned true (src/raft.rs:1745): host runs bcast_append if should_bcast_commit() */
 #define RG_OUT_FAULT 0x2u       /* a precondition of the path was violated (where the reference panics or input is malformed) */
 #define RG_OUT_TIMEOUT_NOW 0x4u /* send_timeout_now(transferee) (src/raft.rs:1764-1774) */
+#define RG_OUT_APPENDED 0x8u    /* the leader's log grew in this tick (RG_MF_APPEND): the bcast_append that follows a proposal is due (src/raft.rs:2049-2053) */
 #define RG_OUT_SEND_APPEND(o) (((uint32_t)(o) >> 8) & 0xffu) /* per slot: send_append(from) (raft.rs:1719, :1750) */
 #define RG_OUT_SEND_MORE(o) (((uint32_t)(o) >> 16) & 0xffu)  /* per slot: the maybe_send_append loop (raft.rs:1761) */
 #define RG_OUT_FREE_TO(o) (((uint32_t)(o) >> 24) & 0xffu)    /* per slot: ins.free_to(m.index) (raft.rs:1742) */
@@ -140,7 +144,9 @@ typedef struct {
     uint32_t n_slots;  /* peer slots per group, 1..8 */
     int32_t device;    /* HIP device ordinal */
     uint32_t variant;  /* kernel variant: 0 = default (RG_VARIANT_*) */
-    uint32_t reserved;
+    uint32_t max_inflight; /* 0 = Inflights stay with the host (RG_MF_INS_FULL in, RG_OUT_FREE_TO out);
+                              1..65535 = Config::max_inflight_msgs (src/config.rs:112): one ring of that many u64
+                              per Progress lives in HBM and rg_send_appends runs the send decision on the device */
 } rg_config;
 
 #define RG_VARIANT_DEFAULT 0u
@@ -266,6 +272,42 @@ int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index);
 int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id);
 /* Run one tick over everything queued since the last flush and clear the queue. */
 int rg_flush(rg_engine *h);
+
+/* ---- send stage (engines created with max_inflight > 0): Inflights on the device and the
+ *      maybe_send_append DECISION (src/raft.rs:773-819, prepare_send_entries :722-731, bcast_append :850-857,
+ *      the loop at :1761; src/tracker/inflights.rs:42-125) ----
+ * Call once after every tick. For every group it (1) applies the tick's Inflights effects -- ins.free_to(m.index)
+ * for an accepted ack in Replicate, ins.free_first_one() for a heartbeat response on a full window, ins.reset()
+ * when the Progress left Replicate -- and (2) serves the tick's send requests in slot order: bcast_append when the
+ * commit index moved (RG_OUT_CHANGED) or the leader appended (RG_OUT_APPENDED), send_append(from) and the `while maybe_send_append(from, false)` loop. Each
+ * message sent applies Progress::update_state(last) (Replicate: next = last+1, ins.add(last); Probe: paused) in
+ * place, so the host writes no RG_MF_SENT events in this mode. Messages are NOT built: the result is one work item
+ * per peer that has something to send. `max_entries_per_msg` models Config::max_size_per_msg for equal-sized
+ * entries (util::limit_size keeps at least one entry), 0 = NO_LIMIT. A peer whose entries are compacted away
+ * (next_idx < first_index = RG_COL_DUMMY_INDEX + 1) or that has a pending snapshot request yields
+ * RG_SEND_SNAPSHOT (if recent_active, raft.rs:665-672); the host then fetches the snapshot and applies
+ * Progress::become_snapshot with rg_write_cells -- the device leaves that Progress untouched.
+ * Sends requested by message k of a tick happen after the whole tick; flush after every step where
+ * that matters. Not available for fused launches. Asynchronous. */
+typedef struct {
+    uint64_t group;
+    uint64_t prev_index; /* Message.index = next_idx - 1 of the first message */
+    uint64_t last_index; /* index of the last entry sent (== prev_index: one empty MsgAppend) */
+    uint32_t slot;
+    uint16_t n_msgs;     /* messages of max_entries_per_msg entries each (the last may be shorter) */
+    uint16_t kind;       /* RG_SEND_* */
+} rg_send_item;
+#define RG_SEND_APPEND 1u
+#define RG_SEND_SNAPSHOT 2u
+int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg);
+/* Work items of the last rg_send_appends (order unspecified) -> host array of capacity `cap`; *n = number of
+ * items (only cap are written if it is larger). Synchronises. rg_send_items_ptr: the same list in device memory. */
+int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n);
+const rg_send_item *rg_send_items_ptr(rg_engine *h);
+/* Inflights in/out (parity, checkpoints): meta u32 [P][stride] = start | count << 16; ring u64 [G][P][cap]. */
+uint64_t rg_inflights_bytes(const rg_engine *h, int ring);
+int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring);
+int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring);
 
 /* ---- sparse path: wire-order records -> slot matrix -> tick over the touched groups only ----
  * For realistic traffic (a small fraction of the groups has events in a tick) the dense sweep of rg_tick

@@ -316,6 +316,7 @@ typedef struct {
 struct ro_cluster {
     size_t n;
     ro_group *g;
+    bool own_inflights; /* SoA ticks use the Progress's own Inflights instead of the RG_MF_INS_FULL bit */
 };
 
 static inline size_t fx_slot(uint64_t id) { /* FxHash: multiply by the Fx seed (src/lib.rs:602-604) */
@@ -672,6 +673,7 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_PF_STATE_MASK 0x03u
 #define RO_PF_PAUSED 0x04u
 #define RO_PF_RECENT_ACTIVE 0x08u
+#define RO_PF_INS_FULL 0x10u
 #define RO_MF_VALID 0x01u
 #define RO_MF_REJECT 0x02u
 #define RO_MF_HAS_RS 0x04u
@@ -683,6 +685,7 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_OUT_CHANGED 0x1u
 #define RO_OUT_FAULT 0x2u
 #define RO_OUT_TIMEOUT_NOW 0x4u
+#define RO_OUT_APPENDED 0x8u
 
 int ro_load_soa(ro_cluster *c, const ro_soa_state *s, uint64_t term, size_t max_inflight) {
     if (s->n_groups > c->n || s->n_slots > 8) return -1;
@@ -778,6 +781,8 @@ int ro_store_soa(ro_cluster *c, ro_soa_state *s) {
             s->gid[o] = pr->commit_group_id;
             s->pflags[g * 8 + p] = (uint8_t)(pr->state | (pr->paused ? RO_PF_PAUSED : 0) |
                                              (pr->recent_active ? RO_PF_RECENT_ACTIVE : 0));
+            if (c->own_inflights && pr->state == RO_REPLICATE && pr->ins.cap && ro_ins_full(&pr->ins))
+                s->pflags[g * 8 + p] |= RO_PF_INS_FULL;
         }
         s->commit[g] = gr->committed;
         s->term_hi[g] = gr->last_index;
@@ -803,7 +808,10 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
             if (p == self_slot) {
                 if (f & RO_MF_APPEND) { /* append_entry, raft.rs:976-991 */
                     uint64_t nl = m->m_commit[o];
-                    if (nl > gr->last_index) ro_group_append(c, g, nl - gr->last_index);
+                    if (nl > gr->last_index) {
+                        ro_group_append(c, g, nl - gr->last_index);
+                        out |= RO_OUT_APPENDED; /* step_leader MsgPropose: bcast_append follows, raft.rs:2049-2053 */
+                    }
                 }
                 if (f & RO_MF_VALID) { /* on_persist_entries, raft.rs:994-1016 */
                     uint64_t idx = m->m_index[o];
@@ -818,7 +826,8 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
             }
             if (f & RO_MF_HEARTBEAT) { /* MsgHeartbeatResponse, raft.rs:1777-1803 */
                 ro_out ho;
-                ro_handle_heartbeat_response(c, g, p + 1, m->m_commit[o], (f & RO_MF_INS_FULL) ? 1 : 0, &ho);
+                ro_handle_heartbeat_response(c, g, p + 1, m->m_commit[o],
+                                             c->own_inflights ? -1 : ((f & RO_MF_INS_FULL) ? 1 : 0), &ho);
                 stepped++;
                 if (ho.send_append) out |= 1u << (8 + p);
                 if (ho.free_to) out |= 1u << (24 + p);
@@ -833,7 +842,7 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
             msg.reject_hint = msg.reject ? m->m_hint[o] : 0;
             msg.request_snapshot = (f & RO_MF_HAS_RS) ? m->m_rs[o] : 0;
             msg.log_term = (msg.reject && (f & RO_MF_HAS_LOGTERM) && m->m_logterm) ? m->m_logterm[o] : 0;
-            msg.ins_full = (f & RO_MF_INS_FULL) ? 1 : 0;
+            msg.ins_full = c->own_inflights ? -1 : ((f & RO_MF_INS_FULL) ? 1 : 0);
             if ((msg.index >> 63) || (!msg.reject && msg.index > gr->last_index))
                 out |= RO_OUT_FAULT;
             ro_out ro;
@@ -848,6 +857,102 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
         if (gout) gout[g] = out;
     }
     return stepped;
+}
+
+/* ------------------------------------------------------------------ */
+/* send decisions -- src/raft.rs:664-731, 773-819, 857-864              */
+/* ------------------------------------------------------------------ */
+
+void ro_set_own_inflights(ro_cluster *c, bool on) { c->own_inflights = on; }
+
+size_t ro_ins_contents(ro_cluster *c, size_t g, uint64_t id, uint64_t *buf, size_t cap) {
+    ro_progress *pr = pmap_get(&c->g[g].progress, id);
+    if (!pr) return 0;
+    size_t idx = pr->ins.start;
+    for (size_t i = 0; i < pr->ins.count; i++) {
+        if (i < cap) buf[i] = pr->ins.buffer[idx];
+        if (++idx >= pr->ins.cap) idx -= pr->ins.cap;
+    }
+    return pr->ins.count;
+}
+
+/* prepare_send_snapshot (raft.rs:664-712) up to the point where the snapshot is fetched */
+static bool ro_decide_send_snapshot(const ro_progress *pr) {
+    return pr->recent_active; /* :665-672 "ignore sending snapshot ... not recently active" */
+}
+
+bool ro_maybe_send_append(ro_cluster *c, size_t g, uint64_t to, bool allow_empty, uint64_t max_entries,
+                          ro_send_msg *m) {
+    ro_group *gr = &c->g[g];
+    ro_progress *pr = pmap_get(&gr->progress, to);
+    memset(m, 0, sizeof(*m));
+    if (!pr) return false;
+    if (ro_progress_is_paused(pr)) return false; /* :780-788 */
+    m->group = g;
+    m->to = to;
+    if (pr->pending_request_snapshot != RO_INVALID_INDEX) { /* :791-795 */
+        if (!ro_decide_send_snapshot(pr)) return false;
+        m->kind = RO_SEND_SNAPSHOT;
+        m->index = pr->next_idx - 1;
+        return true;
+    }
+    /* raft_log.entries(pr.next_idx, max_msg_size) (raft_log.rs:382-389): Ok(empty) above last_index, else
+     * slice(): Err(Compacted) below first_index (:463-470), else the entries up to the size limit */
+    uint64_t first_index = gr->dummy_index + 1;
+    bool ents_err = false;
+    uint64_t n = 0;
+    if (pr->next_idx <= gr->last_index) {
+        if (pr->next_idx < first_index) {
+            ents_err = true;
+        } else {
+            n = gr->last_index - pr->next_idx + 1;
+            if (max_entries && n > max_entries) n = max_entries; /* util::limit_size */
+        }
+    }
+    if (!allow_empty && (ents_err || n == 0)) return false; /* :797-799 */
+    /* raft_log.term(next_idx - 1) (raft_log.rs:122-140) cannot fail inside [dummy, last]; outside it is Ok(0) */
+    if (ents_err) { /* :808-813 send snapshot if we failed to get term or entries */
+        if (!ro_decide_send_snapshot(pr)) return false;
+        m->kind = RO_SEND_SNAPSHOT;
+        m->index = pr->next_idx - 1;
+        return true;
+    }
+    /* prepare_send_entries (:714-731) */
+    m->kind = RO_SEND_APPEND;
+    m->index = pr->next_idx - 1;
+    m->n_entries = n;
+    if (n) ro_progress_update_state(pr, pr->next_idx + n - 1);
+    return true;
+}
+
+size_t ro_send_stage_soa(ro_cluster *c, const uint32_t *gout, uint64_t max_entries, ro_send_msg *msgs, size_t cap,
+                         size_t g_begin, size_t g_end) {
+    size_t k = 0;
+    ro_send_msg m;
+    for (size_t g = g_begin; g < g_end && g < c->n; g++) {
+        ro_group *gr = &c->g[g];
+        uint32_t out = gout[g];
+        if (!out) continue;
+        bool bcast = (out & (RO_OUT_CHANGED | RO_OUT_APPENDED)) != 0;
+        for (uint32_t p = 0; p < RO_MAP_CAP && p < 8; p++) {
+            uint64_t id = p + 1;
+            if (id == gr->id || !pmap_get(&gr->progress, id)) continue; /* bcast_append skips self (:859-863) */
+            bool sa = bcast || ((out >> (8 + p)) & 1u), sm = (out >> (16 + p)) & 1u;
+            bool snap = false;
+            if (sa && ro_maybe_send_append(c, g, id, true, max_entries, &m)) {
+                if (k < cap) msgs[k] = m;
+                k++;
+                snap = m.kind == RO_SEND_SNAPSHOT;
+            }
+            /* become_snapshot (applied by the caller) pauses the Progress: the loop would stop there */
+            while (sm && !snap && ro_maybe_send_append(c, g, id, false, max_entries, &m)) {
+                if (k < cap) msgs[k] = m;
+                k++;
+                snap = m.kind == RO_SEND_SNAPSHOT;
+            }
+        }
+    }
+    return k;
 }
 
 /* Groups are independent, so the CPU baseline may split a tick over threads by group range. */

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "rg_group.h"
+#include "rg_send.h"
 #include "rg_workload.h"
 
 #include "rg_tick_kernels.h"
@@ -304,12 +305,65 @@ __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
 // ------------------------------------------------------------------------------------------------
 // kernels: sparse cell writes, counters, workload
 // ------------------------------------------------------------------------------------------------
-__global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32 P) {
+// The send stage (rg_send.h): one lane per group; the work items of a wave are appended to the compact list
+// with ONE atomic per wave (prefix sum over the lanes' item counts).
+template <int P>
+__global__ __launch_bounds__(RG_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, const u64 *list, u64 n,
+                                                          rg_send_item *items, u32 *counter) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    const u64 g = active ? (list ? list[i] : i) : 0;
+    RgSendRegs<P> it;
+    it.count = 0;
+    it.snap = 0;
+    if (active) {
+        const u32 out = st.out[g];
+        if (out) rg_group_send<P>(st, ins, g, out, max_entries, it);
+    }
+    const u32 lane = threadIdx.x & 63u;
+    u32 incl = it.count;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 v = __shfl_up(incl, d, 64);
+        if (lane >= (u32)d) incl += v;
+    }
+    const u32 total = __shfl(incl, 63, 64);
+    if (total == 0) return; // wave-uniform
+    u32 base = 0;
+    if (lane == 63) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    u32 k = base + incl - it.count;
+    if (it.count) {
+#pragma unroll
+        for (int s = 0; s < P; s++) {
+            const bool snap = (it.snap >> s) & 1u;
+            if (it.n[s] == 0 && !snap) continue;
+            rg_send_item r;
+            r.group = g;
+            r.prev_index = it.prev[s];
+            r.last_index = it.last[s];
+            r.slot = (u32)s;
+            r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
+            r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
+            items[k++] = r;
+        }
+    }
+}
+
+__global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32 P, u32 *ins_meta) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const rg_cell_write c = cells[i];
+    rg_cell_write c = cells[i];
     if (c.group >= st.G || c.slot >= P) return;
     const u64 o = (u64)c.slot * st.stride + c.group;
+    if (ins_meta && (c.field_mask & (1u << RG_COL_PFLAGS))) {
+        // device Inflights: a state change is Progress::reset_state (ins.reset(), progress.rs:75-80); the FULL
+        // bit belongs to the engine and survives every other flag write
+        const u8 old = reinterpret_cast<u8 *>(st.pflags)[c.group * 8 + c.slot];
+        c.pflags &= (u8)~RG_PF_INS_FULL;
+        if ((old ^ c.pflags) & RG_PF_STATE_MASK) ins_meta[o] = 0;
+        else c.pflags |= old & RG_PF_INS_FULL;
+    }
     if (c.field_mask & (1u << RG_COL_MATCH)) st.match[o] = c.match;
     if (c.field_mask & (1u << RG_COL_NEXT)) st.next[o] = c.next;
     if (c.field_mask & (1u << RG_COL_PR_COMMIT)) st.prc[o] = c.pr_commit;
@@ -413,6 +467,15 @@ struct rg_engine {
     u64 ingested_upper;       // records accepted for upload since the last sparse tick (>= touched groups)
     u64 last_sparse_n;        // groups of the last rg_tick_ingested (result arrays are valid for them)
     bool out_is_dense;        // RG_COL_OUT was last written by a dense tick
+    // send stage (rg_config.max_inflight > 0): Inflights rings, work items
+    char *ins_arena;   // meta | ring | items | counter
+    char *ins_ckpt;    // checkpoint copy of meta | ring (lazy)
+    size_t ins_state_bytes;
+    RgIns ins;
+    rg_send_item *send_items;
+    u32 *send_counter;
+    bool send_ready;   // a tick ran since the last rg_send_appends
+    bool ckpt_send_ready;
     bool any_group_commit; // some group's cfg word has RG_CFG_GROUP_COMMIT (tracked on cfg loads)
     // host mirror of RawNode::step (rg_set_peers / rg_step / rg_flush)
     std::vector<u64> peer_ids; // [G][8], 0 = unused
@@ -490,6 +553,20 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->host_mirror = false;
     h->host_cfg_valid = false;
     h->q_any_logterm = false;
+    h->ins_arena = nullptr;
+    h->ins_ckpt = nullptr;
+    h->ins_state_bytes = 0;
+    h->ins.meta = nullptr;
+    h->ins.ring = nullptr;
+    h->ins.cap = 0;
+    h->send_items = nullptr;
+    h->send_counter = nullptr;
+    h->send_ready = false;
+    h->ckpt_send_ready = false;
+    if (cfg->max_inflight > 65535u) {
+        delete h;
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_create: max_inflight=%u, at most 65535", cfg->max_inflight);
+    }
     size_t off = 0;
     for (int c = 0; c < RG_COL_COUNT; c++) {
         h->col_off[c] = off;
@@ -535,6 +612,26 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.cur_term = (u64 *)rg_col(h, RG_COL_CUR_TERM);
     s.G = h->G;
     s.stride = h->stride;
+    if (cfg->max_inflight) { // Inflights rings + the send stage's work-item list
+        const size_t meta_b = rg_align((size_t)h->P * h->stride * 4);
+        const size_t ring_b = rg_align((size_t)h->G * h->P * cfg->max_inflight * 8);
+        const size_t items_b = rg_align((size_t)h->G * h->P * sizeof(rg_send_item));
+        e = hipMalloc(&h->ins_arena, meta_b + ring_b + items_b + 256);
+        if (e == hipSuccess) e = hipMemset(h->ins_arena, 0, meta_b + ring_b + items_b + 256);
+        if (e != hipSuccess) {
+            if (h->ins_arena) (void)hipFree(h->ins_arena);
+            (void)hipFree(h->arena);
+            delete h;
+            return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: %zu bytes of Inflights (cap %u): %s", meta_b + ring_b + items_b,
+                           cfg->max_inflight, hipGetErrorString(e));
+        }
+        h->ins.meta = reinterpret_cast<u32 *>(h->ins_arena);
+        h->ins.ring = reinterpret_cast<u64 *>(h->ins_arena + meta_b);
+        h->ins.cap = cfg->max_inflight;
+        h->ins_state_bytes = meta_b + ring_b;
+        h->send_items = reinterpret_cast<rg_send_item *>(h->ins_arena + meta_b + ring_b);
+        h->send_counter = reinterpret_cast<u32 *>(h->ins_arena + meta_b + ring_b + items_b);
+    }
     *out = h;
     return RG_OK;
 }
@@ -545,6 +642,8 @@ extern "C" void rg_destroy(rg_engine *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
     if (h->ckpt) (void)hipFree(h->ckpt);
+    if (h->ins_arena) (void)hipFree(h->ins_arena);
+    if (h->ins_ckpt) (void)hipFree(h->ins_ckpt);
     if (h->msg_arena) (void)hipFree(h->msg_arena);
     if (h->sparse_arena) (void)hipFree(h->sparse_arena);
     if (h->d_records) (void)hipFree(h->d_records);
@@ -615,6 +714,11 @@ extern "C" int rg_checkpoint(rg_engine *h) {
     RG_HIP(hipSetDevice(h->cfg.device));
     if (!h->ckpt) RG_HIP(hipMalloc(&h->ckpt, h->state_bytes));
     RG_HIP(hipMemcpyAsync(h->ckpt, h->arena, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (h->ins_arena) {
+        if (!h->ins_ckpt) RG_HIP(hipMalloc(&h->ins_ckpt, h->ins_state_bytes));
+        RG_HIP(hipMemcpyAsync(h->ins_ckpt, h->ins_arena, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
+        h->ckpt_send_ready = h->send_ready;
+    }
     return RG_OK;
 }
 
@@ -623,6 +727,10 @@ extern "C" int rg_restore(rg_engine *h) {
     if (!h->ckpt) return rg_fail(RG_ERR_STATE, "rg_restore: no checkpoint taken");
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    if (h->ins_arena && h->ins_ckpt) {
+        RG_HIP(hipMemcpyAsync(h->ins_arena, h->ins_ckpt, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
+        h->send_ready = h->ckpt_send_ready; // RG_COL_OUT is part of the state: the tick's requests are back too
+    }
     return RG_OK;
 }
 
@@ -636,7 +744,7 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
     RG_HIP(hipMalloc(&d, n * sizeof(rg_cell_write)));
     hipError_t e = hipMemcpyAsync(d, cells, n * sizeof(rg_cell_write), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_write_cells, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, d, (u64)n, h->P);
+        hipLaunchKernelGGL(k_write_cells, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, d, (u64)n, h->P, h->ins.meta);
         e = hipStreamSynchronize(h->stream);
     }
     (void)hipFree(d);
@@ -678,6 +786,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
     h->ticked = true;
     h->out_is_dense = true;
+    h->send_ready = true;
     return RG_OK;
 }
 
@@ -705,6 +814,9 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
                                     uint64_t *dev_commit_t) {
     if (!h || !m || !dev_out_t || n_ticks == 0 || n_ticks > RG_MAX_FUSE)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: need 1..%d ticks and an out buffer", RG_MAX_FUSE);
+    if (h->ins_arena)
+        return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: engines with device Inflights (max_inflight > 0) need "
+                                     "rg_send_appends after every tick; fused launches are not available");
     RG_HIP(hipSetDevice(h->cfg.device));
     RgFused fm;
     memset(&fm, 0, sizeof(fm));
@@ -915,6 +1027,7 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
         h->epoch = 1;
     }
     h->ticked = true;
+    h->send_ready = true;
     if (n_groups) *n_groups = h->last_sparse_n;
     return RG_OK;
 }
@@ -983,6 +1096,89 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
     if (d_gc) (void)hipFree(d_gc);
     if (rc) return rc;
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_maximal_committed_index: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// send stage
+// ------------------------------------------------------------------------------------------------
+extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: null engine");
+    if (!h->ins_arena)
+        return rg_fail(RG_ERR_STATE, "rg_send_appends: engine created with max_inflight = 0 (Inflights are the host's)");
+    if (!h->send_ready) return rg_fail(RG_ERR_STATE, "rg_send_appends: no tick since the last send stage");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
+    const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
+    const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;
+    if (n) {
+        const dim3 grid(rg_grid(n, RG_BLOCK)), block(RG_BLOCK);
+        switch (h->P) {
+        case 1: hipLaunchKernelGGL(k_send_appends<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 2: hipLaunchKernelGGL(k_send_appends<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 3: hipLaunchKernelGGL(k_send_appends<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 4: hipLaunchKernelGGL(k_send_appends<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 5: hipLaunchKernelGGL(k_send_appends<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 6: hipLaunchKernelGGL(k_send_appends<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 7: hipLaunchKernelGGL(k_send_appends<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        default: hipLaunchKernelGGL(k_send_appends<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_send_appends: launch failed: %s", hipGetErrorString(e));
+    }
+    h->send_ready = false;
+    return RG_OK;
+}
+
+extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n) {
+    if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u32 cnt = 0;
+    RG_HIP(hipMemcpyAsync(&cnt, h->send_counter, 4, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    *n = cnt;
+    const u64 k = cnt < cap ? cnt : cap;
+    if (k) {
+        RG_HIP(hipMemcpyAsync(host_items, h->send_items, k * sizeof(rg_send_item), hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipStreamSynchronize(h->stream));
+    }
+    return RG_OK;
+}
+
+extern "C" const rg_send_item *rg_send_items_ptr(rg_engine *h) { return h ? h->send_items : nullptr; }
+
+extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
+    if (!h || !h->ins_arena) return 0;
+    return ring ? (uint64_t)h->G * h->P * h->ins.cap * 8 : (uint64_t)h->P * h->stride * 4;
+}
+
+extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_inflights: null engine");
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_read_inflights: engine created with max_inflight = 0");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    if (host_meta) RG_HIP(hipMemcpyAsync(host_meta, h->ins.meta, rg_inflights_bytes(h, 0), hipMemcpyDeviceToHost, h->stream));
+    if (host_ring) RG_HIP(hipMemcpyAsync(host_ring, h->ins.ring, rg_inflights_bytes(h, 1), hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: null engine");
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_load_inflights: engine created with max_inflight = 0");
+    if (host_meta) { // start < cap, count <= cap for every cell
+        const u64 n = (u64)h->P * h->stride;
+        for (u64 i = 0; i < n; i++) {
+            const u32 m = host_meta[i];
+            if ((m & 0xffffu) >= h->ins.cap || (m >> 16) > h->ins.cap)
+                return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: cell %llu: start %u count %u outside cap %u",
+                               (unsigned long long)i, m & 0xffffu, m >> 16, h->ins.cap);
+        }
+    }
+    RG_HIP(hipSetDevice(h->cfg.device));
+    if (host_meta) RG_HIP(hipMemcpyAsync(h->ins.meta, host_meta, rg_inflights_bytes(h, 0), hipMemcpyHostToDevice, h->stream));
+    if (host_ring) RG_HIP(hipMemcpyAsync(h->ins.ring, host_ring, rg_inflights_bytes(h, 1), hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }
 

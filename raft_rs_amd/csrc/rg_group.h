@@ -379,6 +379,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                 if (nl > r.hi) {
                     r.hi = nl;
                     r.dirty |= RG_DIRTY_HI;
+                    out |= RG_OUT_APPENDED; // MsgPropose: append_entry, then bcast_append (raft.rs:2049-2053)
                 }
             }
             if (f & RG_MF_VALID) { // on_persist_entries (raft.rs:994-1016)
@@ -399,7 +400,8 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                     r.dirty |= 1u << (16 + S);
                 }
                 pb = (pb | RG_PF_RECENT_ACTIVE) & ~RG_PF_PAUSED; // recent_active = true; resume()
-                if (state == RG_STATE_REPLICATE && (f & RG_MF_INS_FULL)) out |= 1u << (24 + S); // ins.free_first_one()
+                if (state == RG_STATE_REPLICATE && ((f & RG_MF_INS_FULL) || (pb0 & RG_PF_INS_FULL)))
+                    out |= 1u << (24 + S); // ins.free_first_one()
                 if (r.mt[S] < r.hi || st.prs[o] != 0) out |= 1u << (8 + S); // send_append(m.from)
             } else if (f & RG_MF_VALID) {
                 const u64 idx = r.mi[S];
@@ -448,10 +450,12 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                         out |= 1u << (8 + S); // send_append(m.from), raft.rs:1719
                     }
                 } else {
-                    // Progress::is_paused (progress.rs:210-216); Inflights::full() comes from the host
-                    const bool old_paused = state == RG_STATE_PROBE       ? (pb & RG_PF_PAUSED) != 0
-                                            : state == RG_STATE_REPLICATE ? (f & RG_MF_INS_FULL) != 0
-                                                                          : true;
+                    // Progress::is_paused (progress.rs:210-216); Inflights::full() comes from the host with the
+                    // message or, when the ring lives on the device, from the send stage through the flag byte
+                    const bool old_paused = state == RG_STATE_PROBE ? (pb & RG_PF_PAUSED) != 0
+                                            : state == RG_STATE_REPLICATE
+                                                ? ((f & RG_MF_INS_FULL) | (pb0 & RG_PF_INS_FULL)) != 0
+                                                : true;
                     if (maybe_update<S>(idx, pb)) {
                         if (state == RG_STATE_PROBE) { // become_replicate (progress.rs:111-114)
                             reset_state(pb, RG_STATE_REPLICATE, o);

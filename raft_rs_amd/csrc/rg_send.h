@@ -1,0 +1,151 @@
+// rg_send.h -- the send stage: Inflights in HBM and the maybe_send_append
+// decision, one group per lane. Host+device code so tests/host_check can run it on the CPU.
+//
+// Restated from (pingcap/raft-rs v0.6.0): src/tracker/inflights.rs:42-125 (ring), src/raft.rs:773-819
+// (maybe_send_append), :722-731 (prepare_send_entries), :664-712 (prepare_send_snapshot, decision only),
+// :857-864 (bcast_append), :1745-1761 (who gets what after an ack), src/raft_log.rs:382-389,463-484 (entries /
+// Compacted), src/tracker/progress.rs:210-216,231-243 (is_paused, update_state).
+#pragma once
+
+#include "rg_common.h"
+
+struct RgIns {
+    u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31)
+    u64 *ring; // [(g * P + slot) * cap + i]: Inflights.buffer of that Progress, contiguous per cell
+    u32 cap;   // Inflights::cap()
+};
+
+template <int P> struct RgSendRegs {
+    u64 prev[P], last[P];
+    u32 n[P];   // messages per slot, 0 = nothing to send
+    u32 snap;   // bit s: slot s needs a snapshot instead (RG_SEND_SNAPSHOT)
+    u32 count;  // items of this group
+};
+
+// Inflights::free_to (inflights.rs:84-110)
+RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 to) {
+    if (count == 0 || to < ins.ring[base + start]) return; // out of the left side of the window
+    u32 i = 0, idx = start;
+    while (i < count) {
+        if (to < ins.ring[base + idx]) break; // found the first large inflight
+        idx++;
+        if (idx >= ins.cap) idx -= ins.cap;
+        i++;
+    }
+    count -= i;
+    start = idx;
+}
+
+// One group of the send stage. `out` is the group's RG_OUT_* word of the tick that just ran.
+template <int P>
+RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u64 max_entries, RgSendRegs<P> &it) {
+    const u32 cfg = st.cfg[g];
+    const u32 present = RG_CFG_PRESENT(cfg), self = RG_CFG_SELF(cfg);
+    // bcast_append: the commit index moved (should_bcast_commit(), raft.rs:1745-1748) or the leader appended
+    // entries (a proposal, raft.rs:2049-2053)
+    const bool bcast = (out & (RG_OUT_CHANGED | RG_OUT_APPENDED)) != 0;
+    const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
+    it.snap = 0;
+    it.count = 0;
+#pragma unroll
+    for (int s = 0; s < P; s++) it.n[s] = 0;
+    u32 work = sa_bits | sm_bits | fr_bits;
+    if (bcast) work |= present;
+    work &= present & ~(1u << self);
+    if (work == 0) return;
+
+    const u64 hi = st.hi[g];                    // last_index
+    const u64 first_index = st.dummy_idx[g] + 1; // RaftLog::first_index (dummy entry = first_index - 1)
+    const u64 row0 = st.pflags[g];
+    u64 row = row0;
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        if (!((work >> s) & 1u)) continue;
+        const u64 o = (u64)s * st.stride + g;
+        const u64 base = (g * (u64)P + (u64)s) * ins.cap;
+        u32 pb = (u32)(row >> (8 * s)) & 0xffu;
+        const u32 state = pb & RG_PF_STATE_MASK;
+        const u32 meta0 = ins.meta[o];
+        u32 start = meta0 & 0xffffu, count = meta0 >> 16;
+
+        // ---- what the tick did to this peer's Inflights ----
+        if (state != RG_STATE_REPLICATE) {
+            // Progress::reset_state (progress.rs:75-80) ran when it left Replicate; nothing is added outside it
+            start = 0;
+            count = 0;
+        } else if ((fr_bits >> s) & 1u) {
+            if ((sm_bits >> s) & 1u) rg_ins_free_to(ins, base, start, count, st.match[o]); // accepted ack: m.index == matched
+            else if (count) rg_ins_free_to(ins, base, start, count, ins.ring[base + start]); // free_first_one (:114-117)
+        }
+
+        // ---- send_append(to) then `while maybe_send_append(to, false)` ----
+        const bool sa = bcast || ((sa_bits >> s) & 1u);
+        const bool sm = (sm_bits >> s) & 1u;
+        if (sa || sm) {
+            u64 next = st.next[o];
+            const u64 next0 = next;
+            const u64 prs = st.prs[o];
+            u32 n = 0;
+            bool snap = false;
+            bool first = sa; // the first call is send_append (allow_empty) only if one was requested
+            for (;;) {
+                const bool allow_empty = first;
+                // Progress::is_paused (progress.rs:210-216)
+                const bool paused = state == RG_STATE_PROBE       ? (pb & RG_PF_PAUSED) != 0
+                                    : state == RG_STATE_REPLICATE ? count == ins.cap
+                                                                  : true;
+                bool sent = false;
+                if (!paused) {
+                    if (prs != 0) { // pending_request_snapshot: prepare_send_snapshot
+                        snap = (pb & RG_PF_RECENT_ACTIVE) != 0;
+                    } else {
+                        const u64 avail = next > hi ? 0 : hi - next + 1;
+                        const bool compacted = next <= hi && next < first_index; // entries() = Err(Compacted)
+                        if (compacted) {
+                            if (allow_empty) snap = (pb & RG_PF_RECENT_ACTIVE) != 0; // else: `return false`
+                        } else if (avail != 0 || allow_empty) {
+                            const u64 take = (max_entries && avail > max_entries) ? max_entries : avail;
+                            if (n == 0) it.prev[s] = next - 1;
+                            it.last[s] = next - 1 + take;
+                            n++;
+                            if (take) { // Progress::update_state(last) (progress.rs:231-243)
+                                if (state == RG_STATE_REPLICATE) {
+                                    next += take; // optimistic_update
+                                    u32 pos = start + count;
+                                    if (pos >= ins.cap) pos -= ins.cap;
+                                    ins.ring[base + pos] = next - 1; // Inflights::add (inflights.rs:65-81)
+                                    count++;
+                                } else {
+                                    pb |= RG_PF_PAUSED;
+                                }
+                            }
+                            sent = true;
+                        }
+                    }
+                }
+                // send_append runs once; the loop goes on while something was sent. A snapshot pauses the
+                // Progress (become_snapshot, applied by the host), which ends the loop as well.
+                if (snap) break;
+                if (first) {
+                    first = false;
+                    if (!sm) break;
+                } else if (!sent) {
+                    break;
+                }
+            }
+            if (snap) {
+                it.snap |= 1u << s;
+                it.prev[s] = next - 1;
+                it.last[s] = prs; // the requested snapshot index (0 = any)
+            }
+            it.n[s] = n;
+            if (n || snap) it.count++;
+            if (next != next0) st.next[o] = next;
+        }
+        pb = (pb & ~RG_PF_INS_FULL) | ((state == RG_STATE_REPLICATE && count == ins.cap) ? RG_PF_INS_FULL : 0u);
+        row = (row & ~(0xffULL << (8 * s))) | ((u64)pb << (8 * s));
+        const u32 meta = start | (count << 16);
+        if (meta != meta0) ins.meta[o] = meta;
+    }
+    if (row != row0) st.pflags[g] = row;
+}

@@ -31,7 +31,7 @@ TERM_RUNS = 4
 
 
 class PF:
-    STATE_MASK, PROBE, REPLICATE, SNAPSHOT, PAUSED, RECENT_ACTIVE = 0x3, 0, 1, 2, 0x4, 0x8
+    STATE_MASK, PROBE, REPLICATE, SNAPSHOT, PAUSED, RECENT_ACTIVE, INS_FULL = 0x3, 0, 1, 2, 0x4, 0x8, 0x10
 
 
 class MF:
@@ -39,7 +39,7 @@ class MF:
 
 
 class OUT:
-    CHANGED, FAULT, TIMEOUT_NOW = 0x1, 0x2, 0x4
+    CHANGED, FAULT, TIMEOUT_NOW, APPENDED = 0x1, 0x2, 0x4, 0x8
 
     @staticmethod
     def send_append(o):
@@ -71,7 +71,7 @@ def cfg_make(incoming, outgoing=0, self_slot=0, group_commit=False, transferee_p
 
 class _Config(C.Structure):
     _fields_ = [("n_groups", C.c_uint64), ("n_slots", C.c_uint32), ("device", C.c_int32),
-                ("variant", C.c_uint32), ("reserved", C.c_uint32)]
+                ("variant", C.c_uint32), ("max_inflight", C.c_uint32)]
 
 
 class _Msgs(C.Structure):
@@ -114,6 +114,11 @@ class CellWrite(C.Structure):
                 ("pflags", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
+SEND_APPEND, SEND_SNAPSHOT = 1, 2
+SEND_ITEM_DTYPE = np.dtype([("group", "<u8"), ("prev_index", "<u8"), ("last_index", "<u8"), ("slot", "<u4"),
+                            ("n_msgs", "<u2"), ("kind", "<u2")])
+assert SEND_ITEM_DTYPE.itemsize == 32
+
 # every symbol include/raftgroups.h declares: (restype, argtypes)
 _vp, _u64, _i = C.c_void_p, C.c_uint64, C.c_int
 SYMBOLS = {
@@ -148,6 +153,12 @@ SYMBOLS = {
     "rg_ingested_duplicates": (_i, [_vp, C.POINTER(_u64)]),
     "rg_tick_ingested": (_i, [_vp, C.POINTER(_u64)]),
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "rg_send_appends": (_i, [_vp, _u64]),
+    "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "rg_send_items_ptr": (_vp, [_vp]),
+    "rg_inflights_bytes": (_u64, [_vp, _i]),
+    "rg_read_inflights": (_i, [_vp, _vp, _vp]),
+    "rg_load_inflights": (_i, [_vp, _vp, _vp]),
     "rg_vote_result": (_i, [_vp, _vp, _vp, _vp]),
     "rg_quorum_recently_active": (_i, [_vp, _vp]),
     "rg_set_peers": (_i, [_vp, _u64, C.POINTER(_u64), C.c_uint32, _u64]),
@@ -222,12 +233,13 @@ class MsgBuffers:
 class Engine:
     """One shard of raft groups resident on one MI355X (rg_engine)."""
 
-    def __init__(self, n_groups, n_slots, device=0, variant=VARIANT_DEFAULT):
+    def __init__(self, n_groups, n_slots, device=0, variant=VARIANT_DEFAULT, max_inflight=0):
+        """max_inflight > 0: Inflights rings of that capacity live on the device (send_appends after each tick)."""
         self.L = load_library()
         self.h = _vp()
-        cfg = _Config(n_groups, n_slots, device, variant, 0)
+        cfg = _Config(n_groups, n_slots, device, variant, max_inflight)
         self._check(self.L.rg_create(C.byref(cfg), C.byref(self.h)))
-        self.n_groups, self.n_slots, self.device = n_groups, n_slots, device
+        self.n_groups, self.n_slots, self.device, self.max_inflight = n_groups, n_slots, device, max_inflight
         self.stride = self.L.rg_stride(self.h)
 
     def close(self):
@@ -369,6 +381,41 @@ class Engine:
         for i, t in enumerate(ticks):
             arr[i] = _Msgs(*([_ptr(x) for x in t] + [None] * (6 - len(t))))
         self._check(self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t)))
+
+    # ---- send stage (device Inflights + maybe_send_append decisions) ------------------------------
+    def send_appends(self, max_entries_per_msg=0):
+        """Run the send stage for the tick that just ran (asynchronous)."""
+        self._check(self.L.rg_send_appends(self.h, max_entries_per_msg))
+
+    def send_items(self):
+        """Work items of the last send stage as a SEND_ITEM_DTYPE array (order unspecified)."""
+        n = _u64(0)
+        self._check(self.L.rg_send_items(self.h, None, 0, C.byref(n)))
+        items = np.empty(n.value, dtype=SEND_ITEM_DTYPE)
+        if n.value:
+            self._check(self.L.rg_send_items(self.h, items.ctypes.data, n.value, C.byref(n)))
+        return items
+
+    def read_inflights(self):
+        """(meta u32 [P][stride] = start | count << 16, ring u64 [G][P][cap])."""
+        meta = np.empty((self.n_slots, self.stride), dtype=np.uint32)
+        ring = np.empty((self.n_groups, self.n_slots, self.max_inflight), dtype=np.uint64)
+        self._check(self.L.rg_read_inflights(self.h, meta.ctypes.data, ring.ctypes.data))
+        return meta, ring
+
+    def load_inflights(self, meta, ring):
+        meta = np.ascontiguousarray(meta, dtype=np.uint32)
+        ring = np.ascontiguousarray(ring, dtype=np.uint64)
+        assert meta.shape == (self.n_slots, self.stride) and ring.shape == (self.n_groups, self.n_slots, self.max_inflight)
+        self._check(self.L.rg_load_inflights(self.h, meta.ctypes.data, ring.ctypes.data))
+
+    def inflights(self, group, slot, meta=None, ring=None):
+        """Logical contents (oldest first) of one Progress's Inflights."""
+        if meta is None:
+            meta, ring = self.read_inflights()
+        m = int(meta[slot, group])
+        start, count = m & 0xffff, m >> 16
+        return [int(ring[group, slot, (start + i) % self.max_inflight]) for i in range(count)]
 
     def recompute(self):
         self._check(self.L.rg_recompute(self.h))

@@ -14,11 +14,42 @@ class OracleLeader:
     name = "oracle"
 
     def __init__(self, self_id, term, voters, outgoing=(), learners=(), log=(), committed=0, dummy=(0, 0),
-                 next_idx=1):
-        self.cl = O.Cluster(1).config(0, self_id, term, voters, outgoing, learners, next_idx=next_idx)
+                 next_idx=1, max_inflight=256, max_entries=0):
+        self.cl = O.Cluster(1).config(0, self_id, term, voters, outgoing, learners, next_idx=next_idx,
+                                      max_inflight=max_inflight)
         self.cl.set_log(0, list(log), committed=committed, dummy=dummy)
         self.term = term
         self._voters, self._self_id = list(voters), self_id
+        self.max_inflight, self.max_entries = max_inflight, max_entries
+
+    # ---- flow control: the Progress's own Inflights + the send decisions (test_raft_flow_control.rs) ----
+    def _send(self, out_word):
+        """Serve the send requests of one step the way the reference does right after it."""
+        m = self.cl.send_stage_soa(np.array([out_word], dtype=np.uint32), self.max_entries, capacity=1 << 16)
+        return [(int(x["to"]), int(x["kind"]), int(x["index"]), int(x["n_entries"])) for x in m]
+
+    def propose(self, n=1):
+        """step(MsgPropose): append_entry + bcast_append (raft.rs:2044-2053). Returns the messages sent."""
+        self.append(n)
+        return self._send(0x8)
+
+    def ack(self, from_, index, commit=0):
+        """step(MsgAppendResponse) followed by its sends. Returns the messages sent."""
+        o = self.cl.step(0, from_, index, commit, ins_full=-1)
+        s = from_ - 1
+        word = (1 if o.commit_changed else 0) | (int(o.send_append) << (8 + s)) | (int(o.send_more) << (16 + s))
+        return self._send(word)
+
+    def heartbeat_response(self, from_, commit=0):
+        o = O.Out()
+        O.lib().ro_handle_heartbeat_response(self.cl.h, 0, from_, commit, -1, o)
+        return self._send(int(o.send_append) << (8 + from_ - 1))
+
+    def ins_full(self, pid):
+        return bool(O.lib().ro_ins_full(self.cl.pr(0, pid).ins))
+
+    def inflights(self, pid):
+        return self.cl.ins_contents(0, pid)
 
     def set_progress(self, pid, **kw):
         p = self.cl.pr(0, pid)
@@ -94,12 +125,13 @@ class EngineLeader:
     name = "engine"
 
     def __init__(self, self_id, term, voters, outgoing=(), learners=(), log=(), committed=0, dummy=(0, 0),
-                 next_idx=1, n_slots=None):
+                 next_idx=1, n_slots=None, max_inflight=0, max_entries=0):
         import raft_rs_amd as rg
         self.rg = rg
         ids = sorted(set(voters) | set(outgoing) | set(learners))
         self.P = n_slots or max(ids)
-        self.eng = rg.Engine(1, self.P)
+        self.eng = rg.Engine(1, self.P, max_inflight=max_inflight)
+        self.max_inflight, self.max_entries = max_inflight, max_entries
         self.term = term
         self.self_id = self_id
         mask = lambda s: sum(1 << (i - 1) for i in s)
@@ -210,6 +242,54 @@ class EngineLeader:
         self.msgs.clear()
         _, out = self.eng.results()
         return int(out[0])
+
+    # ---- flow control: Inflights on the device + the send stage (needs max_inflight > 0) ----
+    def _send(self):
+        """rg_send_appends for the tick that just ran; the per-peer items expanded to single messages."""
+        self.eng.send_appends(self.max_entries)
+        msgs = []
+        for it in self.eng.send_items():
+            to, kind, prev, last, n = int(it["slot"]) + 1, int(it["kind"]), int(it["prev_index"]), int(it["last_index"]), int(it["n_msgs"])
+            if kind == self.rg.engine.SEND_SNAPSHOT:
+                msgs.append((to, kind, prev, 0))
+                continue
+            E = self.max_entries
+            for k in range(n):
+                cnt = (last - prev) if not E else min(E, last - prev)
+                msgs.append((to, kind, prev, cnt))
+                prev += cnt
+            assert prev == last
+        return sorted(msgs)
+
+    def propose(self, n=1):
+        hi = int(self.eng.read_column(self.rg.COL.TERM_HI)[0])
+        s = self.self_id - 1
+        self.msgs.m_commit[s, 0] = hi + n
+        self.msgs.m_flags[0, s] = self.rg.MF.APPEND
+        out = self._tick()
+        assert out & self.rg.OUT.APPENDED
+        return self._send()
+
+    def ack(self, from_, index, commit=0):
+        s = from_ - 1
+        self.msgs.m_index[s, 0] = index
+        self.msgs.m_commit[s, 0] = commit
+        self.msgs.m_flags[0, s] = self.rg.MF.VALID
+        self._tick()
+        return self._send()
+
+    def heartbeat_response(self, from_, commit=0):
+        s = from_ - 1
+        self.msgs.m_commit[s, 0] = commit
+        self.msgs.m_flags[0, s] = self.rg.MF.HEARTBEAT
+        self._tick()
+        return self._send()
+
+    def ins_full(self, pid):
+        return bool(int(self.eng.read_column(self.rg.COL.PFLAGS)[0, pid - 1]) & self.rg.PF.INS_FULL)
+
+    def inflights(self, pid):
+        return self.eng.inflights(0, pid - 1)
 
     def append(self, n):
         hi = int(self.eng.read_column(self.rg.COL.TERM_HI)[0])

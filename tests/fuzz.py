@@ -62,9 +62,9 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
         paused = (rng.random(G) < 0.3).astype(np.uint8)
         ra = (rng.random(G) < 0.5).astype(np.uint8)
         st["pflags"][:, p] = state | (paused << 2) | (ra << 3)
-        ps = np.where(state == 2, m + rng.integers(0, 5, size=G).astype(np.uint64) - 2, 0)
+        ps = np.where(state == 2, m.astype(np.int64) + rng.integers(0, 5, size=G) - 2, 0)
         ps = np.where(rng.random(G) < 0.02, rng.integers(0, 50, size=G), ps)  # stale pending_snapshot on non-Snapshot
-        st["pend_snap"][p, :G] = np.maximum(ps.astype(np.int64), 0).astype(np.uint64)
+        st["pend_snap"][p, :G] = np.maximum(ps, 0).astype(np.uint64)
         st["pend_rs"][p, :G] = np.where(rng.random(G) < 0.05, rng.integers(1, 30, size=G), 0).astype(np.uint64)
         if with_gids:
             st["gid"][p, :G] = rng.integers(0, 4, size=G).astype(np.uint64)

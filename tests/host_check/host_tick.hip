@@ -3,6 +3,7 @@
 // tests can diff it against the oracle. This file is never part of libraftgroups.so: the product has
 // no CPU path. Build: hipcc -O3 -shared -fPIC --offload-arch=gfx950 host_tick.hip -o libhost_tick.so
 #include "../../raft_rs_amd/csrc/rg_tick_kernels.h"
+#include "../../raft_rs_amd/csrc/rg_send.h"
 
 // state[]: match next pr_commit pend_snap pend_rs gid pflags commit term_lo term_hi cfg out
 //          run_first run_term dummy_index dummy_term cur_term   (17 pointers)
@@ -104,4 +105,41 @@ extern "C" int rg_host_check_fused(unsigned P, unsigned long G, unsigned long st
     const bool gc = group_commit_kernel != 0;
     RG_DISPATCH_P(P, host_fused<N>(st, ms, T, out_t, commit_t, gc));
     return 0;
+}
+
+// The send stage (rg_send.h) group by group, exactly what k_send_appends runs per lane; items are appended in
+// group order. Returns the number of items (may exceed cap), -1 on a bad slot count.
+template <int P>
+static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, rg_send_item *items, u64 cap) {
+    u64 k = 0;
+    for (u64 g = 0; g < st.G; g++) {
+        const u32 out = st.out[g];
+        if (!out) continue;
+        RgSendRegs<P> it;
+        rg_group_send<P>(st, ins, g, out, max_entries, it);
+        for (int s = 0; s < P; s++) {
+            const bool snap = (it.snap >> s) & 1u;
+            if (it.n[s] == 0 && !snap) continue;
+            if (k < cap) {
+                rg_send_item r;
+                r.group = g; r.prev_index = it.prev[s]; r.last_index = it.last[s]; r.slot = (u32)s;
+                r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
+                r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
+                items[k] = r;
+            }
+            k++;
+        }
+    }
+    return (long)k;
+}
+
+extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long stride, void *const *state, u32 *meta,
+                                   u64 *ring, unsigned cap, unsigned long max_entries, rg_send_item *items,
+                                   unsigned long items_cap) {
+    const RgState st = make_state(state, G, stride);
+    RgIns ins;
+    ins.meta = meta; ins.ring = ring; ins.cap = cap;
+    long n = -1;
+    RG_DISPATCH_P(P, n = host_send<N>(st, ins, max_entries, items, items_cap));
+    return n;
 }

@@ -58,6 +58,16 @@ class Out(C.Structure):
                 ("commit_changed", C.c_bool), ("free_to", C.c_bool), ("timeout_now", C.c_bool)]
 
 
+class SendMsg(C.Structure):
+    _fields_ = [("group", C.c_uint64), ("to", C.c_uint64), ("index", C.c_uint64), ("n_entries", C.c_uint64),
+                ("kind", C.c_uint32), ("pad", C.c_uint32)]
+
+
+SEND_MSG_DTYPE = np.dtype([("group", "<u8"), ("to", "<u8"), ("index", "<u8"), ("n_entries", "<u8"), ("kind", "<u4"),
+                           ("pad", "<u4")])
+SEND_APPEND, SEND_SNAPSHOT = 1, 2
+
+
 class SoaState(C.Structure):
     _fields_ = [("n_groups", C.c_size_t), ("n_slots", C.c_size_t), ("stride", C.c_size_t)] + \
                [(n, C.c_void_p) for n in ("match", "next", "pr_commit", "pend_snap", "pend_rs",
@@ -124,6 +134,10 @@ def lib():
         "ro_store_soa": (C.c_int, [vp, C.POINTER(SoaState)]),
         "ro_tick_soa": (u64, [vp, C.POINTER(SoaMsgs), vp, sz, sz]),
         "ro_tick_soa_mt": (u64, [vp, C.POINTER(SoaMsgs), vp, sz]),
+        "ro_maybe_send_append": (C.c_bool, [vp, sz, u64, C.c_bool, u64, C.POINTER(SendMsg)]),
+        "ro_set_own_inflights": (None, [vp, C.c_bool]),
+        "ro_send_stage_soa": (sz, [vp, vp, u64, vp, sz, sz, sz]),
+        "ro_ins_contents": (sz, [vp, sz, u64, C.POINTER(u64), sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -220,6 +234,28 @@ class Cluster:
         m = _soa_msgs_struct(msgs)
         return self.L.ro_tick_soa(self.h, C.byref(m), gout.ctypes.data, g_begin,
                                   self.n if g_end is None else g_end)
+
+    def set_own_inflights(self, on=True):
+        self.L.ro_set_own_inflights(self.h, on)
+
+    def maybe_send_append(self, g, to, allow_empty, max_entries=0):
+        m = SendMsg()
+        sent = self.L.ro_maybe_send_append(self.h, g, to, allow_empty, max_entries, C.byref(m))
+        return sent, m
+
+    def send_stage_soa(self, gout, max_entries=0, capacity=1 << 20, g_begin=0, g_end=None):
+        """The reference's send decisions for the tick whose result words are gout -> SEND_MSG_DTYPE array
+        (one record per message sent, in the order sent). Mutates the cluster: never re-run."""
+        buf = np.zeros(capacity, dtype=SEND_MSG_DTYPE)
+        n = self.L.ro_send_stage_soa(self.h, gout.ctypes.data, max_entries, buf.ctypes.data, len(buf), g_begin,
+                                     self.n if g_end is None else g_end)
+        assert n <= capacity, "send_stage_soa: capacity too small"
+        return buf[:n]
+
+    def ins_contents(self, g, pid, cap=65536):
+        buf = (C.c_uint64 * cap)()
+        n = self.L.ro_ins_contents(self.h, g, pid, buf, cap)
+        return [int(buf[i]) for i in range(min(n, cap))]
 
     def tick_soa_mt(self, msgs, gout, n_threads):
         m = _soa_msgs_struct(msgs)

@@ -319,6 +319,91 @@ def scenario_send_path_update_state(B):
     assert ld.sent(3) != 0, "Snapshot: update_state panics in the reference -> reported as a fault"
 
 
+def _flow_leader(B, cap):
+    """new_test_raft(1, [1, 2], ..) after become_candidate + become_leader (noop at index 1), peer 2 forced
+    into Replicate (test_raft_flow_control.rs:24-31)."""
+    ld = B(1, 1, [1, 2], log=[(1, 1)], committed=0, next_idx=1, max_inflight=cap)
+    ld.set_progress(1, match=1, next=2, state=REPLICATE)
+    ld.set_progress(2, match=0, next=1, state=REPLICATE)
+    return ld
+
+
+def scenario_msg_app_flow_control_full(B, cap=16):
+    """test_raft_flow_control.rs:24-56 test_msg_app_flow_control_full: one MsgAppend per proposal until the
+    inflight window is full, then none."""
+    ld = _flow_leader(B, cap)
+    for i in range(cap):
+        ms = ld.propose()
+        assert len(ms) == 1 and ms[0][0] == 2, f"#{i}: ms = {ms}, want 1 message"
+    assert ld.ins_full(2)
+    for i in range(10):
+        assert ld.propose() == [], f"#{i}: want no message on a full window"
+
+
+def scenario_msg_app_flow_control_move_forward(B, cap=12):
+    """test_raft_flow_control.rs:63-108 test_msg_app_flow_control_move_forward: an ack of index tt frees the
+    window up to tt; stale acks below it free nothing."""
+    ld = _flow_leader(B, cap)
+    for _ in range(cap):
+        ld.propose()
+    for tt in range(2, cap):  # 1 is the noop, 2 the first proposal
+        ld.ack(2, tt)  # move the window forward
+        ms = ld.propose()  # fill it again
+        assert len(ms) == 1, f"#{tt}: ms = {ms}, want 1 message"
+        assert ld.ins_full(2), f"#{tt}: the window must be full again"
+        for i in range(tt):
+            ld.ack(2, i)
+            assert ld.ins_full(2), f"#{tt}.{i}: a stale ack must not free the window"
+
+
+def scenario_msg_app_flow_control_recv_heartbeat(B, cap=8):
+    """test_raft_flow_control.rs:115-177 test_msg_app_flow_control_recv_heartbeat: a heartbeat response on a
+    full window frees exactly one slot."""
+    ld = _flow_leader(B, cap)
+    for _ in range(cap):
+        ld.propose()
+    for tt in range(1, 5):
+        assert ld.ins_full(2), f"#{tt}: window must be full"
+        for i in range(tt):  # the first response frees a slot, the others find the window not full
+            ld.heartbeat_response(2)
+            assert not ld.ins_full(2), f"#{tt}.{i}: want a free slot"
+        ms = ld.propose()  # one slot
+        assert len(ms) == 1, f"#{tt}: free slot = 0, want 1"
+        for i in range(10):  # and just one slot
+            assert ld.propose() == [], f"#{tt}.{i}: ms should be empty"
+        ld.heartbeat_response(2)  # clear all pending messages (frees one slot and re-sends the backlog)
+
+
+def scenario_send_append_for_progress(B):
+    """test_raft.rs:2830-2910 test_send_append_for_progress_{probe,replicate,snapshot} at the decision level:
+    Probe sends once and pauses, a heartbeat response resumes it; Replicate keeps sending optimistically;
+    Snapshot sends nothing."""
+    ld = B(1, 1, [1, 2], log=[(1, 1)], committed=0, next_idx=2, max_inflight=256)
+    ld.set_progress(1, match=1, next=2, state=REPLICATE)
+    ld.set_progress(2, match=0, next=2, state=PROBE, paused=False)
+    ms = ld.propose()
+    assert [m[0] for m in ms] == [2] and ld.progress(2)["paused"], "probe: the first proposal is sent, then paused"
+    for _ in range(3):
+        assert ld.propose() == [], "probe: paused, nothing is sent"
+    pr = ld.progress(2)
+    assert pr["next"] == 2 and pr["paused"]
+    ms = ld.heartbeat_response(2)  # resume() + send_append: the whole backlog in one message
+    assert len(ms) == 1 and ms[0][2] == 1 and ms[0][3] == 4 and ld.progress(2)["paused"]
+    # replicate: every proposal goes out, next runs ahead of matched
+    ld.set_progress(2, match=1, next=2, state=REPLICATE)
+    for i in range(10):
+        ms = ld.propose()
+        assert len(ms) == 1, (i, ms)
+    assert ld.progress(2)["next"] == 16, "optimistic next = last_index + 1 (1 noop + 4 + 10 proposals)"
+    # snapshot: nothing is sent
+    ld.set_progress(2, state=SNAPSHOT, pending_snapshot=10)
+    for _ in range(3):
+        assert ld.propose() == []
+
+
+FLOW = [scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+        scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
+
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,
        scenario_leader_acknowledge_commit, scenario_snapshot_abort, scenario_request_snapshot,

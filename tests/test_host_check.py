@@ -12,6 +12,7 @@ import pytest
 
 import fuzz
 import oracle_lib as O
+import sendstage
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "host_check", "host_tick.hip")
@@ -23,7 +24,7 @@ def build_lib():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         return None
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h", "rg_send.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         # no -march=native: the built .so travels with gpurun snapshots to hosts with other CPUs
         subprocess.check_call([hipcc, "-O3", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
@@ -297,3 +298,86 @@ def test_soak_many_ticks(host_tick, workload, n_slots):
         if t % 10 == 9:
             assert not fuzz.diff_states(st, eng_st, G, n_slots), t
     assert (st["commit"] > 1000).all()
+
+
+# ---- the send stage (rg_send.h): device Inflights + maybe_send_append decisions ----------------------------
+SEND_ITEM_DTYPE = np.dtype([("group", "<u8"), ("prev_index", "<u8"), ("last_index", "<u8"), ("slot", "<u4"),
+                            ("n_msgs", "<u2"), ("kind", "<u2")])
+
+
+@pytest.fixture(scope="module")
+def host_send():
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_send
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_ulong, C.c_void_p,
+                   C.c_ulong]
+
+    def send(st, out, meta, ring, cap, max_entries):
+        items = np.zeros(st["n_groups"] * st["n_slots"], dtype=SEND_ITEM_DTYPE)
+        n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), meta.ctypes.data, ring.ctypes.data,
+               cap, max_entries, items.ctypes.data, len(items))
+        assert 0 <= n <= len(items)
+        return items[:n]
+    return send
+
+
+def apply_snapshots(rng, items, cl, st, meta):
+    """The host's half of a snapshot send: Progress::become_snapshot(snapshot index) on both sides."""
+    for (g, p), (kind, prev, last, n) in items.items():
+        if kind != O.SEND_SNAPSHOT:
+            continue
+        sidx = int(st["commit"][g])  # what a storage would hand out: a snapshot at the applied index
+        pr = cl.pr(g, p + 1)
+        cl.L.ro_progress_become_snapshot(C.byref(pr), sidx)
+        st["pflags"][g, p] = (int(st["pflags"][g, p]) & ~(0x3 | 0x4 | 0x10)) | O.SNAPSHOT
+        st["pend_snap"][p, g] = sidx
+        meta[p, g] = 0  # what rg_write_cells does on a state change
+
+
+@pytest.mark.parametrize("cap,max_entries", [(1, 0), (3, 2), (4, 1), (256, 0), (2, 7)])
+@pytest.mark.parametrize("n_slots", [1, 3, 5, 8])
+def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, max_entries):
+    rng = np.random.default_rng(9100 + 17 * n_slots + cap + max_entries)
+    G = 1500
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, term=6)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    cl.set_own_inflights(True)
+    eng_st = copy_state(st)
+    meta = np.zeros((n_slots, st["stride"]), dtype=np.uint32)
+    ring = np.zeros((G, n_slots, cap), dtype=np.uint64)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    seen = {"items": 0, "multi": 0, "snap": 0, "full": 0}
+    for t in range(10):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
+        sendstage.prepare_msgs(msgs)
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        items = host_send(eng_st, out, meta, ring, cap, max_entries)
+        omsgs = cl.send_stage_soa(gout, max_entries)
+        got = sendstage.compare_items(items, omsgs)
+        apply_snapshots(rng, got, cl, eng_st, meta)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        sendstage.compare_rings(cl, meta, ring, st, cap)
+        seen["items"] += len(got)
+        seen["multi"] += sum(1 for v in got.values() if v[3] > 1)
+        seen["snap"] += sum(1 for v in got.values() if v[0] == O.SEND_SNAPSHOT)
+        seen["full"] += int(((st["pflags"][:, :n_slots] & 0x10) != 0).sum())
+    if n_slots > 1:
+        assert seen["items"] > 100, seen
+        assert seen["snap"] > 0, seen
+        if cap <= 4:
+            assert seen["full"] > 0, seen
+        if max_entries in (1, 2) and cap > 1:
+            assert seen["multi"] > 0, seen

@@ -1,0 +1,174 @@
+"""GPU: the send stage -- Inflights rings in HBM and the maybe_send_append decision
+(k_send_appends) -- against the oracle's message-at-a-time restatement of src/raft.rs:773-819 /
+src/tracker/inflights.rs: identical work items, Progress columns and ring contents after every tick."""
+import numpy as np
+import pytest
+
+import fuzz
+import oracle_lib as O
+import sendstage
+
+pytestmark = pytest.mark.gpu
+
+
+def apply_snapshots(rg, eng, cl, st, items):
+    """The host's half of a snapshot send on both sides: Progress::become_snapshot(index) -- on the engine through
+    rg_write_cells, whose state change must also reset the device ring."""
+    cells = []
+    flags = None
+    for (g, p), (kind, prev, last, n) in items.items():
+        if kind != O.SEND_SNAPSHOT:
+            continue
+        if flags is None:
+            flags = eng.read_column(rg.COL.PFLAGS)
+        sidx = int(st["commit"][g])
+        import ctypes as C
+        cl.L.ro_progress_become_snapshot(C.byref(cl.pr(g, p + 1)), sidx)
+        # INS_FULL is engine-owned: rg_write_cells must ignore whatever the caller passes for it
+        cells.append({"group": g, "slot": p, "pend_snap": sidx,
+                      "pflags": (int(flags[g, p]) & ~0x7) | O.SNAPSHOT | 0x10})
+    if cells:
+        eng.write_cells(cells)
+    return len(cells)
+
+
+def check(rg, eng, cl, st, cap, what):
+    got = eng.read_state()
+    cl.store_soa(st)
+    diffs = fuzz.diff_states(st, got, st["n_groups"], st["n_slots"])
+    assert not diffs, f"{what}: state differs from the oracle:\n" + "\n".join(diffs[:10])
+    meta, ring = eng.read_inflights()
+    sendstage.compare_rings(cl, meta, ring, st, cap)
+
+
+@pytest.mark.parametrize("n_slots,cap,max_entries", [(3, 2, 1), (5, 3, 2), (5, 256, 0), (7, 4, 0), (8, 1, 3)])
+def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries):
+    rng = np.random.default_rng(7700 + 31 * n_slots + cap)
+    G = 6000 + 13
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, term=6)
+    eng = rg.Engine(G, n_slots, max_inflight=cap)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    cl.set_own_inflights(True)
+    msgs = O.alloc_msgs(G, n_slots)
+    mb = rg.MsgBuffers(G, n_slots, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    seen = {"items": 0, "multi": 0, "snap": 0}
+    for t in range(8):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
+        sendstage.prepare_msgs(msgs)
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+            getattr(mb, k)[...] = msgs[k]
+        eng.tick(mb)
+        cl.tick_soa(msgs, gout)
+        _, out = eng.results()
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        eng.send_appends(max_entries)
+        items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, max_entries))
+        seen["snap"] += apply_snapshots(rg, eng, cl, st, items)
+        check(rg, eng, cl, st, cap, f"P={n_slots} cap={cap} tick {t}")
+        seen["items"] += len(items)
+        seen["multi"] += sum(1 for v in items.values() if v[3] > 1)
+    assert seen["items"] > 1000 and seen["snap"] > 0, seen
+    if max_entries and cap > 1:
+        assert seen["multi"] > 0, seen
+    eng.close()
+
+
+def test_send_stage_after_sparse_ticks(rg):
+    """rg_ingest -> rg_tick_ingested -> rg_send_appends: the stage walks the touched groups only."""
+    from test_sparse_path_gpu import records_from_msgs
+    rng = np.random.default_rng(7801)
+    G, P, cap = 20000, 5, 3
+    st = O.add_term_table(O.alloc_state(G, P))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, term=6)
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    cl.set_own_inflights(True)
+    msgs = O.alloc_msgs(G, P)
+    gout = np.zeros(G, dtype=np.uint32)
+    total = 0
+    for t in range(5):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
+        sendstage.prepare_msgs(msgs)
+        touched = np.sort(rng.choice(G, size=G // 25, replace=False))
+        keep = np.zeros(G, dtype=bool)
+        keep[touched] = True
+        msgs["m_flags"][~keep] = 0
+        assert eng.ingest(records_from_msgs(rg, msgs, touched, rng, P)) == 0
+        eng.tick_ingested()
+        gout[:] = 0
+        cl.tick_soa(msgs, gout)
+        eng.send_appends(2)
+        items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, 2))
+        assert all(keep[g] for g, _ in items)
+        apply_snapshots(rg, eng, cl, st, items)
+        check(rg, eng, cl, st, cap, f"sparse tick {t}")
+        total += len(items)
+    assert total > 500
+    eng.close()
+
+
+def test_send_stage_call_sequence_and_checkpoint(rg):
+    from raft_rs_amd.engine import EngineError, ERR
+    G, P, cap = 300, 3, 2
+    host = rg.Engine(G, P)  # Inflights stay with the host
+    with pytest.raises(EngineError) as e:
+        host.send_appends()
+    assert e.value.code == ERR["STATE"]
+    host.close()
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.workload_init(2)
+    with pytest.raises(EngineError) as e:
+        eng.send_appends()  # no tick yet
+    assert e.value.code == ERR["STATE"]
+    mb = rg.MsgBuffers(G, P, eng.stride)
+    hi = eng.read_column(rg.COL.TERM_HI)
+    mb.m_commit[0, :G] = hi + 3  # every leader (slot 0) proposes 3 entries: bcast_append = ONE message per peer
+    mb.m_flags[:, 0] = rg.MF.APPEND
+    eng.tick(mb)
+    eng.send_appends(1)
+    items = eng.send_items()
+    assert len(items) == G * (P - 1) and (items["n_msgs"] == 1).all()
+    assert (items["last_index"] == items["prev_index"] + 1).all(), "max_entries_per_msg = 1"
+    assert not (eng.read_column(rg.COL.PFLAGS)[:, :P] & rg.PF.INS_FULL).any()
+    mb.m_commit[0, :G] = hi + 4  # a second proposal fills the window of 2
+    eng.tick(mb)
+    eng.checkpoint()
+    eng.send_appends(1)
+    assert len(eng.send_items()) == G * (P - 1)
+    meta1, ring1 = eng.read_inflights()
+    assert (eng.read_column(rg.COL.PFLAGS)[:, 1:P] & rg.PF.INS_FULL).all()
+    with pytest.raises(EngineError) as e:
+        eng.send_appends(1)  # the stage already ran for this tick
+    assert e.value.code == ERR["STATE"]
+    mb.m_commit[0, :G] = hi + 5  # full windows: a proposal sends nothing
+    eng.tick(mb)
+    eng.send_appends(1)
+    assert len(eng.send_items()) == 0
+    eng.restore()  # back to "second tick done, its stage not run": rings and flags are part of the checkpoint
+    meta0, _ = eng.read_inflights()
+    assert ((meta0[1:P, :G] >> 16) == 1).all() and (meta0[0, :G] == 0).all()
+    assert not (eng.read_column(rg.COL.PFLAGS)[:, :P] & rg.PF.INS_FULL).any()
+    eng.send_appends(1)  # replays identically
+    m2, r2 = eng.read_inflights()
+    assert (m2 == meta1).all() and (r2 == ring1).all()
+    eng.load_inflights(meta0, ring1)
+    m3, _ = eng.read_inflights()
+    assert (m3 == meta0).all()
+    import torch
+    with pytest.raises(EngineError) as e:  # fused launches cannot interleave the send stage
+        d = torch.zeros(8, dtype=torch.int64, device="cuda")
+        eng.tick_device_fused([(d.data_ptr(),) * 5], d.data_ptr())
+    assert e.value.code == ERR["STATE"]
+    eng.close()
