@@ -306,8 +306,8 @@ int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t
 const rg_send_item *rg_send_items_ptr(rg_engine *h);
 /* Inflights in/out (parity, checkpoints): meta u32 [P][stride] = start | count << 16; ring u64 [G][P][cap]. */
 uint64_t rg_inflights_bytes(const rg_engine *h, int ring);
-int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring);
-int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring);
+int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring); /* either may be NULL */
+int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring); /* both required */
 
 /* ---- sparse path: wire-order records -> slot matrix -> tick over the touched groups only ----
  * For realistic traffic (a small fraction of the groups has events in a tick) the dense sweep of rg_tick

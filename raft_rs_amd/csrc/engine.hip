@@ -305,11 +305,15 @@ __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
 // ------------------------------------------------------------------------------------------------
 // kernels: sparse cell writes, counters, workload
 // ------------------------------------------------------------------------------------------------
-// The send stage (rg_send.h): one lane per group; the work items of a wave are appended to the compact list
-// with ONE atomic per wave (prefix sum over the lanes' item counts).
+// The send stage (rg_send.h): one lane per group. The work items of a whole 1024-thread workgroup are appended
+// to the compact list with ONE atomic (wave prefix sums by shuffles, the 16 wave totals through LDS): at one
+// atomic per wave the 15.6 K same-address atomics of a 1 M-group launch cost more than everything else together.
+#define RG_SEND_BLOCK 1024
 template <int P>
-__global__ __launch_bounds__(RG_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, const u64 *list, u64 n,
-                                                          rg_send_item *items, u32 *counter) {
+__global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, const u64 *list,
+                                                               u64 n, rg_send_item *items, u32 *counter) {
+    __shared__ u32 wave_tot[RG_SEND_BLOCK / 64];
+    __shared__ u32 block_base;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const u64 g = active ? (list ? list[i] : i) : 0;
@@ -320,33 +324,41 @@ __global__ __launch_bounds__(RG_BLOCK) void k_send_appends(RgState st, RgIns ins
         const u32 out = st.out[g];
         if (out) rg_group_send<P>(st, ins, g, out, max_entries, it);
     }
-    const u32 lane = threadIdx.x & 63u;
+    if (RG_SEND_EXP & 1) return;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u32 incl = it.count;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const u32 v = __shfl_up(incl, d, 64);
         if (lane >= (u32)d) incl += v;
     }
-    const u32 total = __shfl(incl, 63, 64);
-    if (total == 0) return; // wave-uniform
-    u32 base = 0;
-    if (lane == 63) base = atomicAdd(counter, total);
-    base = __shfl(base, 63, 64);
-    u32 k = base + incl - it.count;
-    if (it.count) {
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
 #pragma unroll
-        for (int s = 0; s < P; s++) {
-            const bool snap = (it.snap >> s) & 1u;
-            if (it.n[s] == 0 && !snap) continue;
-            rg_send_item r;
-            r.group = g;
-            r.prev_index = it.prev[s];
-            r.last_index = it.last[s];
-            r.slot = (u32)s;
-            r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
-            r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
-            items[k++] = r;
+        for (int w = 0; w < RG_SEND_BLOCK / 64; w++) {
+            const u32 t = wave_tot[w];
+            wave_tot[w] = total; // exclusive prefix
+            total += t;
         }
+        block_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    if (it.count == 0) return;
+    u32 k = block_base + wave_tot[wave] + incl - it.count;
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const bool snap = (it.snap >> s) & 1u;
+        if (it.n[s] == 0 && !snap) continue;
+        rg_send_item r;
+        r.group = g;
+        r.prev_index = it.prev[s];
+        r.last_index = it.last[s];
+        r.slot = (u32)s;
+        r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
+        r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
+        items[k++] = r;
     }
 }
 
@@ -468,7 +480,7 @@ struct rg_engine {
     u64 last_sparse_n;        // groups of the last rg_tick_ingested (result arrays are valid for them)
     bool out_is_dense;        // RG_COL_OUT was last written by a dense tick
     // send stage (rg_config.max_inflight > 0): Inflights rings, work items
-    char *ins_arena;   // meta | ring | items | counter
+    char *ins_arena;   // meta | head | tail | ring | items | counter
     char *ins_ckpt;    // checkpoint copy of meta | ring (lazy)
     size_t ins_state_bytes;
     RgIns ins;
@@ -557,6 +569,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->ins_ckpt = nullptr;
     h->ins_state_bytes = 0;
     h->ins.meta = nullptr;
+    h->ins.head = nullptr;
+    h->ins.tail = nullptr;
     h->ins.ring = nullptr;
     h->ins.cap = 0;
     h->send_items = nullptr;
@@ -613,7 +627,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.G = h->G;
     s.stride = h->stride;
     if (cfg->max_inflight) { // Inflights rings + the send stage's work-item list
-        const size_t meta_b = rg_align((size_t)h->P * h->stride * 4);
+        const size_t meta_b = rg_align((size_t)h->P * h->stride * 4) + 2 * rg_align((size_t)h->P * h->stride * 8); // meta | head | tail
         const size_t ring_b = rg_align((size_t)h->G * h->P * cfg->max_inflight * 8);
         const size_t items_b = rg_align((size_t)h->G * h->P * sizeof(rg_send_item));
         e = hipMalloc(&h->ins_arena, meta_b + ring_b + items_b + 256);
@@ -626,6 +640,9 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
                            cfg->max_inflight, hipGetErrorString(e));
         }
         h->ins.meta = reinterpret_cast<u32 *>(h->ins_arena);
+        h->ins.head = reinterpret_cast<u64 *>(h->ins_arena + rg_align((size_t)h->P * h->stride * 4));
+        h->ins.tail = reinterpret_cast<u64 *>(h->ins_arena + rg_align((size_t)h->P * h->stride * 4) +
+                                              rg_align((size_t)h->P * h->stride * 8));
         h->ins.ring = reinterpret_cast<u64 *>(h->ins_arena + meta_b);
         h->ins.cap = cfg->max_inflight;
         h->ins_state_bytes = meta_b + ring_b;
@@ -1112,7 +1129,7 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg) {
     const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
     const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;
     if (n) {
-        const dim3 grid(rg_grid(n, RG_BLOCK)), block(RG_BLOCK);
+        const dim3 grid(rg_grid(n, RG_SEND_BLOCK)), block(RG_SEND_BLOCK);
         switch (h->P) {
         case 1: hipLaunchKernelGGL(k_send_appends<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
         case 2: hipLaunchKernelGGL(k_send_appends<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
@@ -1153,31 +1170,61 @@ extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
     return ring ? (uint64_t)h->G * h->P * h->ins.cap * 8 : (uint64_t)h->P * h->stride * 4;
 }
 
+// The oldest inflight of a window lives in the `head` column (rg_send.h); to the outside the ring is whole.
 extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_inflights: null engine");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_read_inflights: engine created with max_inflight = 0");
     RG_HIP(hipSetDevice(h->cfg.device));
-    if (host_meta) RG_HIP(hipMemcpyAsync(host_meta, h->ins.meta, rg_inflights_bytes(h, 0), hipMemcpyDeviceToHost, h->stream));
-    if (host_ring) RG_HIP(hipMemcpyAsync(host_ring, h->ins.ring, rg_inflights_bytes(h, 1), hipMemcpyDeviceToHost, h->stream));
+    const u64 cells = (u64)h->P * h->stride;
+    std::vector<u32> meta_tmp;
+    std::vector<u64> head;
+    u32 *meta = host_meta;
+    if (host_ring) {
+        head.resize(cells);
+        if (!meta) {
+            meta_tmp.resize(cells);
+            meta = meta_tmp.data();
+        }
+        RG_HIP(hipMemcpyAsync(head.data(), h->ins.head, cells * 8, hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipMemcpyAsync(host_ring, h->ins.ring, rg_inflights_bytes(h, 1), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (meta) RG_HIP(hipMemcpyAsync(meta, h->ins.meta, cells * 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
+    if (host_ring)
+        for (u32 p = 0; p < h->P; p++)
+            for (u64 g = 0; g < h->G; g++) {
+                const u32 m = meta[(u64)p * h->stride + g];
+                if (m >> 16) host_ring[(g * h->P + p) * h->ins.cap + (m & 0xffffu)] = head[(u64)p * h->stride + g];
+            }
     return RG_OK;
 }
 
 extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring) {
-    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: null engine");
+    if (!h || !host_meta || !host_ring) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: meta and ring are both required");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_load_inflights: engine created with max_inflight = 0");
-    if (host_meta) { // start < cap, count <= cap for every cell
-        const u64 n = (u64)h->P * h->stride;
-        for (u64 i = 0; i < n; i++) {
-            const u32 m = host_meta[i];
-            if ((m & 0xffffu) >= h->ins.cap || (m >> 16) > h->ins.cap)
-                return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: cell %llu: start %u count %u outside cap %u",
-                               (unsigned long long)i, m & 0xffffu, m >> 16, h->ins.cap);
+    const u64 cells = (u64)h->P * h->stride;
+    std::vector<u64> head(cells, 0), tail(cells, 0);
+    for (u32 p = 0; p < h->P; p++)
+        for (u64 g = 0; g < h->G; g++) { // start < cap, count <= cap for every cell
+            const u64 o = (u64)p * h->stride + g;
+            const u32 m = host_meta[o], start = m & 0xffffu, count = m >> 16;
+            if (start >= h->ins.cap || count > h->ins.cap)
+                return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: group %llu slot %u: start %u count %u outside cap %u",
+                               (unsigned long long)g, p, start, count, h->ins.cap);
+            if (!count) continue;
+            const u64 *cell = host_ring + (g * h->P + p) * h->ins.cap;
+            head[o] = cell[start];
+            for (u32 i = 1; i < count; i++) // last indices of consecutive MsgAppends
+                if (cell[(start + i) % h->ins.cap] <= cell[(start + i - 1) % h->ins.cap])
+                    return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: group %llu slot %u: inflights must be strictly "
+                                                       "increasing, oldest first", (unsigned long long)g, p);
+            tail[o] = cell[(start + count - 1) % h->ins.cap];
         }
-    }
     RG_HIP(hipSetDevice(h->cfg.device));
-    if (host_meta) RG_HIP(hipMemcpyAsync(h->ins.meta, host_meta, rg_inflights_bytes(h, 0), hipMemcpyHostToDevice, h->stream));
-    if (host_ring) RG_HIP(hipMemcpyAsync(h->ins.ring, host_ring, rg_inflights_bytes(h, 1), hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(h->ins.meta, host_meta, cells * 4, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(h->ins.head, head.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(h->ins.tail, tail.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(h->ins.ring, host_ring, rg_inflights_bytes(h, 1), hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }

@@ -9,8 +9,19 @@
 
 #include "rg_common.h"
 
+// RG_SEND_EXP: measurement-only knobs (never set in the product build): bit0 = no work-item list,
+// bit1 = no ring accesses (results are wrong for windows deeper than one message)
+#ifndef RG_SEND_EXP
+#define RG_SEND_EXP 0
+#endif
+
 struct RgIns {
     u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31)
+    u64 *head; // [P][stride]: Inflights.buffer[start], the oldest inflight. This peer-major column (coalesced
+               // across a wave) is the authoritative copy of that one entry; the ring's own word for position
+               // `start` may be stale. A window of <= 1 message in flight therefore never touches the ring.
+    u64 *tail; // [P][stride]: the newest inflight (copy of the ring's last entry). Entries are the last indices of
+               // consecutive MsgAppends, strictly increasing, so `to >= tail` frees the whole window unread.
     u64 *ring; // [(g * P + slot) * cap + i]: Inflights.buffer of that Progress, contiguous per cell
     u32 cap;   // Inflights::cap()
 };
@@ -22,12 +33,23 @@ template <int P> struct RgSendRegs {
     u32 count;  // items of this group
 };
 
-// Inflights::free_to (inflights.rs:84-110)
-RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 to) {
-    if (count == 0 || to < ins.ring[base + start]) return; // out of the left side of the window
-    u32 i = 0, idx = start;
+// Inflights::free_to (inflights.rs:84-110); `head` = buffer[start]
+RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &head, u64 tail, u64 to) {
+    if (count == 0 || to < head) return; // out of the left side of the window
+    if (to >= tail) {                    // everything in the window is <= tail <= to
+        start += count;
+        if (start >= ins.cap) start -= ins.cap;
+        count = 0;
+        return;
+    }
+    u32 i = 1, idx = start + 1;          // buffer[start] <= to: freed
+    if (idx >= ins.cap) idx -= ins.cap;
     while (i < count) {
-        if (to < ins.ring[base + idx]) break; // found the first large inflight
+        const u64 v = (RG_SEND_EXP & 2) ? ~0ULL : ins.ring[base + idx];
+        if (to < v) { // found the first large inflight: the new oldest
+            head = v;
+            break;
+        }
         idx++;
         if (idx >= ins.cap) idx -= ins.cap;
         i++;
@@ -58,6 +80,21 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
     const u64 first_index = st.dummy_idx[g] + 1; // RaftLog::first_index (dummy entry = first_index - 1)
     const u64 row0 = st.pflags[g];
     u64 row = row0;
+    // all column loads of the group are issued before any of the (dependent, scattered) ring accesses
+    u32 meta_v[P];
+    u64 head_v[P], tail_v[P], next_v[P], prs_v[P], match_v[P];
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const bool w = (work >> s) & 1u;
+        const u64 o = (u64)s * st.stride + g;
+        const bool sends = w && (bcast || (((sa_bits | sm_bits) >> s) & 1u));
+        meta_v[s] = w ? ins.meta[o] : 0u;
+        head_v[s] = w ? ins.head[o] : 0ULL;
+        tail_v[s] = w ? ins.tail[o] : 0ULL;
+        next_v[s] = sends ? st.next[o] : 0ULL;
+        prs_v[s] = sends ? st.prs[o] : 0ULL;
+        match_v[s] = (w && ((fr_bits & sm_bits) >> s) & 1u) ? st.match[o] : 0ULL;
+    }
 #pragma unroll
     for (int s = 0; s < P; s++) {
         if (!((work >> s) & 1u)) continue;
@@ -65,8 +102,12 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
         const u64 base = (g * (u64)P + (u64)s) * ins.cap;
         u32 pb = (u32)(row >> (8 * s)) & 0xffu;
         const u32 state = pb & RG_PF_STATE_MASK;
-        const u32 meta0 = ins.meta[o];
+        const u32 meta0 = meta_v[s];
         u32 start = meta0 & 0xffffu, count = meta0 >> 16;
+        const u64 head0 = head_v[s];
+        u64 head = head0;
+        const u64 tail0 = tail_v[s];
+        u64 tail = tail0;
 
         // ---- what the tick did to this peer's Inflights ----
         if (state != RG_STATE_REPLICATE) {
@@ -74,17 +115,17 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
             start = 0;
             count = 0;
         } else if ((fr_bits >> s) & 1u) {
-            if ((sm_bits >> s) & 1u) rg_ins_free_to(ins, base, start, count, st.match[o]); // accepted ack: m.index == matched
-            else if (count) rg_ins_free_to(ins, base, start, count, ins.ring[base + start]); // free_first_one (:114-117)
+            if ((sm_bits >> s) & 1u) rg_ins_free_to(ins, base, start, count, head, tail, match_v[s]); // accepted ack: m.index == matched
+            else if (count) rg_ins_free_to(ins, base, start, count, head, tail, head);                // free_first_one (:114-117)
         }
 
         // ---- send_append(to) then `while maybe_send_append(to, false)` ----
         const bool sa = bcast || ((sa_bits >> s) & 1u);
         const bool sm = (sm_bits >> s) & 1u;
         if (sa || sm) {
-            u64 next = st.next[o];
+            u64 next = next_v[s];
             const u64 next0 = next;
-            const u64 prs = st.prs[o];
+            const u64 prs = prs_v[s];
             u32 n = 0;
             bool snap = false;
             bool first = sa; // the first call is send_append (allow_empty) only if one was requested
@@ -111,9 +152,15 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
                             if (take) { // Progress::update_state(last) (progress.rs:231-243)
                                 if (state == RG_STATE_REPLICATE) {
                                     next += take; // optimistic_update
-                                    u32 pos = start + count;
-                                    if (pos >= ins.cap) pos -= ins.cap;
-                                    ins.ring[base + pos] = next - 1; // Inflights::add (inflights.rs:65-81)
+                                    // Inflights::add (inflights.rs:65-81)
+                                    if (count == 0) {
+                                        head = next - 1;
+                                    } else {
+                                        u32 pos = start + count;
+                                        if (pos >= ins.cap) pos -= ins.cap;
+                                        if (!(RG_SEND_EXP & 2)) ins.ring[base + pos] = next - 1;
+                                    }
+                                    tail = next - 1;
                                     count++;
                                 } else {
                                     pb |= RG_PF_PAUSED;
@@ -146,6 +193,8 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
         row = (row & ~(0xffULL << (8 * s))) | ((u64)pb << (8 * s));
         const u32 meta = start | (count << 16);
         if (meta != meta0) ins.meta[o] = meta;
+        if (head != head0 && count) ins.head[o] = head;
+        if (tail != tail0 && count) ins.tail[o] = tail;
     }
     if (row != row0) st.pflags[g] = row;
 }

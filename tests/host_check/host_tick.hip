@@ -134,11 +134,11 @@ static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, rg_s
 }
 
 extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long stride, void *const *state, u32 *meta,
-                                   u64 *ring, unsigned cap, unsigned long max_entries, rg_send_item *items,
+                                   u64 *head, u64 *tail, u64 *ring, unsigned cap, unsigned long max_entries, rg_send_item *items,
                                    unsigned long items_cap) {
     const RgState st = make_state(state, G, stride);
     RgIns ins;
-    ins.meta = meta; ins.ring = ring; ins.cap = cap;
+    ins.meta = meta; ins.head = head; ins.tail = tail; ins.ring = ring; ins.cap = cap;
     long n = -1;
     RG_DISPATCH_P(P, n = host_send<N>(st, ins, max_entries, items, items_cap));
     return n;

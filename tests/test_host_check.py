@@ -311,14 +311,23 @@ def host_send():
         pytest.skip("hipcc not available")
     fn = C.CDLL(LIB).rg_host_check_send
     fn.restype = C.c_long
-    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_ulong, C.c_void_p,
-                   C.c_ulong]
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
+                   C.c_ulong, C.c_void_p, C.c_ulong]
 
-    def send(st, out, meta, ring, cap, max_entries):
+    def send(st, out, meta, head, ring, cap, max_entries):
+        """meta/ring as rg_read_inflights reports them; `head` = (head, tail), the engine-internal columns of the
+        oldest / newest entry of every window."""
+        head, tail = head
         items = np.zeros(st["n_groups"] * st["n_slots"], dtype=SEND_ITEM_DTYPE)
-        n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), meta.ctypes.data, ring.ctypes.data,
-               cap, max_entries, items.ctypes.data, len(items))
+        n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), meta.ctypes.data, head.ctypes.data,
+               tail.ctypes.data, ring.ctypes.data, cap, max_entries, items.ctypes.data, len(items))
         assert 0 <= n <= len(items)
+        # what rg_read_inflights does: the oldest entry of a window lives in the head column
+        G, P = st["n_groups"], st["n_slots"]
+        for p in range(P):
+            m = meta[p, :G]
+            live = np.nonzero(m >> 16)[0]
+            ring[live, p, (m[live] & 0xffff)] = head[p, live]
         return items[:n]
     return send
 
@@ -350,6 +359,7 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
     cl.set_own_inflights(True)
     eng_st = copy_state(st)
     meta = np.zeros((n_slots, st["stride"]), dtype=np.uint32)
+    head = (np.zeros((n_slots, st["stride"]), dtype=np.uint64), np.zeros((n_slots, st["stride"]), dtype=np.uint64))
     ring = np.zeros((G, n_slots, cap), dtype=np.uint64)
     msgs = O.alloc_msgs(G, n_slots)
     gout = np.zeros(G, dtype=np.uint32)
@@ -362,7 +372,7 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
         host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
-        items = host_send(eng_st, out, meta, ring, cap, max_entries)
+        items = host_send(eng_st, out, meta, head, ring, cap, max_entries)
         omsgs = cl.send_stage_soa(gout, max_entries)
         got = sendstage.compare_items(items, omsgs)
         apply_snapshots(rng, got, cl, eng_st, meta)
