@@ -172,3 +172,43 @@ def test_send_stage_call_sequence_and_checkpoint(rg):
         eng.tick_device_fused([(d.data_ptr(),) * 5], d.data_ptr())
     assert e.value.code == ERR["STATE"]
     eng.close()
+
+
+def test_mirror_steps_with_device_inflights(rg):
+    """RawNode::step mirror (rg_step / rg_local_append / rg_flush) followed by the send stage: proposals fill the
+    window of every follower, an ack moves it forward and the backlog goes out in one MsgAppend."""
+    G, P, cap = 64, 3, 4
+    eng = rg.Engine(G, P, max_inflight=cap)
+    st = O.alloc_state(G, P, stride=eng.stride)
+    st["match"][:, :G], st["next"][:, :G] = 10, 11
+    st["pr_commit"][:, :G] = 10
+    st["pflags"][:, :P] = rg.PF.REPLICATE | rg.PF.RECENT_ACTIVE
+    st["commit"][:], st["term_lo"][:], st["term_hi"][:] = 10, 1, 10
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    eng.load_state(st)
+    for g in range(G):
+        eng.set_peers(g, [1, 2, 3], term=5)
+    for r in range(1, 7):  # six proposals of one entry each
+        for g in range(G):
+            eng.local_append(g, 10 + r)
+        eng.flush()
+        eng.send_appends()
+        items = eng.send_items()
+        if r <= cap:
+            assert len(items) == G * 2 and (items["prev_index"] == 9 + r).all() and (items["last_index"] == 10 + r).all()
+        else:
+            assert len(items) == 0, "full windows: Progress::is_paused"
+    assert eng.inflights(3, 1) == [11, 12, 13, 14] and eng.inflights(3, 2) == [11, 12, 13, 14]
+    assert (eng.read_column(rg.COL.PFLAGS)[:, 1:3] & rg.PF.INS_FULL).all()
+    for g in range(0, G, 2):  # peer 2 of every other group acks index 12
+        eng.step(g, from_=2, term=5, index=12)
+    eng.flush()  # < 50 % of the groups: the sparse path
+    eng.send_appends()
+    items = eng.send_items()
+    assert len(items) == G // 2 and (items["slot"] == 1).all() and (items["group"] % 2 == 0).all()
+    assert (items["prev_index"] == 14).all() and (items["last_index"] == 16).all() and (items["n_msgs"] == 1).all()
+    meta, ring = eng.read_inflights()
+    assert eng.inflights(4, 1, meta, ring) == [13, 14, 16] and eng.inflights(5, 1, meta, ring) == [11, 12, 13, 14]
+    nxt = eng.read_column(rg.COL.NEXT)
+    assert nxt[1, 4] == 17 and nxt[1, 5] == 15 and nxt[2, 4] == 15
+    eng.close()
