@@ -107,7 +107,7 @@ def test_host_mirror_steps_like_raw_node(rg):
             eng.local_persisted(g, new_last)
             O.lib().ro_group_append(cl.h, g, new_last - hi)
             changed = O.lib().ro_on_persist_entries(cl.h, g, new_last)
-            outw = 1 if changed else 0
+            outw = (1 if changed else 0) | (rg.OUT.APPENDED if new_last > hi else 0)
             for pid, oid in ((102, 2), (103, 3)):
                 if rng.random() < 0.8:
                     pr = cl.pr(g, oid)
