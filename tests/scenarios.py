@@ -401,7 +401,43 @@ def scenario_send_append_for_progress(B):
         assert ld.propose() == []
 
 
-FLOW = [scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+def scenario_progress_flow_control(B):
+    """test_raft.rs:369-435 test_progress_flow_control: max_inflight_msgs = 3, max_size_per_msg = 2048 with
+    1000-byte proposals = two entries per MsgAppend. Probe sends one message; its ack switches to Replicate and
+    releases three messages of two entries; acking those releases the last two (2 + 1 entries)."""
+    ld = B(1, 1, [1, 2], log=[(1, 1)], committed=0, next_idx=1, max_inflight=3, max_entries=2)
+    ld.set_progress(1, match=0, next=2, state=REPLICATE)  # nothing persisted: the commit index cannot move
+    ld.set_progress(2, match=0, next=1, state=PROBE, paused=False)
+    ms = []
+    for _ in range(10):
+        ms += ld.propose()
+    assert ms == [(2, 1, 0, 2)], "one MsgAppend in Probe: the noop and the first proposal"
+    ms = ld.ack(2, 2)  # -> Replicate, and multiple messages at once
+    assert ms == [(2, 1, 2, 2), (2, 1, 4, 2), (2, 1, 6, 2)], ms
+    assert ld.ins_full(2) and ld.inflights(2) == [4, 6, 8]
+    ms = ld.ack(2, 8)  # ack all three: the last two messages carry three entries
+    assert ms == [(2, 1, 8, 2), (2, 1, 10, 1)], ms
+    assert ld.inflights(2) == [10, 11] and ld.progress(2)["next"] == 12
+
+
+def scenario_msg_append_response_wait_reset(B):
+    """test_raft.rs:1484-1529 test_msg_append_response_wait_reset: an ack releases a peer from the probe wait;
+    a proposal is broadcast only to peers that are not waiting."""
+    ld = B(1, 1, [1, 2, 3], log=[(1, 1)], committed=0, next_idx=1, max_inflight=256)
+    ld.set_progress(1, match=1, next=2, state=REPLICATE)  # the noop is persisted
+    for pid in (2, 3):  # bcast_append after the election: one probe message each, now waiting
+        ld.set_progress(pid, match=0, next=1, state=PROBE, paused=True)
+    ms = ld.ack(2, 1)  # node 2 acks the first entry, making it committed
+    assert ld.committed() == 1
+    assert ms == [(2, 1, 1, 0)], "the commit is broadcast; node 3 is still waiting"
+    ms = ld.propose()
+    ld.persisted(2)
+    assert ms == [(2, 1, 1, 1)], "node 2 left the wait state due to its MsgAppResp, node 3 is still waiting"
+    ms = ld.ack(3, 1)  # releases the wait: entry 2 is sent
+    assert ms == [(3, 1, 1, 1)], ms
+
+
+FLOW = [scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
