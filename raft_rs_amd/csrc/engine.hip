@@ -744,6 +744,7 @@ extern "C" int rg_restore(rg_engine *h) {
     if (!h->ckpt) return rg_fail(RG_ERR_STATE, "rg_restore: no checkpoint taken");
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->out_is_dense = true; // RG_COL_OUT is whatever it was at the checkpoint: the next sparse tick clears all of it
     if (h->ins_arena && h->ins_ckpt) {
         RG_HIP(hipMemcpyAsync(h->ins_arena, h->ins_ckpt, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
         h->send_ready = h->ckpt_send_ready; // RG_COL_OUT is part of the state: the tick's requests are back too
@@ -1090,7 +1091,11 @@ extern "C" int rg_recompute(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_recompute: null engine");
     RG_HIP(hipSetDevice(h->cfg.device));
     int rc = rg_recompute_impl<true>(h, nullptr, nullptr);
-    if (rc == RG_OK) h->ticked = true;
+    if (rc == RG_OK) {
+        h->ticked = true;
+        h->out_is_dense = true; // every group's result word was rewritten
+        h->send_ready = true;   // post_conf_change: `if self.maybe_commit() { self.bcast_append() }` (raft.rs:2630-2633)
+    }
     return rc;
 }
 

@@ -212,3 +212,25 @@ def test_mirror_steps_with_device_inflights(rg):
     nxt = eng.read_column(rg.COL.NEXT)
     assert nxt[1, 4] == 17 and nxt[1, 5] == 15 and nxt[2, 4] == 15
     eng.close()
+
+
+def test_send_stage_serves_the_broadcast_after_recompute(rg):
+    """post_conf_change (raft.rs:2618-2634): maybe_commit() on the new quorum, then bcast_append."""
+    G, P, cap = 512, 3, 8
+    eng = rg.Engine(G, P, max_inflight=cap)
+    st = O.alloc_state(G, P, stride=eng.stride)
+    st["match"][0, :G], st["match"][1, :G], st["match"][2, :G] = 9, 9, 5
+    st["next"][0, :G], st["next"][1, :G], st["next"][2, :G] = 10, 10, 6
+    st["pflags"][:, :P] = rg.PF.REPLICATE | rg.PF.RECENT_ACTIVE
+    st["commit"][:], st["term_lo"][:], st["term_hi"][:] = 5, 1, 9
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    eng.load_state(st)
+    eng.recompute()
+    eng.send_appends()
+    items = np.sort(eng.send_items(), order=["group", "slot"])
+    assert len(items) == 2 * G
+    a, b = items[0::2], items[1::2]
+    assert (a["slot"] == 1).all() and (a["prev_index"] == 9).all() and (a["last_index"] == 9).all(), "empty append: new commit"
+    assert (b["slot"] == 2).all() and (b["prev_index"] == 5).all() and (b["last_index"] == 9).all()
+    assert eng.inflights(5, 2) == [9] and eng.inflights(5, 1) == []
+    eng.close()

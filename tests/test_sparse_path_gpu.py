@@ -157,3 +157,29 @@ def test_device_resident_records(rg):
         assert (a[k] == b[k]).all(), k
     for e in engs:
         e.close()
+
+
+def test_recompute_between_sparse_ticks_leaves_no_stale_results(rg):
+    """rg_recompute rewrites every group's result word; the next sparse tick must clear all of them again."""
+    G, P = 4096, 3
+    eng = rg.Engine(G, P)
+    st = O.alloc_state(G, P, stride=eng.stride)
+    st["match"][0, :G], st["match"][1, :G], st["match"][2, :G] = 9, 9, 5
+    st["next"][:, :G] = 10
+    st["pflags"][:, :P] = rg.PF.REPLICATE
+    st["commit"][:], st["term_lo"][:], st["term_hi"][:] = 5, 1, 9
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    eng.load_state(st)
+    from raft_rs_amd.engine import WIRE_DTYPE
+    rec = np.zeros(1, dtype=WIRE_DTYPE)
+    rec["group"], rec["slot"], rec["flags"], rec["index"], rec["commit"] = 7, 2, rg.MF.VALID, 6, 5
+    assert eng.ingest(rec) == 0 and eng.tick_ingested() == 1
+    eng.recompute()  # post_conf_change style: every group commits 9
+    commit, out = eng.results()
+    changed = (out & rg.OUT.CHANGED) != 0
+    assert (commit == 9).all() and changed.sum() == G - 1 and not changed[7], "group 7 committed in the sparse tick"
+    rec["group"], rec["index"] = 11, 7
+    assert eng.ingest(rec) == 0 and eng.tick_ingested() == 1
+    out = eng.read_column(rg.COL.OUT)
+    assert out[11] != 0 and np.count_nonzero(out) == 1, "stale RG_OUT_CHANGED words of the recompute survived"
+    eng.close()
