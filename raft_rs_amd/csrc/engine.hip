@@ -488,6 +488,7 @@ struct rg_engine {
     u32 *send_counter;
     bool send_ready;   // a tick ran since the last rg_send_appends
     bool ckpt_send_ready;
+    bool ckpt_any_group_commit;
     bool any_group_commit; // some group's cfg word has RG_CFG_GROUP_COMMIT (tracked on cfg loads)
     // host mirror of RawNode::step (rg_set_peers / rg_step / rg_flush)
     std::vector<u64> peer_ids; // [G][8], 0 = unused
@@ -577,6 +578,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_counter = nullptr;
     h->send_ready = false;
     h->ckpt_send_ready = false;
+    h->ckpt_any_group_commit = false;
     if (cfg->max_inflight > 65535u) {
         delete h;
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: max_inflight=%u, at most 65535", cfg->max_inflight);
@@ -731,6 +733,7 @@ extern "C" int rg_checkpoint(rg_engine *h) {
     RG_HIP(hipSetDevice(h->cfg.device));
     if (!h->ckpt) RG_HIP(hipMalloc(&h->ckpt, h->state_bytes));
     RG_HIP(hipMemcpyAsync(h->ckpt, h->arena, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->ckpt_any_group_commit = h->any_group_commit;
     if (h->ins_arena) {
         if (!h->ins_ckpt) RG_HIP(hipMalloc(&h->ins_ckpt, h->ins_state_bytes));
         RG_HIP(hipMemcpyAsync(h->ins_ckpt, h->ins_arena, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -745,6 +748,8 @@ extern "C" int rg_restore(rg_engine *h) {
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
     h->out_is_dense = true; // RG_COL_OUT is whatever it was at the checkpoint: the next sparse tick clears all of it
+    h->host_cfg_valid = false; // RG_COL_CFG came back too: the mirror re-reads its copy
+    if (h->ckpt_any_group_commit) h->any_group_commit = true; // ... and so may group-commit configurations
     if (h->ins_arena && h->ins_ckpt) {
         RG_HIP(hipMemcpyAsync(h->ins_arena, h->ins_ckpt, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
         h->send_ready = h->ckpt_send_ready; // RG_COL_OUT is part of the state: the tick's requests are back too
