@@ -400,6 +400,8 @@ def main():
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
                    "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
+                   "device": {k: v for k, v in parts[0].eng.device_info().items() if k != "engine_bytes"},
+                   "engine_hbm_bytes": sum(pt.eng.device_info()["engine_bytes"] for pt in parts),
                    "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks ({'gloo, shared GPU test hook' if share_gpu else 'RCCL'})" if distributed else ""),
                    "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not distributed else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -163,6 +163,18 @@ int rg_device_count(void);
 int rg_create(const rg_config *cfg, rg_engine **out);
 void rg_destroy(rg_engine *h);
 uint64_t rg_stride(const rg_engine *h); /* column stride in elements */
+/* What hipGetDeviceProperties reports for the engine's device (queried once in rg_create, which refuses
+ * devices other than gfx950: the library carries CDNA4 code objects only). */
+typedef struct {
+    char arch[32];            /* gcnArchName up to the first ':' ("gfx950") */
+    uint32_t compute_units;   /* multiProcessorCount (256 on MI355X) */
+    uint32_t wavefront;       /* warpSize (64) */
+    uint64_t lds_per_workgroup; /* sharedMemPerBlock, bytes */
+    uint64_t hbm_bytes;       /* totalGlobalMem */
+    uint64_t l2_bytes;        /* l2CacheSize (one XCD's L2) */
+    uint64_t engine_bytes;    /* device memory this engine allocated in rg_create */
+} rg_device_info;
+int rg_get_device_info(const rg_engine *h, rg_device_info *info);
 /* Run all engine work on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
 int rg_set_stream(rg_engine *h, void *hip_stream);
 int rg_sync(rg_engine *h);

@@ -454,6 +454,7 @@ __global__ __launch_bounds__(RG_BLOCK) void k_wl_gen(RgState st, u64 seed, u32 w
 // ------------------------------------------------------------------------------------------------
 struct rg_engine {
     rg_config cfg;
+    rg_device_info dev;
     u64 G, stride;
     u32 P;
     hipStream_t stream;
@@ -545,8 +546,22 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (cfg->device < 0 || cfg->device >= ndev)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: device %d of %d", cfg->device, ndev);
     RG_HIP(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    RG_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rg_fail(RG_ERR_NO_DEVICE, "rg_create: device %d is %s; this library carries gfx950 (CDNA4) kernels only",
+                       cfg->device, prop.gcnArchName);
+    if (prop.warpSize != 64)
+        return rg_fail(RG_ERR_NO_DEVICE, "rg_create: wavefront size %d, the kernels are written for 64", prop.warpSize);
     rg_engine *h = new (std::nothrow) rg_engine();
     if (!h) return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: host allocation failed");
+    memset(&h->dev, 0, sizeof(h->dev));
+    for (int i = 0; i < 31 && prop.gcnArchName[i] && prop.gcnArchName[i] != ':'; i++) h->dev.arch[i] = prop.gcnArchName[i];
+    h->dev.compute_units = (uint32_t)prop.multiProcessorCount;
+    h->dev.wavefront = (uint32_t)prop.warpSize;
+    h->dev.lds_per_workgroup = prop.sharedMemPerBlock;
+    h->dev.hbm_bytes = prop.totalGlobalMem;
+    h->dev.l2_bytes = (uint64_t)prop.l2CacheSize;
     h->cfg = *cfg;
     h->G = cfg->n_groups;
     h->P = cfg->n_slots;
@@ -604,6 +619,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         delete h;
         return rg_fail(RG_ERR_NO_DEVICE, "rg_create: hipMemset failed: %s", hipGetErrorString(e));
     }
+    h->dev.engine_bytes = off + 2 * zero_bytes + 256 + rg_align(h->stride * 8);
     h->zero_col = reinterpret_cast<u64 *>(h->arena + off);
     h->d_counts = reinterpret_cast<u64 *>(h->arena + off + zero_bytes);
     h->d_scratch = h->arena + off + zero_bytes + 256;
@@ -650,6 +666,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         h->ins_state_bytes = meta_b + ring_b;
         h->send_items = reinterpret_cast<rg_send_item *>(h->ins_arena + meta_b + ring_b);
         h->send_counter = reinterpret_cast<u32 *>(h->ins_arena + meta_b + ring_b + items_b);
+        h->dev.engine_bytes += meta_b + ring_b + items_b + 256;
     }
     *out = h;
     return RG_OK;
@@ -670,6 +687,12 @@ extern "C" void rg_destroy(rg_engine *h) {
 }
 
 extern "C" uint64_t rg_stride(const rg_engine *h) { return h ? h->stride : 0; }
+
+extern "C" int rg_get_device_info(const rg_engine *h, rg_device_info *info) {
+    if (!h || !info) return rg_fail(RG_ERR_INVALID_ARG, "rg_get_device_info: bad argument");
+    *info = h->dev;
+    return RG_OK;
+}
 
 extern "C" int rg_set_stream(rg_engine *h, void *hip_stream) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_stream: null engine");

@@ -74,6 +74,12 @@ class _Config(C.Structure):
                 ("variant", C.c_uint32), ("max_inflight", C.c_uint32)]
 
 
+class DeviceInfo(C.Structure):
+    _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("wavefront", C.c_uint32),
+                ("lds_per_workgroup", C.c_uint64), ("hbm_bytes", C.c_uint64), ("l2_bytes", C.c_uint64),
+                ("engine_bytes", C.c_uint64)]
+
+
 class _Msgs(C.Structure):
     _fields_ = [("m_index", C.c_void_p), ("m_commit", C.c_void_p), ("m_hint", C.c_void_p),
                 ("m_rs", C.c_void_p), ("m_flags", C.c_void_p), ("m_logterm", C.c_void_p)]
@@ -128,6 +134,7 @@ SYMBOLS = {
     "rg_create": (_i, [C.POINTER(_Config), C.POINTER(_vp)]),
     "rg_destroy": (None, [_vp]),
     "rg_stride": (_u64, [_vp]),
+    "rg_get_device_info": (_i, [_vp, C.POINTER(DeviceInfo)]),
     "rg_set_stream": (_i, [_vp, _vp]),
     "rg_sync": (_i, [_vp]),
     "rg_column_bytes": (_u64, [_vp, _i]),
@@ -264,6 +271,14 @@ class Engine:
 
     def sync(self):
         self._check(self.L.rg_sync(self.h))
+
+    def device_info(self):
+        """hipGetDeviceProperties of the engine's device + the device memory the engine holds."""
+        d = DeviceInfo()
+        self._check(self.L.rg_get_device_info(self.h, C.byref(d)))
+        return {"arch": d.arch.decode(), "compute_units": d.compute_units, "wavefront": d.wavefront,
+                "lds_per_workgroup": d.lds_per_workgroup, "hbm_bytes": d.hbm_bytes, "l2_bytes": d.l2_bytes,
+                "engine_bytes": d.engine_bytes}
 
     def column_shape_dtype(self, col):
         if col in COL.PER_SLOT:

@@ -444,3 +444,13 @@ def test_bench_two_ranks_sharing_the_gpu(rg, tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
     assert d["config"]["groups_per_gpu"] == 60000 and "all-gather every 4 ticks" in d["config"]["sharding"]
+
+
+def test_device_info_is_queried_not_assumed(rg):
+    eng = rg.Engine(1000, 5)
+    info = eng.device_info()
+    assert info["arch"] == "gfx950" and info["wavefront"] == 64
+    assert info["compute_units"] >= 64 and info["lds_per_workgroup"] >= 64 * 1024 and info["hbm_bytes"] > (100 << 30)
+    cols = sum(eng.L.rg_column_bytes(eng.h, c) for c in range(17))
+    assert cols <= info["engine_bytes"] <= cols + (64 << 10) + 4 * 5 * eng.stride * 8
+    eng.close()
