@@ -147,6 +147,10 @@ def main():
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
+    ap.add_argument("--inflights", type=int, default=0,
+                    help="N > 0: keep the Inflights (cap N) on the device and run the send stage (rg_send_appends: "
+                         "maybe_send_append decisions, SURVEY 8f row 3) after every tick, inside the timed region; the "
+                         "stream then carries no host SENT events. Not the headline configuration.")
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
@@ -204,7 +208,7 @@ def main():
         pt = Part()
         pt.n, pt.slots, pt.first = n, slots, first
         pt.fixed = slots if (args.workload == 5 and not args.one_engine) else 0
-        pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant)
+        pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant, max_inflight=args.inflights)
         pt.eng.set_stream(stream.cuda_stream)
         pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed)
         pt.eng.checkpoint()
@@ -223,11 +227,15 @@ def main():
         for pt in parts:
             pt.eng.workload_gen(args.workload, t, *tick_ptrs(pt, t), seed=args.seed, first_group=pt.first,
                                 fixed_peers=pt.fixed)
+            if args.inflights:
+                pt.flags[t] &= 0xE7  # no RG_MF_SENT / RG_MF_INS_FULL: the device owns the send path
             s = pt.eng.msg_stats(pt.flags[t].data_ptr())
             for k in census[t]:
                 census[t][k] += s[k]
             alg_bytes[t] += algorithmic_bytes(pt.n, s["slots"], s["valid"], s["rejects"])
             pt.eng.tick_device(*tick_ptrs(pt, t))
+            if args.inflights:
+                pt.eng.send_appends(0)
     n_changed = 0
     for pt in parts:
         pt.eng.sync()
@@ -268,7 +276,7 @@ def main():
             fork.record(stream)
             for pt in parts:
                 pt.stream.wait_event(fork)
-        F = max(1, min(8, args.fuse))
+        F = 1 if args.inflights else max(1, min(8, args.fuse))
         if F > 1 and publishers is None:
             # temporal fusion: F consecutive recorded ticks per launch (state stays in registers between them)
             for pt in parts:
@@ -283,6 +291,8 @@ def main():
             pub_now = publishers is not None and ((i + 1) % E == 0 or i == n - 1)
             for j, pt in enumerate(parts):
                 pt.eng.tick_device(*tick_ptrs(pt, t0 + i))
+                if args.inflights:
+                    pt.eng.send_appends(0)
                 if pub_now:
                     publishers[j].publish(n_pub[0], pt.commit_view, pt.stream)
             if pub_now:
@@ -356,6 +366,12 @@ def main():
     wall = time.perf_counter() - wall0
     kernel_ms = e0.elapsed_time(e1)  # HIP events on the stream the tick kernels run on
 
+    send_stage_info = None
+    if args.inflights:
+        send_stage_info = {"max_inflight": args.inflights, "max_entries_per_msg": 0,
+                           "work_items_last_tick": int(sum(len(pt.eng.send_items()) for pt in parts)),
+                           "full_windows": int(sum((pt.eng.read_column(rg.COL.PFLAGS) & rg.PF.INS_FULL).astype(bool).sum()
+                                                   for pt in parts))}
     # replay determinism: the timed replay must land on the state the recorded pass produced
     for j, pt in enumerate(parts):
         commit, out = pt.eng.results()
@@ -383,7 +399,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f).get(f"{args.workload}:{G}:{P}", {}).get("bytes") if len(parts) == 1 else None
+            traffic = json.load(f).get(f"{args.workload}:{G}:{P}", {}).get("bytes") if (len(parts) == 1 and not args.inflights) else None
     except (OSError, ValueError):
         pass
 
@@ -403,15 +419,20 @@ def main():
                    "device": {k: v for k, v in parts[0].eng.device_info().items() if k != "engine_bytes"},
                    "engine_hbm_bytes": sum(pt.eng.device_info()["engine_bytes"] for pt in parts),
                    "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks ({'gloo, shared GPU test hook' if share_gpu else 'RCCL'})" if distributed else ""),
-                   "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not distributed else 1},
+                   "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_tick_lane" if args.variant != 2 else "k_tick_lds",
+                     "kernel": ("k_tick_lane" if args.variant != 2 else "k_tick_lds") +
+                               (" + k_send_appends" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6,
                      **({"note": "temporal fusion: state stays in registers across the fused ticks, so fewer bytes "
                                  "move than the per-tick algorithmic model counts; frac is not a per-tick HBM "
-                                 "efficiency in this mode"} if args.fuse > 1 and not distributed else {})},
+                                 "efficiency in this mode"} if args.fuse > 1 and not distributed and not args.inflights else {}),
+                     **({"note": "avg_launch_us is the tick AND its send stage; the algorithmic bytes are the tick's "
+                                 "(SURVEY 8d counts no bytes for the send path), so frac understates this mode"}
+                        if args.inflights else {})},
+        **({"send_stage": send_stage_info} if args.inflights else {}),
         "commit_changed_last_tick": int(n_changed),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

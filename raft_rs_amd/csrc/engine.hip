@@ -474,6 +474,8 @@ struct rg_engine {
     char *sparse_arena;       // gmark | list | res_list | res_commit | res_out | counters
     u32 *gmark, *counters, *res_out;
     u64 *list, *res_list, *res_commit;
+    rg_cell_write *d_cells;   // device staging for rg_write_cells
+    u64 d_cells_cap;
     rg_wire_msg *d_records;   // device staging for records
     u64 d_records_cap;
     u32 epoch;
@@ -573,6 +575,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->sparse_arena = nullptr;
     h->d_records = nullptr;
     h->d_records_cap = 0;
+    h->d_cells = nullptr;
+    h->d_cells_cap = 0;
     h->epoch = 1;
     h->ingested_upper = 0;
     h->last_sparse_n = 0;
@@ -683,6 +687,7 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->msg_arena) (void)hipFree(h->msg_arena);
     if (h->sparse_arena) (void)hipFree(h->sparse_arena);
     if (h->d_records) (void)hipFree(h->d_records);
+    if (h->d_cells) (void)hipFree(h->d_cells);
     delete h;
 }
 
@@ -786,15 +791,22 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
     if (!h || (!cells && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_write_cells: bad argument");
     if (n == 0) return RG_OK;
     RG_HIP(hipSetDevice(h->cfg.device));
-    rg_cell_write *d = nullptr;
-    RG_HIP(hipMalloc(&d, n * sizeof(rg_cell_write)));
-    hipError_t e = hipMemcpyAsync(d, cells, n * sizeof(rg_cell_write), hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_write_cells, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, d, (u64)n, h->P, h->ins.meta);
-        e = hipStreamSynchronize(h->stream);
+    if (n > h->d_cells_cap) { // engine-owned staging, grown geometrically (this call sits between ticks)
+        if (h->d_cells) {
+            RG_HIP(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_cells);
+            h->d_cells = nullptr;
+            h->d_cells_cap = 0;
+        }
+        u64 cap = 1024;
+        while (cap < n) cap *= 2;
+        RG_HIP(hipMalloc(&h->d_cells, cap * sizeof(rg_cell_write)));
+        h->d_cells_cap = cap;
     }
-    (void)hipFree(d);
-    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_write_cells: %s", hipGetErrorString(e));
+    RG_HIP(hipMemcpyAsync(h->d_cells, cells, n * sizeof(rg_cell_write), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_write_cells, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->d_cells, (u64)n, h->P,
+                       h->ins.meta);
+    RG_HIP(hipStreamSynchronize(h->stream)); // the caller's array may be reused after return
     return RG_OK;
 }
 
