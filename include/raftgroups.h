@@ -57,6 +57,8 @@ typedef enum {
 #define RG_STATE_SNAPSHOT 2u
 #define RG_PF_PAUSED 0x04u        /* Progress.paused */
 #define RG_PF_RECENT_ACTIVE 0x08u /* Progress.recent_active */
+#define RG_PF_PENDING_CONF 0x20u   /* host-owned, meaningful on the LEADER'S OWN slot only: Raft::has_pending_conf()
+                                     (src/raft.rs:2684-2686), read by rg_send_appends(RG_SEND_SKIP_BCAST_COMMIT) */
 #define RG_PF_INS_FULL 0x10u      /* engine-owned, only with rg_config.max_inflight > 0: Inflights::full() of the
                                      device-side ring (rg_send_appends maintains it; OR-ed with RG_MF_INS_FULL) */
 
@@ -311,7 +313,10 @@ typedef struct {
 } rg_send_item;
 #define RG_SEND_APPEND 1u
 #define RG_SEND_SNAPSHOT 2u
-int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg);
+#define RG_SEND_SKIP_BCAST_COMMIT 0x1u /* Config::skip_bcast_commit (src/config.rs:87): a commit advance is broadcast
+                                          only by groups with a pending conf change -- should_bcast_commit(),
+                                          src/raft.rs:2684-2686; RG_PF_PENDING_CONF on the leader's slot */
+int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
 /* Work items of the last rg_send_appends (order unspecified) -> host array of capacity `cap`; *n = number of
  * items (only cap are written if it is larger). Synchronises. rg_send_items_ptr: the same list in device memory. */
 int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n);

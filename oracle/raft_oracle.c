@@ -306,6 +306,7 @@ typedef struct {
     size_t max_inflight;
     /* Raft (src/raft.rs:164-260): the fields the path reads */
     uint64_t id, term, lead_transferee;
+    bool pending_conf; /* has_pending_conf(): pending_conf_index > raft_log.applied (raft.rs:2679-2682) */
     /* RaftLog (src/raft_log.rs:33-59) reduced to what term()/commit_to() read */
     uint64_t dummy_index, dummy_term, last_index, committed;
     ro_run *runs;
@@ -674,6 +675,7 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_PF_PAUSED 0x04u
 #define RO_PF_RECENT_ACTIVE 0x08u
 #define RO_PF_INS_FULL 0x10u
+#define RO_PF_PENDING_CONF 0x20u
 #define RO_MF_VALID 0x01u
 #define RO_MF_REJECT 0x02u
 #define RO_MF_HAS_RS 0x04u
@@ -716,6 +718,7 @@ int ro_load_soa(ro_cluster *c, const ro_soa_state *s, uint64_t term, size_t max_
         }
         gr->group_commit = (cfg & 0x00080000u) != 0;
         gr->lead_transferee = xfer; /* slot+1 == id */
+        gr->pending_conf = (s->pflags[g * 8 + self] & RO_PF_PENDING_CONF) != 0;
         for (uint32_t p = 0; p < s->n_slots; p++) {
             ro_progress *pr = pmap_get(&gr->progress, p + 1);
             if (!pr) continue;
@@ -783,6 +786,7 @@ int ro_store_soa(ro_cluster *c, ro_soa_state *s) {
                                              (pr->recent_active ? RO_PF_RECENT_ACTIVE : 0));
             if (c->own_inflights && pr->state == RO_REPLICATE && pr->ins.cap && ro_ins_full(&pr->ins))
                 s->pflags[g * 8 + p] |= RO_PF_INS_FULL;
+            if (gr->pending_conf && p + 1 == gr->id) s->pflags[g * 8 + p] |= RO_PF_PENDING_CONF;
         }
         s->commit[g] = gr->committed;
         s->term_hi[g] = gr->last_index;
@@ -925,15 +929,19 @@ bool ro_maybe_send_append(ro_cluster *c, size_t g, uint64_t to, bool allow_empty
     return true;
 }
 
-size_t ro_send_stage_soa(ro_cluster *c, const uint32_t *gout, uint64_t max_entries, ro_send_msg *msgs, size_t cap,
-                         size_t g_begin, size_t g_end) {
+void ro_group_set_pending_conf(ro_cluster *c, size_t g, bool pending) { c->g[g].pending_conf = pending; }
+
+size_t ro_send_stage_soa(ro_cluster *c, const uint32_t *gout, uint64_t max_entries, bool skip_bcast_commit,
+                         ro_send_msg *msgs, size_t cap, size_t g_begin, size_t g_end) {
     size_t k = 0;
     ro_send_msg m;
     for (size_t g = g_begin; g < g_end && g < c->n; g++) {
         ro_group *gr = &c->g[g];
         uint32_t out = gout[g];
         if (!out) continue;
-        bool bcast = (out & (RO_OUT_CHANGED | RO_OUT_APPENDED)) != 0;
+        /* should_bcast_commit() (raft.rs:2684-2686) gates the broadcast of a commit advance only */
+        bool should_bcast_commit = !skip_bcast_commit || gr->pending_conf;
+        bool bcast = (out & RO_OUT_APPENDED) != 0 || ((out & RO_OUT_CHANGED) != 0 && should_bcast_commit);
         for (uint32_t p = 0; p < RO_MAP_CAP && p < 8; p++) {
             uint64_t id = p + 1;
             if (id == gr->id || !pmap_get(&gr->progress, id)) continue; /* bcast_append skips self (:859-863) */

@@ -310,8 +310,9 @@ __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
 // atomic per wave the 15.6 K same-address atomics of a 1 M-group launch cost more than everything else together.
 #define RG_SEND_BLOCK 1024
 template <int P>
-__global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, const u64 *list,
-                                                               u64 n, rg_send_item *items, u32 *counter) {
+__global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, u32 flags,
+                                                               const u64 *list, u64 n, rg_send_item *items,
+                                                               u32 *counter) {
     __shared__ u32 wave_tot[RG_SEND_BLOCK / 64];
     __shared__ u32 block_base;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
     it.snap = 0;
     if (active) {
         const u32 out = st.out[g];
-        if (out) rg_group_send<P>(st, ins, g, out, max_entries, it);
+        if (out) rg_group_send<P>(st, ins, g, out, max_entries, flags, it);
     }
     if (RG_SEND_EXP & 1) return;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1164,11 +1165,12 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
 // ------------------------------------------------------------------------------------------------
 // send stage
 // ------------------------------------------------------------------------------------------------
-extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg) {
+extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: null engine");
     if (!h->ins_arena)
         return rg_fail(RG_ERR_STATE, "rg_send_appends: engine created with max_inflight = 0 (Inflights are the host's)");
     if (!h->send_ready) return rg_fail(RG_ERR_STATE, "rg_send_appends: no tick since the last send stage");
+    if (flags & ~RG_SEND_SKIP_BCAST_COMMIT) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: unknown flags %#x", flags);
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
     const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
@@ -1176,14 +1178,14 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg) {
     if (n) {
         const dim3 grid(rg_grid(n, RG_SEND_BLOCK)), block(RG_SEND_BLOCK);
         switch (h->P) {
-        case 1: hipLaunchKernelGGL(k_send_appends<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        case 2: hipLaunchKernelGGL(k_send_appends<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        case 3: hipLaunchKernelGGL(k_send_appends<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        case 4: hipLaunchKernelGGL(k_send_appends<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        case 5: hipLaunchKernelGGL(k_send_appends<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        case 6: hipLaunchKernelGGL(k_send_appends<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        case 7: hipLaunchKernelGGL(k_send_appends<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
-        default: hipLaunchKernelGGL(k_send_appends<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, list, n, h->send_items, h->send_counter); break;
+        case 1: hipLaunchKernelGGL(k_send_appends<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        case 2: hipLaunchKernelGGL(k_send_appends<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        case 3: hipLaunchKernelGGL(k_send_appends<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        case 4: hipLaunchKernelGGL(k_send_appends<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        case 5: hipLaunchKernelGGL(k_send_appends<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        case 6: hipLaunchKernelGGL(k_send_appends<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        case 7: hipLaunchKernelGGL(k_send_appends<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
+        default: hipLaunchKernelGGL(k_send_appends<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_send_appends: launch failed: %s", hipGetErrorString(e));

@@ -60,12 +60,15 @@ RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u6
 
 // One group of the send stage. `out` is the group's RG_OUT_* word of the tick that just ran.
 template <int P>
-RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u64 max_entries, RgSendRegs<P> &it) {
+RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u64 max_entries, u32 flags,
+                         RgSendRegs<P> &it) {
     const u32 cfg = st.cfg[g];
     const u32 present = RG_CFG_PRESENT(cfg), self = RG_CFG_SELF(cfg);
-    // bcast_append: the commit index moved (should_bcast_commit(), raft.rs:1745-1748) or the leader appended
-    // entries (a proposal, raft.rs:2049-2053)
-    const bool bcast = (out & (RG_OUT_CHANGED | RG_OUT_APPENDED)) != 0;
+    // bcast_append: the leader appended entries (a proposal, raft.rs:2049-2053), or the commit index moved and
+    // should_bcast_commit() (raft.rs:1745-1748, :2684-2686: !skip_bcast_commit || has_pending_conf())
+    bool bcast = (out & RG_OUT_APPENDED) != 0;
+    if (out & RG_OUT_CHANGED)
+        bcast = bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((st.pflags[g] >> (8 * self)) & RG_PF_PENDING_CONF);
     const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
     it.snap = 0;
     it.count = 0;

@@ -31,7 +31,7 @@ TERM_RUNS = 4
 
 
 class PF:
-    STATE_MASK, PROBE, REPLICATE, SNAPSHOT, PAUSED, RECENT_ACTIVE, INS_FULL = 0x3, 0, 1, 2, 0x4, 0x8, 0x10
+    STATE_MASK, PROBE, REPLICATE, SNAPSHOT, PAUSED, RECENT_ACTIVE, INS_FULL, PENDING_CONF = 0x3, 0, 1, 2, 0x4, 0x8, 0x10, 0x20
 
 
 class MF:
@@ -121,6 +121,7 @@ class CellWrite(C.Structure):
 
 
 SEND_APPEND, SEND_SNAPSHOT = 1, 2
+SEND_SKIP_BCAST_COMMIT = 1
 SEND_ITEM_DTYPE = np.dtype([("group", "<u8"), ("prev_index", "<u8"), ("last_index", "<u8"), ("slot", "<u4"),
                             ("n_msgs", "<u2"), ("kind", "<u2")])
 assert SEND_ITEM_DTYPE.itemsize == 32
@@ -160,7 +161,7 @@ SYMBOLS = {
     "rg_ingested_duplicates": (_i, [_vp, C.POINTER(_u64)]),
     "rg_tick_ingested": (_i, [_vp, C.POINTER(_u64)]),
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
-    "rg_send_appends": (_i, [_vp, _u64]),
+    "rg_send_appends": (_i, [_vp, _u64, C.c_uint32]),
     "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_items_ptr": (_vp, [_vp]),
     "rg_inflights_bytes": (_u64, [_vp, _i]),
@@ -398,9 +399,9 @@ class Engine:
         self._check(self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t)))
 
     # ---- send stage (device Inflights + maybe_send_append decisions) ------------------------------
-    def send_appends(self, max_entries_per_msg=0):
+    def send_appends(self, max_entries_per_msg=0, skip_bcast_commit=False):
         """Run the send stage for the tick that just ran (asynchronous)."""
-        self._check(self.L.rg_send_appends(self.h, max_entries_per_msg))
+        self._check(self.L.rg_send_appends(self.h, max_entries_per_msg, SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0))
 
     def send_items(self):
         """Work items of the last send stage as a SEND_ITEM_DTYPE array (order unspecified)."""

@@ -21,11 +21,13 @@ class OracleLeader:
         self.term = term
         self._voters, self._self_id = list(voters), self_id
         self.max_inflight, self.max_entries = max_inflight, max_entries
+        self.skip_bcast_commit = False
 
     # ---- flow control: the Progress's own Inflights + the send decisions (test_raft_flow_control.rs) ----
     def _send(self, out_word):
         """Serve the send requests of one step the way the reference does right after it."""
-        m = self.cl.send_stage_soa(np.array([out_word], dtype=np.uint32), self.max_entries, capacity=1 << 16)
+        m = self.cl.send_stage_soa(np.array([out_word], dtype=np.uint32), self.max_entries, capacity=1 << 16,
+                                   skip_bcast_commit=self.skip_bcast_commit)
         return [(int(x["to"]), int(x["kind"]), int(x["index"]), int(x["n_entries"])) for x in m]
 
     def propose(self, n=1):
@@ -44,6 +46,9 @@ class OracleLeader:
         o = O.Out()
         O.lib().ro_handle_heartbeat_response(self.cl.h, 0, from_, commit, -1, o)
         return self._send(int(o.send_append) << (8 + from_ - 1))
+
+    def set_pending_conf(self, on):
+        O.lib().ro_group_set_pending_conf(self.cl.h, 0, on)
 
     def ins_full(self, pid):
         return bool(O.lib().ro_ins_full(self.cl.pr(0, pid).ins))
@@ -132,6 +137,7 @@ class EngineLeader:
         self.P = n_slots or max(ids)
         self.eng = rg.Engine(1, self.P, max_inflight=max_inflight)
         self.max_inflight, self.max_entries = max_inflight, max_entries
+        self.skip_bcast_commit = False
         self.term = term
         self.self_id = self_id
         mask = lambda s: sum(1 << (i - 1) for i in s)
@@ -246,7 +252,7 @@ class EngineLeader:
     # ---- flow control: Inflights on the device + the send stage (needs max_inflight > 0) ----
     def _send(self):
         """rg_send_appends for the tick that just ran; the per-peer items expanded to single messages."""
-        self.eng.send_appends(self.max_entries)
+        self.eng.send_appends(self.max_entries, skip_bcast_commit=self.skip_bcast_commit)
         msgs = []
         for it in self.eng.send_items():
             to, kind, prev, last, n = int(it["slot"]) + 1, int(it["kind"]), int(it["prev_index"]), int(it["last_index"]), int(it["n_msgs"])
@@ -284,6 +290,13 @@ class EngineLeader:
         self.msgs.m_flags[0, s] = self.rg.MF.HEARTBEAT
         self._tick()
         return self._send()
+
+    def set_pending_conf(self, on):
+        """Raft::has_pending_conf(): flag bit RG_PF_PENDING_CONF on the leader's own slot."""
+        s = self.self_id - 1
+        f = int(self.eng.read_column(self.rg.COL.PFLAGS)[0, s])
+        f = (f | self.rg.PF.PENDING_CONF) if on else (f & ~self.rg.PF.PENDING_CONF)
+        self.eng.write_cells([{"group": 0, "slot": s, "pflags": f}])
 
     def ins_full(self, pid):
         return bool(int(self.eng.read_column(self.rg.COL.PFLAGS)[0, pid - 1]) & self.rg.PF.INS_FULL)

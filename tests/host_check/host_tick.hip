@@ -110,13 +110,13 @@ extern "C" int rg_host_check_fused(unsigned P, unsigned long G, unsigned long st
 // The send stage (rg_send.h) group by group, exactly what k_send_appends runs per lane; items are appended in
 // group order. Returns the number of items (may exceed cap), -1 on a bad slot count.
 template <int P>
-static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, rg_send_item *items, u64 cap) {
+static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, u32 flags, rg_send_item *items, u64 cap) {
     u64 k = 0;
     for (u64 g = 0; g < st.G; g++) {
         const u32 out = st.out[g];
         if (!out) continue;
         RgSendRegs<P> it;
-        rg_group_send<P>(st, ins, g, out, max_entries, it);
+        rg_group_send<P>(st, ins, g, out, max_entries, flags, it);
         for (int s = 0; s < P; s++) {
             const bool snap = (it.snap >> s) & 1u;
             if (it.n[s] == 0 && !snap) continue;
@@ -134,12 +134,12 @@ static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, rg_s
 }
 
 extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long stride, void *const *state, u32 *meta,
-                                   u64 *head, u64 *tail, u64 *ring, unsigned cap, unsigned long max_entries, rg_send_item *items,
-                                   unsigned long items_cap) {
+                                   u64 *head, u64 *tail, u64 *ring, unsigned cap, unsigned long max_entries, unsigned flags,
+                                   rg_send_item *items, unsigned long items_cap) {
     const RgState st = make_state(state, G, stride);
     RgIns ins;
     ins.meta = meta; ins.head = head; ins.tail = tail; ins.ring = ring; ins.cap = cap;
     long n = -1;
-    RG_DISPATCH_P(P, n = host_send<N>(st, ins, max_entries, items, items_cap));
+    RG_DISPATCH_P(P, n = host_send<N>(st, ins, max_entries, flags, items, items_cap));
     return n;
 }

@@ -136,7 +136,8 @@ def lib():
         "ro_tick_soa_mt": (u64, [vp, C.POINTER(SoaMsgs), vp, sz]),
         "ro_maybe_send_append": (C.c_bool, [vp, sz, u64, C.c_bool, u64, C.POINTER(SendMsg)]),
         "ro_set_own_inflights": (None, [vp, C.c_bool]),
-        "ro_send_stage_soa": (sz, [vp, vp, u64, vp, sz, sz, sz]),
+        "ro_send_stage_soa": (sz, [vp, vp, u64, C.c_bool, vp, sz, sz, sz]),
+        "ro_group_set_pending_conf": (None, [vp, sz, C.c_bool]),
         "ro_ins_contents": (sz, [vp, sz, u64, C.POINTER(u64), sz]),
     }
     for name, (res, args) in sig.items():
@@ -243,11 +244,11 @@ class Cluster:
         sent = self.L.ro_maybe_send_append(self.h, g, to, allow_empty, max_entries, C.byref(m))
         return sent, m
 
-    def send_stage_soa(self, gout, max_entries=0, capacity=1 << 20, g_begin=0, g_end=None):
+    def send_stage_soa(self, gout, max_entries=0, capacity=1 << 20, g_begin=0, g_end=None, skip_bcast_commit=False):
         """The reference's send decisions for the tick whose result words are gout -> SEND_MSG_DTYPE array
         (one record per message sent, in the order sent). Mutates the cluster: never re-run."""
         buf = np.zeros(capacity, dtype=SEND_MSG_DTYPE)
-        n = self.L.ro_send_stage_soa(self.h, gout.ctypes.data, max_entries, buf.ctypes.data, len(buf), g_begin,
+        n = self.L.ro_send_stage_soa(self.h, gout.ctypes.data, max_entries, skip_bcast_commit, buf.ctypes.data, len(buf), g_begin,
                                      self.n if g_end is None else g_end)
         assert n <= capacity, "send_stage_soa: capacity too small"
         return buf[:n]

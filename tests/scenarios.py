@@ -437,7 +437,35 @@ def scenario_msg_append_response_wait_reset(B):
     assert ms == [(3, 1, 1, 1)], ms
 
 
-FLOW = [scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+def scenario_skip_bcast_commit(B):
+    """test_raw_node.rs:714-779 test_skip_bcast_commit, leader side: with Config::skip_bcast_commit the empty
+    MsgAppend that only carries a new commit index is not sent -- unless a conf change is pending
+    (should_bcast_commit, raft.rs:2684-2686); the switch can be flipped at run time."""
+    ld = B(1, 1, [1, 2, 3], log=[(1, 1)], committed=1, next_idx=2, max_inflight=256)
+    for pid in (1, 2, 3):
+        ld.set_progress(pid, match=1, next=2, state=REPLICATE)
+    ld.skip_bcast_commit = True
+    assert ld.propose() == [(2, 1, 1, 1), (3, 1, 1, 1)]
+    ld.persisted(2)
+    assert ld.ack(2, 2) == [] and ld.committed() == 2, "the commit moved, nobody is told until the next message"
+    assert ld.ack(3, 2) == []
+    ld.skip_bcast_commit = False  # adjustable at run time
+    assert ld.propose() == [(2, 1, 2, 1), (3, 1, 2, 1)]
+    ld.persisted(3)
+    assert ld.ack(2, 3) == [(2, 1, 3, 0), (3, 1, 3, 0)] and ld.committed() == 3, "empty appends broadcast the commit"
+    ld.ack(3, 3)
+    ld.skip_bcast_commit = True
+    ld.set_pending_conf(True)  # when committing a conf change the leader always broadcasts the commit
+    assert ld.propose() == [(2, 1, 3, 1), (3, 1, 3, 1)]
+    ld.persisted(4)
+    assert ld.ack(3, 4) == [(2, 1, 4, 0), (3, 1, 4, 0)] and ld.committed() == 4
+    ld.set_pending_conf(False)
+    assert ld.propose() == [(2, 1, 4, 1), (3, 1, 4, 1)]
+    ld.persisted(5)
+    assert ld.ack(2, 5) == [] and ld.committed() == 5
+
+
+FLOW = [scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,

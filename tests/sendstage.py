@@ -72,3 +72,11 @@ def compare_rings(cl, meta, ring, st, cap):
                 continue
             got = ring_contents(meta, ring, g, p, cap)
             assert got == want, (g, p, got, want)
+
+
+def mark_pending_conf(rng, st, frac=0.15):
+    """Raft::has_pending_conf() for a random subset of the groups: flag bit 0x20 on the leader's own slot."""
+    G = st["n_groups"]
+    self_slot = ((st["cfg"] >> 16) & 7).astype(np.int64)
+    pick = np.nonzero(rng.random(G) < frac)[0]
+    st["pflags"][pick, self_slot[pick]] |= 0x20

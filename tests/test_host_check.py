@@ -312,15 +312,15 @@ def host_send():
     fn = C.CDLL(LIB).rg_host_check_send
     fn.restype = C.c_long
     fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
-                   C.c_ulong, C.c_void_p, C.c_ulong]
+                   C.c_ulong, C.c_uint, C.c_void_p, C.c_ulong]
 
-    def send(st, out, meta, head, ring, cap, max_entries):
+    def send(st, out, meta, head, ring, cap, max_entries, flags=0):
         """meta/ring as rg_read_inflights reports them; `head` = (head, tail), the engine-internal columns of the
         oldest / newest entry of every window."""
         head, tail = head
         items = np.zeros(st["n_groups"] * st["n_slots"], dtype=SEND_ITEM_DTYPE)
         n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), meta.ctypes.data, head.ctypes.data,
-               tail.ctypes.data, ring.ctypes.data, cap, max_entries, items.ctypes.data, len(items))
+               tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items))
         assert 0 <= n <= len(items)
         # what rg_read_inflights does: the oldest entry of a window lives in the head column
         G, P = st["n_groups"], st["n_slots"]
@@ -354,6 +354,7 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
     st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
     fuzz.random_state(rng, st, small_values=True)
     fuzz.random_term_table(rng, st, term=6)
+    sendstage.mark_pending_conf(rng, st)
     cl = O.Cluster(G)
     cl.load_soa(st, term=6, max_inflight=cap)
     cl.set_own_inflights(True)
@@ -372,8 +373,9 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
         host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
-        items = host_send(eng_st, out, meta, head, ring, cap, max_entries)
-        omsgs = cl.send_stage_soa(gout, max_entries)
+        skip = t % 2 == 1  # Config::skip_bcast_commit on every other tick
+        items = host_send(eng_st, out, meta, head, ring, cap, max_entries, 1 if skip else 0)
+        omsgs = cl.send_stage_soa(gout, max_entries, skip_bcast_commit=skip)
         got = sendstage.compare_items(items, omsgs)
         apply_snapshots(rng, got, cl, eng_st, meta)
         cl.store_soa(st)

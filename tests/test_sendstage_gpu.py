@@ -49,6 +49,7 @@ def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries):
     st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
     fuzz.random_state(rng, st, small_values=True)
     fuzz.random_term_table(rng, st, term=6)
+    sendstage.mark_pending_conf(rng, st)
     eng = rg.Engine(G, n_slots, max_inflight=cap)
     eng.load_state(st)
     cl = O.Cluster(G)
@@ -68,8 +69,9 @@ def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries):
         cl.tick_soa(msgs, gout)
         _, out = eng.results()
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
-        eng.send_appends(max_entries)
-        items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, max_entries))
+        skip = t % 2 == 1  # Config::skip_bcast_commit on every other tick
+        eng.send_appends(max_entries, skip_bcast_commit=skip)
+        items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, max_entries, skip_bcast_commit=skip))
         seen["snap"] += apply_snapshots(rg, eng, cl, st, items)
         check(rg, eng, cl, st, cap, f"P={n_slots} cap={cap} tick {t}")
         seen["items"] += len(items)

@@ -39,9 +39,10 @@ for wl, P, cap, max_entries in ((2, 5, 4, 3), (5, 7, 256, 0), (3, 5, 2, 1)):
         mb.m_flags &= np.uint8(0xE7)  # no SENT, no host INS_FULL: the device owns the send path
         eng.tick(mb)
         cl.tick_soa_mt(mb.as_dict(), gout, 32)
-        eng.send_appends(max_entries)
+        skip = t % 3 == 2
+        eng.send_appends(max_entries, skip_bcast_commit=skip)
         items = eng.send_items()
-        omsgs = cl.send_stage_soa(gout, max_entries, capacity=G * P * max(4, min(cap, 64)))
+        omsgs = cl.send_stage_soa(gout, max_entries, capacity=G * P * max(4, min(cap, 64)), skip_bcast_commit=skip)
         cl.store_soa(st)
         n_items += len(items)
         if t % 25 == 24 or t == ticks - 1:
