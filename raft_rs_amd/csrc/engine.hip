@@ -359,7 +359,8 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
         r.slot = (u32)s;
         r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
         r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
-        items[k++] = r;
+        if (!(RG_SEND_EXP & 4)) items[k] = r;
+        k++;
     }
 }
 

@@ -10,7 +10,8 @@
 #include "rg_common.h"
 
 // RG_SEND_EXP: measurement-only knobs (never set in the product build): bit0 = no work-item list,
-// bit1 = no ring accesses (results are wrong for windows deeper than one message)
+// bit1 = no ring accesses (results are wrong for windows deeper than one message), bit2 = list positions are
+// computed (scan + atomic) but the items are not stored
 #ifndef RG_SEND_EXP
 #define RG_SEND_EXP 0
 #endif
