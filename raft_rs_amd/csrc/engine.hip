@@ -287,14 +287,35 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(const rg_wire_msg *r
     if (atomicExch(&gmark[group], epoch) != epoch) list[atomicAdd(&counters[0], 1u)] = group;
 }
 
+// 24-byte result record of the single-copy flush path (header: u32 n_groups, u32 n_duplicates, 8 B pad)
+struct rg_res_rec {
+    u64 group, commit;
+    u32 out, pad;
+};
+#define RG_PACKED_HDR 16
+
 __global__ void k_gather_results(const u64 *list, const u32 *n_ptr, const u64 *commit, const u32 *out, u64 *rl, u64 *rc,
-                                 u32 *ro) {
+                                 u32 *ro, char *packed) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (packed && i == 0) {
+        reinterpret_cast<u32 *>(packed)[0] = n_ptr[0];
+        reinterpret_cast<u32 *>(packed)[1] = n_ptr[1];
+    }
     if (i >= *n_ptr) return;
     const u64 g = list[i];
+    const u64 c = commit[g];
+    const u32 o = out[g];
     rl[i] = g;
-    rc[i] = commit[g];
-    ro[i] = out[g];
+    rc[i] = c;
+    ro[i] = o;
+    if (packed) {
+        rg_res_rec r;
+        r.group = g;
+        r.commit = c;
+        r.out = o;
+        r.pad = 0;
+        reinterpret_cast<rg_res_rec *>(packed + RG_PACKED_HDR)[i] = r;
+    }
 }
 
 __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
@@ -476,6 +497,14 @@ struct rg_engine {
     char *sparse_arena;       // gmark | list | res_list | res_commit | res_out | counters
     u32 *gmark, *counters, *res_out;
     u64 *list, *res_list, *res_commit;
+    // single-sync flush of the host mirror: pinned staging for the records, one packed D2H copy of the results
+    rg_wire_msg *pin_records; // hipHostMalloc
+    u64 pin_records_cap;
+    char *d_packed, *pin_packed; // device / pinned host: header + rg_res_rec[]
+    u64 packed_cap;           // records
+    std::vector<u64> host_res_groups, host_res_commit;
+    std::vector<u32> host_res_out;
+    bool host_res_valid;      // the vectors hold the results of the last tick (served by rg_ingested_results)
     rg_cell_write *d_cells;   // device staging for rg_write_cells
     u64 d_cells_cap;
     rg_wire_msg *d_records;   // device staging for records
@@ -579,6 +608,12 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->d_records_cap = 0;
     h->d_cells = nullptr;
     h->d_cells_cap = 0;
+    h->pin_records = nullptr;
+    h->pin_records_cap = 0;
+    h->d_packed = nullptr;
+    h->pin_packed = nullptr;
+    h->packed_cap = 0;
+    h->host_res_valid = false;
     h->epoch = 1;
     h->ingested_upper = 0;
     h->last_sparse_n = 0;
@@ -690,6 +725,9 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->sparse_arena) (void)hipFree(h->sparse_arena);
     if (h->d_records) (void)hipFree(h->d_records);
     if (h->d_cells) (void)hipFree(h->d_cells);
+    if (h->pin_records) (void)hipHostFree(h->pin_records);
+    if (h->d_packed) (void)hipFree(h->d_packed);
+    if (h->pin_packed) (void)hipHostFree(h->pin_packed);
     delete h;
 }
 
@@ -777,6 +815,7 @@ extern "C" int rg_restore(rg_engine *h) {
     if (!h->ckpt) return rg_fail(RG_ERR_STATE, "rg_restore: no checkpoint taken");
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->host_res_valid = false;
     h->out_is_dense = true; // RG_COL_OUT is whatever it was at the checkpoint: the next sparse tick clears all of it
     h->host_cfg_valid = false; // RG_COL_CFG came back too: the mirror re-reads its copy
     if (h->ckpt_any_group_commit) h->any_group_commit = true; // ... and so may group-commit configurations
@@ -847,6 +886,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     h->ticked = true;
     h->out_is_dense = true;
     h->send_ready = true;
+    h->host_res_valid = false;
     return RG_OK;
 }
 
@@ -910,6 +950,7 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "fused tick launch failed: %s", hipGetErrorString(e));
     h->ticked = true;
+    h->host_res_valid = false;
     h->out_is_dense = true;
     return RG_OK;
 }
@@ -1038,12 +1079,9 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
     return RG_OK;
 }
 
-extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
-    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_ingested: null engine");
-    if (n_groups) *n_groups = 0;
-    RG_HIP(hipSetDevice(h->cfg.device));
-    int rc = rg_ensure_sparse(h);
-    if (rc) return rc;
+// Everything of a sparse tick that needs no host round trip: clear the previous results, resolve hints, tick the
+// listed groups, gather their results (also into `packed` when given). `upper` bounds the list length.
+static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm) {
     // RG_COL_OUT must hold zeros for every group this tick does not touch
     if (h->out_is_dense) {
         RG_HIP(hipMemsetAsync(h->st.out, 0, h->stride * 4, h->stream));
@@ -1053,33 +1091,36 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     }
     h->out_is_dense = false;
     h->last_sparse_n = 0;
-    u64 upper = h->ingested_upper < h->G ? h->ingested_upper : h->G;
-    if (upper) {
-        RgMsgs ms = h->staged;
-        ms.mhr = h->rhint; // records may carry log terms: resolve the touched groups' flagged hints first
-        hipLaunchKernelGGL(k_resolve_hints_list, dim3(rg_grid(upper, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms, h->P,
-                           h->rhint, (const u64 *)h->list, (const u32 *)h->counters);
-        u64 *mf = (u64 *)h->staged.mflags;
-        switch (h->P) {
-        case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        case 2: rg_launch_tick_list_t<2>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        case 3: rg_launch_tick_list_t<3>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        case 4: rg_launch_tick_list_t<4>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        case 5: rg_launch_tick_list_t<5>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        case 6: rg_launch_tick_list_t<6>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        case 7: rg_launch_tick_list_t<7>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        default: rg_launch_tick_list_t<8>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-        }
-        hipLaunchKernelGGL(k_gather_results, dim3(rg_grid(upper, 256)), dim3(256), 0, h->stream, h->list, h->counters,
-                           (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_tick_ingested: launch failed: %s", hipGetErrorString(e));
-        u32 n = 0;
-        RG_HIP(hipMemcpyAsync(&n, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
-        RG_HIP(hipMemsetAsync(h->counters, 0, 8, h->stream)); // group count and duplicate count of the window
-        RG_HIP(hipStreamSynchronize(h->stream));
-        h->last_sparse_n = n;
+    h->host_res_valid = false;
+    if (!upper) return RG_OK;
+    RgMsgs ms = h->staged;
+    ms.mhr = ms.mh;
+    if (any_logterm) { // records may carry log terms: resolve the touched groups' flagged hints first
+        ms.mhr = h->rhint;
+        hipLaunchKernelGGL(k_resolve_hints_list, dim3(rg_grid(upper, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms,
+                           h->P, h->rhint, (const u64 *)h->list, (const u32 *)h->counters);
     }
+    u64 *mf = (u64 *)h->staged.mflags;
+    switch (h->P) {
+    case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 2: rg_launch_tick_list_t<2>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 3: rg_launch_tick_list_t<3>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 4: rg_launch_tick_list_t<4>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 5: rg_launch_tick_list_t<5>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 6: rg_launch_tick_list_t<6>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 7: rg_launch_tick_list_t<7>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    default: rg_launch_tick_list_t<8>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    }
+    hipLaunchKernelGGL(k_gather_results, dim3(rg_grid(upper, 256)), dim3(256), 0, h->stream, h->list, h->counters,
+                       (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out, packed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "sparse tick: launch failed: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+// Bookkeeping once the sparse tick's group count is known on the host.
+static int rg_sparse_finish(rg_engine *h, u64 n_groups) {
+    h->last_sparse_n = n_groups;
     h->ingested_upper = 0;
     h->epoch++;
     if (h->epoch == 0) { // epoch wrapped: the marks are ambiguous, reset them
@@ -1088,6 +1129,26 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     }
     h->ticked = true;
     h->send_ready = true;
+    return RG_OK;
+}
+
+extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_ingested: null engine");
+    if (n_groups) *n_groups = 0;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_ensure_sparse(h);
+    if (rc) return rc;
+    const u64 upper = h->ingested_upper < h->G ? h->ingested_upper : h->G;
+    rc = rg_sparse_enqueue(h, upper, nullptr, true); // device-side ingests may carry log terms
+    if (rc) return rc;
+    u32 n = 0;
+    if (upper) {
+        RG_HIP(hipMemcpyAsync(&n, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipMemsetAsync(h->counters, 0, 8, h->stream)); // group count and duplicate count of the window
+        RG_HIP(hipStreamSynchronize(h->stream));
+    }
+    rc = rg_sparse_finish(h, n);
+    if (rc) return rc;
     if (n_groups) *n_groups = h->last_sparse_n;
     return RG_OK;
 }
@@ -1098,6 +1159,12 @@ extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *com
     *n = h->last_sparse_n;
     const u64 k = h->last_sparse_n < cap ? h->last_sparse_n : cap;
     if (k == 0) return RG_OK;
+    if (h->host_res_valid) { // the single-copy flush already brought them over
+        if (groups) memcpy(groups, h->host_res_groups.data(), k * 8);
+        if (commit) memcpy(commit, h->host_res_commit.data(), k * 8);
+        if (out) memcpy(out, h->host_res_out.data(), k * 4);
+        return RG_OK;
+    }
     RG_HIP(hipSetDevice(h->cfg.device));
     if (groups) RG_HIP(hipMemcpyAsync(groups, h->res_list, k * 8, hipMemcpyDeviceToHost, h->stream));
     if (commit) RG_HIP(hipMemcpyAsync(commit, h->res_commit, k * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1135,6 +1202,7 @@ extern "C" int rg_recompute(rg_engine *h) {
     int rc = rg_recompute_impl<true>(h, nullptr, nullptr);
     if (rc == RG_OK) {
         h->ticked = true;
+        h->host_res_valid = false;
         h->out_is_dense = true; // every group's result word was rewritten
         h->send_ready = true;   // post_conf_change: `if self.maybe_commit() { self.bcast_append() }` (raft.rs:2630-2633)
     }
@@ -1499,6 +1567,104 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
     return RG_OK;
 }
 
+static int rg_flush_sparse(rg_engine *h) {
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_ensure_sparse(h);
+    if (rc) return rc;
+    u64 n = 0; // records
+    for (u64 g : h->q_dirty)
+        for (u32 p = 0; p < h->P; p++) n += h->q_mf[g * 8 + p] != 0;
+    if (n > h->pin_records_cap) {
+        if (h->pin_records) {
+            RG_HIP(hipStreamSynchronize(h->stream));
+            (void)hipHostFree(h->pin_records);
+            h->pin_records = nullptr;
+        }
+        u64 cap = 4096;
+        while (cap < n) cap *= 2;
+        RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_records), cap * sizeof(rg_wire_msg), hipHostMallocDefault));
+        h->pin_records_cap = cap;
+    }
+    if (n > h->d_records_cap) {
+        if (h->d_records) {
+            RG_HIP(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_records);
+            h->d_records = nullptr;
+        }
+        u64 cap = h->d_records_cap ? h->d_records_cap : 4096;
+        while (cap < n) cap *= 2;
+        RG_HIP(hipMalloc(&h->d_records, (cap + RG_INGEST_BLOCK) * sizeof(rg_wire_msg)));
+        h->d_records_cap = cap;
+    }
+    const u64 upper_all = h->ingested_upper + n; // device ingests of this window count too
+    const u64 upper = upper_all < h->G ? upper_all : h->G;
+    if (upper > h->packed_cap) {
+        if (h->d_packed) {
+            RG_HIP(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->d_packed);
+            (void)hipHostFree(h->pin_packed);
+            h->d_packed = h->pin_packed = nullptr;
+        }
+        u64 cap = 4096;
+        while (cap < upper) cap *= 2;
+        RG_HIP(hipMalloc(&h->d_packed, RG_PACKED_HDR + cap * sizeof(rg_res_rec)));
+        RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_packed), RG_PACKED_HDR + cap * sizeof(rg_res_rec),
+                             hipHostMallocDefault));
+        h->packed_cap = cap;
+    }
+    u64 k = 0;
+    for (u64 g : h->q_dirty) {
+        for (u32 p = 0; p < h->P; p++) {
+            const u8 f = h->q_mf[g * 8 + p];
+            if (!f) continue;
+            const size_t o = (size_t)p * h->stride + g;
+            rg_wire_msg &r = h->pin_records[k++];
+            r.group = g;
+            r.index = h->q_mi[o];
+            r.commit = h->q_mc[o];
+            r.hint = h->q_mh[o];
+            r.rs = h->q_mrs[o];
+            r.log_term = h->q_mlt[o];
+            r.slot = p;
+            r.flags = f;
+            r.pad = 0;
+        }
+    }
+    if (n) {
+        RG_HIP(hipMemcpyAsync(h->d_records, h->pin_records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
+                           h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
+                           (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
+                           h->counters);
+    }
+    // (records ingested on the device in this window may carry log terms the host has not seen)
+    rc = rg_sparse_enqueue(h, upper, h->d_packed, h->q_any_logterm || h->ingested_upper != 0);
+    if (rc) return rc;
+    u32 n_groups = 0, dup = 0;
+    if (upper) {
+        RG_HIP(hipMemcpyAsync(h->pin_packed, h->d_packed, RG_PACKED_HDR + upper * sizeof(rg_res_rec), hipMemcpyDeviceToHost,
+                              h->stream));
+        RG_HIP(hipMemsetAsync(h->counters, 0, 8, h->stream));
+        RG_HIP(hipStreamSynchronize(h->stream));
+        n_groups = reinterpret_cast<const u32 *>(h->pin_packed)[0];
+        dup = reinterpret_cast<const u32 *>(h->pin_packed)[1];
+    }
+    rc = rg_sparse_finish(h, n_groups);
+    if (rc) return rc;
+    if (dup) return rg_fail(RG_ERR_STATE, "rg_flush: %u duplicate cells (internal error)", dup);
+    const rg_res_rec *rec = reinterpret_cast<const rg_res_rec *>(h->pin_packed + RG_PACKED_HDR);
+    h->host_res_groups.resize(n_groups);
+    h->host_res_commit.resize(n_groups);
+    h->host_res_out.resize(n_groups);
+    for (u32 i = 0; i < n_groups; i++) {
+        h->host_res_groups[i] = rec[i].group;
+        h->host_res_commit[i] = rec[i].commit;
+        h->host_res_out[i] = rec[i].out;
+    }
+    h->host_res_valid = true;
+    return RG_OK;
+}
+
 extern "C" int rg_flush(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
@@ -1522,7 +1688,8 @@ extern "C" int rg_flush(rg_engine *h) {
             if (e == hipSuccess) e = hipMemcpyAsync(h->counters, &n, 4, hipMemcpyHostToDevice, h->stream);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_gather_results, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->list, h->counters,
-                                   (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out);
+                                   (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out,
+                                   (char *)nullptr);
                 e = hipMemsetAsync(h->counters, 0, 4, h->stream);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1530,31 +1697,9 @@ extern "C" int rg_flush(rg_engine *h) {
             else h->last_sparse_n = n;
         }
     } else {
-        // few groups have events: ship only their records and tick only them
-        std::vector<rg_wire_msg> &recs = h->q_records;
-        recs.clear();
-        for (u64 g : h->q_dirty) {
-            for (u32 p = 0; p < h->P; p++) {
-                const u8 f = h->q_mf[g * 8 + p];
-                if (!f) continue;
-                const size_t o = (size_t)p * h->stride + g;
-                rg_wire_msg r;
-                r.group = g;
-                r.index = h->q_mi[o];
-                r.commit = h->q_mc[o];
-                r.hint = h->q_mh[o];
-                r.rs = h->q_mrs[o];
-                r.log_term = h->q_mlt[o];
-                r.slot = p;
-                r.flags = f;
-                r.pad = 0;
-                recs.push_back(r);
-            }
-        }
-        uint64_t dup = 0, ng = 0;
-        rc = rg_ingest(h, recs.data(), recs.size(), &dup);
-        if (rc == RG_OK && dup) rc = rg_fail(RG_ERR_STATE, "rg_flush: %llu duplicate cells (internal error)", (unsigned long long)dup);
-        if (rc == RG_OK) rc = rg_tick_ingested(h, &ng);
+        // few groups have events: ship only their records and tick only them -- ONE host<->device round trip
+        // (pinned record staging, five back-to-back launches, one packed D2H copy, one synchronisation)
+        rc = rg_flush_sparse(h);
     }
     for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
     h->q_dirty.clear();
