@@ -330,6 +330,7 @@ __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
 // to the compact list with ONE atomic (wave prefix sums by shuffles, the 16 wave totals through LDS): at one
 // atomic per wave the 15.6 K same-address atomics of a 1 M-group launch cost more than everything else together.
 #define RG_SEND_BLOCK 1024
+#define RG_SEND_SPEC 16384 /* work items copied speculatively with their count (512 KB of pinned memory) */
 template <int P>
 __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, u32 flags,
                                                                const u64 *list, u64 n, rg_send_item *items,
@@ -520,6 +521,8 @@ struct rg_engine {
     RgIns ins;
     rg_send_item *send_items;
     u32 *send_counter;
+    u64 send_bound;    // upper bound of the last stage's work items (groups it walked x peers)
+    char *pin_send;    // pinned host: u32 count | pad | rg_send_item[RG_SEND_SPEC] (small stages: one round trip)
     bool send_ready;   // a tick ran since the last rg_send_appends
     bool ckpt_send_ready;
     bool ckpt_any_group_commit;
@@ -633,6 +636,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_items = nullptr;
     h->send_counter = nullptr;
     h->send_ready = false;
+    h->send_bound = 0;
+    h->pin_send = nullptr;
     h->ckpt_send_ready = false;
     h->ckpt_any_group_commit = false;
     if (cfg->max_inflight > 65535u) {
@@ -726,6 +731,7 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->d_records) (void)hipFree(h->d_records);
     if (h->d_cells) (void)hipFree(h->d_cells);
     if (h->pin_records) (void)hipHostFree(h->pin_records);
+    if (h->pin_send) (void)hipHostFree(h->pin_send);
     if (h->d_packed) (void)hipFree(h->d_packed);
     if (h->pin_packed) (void)hipHostFree(h->pin_packed);
     delete h;
@@ -1260,6 +1266,7 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_send_appends: launch failed: %s", hipGetErrorString(e));
     }
     h->send_ready = false;
+    h->send_bound = n * h->P;
     return RG_OK;
 }
 
@@ -1267,6 +1274,21 @@ extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t ca
     if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
     RG_HIP(hipSetDevice(h->cfg.device));
+    // small stages (the sparse path): counter and items come back together through pinned memory -- one round trip
+    const u64 spec = h->send_bound < cap ? h->send_bound : cap;
+    if (spec && spec <= RG_SEND_SPEC) {
+        if (!h->pin_send)
+            RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_send), 16 + RG_SEND_SPEC * sizeof(rg_send_item),
+                                 hipHostMallocDefault));
+        RG_HIP(hipMemcpyAsync(h->pin_send, h->send_counter, 4, hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipMemcpyAsync(h->pin_send + 16, h->send_items, spec * sizeof(rg_send_item), hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipStreamSynchronize(h->stream));
+        const u32 cnt = *reinterpret_cast<const u32 *>(h->pin_send);
+        *n = cnt;
+        const u64 k = cnt < cap ? cnt : cap; // cnt <= send_bound, so k <= spec
+        if (k) memcpy(host_items, h->pin_send + 16, k * sizeof(rg_send_item));
+        return RG_OK;
+    }
     u32 cnt = 0;
     RG_HIP(hipMemcpyAsync(&cnt, h->send_counter, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));

@@ -406,11 +406,12 @@ class Engine:
     def send_items(self):
         """Work items of the last send stage as a SEND_ITEM_DTYPE array (order unspecified)."""
         n = _u64(0)
-        self._check(self.L.rg_send_items(self.h, None, 0, C.byref(n)))
-        items = np.empty(n.value, dtype=SEND_ITEM_DTYPE)
-        if n.value:
+        items = np.empty(4096, dtype=SEND_ITEM_DTYPE)  # small stages come back in one call
+        self._check(self.L.rg_send_items(self.h, items.ctypes.data, len(items), C.byref(n)))
+        if n.value > len(items):
+            items = np.empty(n.value, dtype=SEND_ITEM_DTYPE)
             self._check(self.L.rg_send_items(self.h, items.ctypes.data, n.value, C.byref(n)))
-        return items
+        return items[:n.value]
 
     def read_inflights(self):
         """(meta u32 [P][stride] = start | count << 16, ring u64 [G][P][cap])."""

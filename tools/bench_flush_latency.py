@@ -48,3 +48,26 @@ for k in (1, 10, 100, 1000, 10000):
     f = lambda a: float(np.median(a[5:])) * 1e6
     print(f"  k={k:6d}: steps {f(lat_step):9.1f} us (python loop)  flush {f(lat_flush):8.1f} us  results {f(lat_res):7.1f} us")
 eng.close()
+
+# the same round trip with the Inflights on the device: + rg_send_appends + rg_send_items
+eng = rg.Engine(G, P, max_inflight=8)
+eng.workload_init(rg.WL_MAJORITY)
+L, h = eng.L, eng.h
+for g in range(G):
+    L.rg_set_peers(h, g, arr, 5, 4)
+print("with device Inflights: k x rg_step + rg_flush + rg_send_appends + rg_send_items + rg_ingested_results")
+for k in (1, 100, 1000):
+    lat = []
+    for rep in range(30):
+        groups = rng.choice(G, size=k, replace=False)
+        idx = np.minimum(st["term_hi"][groups], st["match"][1, groups] + rep + 1)
+        for g, i in zip(groups.tolist(), idx.tolist()):
+            eng.step(g, 2, 4, i)
+        t1 = time.perf_counter()
+        eng.flush()
+        eng.send_appends()
+        items = eng.send_items()
+        gr, commit, out = eng.ingested_results()
+        lat.append(time.perf_counter() - t1)
+    print(f"  k={k:6d}: {float(np.median(lat[5:]))*1e6:8.1f} us ({len(items)} work items in the last round)")
+eng.close()
