@@ -1589,13 +1589,18 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
     return RG_OK;
 }
 
-static int rg_flush_sparse(rg_engine *h) {
+// One sparse tick in ONE host<->device round trip: records (the caller's, or built from the mirror's queues when
+// `recs` is NULL) -> pinned staging -> ingest / clear / hint resolve / tick / gather back to back -> one packed D2H
+// copy of (groups, duplicates, {group, commit, out}...) -> one synchronisation. Results stay cached on the host.
+static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out) {
     RG_HIP(hipSetDevice(h->cfg.device));
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
-    u64 n = 0; // records
-    for (u64 g : h->q_dirty)
-        for (u32 p = 0; p < h->P; p++) n += h->q_mf[g * 8 + p] != 0;
+    if (!recs) {
+        n = 0;
+        for (u64 g : h->q_dirty)
+            for (u32 p = 0; p < h->P; p++) n += h->q_mf[g * 8 + p] != 0;
+    }
     if (n > h->pin_records_cap) {
         if (h->pin_records) {
             RG_HIP(hipStreamSynchronize(h->stream));
@@ -1634,22 +1639,26 @@ static int rg_flush_sparse(rg_engine *h) {
                              hipHostMallocDefault));
         h->packed_cap = cap;
     }
-    u64 k = 0;
-    for (u64 g : h->q_dirty) {
-        for (u32 p = 0; p < h->P; p++) {
-            const u8 f = h->q_mf[g * 8 + p];
-            if (!f) continue;
-            const size_t o = (size_t)p * h->stride + g;
-            rg_wire_msg &r = h->pin_records[k++];
-            r.group = g;
-            r.index = h->q_mi[o];
-            r.commit = h->q_mc[o];
-            r.hint = h->q_mh[o];
-            r.rs = h->q_mrs[o];
-            r.log_term = h->q_mlt[o];
-            r.slot = p;
-            r.flags = f;
-            r.pad = 0;
+    if (recs) {
+        if (n) memcpy(h->pin_records, recs, n * sizeof(rg_wire_msg));
+    } else {
+        u64 k = 0;
+        for (u64 g : h->q_dirty) {
+            for (u32 p = 0; p < h->P; p++) {
+                const u8 f = h->q_mf[g * 8 + p];
+                if (!f) continue;
+                const size_t o = (size_t)p * h->stride + g;
+                rg_wire_msg &r = h->pin_records[k++];
+                r.group = g;
+                r.index = h->q_mi[o];
+                r.commit = h->q_mc[o];
+                r.hint = h->q_mh[o];
+                r.rs = h->q_mrs[o];
+                r.log_term = h->q_mlt[o];
+                r.slot = p;
+                r.flags = f;
+                r.pad = 0;
+            }
         }
     }
     if (n) {
@@ -1660,7 +1669,7 @@ static int rg_flush_sparse(rg_engine *h) {
                            h->counters);
     }
     // (records ingested on the device in this window may carry log terms the host has not seen)
-    rc = rg_sparse_enqueue(h, upper, h->d_packed, h->q_any_logterm || h->ingested_upper != 0);
+    rc = rg_sparse_enqueue(h, upper, h->d_packed, any_logterm || h->ingested_upper != 0);
     if (rc) return rc;
     u32 n_groups = 0, dup = 0;
     if (upper) {
@@ -1673,7 +1682,7 @@ static int rg_flush_sparse(rg_engine *h) {
     }
     rc = rg_sparse_finish(h, n_groups);
     if (rc) return rc;
-    if (dup) return rg_fail(RG_ERR_STATE, "rg_flush: %u duplicate cells (internal error)", dup);
+    if (dup_out) *dup_out = dup;
     const rg_res_rec *rec = reinterpret_cast<const rg_res_rec *>(h->pin_packed + RG_PACKED_HDR);
     h->host_res_groups.resize(n_groups);
     h->host_res_commit.resize(n_groups);
@@ -1684,6 +1693,28 @@ static int rg_flush_sparse(rg_engine *h) {
         h->host_res_out[i] = rec[i].out;
     }
     h->host_res_valid = true;
+    return RG_OK;
+}
+
+static int rg_flush_sparse(rg_engine *h) {
+    u32 dup = 0;
+    int rc = rg_sparse_roundtrip(h, nullptr, 0, h->q_any_logterm, &dup);
+    if (rc) return rc;
+    if (dup) return rg_fail(RG_ERR_STATE, "rg_flush: %u duplicate cells (internal error)", dup);
+    return RG_OK;
+}
+
+extern "C" int rg_ingest_tick(rg_engine *h, const rg_wire_msg *records, uint64_t n, uint64_t *n_groups,
+                              uint64_t *n_duplicates) {
+    if (!h || (!records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest_tick: bad argument");
+    if (n_groups) *n_groups = 0;
+    if (n_duplicates) *n_duplicates = 0;
+    static const rg_wire_msg none = {};
+    u32 dup = 0;
+    int rc = rg_sparse_roundtrip(h, records ? records : &none, n, true, &dup);
+    if (rc) return rc;
+    if (n_groups) *n_groups = h->last_sparse_n;
+    if (n_duplicates) *n_duplicates = dup;
     return RG_OK;
 }
 

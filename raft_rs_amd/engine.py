@@ -160,6 +160,7 @@ SYMBOLS = {
     "rg_ingest_device": (_i, [_vp, _vp, _u64]),
     "rg_ingested_duplicates": (_i, [_vp, C.POINTER(_u64)]),
     "rg_tick_ingested": (_i, [_vp, C.POINTER(_u64)]),
+    "rg_ingest_tick": (_i, [_vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_appends": (_i, [_vp, _u64, C.c_uint32]),
     "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
@@ -377,6 +378,13 @@ class Engine:
         n = _u64(0)
         self._check(self.L.rg_tick_ingested(self.h, C.byref(n)))
         return n.value
+
+    def ingest_tick(self, records):
+        """ingest + tick_ingested in one host<->device round trip. Returns (groups touched, dropped records)."""
+        rec = np.ascontiguousarray(records, dtype=WIRE_DTYPE)
+        n, dup = _u64(0), _u64(0)
+        self._check(self.L.rg_ingest_tick(self.h, rec.ctypes.data, len(rec), C.byref(n), C.byref(dup)))
+        return n.value, dup.value
 
     def ingested_results(self):
         n = _u64(0)

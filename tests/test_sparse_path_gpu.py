@@ -183,3 +183,56 @@ def test_recompute_between_sparse_ticks_leaves_no_stale_results(rg):
     out = eng.read_column(rg.COL.OUT)
     assert out[11] != 0 and np.count_nonzero(out) == 1, "stale RG_OUT_CHANGED words of the recompute survived"
     eng.close()
+
+
+def test_ingest_tick_is_one_round_trip_with_identical_results(rg):
+    """rg_ingest_tick == rg_ingest + rg_tick_ingested (+ rg_ingested_results from the host copy): same state, same
+    results, duplicates of the whole window reported, log-term rejects resolved on the way."""
+    from raft_rs_amd.engine import WIRE_DTYPE
+    rng = np.random.default_rng(911)
+    G, P, TERM = 9000, 5, 6
+    st = O.add_term_table(O.alloc_state(G, P))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, TERM)
+    a, b = rg.Engine(G, P), rg.Engine(G, P)
+    a.load_state(st)
+    b.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    msgs = O.alloc_msgs(G, P)
+    gout = np.zeros(G, dtype=np.uint32)
+    for t in range(5):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, logterm_max=TERM)
+        touched = np.sort(rng.choice(G, size=[3, 40, 900, 1, 2000][t], replace=False))
+        keep = np.zeros(G, dtype=bool)
+        keep[touched] = True
+        msgs["m_flags"][~keep] = 0
+        recs = []
+        for g in touched:
+            for p in range(P):
+                f = int(msgs["m_flags"][g, p])
+                if f:
+                    recs.append((g, msgs["m_index"][p, g], msgs["m_commit"][p, g], msgs["m_hint"][p, g],
+                                 msgs["m_rs"][p, g], msgs["m_logterm"][p, g], p, f, 0))
+        recs = np.array(recs, dtype=WIRE_DTYPE)
+        rng.shuffle(recs)
+        dup_rec = recs[:1].copy() if t == 2 and len(recs) else recs[:0]
+        n, dup = a.ingest_tick(np.concatenate([recs, dup_rec]))
+        assert dup == len(dup_rec)
+        assert b.ingest(recs) == 0
+        assert b.tick_ingested() == n == int(msgs["m_flags"].any(axis=1).sum())
+        cl.tick_soa(msgs, gout)
+        ga, ca, oa = a.ingested_results()
+        gb, cb, ob = b.ingested_results()
+        ia, ib = np.argsort(ga), np.argsort(gb)
+        assert (ga[ia] == gb[ib]).all() and (ca[ia] == cb[ib]).all() and (oa[ia] == ob[ib]).all()
+        assert (oa[ia] == gout[ga[ia]]).all()
+        sa, sb = a.read_state(), b.read_state()
+        cl.store_soa(st)
+        assert not fuzz.diff_states(st, sa, G, P) and not fuzz.diff_states(st, sb, G, P)
+        assert (sa["out"] == gout).all() and (sb["out"] == gout).all()
+    assert a.ingest_tick(np.zeros(0, dtype=WIRE_DTYPE)) == (0, 0)
+    a.close()
+    b.close()
