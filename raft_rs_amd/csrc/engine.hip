@@ -293,6 +293,7 @@ struct rg_res_rec {
     u32 out, pad;
 };
 #define RG_PACKED_HDR 16
+#define RG_ROUNDTRIP_MAX 16384 /* records: above this the three-call sequence wins (measured crossover ~20 k) */
 
 __global__ void k_gather_results(const u64 *list, const u32 *n_ptr, const u64 *commit, const u32 *out, u64 *rl, u64 *rc,
                                  u32 *ro, char *packed) {
@@ -1592,10 +1593,21 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
 // One sparse tick in ONE host<->device round trip: records (the caller's, or built from the mirror's queues when
 // `recs` is NULL) -> pinned staging -> ingest / clear / hint resolve / tick / gather back to back -> one packed D2H
 // copy of (groups, duplicates, {group, commit, out}...) -> one synchronisation. Results stay cached on the host.
+static int rg_sparse_threecall(rg_engine *h, const rg_wire_msg *recs, u64 n, u32 *dup_out) {
+    // big batches are throughput-bound, not latency-bound: the packed copy (one slot per RECORD, not per group)
+    // and the host-side unpacking cost more than two extra synchronisations (profiles/r01_sparse_path...)
+    uint64_t d64 = 0, ng = 0;
+    int rc = rg_ingest(h, recs, n, &d64);
+    if (rc == RG_OK) rc = rg_tick_ingested(h, &ng);
+    if (dup_out) *dup_out = (u32)d64;
+    return rc;
+}
+
 static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out) {
     RG_HIP(hipSetDevice(h->cfg.device));
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
+    if (recs && n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, recs, n, dup_out);
     if (!recs) {
         n = 0;
         for (u64 g : h->q_dirty)
@@ -1611,6 +1623,29 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         while (cap < n) cap *= 2;
         RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_records), cap * sizeof(rg_wire_msg), hipHostMallocDefault));
         h->pin_records_cap = cap;
+    }
+    if (recs) {
+        if (n) memcpy(h->pin_records, recs, n * sizeof(rg_wire_msg));
+    } else {
+        u64 k = 0;
+        for (u64 g : h->q_dirty) {
+            for (u32 p = 0; p < h->P; p++) {
+                const u8 f = h->q_mf[g * 8 + p];
+                if (!f) continue;
+                const size_t o = (size_t)p * h->stride + g;
+                rg_wire_msg &r = h->pin_records[k++];
+                r.group = g;
+                r.index = h->q_mi[o];
+                r.commit = h->q_mc[o];
+                r.hint = h->q_mh[o];
+                r.rs = h->q_mrs[o];
+                r.log_term = h->q_mlt[o];
+                r.slot = p;
+                r.flags = f;
+                r.pad = 0;
+            }
+        }
+        if (n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, h->pin_records, n, dup_out);
     }
     if (n > h->d_records_cap) {
         if (h->d_records) {
@@ -1638,28 +1673,6 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_packed), RG_PACKED_HDR + cap * sizeof(rg_res_rec),
                              hipHostMallocDefault));
         h->packed_cap = cap;
-    }
-    if (recs) {
-        if (n) memcpy(h->pin_records, recs, n * sizeof(rg_wire_msg));
-    } else {
-        u64 k = 0;
-        for (u64 g : h->q_dirty) {
-            for (u32 p = 0; p < h->P; p++) {
-                const u8 f = h->q_mf[g * 8 + p];
-                if (!f) continue;
-                const size_t o = (size_t)p * h->stride + g;
-                rg_wire_msg &r = h->pin_records[k++];
-                r.group = g;
-                r.index = h->q_mi[o];
-                r.commit = h->q_mc[o];
-                r.hint = h->q_mh[o];
-                r.rs = h->q_mrs[o];
-                r.log_term = h->q_mlt[o];
-                r.slot = p;
-                r.flags = f;
-                r.pad = 0;
-            }
-        }
     }
     if (n) {
         RG_HIP(hipMemcpyAsync(h->d_records, h->pin_records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));

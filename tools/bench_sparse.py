@@ -42,9 +42,27 @@ for frac in (0.001, 0.01, 0.05, 0.2):
         assert dup == 0 and n == n_g
         times_i.append(t1 - t0)
         times_t.append(t2 - t1)
+    # the same work through rg_ingest_tick (one host<->device round trip, results cached on the host)
+    times_c = []
+    for rep in range(6, 12):
+        groups = rng.choice(G, size=n_g, replace=False).astype(np.uint64)
+        k = 0
+        for p in range(1, 5):
+            sl = recs[k:k + n_g]
+            sl["group"] = groups
+            sl["index"] = np.minimum(st["term_hi"][groups], st["match"][p, groups] + rep + 1)
+            sl["commit"] = np.minimum(st["commit"][groups], sl["index"])
+            k += n_g
+        t0 = time.perf_counter()
+        n, dup = eng.ingest_tick(recs)
+        eng.ingested_results()
+        times_c.append(time.perf_counter() - t0)
+        assert dup == 0 and n == n_g
+    tc = np.median(times_c[1:])
     ti, tt = np.median(times_i[1:]), np.median(times_t[1:])
     print(f"  {frac*100:5.1f}% of groups touched: {len(recs):8d} records  ingest {ti*1e6:8.1f} us  "
-          f"tick {tt*1e6:7.1f} us  -> {len(recs)/(ti+tt)/1e6:7.1f} M msgs/s, {n_g/(ti+tt)/1e6:6.2f} M group-evals/s")
+          f"tick {tt*1e6:7.1f} us  -> {len(recs)/(ti+tt)/1e6:7.1f} M msgs/s, {n_g/(ti+tt)/1e6:6.2f} M group-evals/s"
+          f"  | rg_ingest_tick + results {tc*1e6:8.1f} us -> {len(recs)/tc/1e6:7.1f} M msgs/s")
 
 # recompute-only (Raft::maybe_commit for every group, no messages): B0 = 8P+37 bytes per group
 coop = rg.Engine(G, P, variant=rg.VARIANT_COOP)
