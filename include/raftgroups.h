@@ -317,6 +317,9 @@ typedef struct {
                                           only by groups with a pending conf change -- should_bcast_commit(),
                                           src/raft.rs:2684-2686; RG_PF_PENDING_CONF on the leader's slot */
 int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
+/* rg_flush followed by rg_send_appends, and for small batches in the SAME host<->device round trip (the work items
+ * come back with the tick's results; rg_send_items / rg_ingested_results then read host memory). */
+int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
 /* Work items of the last rg_send_appends (order unspecified) -> host array of capacity `cap`; *n = number of
  * items (only cap are written if it is larger). Synchronises. rg_send_items_ptr: the same list in device memory. */
 int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n);

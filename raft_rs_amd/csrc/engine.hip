@@ -334,11 +334,12 @@ __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
 #define RG_SEND_SPEC 16384 /* work items copied speculatively with their count (512 KB of pinned memory) */
 template <int P>
 __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIns ins, u64 max_entries, u32 flags,
-                                                               const u64 *list, u64 n, rg_send_item *items,
-                                                               u32 *counter) {
+                                                               const u64 *list, u64 n, const u32 *n_ptr,
+                                                               rg_send_item *items, u32 *counter) {
     __shared__ u32 wave_tot[RG_SEND_BLOCK / 64];
     __shared__ u32 block_base;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_ptr) n = *n_ptr; // list length still on the device (the single-round-trip flush); the grid covers a bound
     const bool active = i < n;
     const u64 g = active ? (list ? list[i] : i) : 0;
     RgSendRegs<P> it;
@@ -523,6 +524,8 @@ struct rg_engine {
     rg_send_item *send_items;
     u32 *send_counter;
     u64 send_bound;    // upper bound of the last stage's work items (groups it walked x peers)
+    std::vector<rg_send_item> host_items; // items of the last stage when rg_flush_send fetched them
+    bool host_items_valid;
     char *pin_send;    // pinned host: u32 count | pad | rg_send_item[RG_SEND_SPEC] (small stages: one round trip)
     bool send_ready;   // a tick ran since the last rg_send_appends
     bool ckpt_send_ready;
@@ -639,6 +642,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_ready = false;
     h->send_bound = 0;
     h->pin_send = nullptr;
+    h->host_items_valid = false;
     h->ckpt_send_ready = false;
     h->ckpt_any_group_commit = false;
     if (cfg->max_inflight > 65535u) {
@@ -1241,6 +1245,30 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
 // ------------------------------------------------------------------------------------------------
 // send stage
 // ------------------------------------------------------------------------------------------------
+// Enqueue the send stage over `list[0..n)` (NULL = all groups); n_ptr != NULL: the length is read on the device and
+// `n` only sizes the grid.
+static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, const u64 *list, u64 n,
+                           const u32 *n_ptr) {
+    RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
+    if (n) {
+        const dim3 grid(rg_grid(n, RG_SEND_BLOCK)), block(RG_SEND_BLOCK);
+        switch (h->P) {
+        case 1: hipLaunchKernelGGL(k_send_appends<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        case 2: hipLaunchKernelGGL(k_send_appends<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        case 3: hipLaunchKernelGGL(k_send_appends<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        case 4: hipLaunchKernelGGL(k_send_appends<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        case 5: hipLaunchKernelGGL(k_send_appends<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        case 6: hipLaunchKernelGGL(k_send_appends<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        case 7: hipLaunchKernelGGL(k_send_appends<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        default: hipLaunchKernelGGL(k_send_appends<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, n_ptr, h->send_items, h->send_counter); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "send stage: launch failed: %s", hipGetErrorString(e));
+    }
+    h->host_items_valid = false;
+    return RG_OK;
+}
+
 extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: null engine");
     if (!h->ins_arena)
@@ -1248,24 +1276,10 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
     if (!h->send_ready) return rg_fail(RG_ERR_STATE, "rg_send_appends: no tick since the last send stage");
     if (flags & ~RG_SEND_SKIP_BCAST_COMMIT) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: unknown flags %#x", flags);
     RG_HIP(hipSetDevice(h->cfg.device));
-    RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
     const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
     const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;
-    if (n) {
-        const dim3 grid(rg_grid(n, RG_SEND_BLOCK)), block(RG_SEND_BLOCK);
-        switch (h->P) {
-        case 1: hipLaunchKernelGGL(k_send_appends<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        case 2: hipLaunchKernelGGL(k_send_appends<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        case 3: hipLaunchKernelGGL(k_send_appends<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        case 4: hipLaunchKernelGGL(k_send_appends<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        case 5: hipLaunchKernelGGL(k_send_appends<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        case 6: hipLaunchKernelGGL(k_send_appends<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        case 7: hipLaunchKernelGGL(k_send_appends<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        default: hipLaunchKernelGGL(k_send_appends<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, list, n, h->send_items, h->send_counter); break;
-        }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_send_appends: launch failed: %s", hipGetErrorString(e));
-    }
+    int rc = rg_send_enqueue(h, max_entries_per_msg, flags, list, n, nullptr);
+    if (rc) return rc;
     h->send_ready = false;
     h->send_bound = n * h->P;
     return RG_OK;
@@ -1275,6 +1289,12 @@ extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t ca
     if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
     RG_HIP(hipSetDevice(h->cfg.device));
+    if (h->host_items_valid) { // rg_flush_send already brought them over with the tick's results
+        *n = h->host_items.size();
+        const u64 k = *n < cap ? *n : cap;
+        if (k) memcpy(host_items, h->host_items.data(), k * sizeof(rg_send_item));
+        return RG_OK;
+    }
     // small stages (the sparse path): counter and items come back together through pinned memory -- one round trip
     const u64 spec = h->send_bound < cap ? h->send_bound : cap;
     if (spec && spec <= RG_SEND_SPEC) {
@@ -1593,21 +1613,28 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
 // One sparse tick in ONE host<->device round trip: records (the caller's, or built from the mirror's queues when
 // `recs` is NULL) -> pinned staging -> ingest / clear / hint resolve / tick / gather back to back -> one packed D2H
 // copy of (groups, duplicates, {group, commit, out}...) -> one synchronisation. Results stay cached on the host.
-static int rg_sparse_threecall(rg_engine *h, const rg_wire_msg *recs, u64 n, u32 *dup_out) {
+struct rg_send_req { // run the send stage inside the same round trip (engines with device Inflights)
+    u64 max_entries;
+    u32 flags;
+};
+
+static int rg_sparse_threecall(rg_engine *h, const rg_wire_msg *recs, u64 n, u32 *dup_out, const rg_send_req *send) {
     // big batches are throughput-bound, not latency-bound: the packed copy (one slot per RECORD, not per group)
     // and the host-side unpacking cost more than two extra synchronisations (profiles/r01_sparse_path...)
     uint64_t d64 = 0, ng = 0;
     int rc = rg_ingest(h, recs, n, &d64);
     if (rc == RG_OK) rc = rg_tick_ingested(h, &ng);
+    if (rc == RG_OK && send) rc = rg_send_appends(h, send->max_entries, send->flags);
     if (dup_out) *dup_out = (u32)d64;
     return rc;
 }
 
-static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out) {
+static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out,
+                               const rg_send_req *send = nullptr) {
     RG_HIP(hipSetDevice(h->cfg.device));
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
-    if (recs && n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, recs, n, dup_out);
+    if (recs && n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, recs, n, dup_out, send);
     if (!recs) {
         n = 0;
         for (u64 g : h->q_dirty)
@@ -1645,7 +1672,7 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
                 r.pad = 0;
             }
         }
-        if (n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, h->pin_records, n, dup_out);
+        if (n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, h->pin_records, n, dup_out, send);
     }
     if (n > h->d_records_cap) {
         if (h->d_records) {
@@ -1684,6 +1711,21 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     // (records ingested on the device in this window may carry log terms the host has not seen)
     rc = rg_sparse_enqueue(h, upper, h->d_packed, any_logterm || h->ingested_upper != 0);
     if (rc) return rc;
+    // the send stage rides along: it walks the gathered list, whose length is still only on the device
+    const u64 item_bound = upper * h->P;
+    const bool fetch_items = send && upper && item_bound <= RG_SEND_SPEC;
+    if (send && upper) {
+        rc = rg_send_enqueue(h, send->max_entries, send->flags, h->res_list, upper, h->counters);
+        if (rc) return rc;
+        if (fetch_items) {
+            if (!h->pin_send)
+                RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_send), 16 + RG_SEND_SPEC * sizeof(rg_send_item),
+                                     hipHostMallocDefault));
+            RG_HIP(hipMemcpyAsync(h->pin_send, h->send_counter, 4, hipMemcpyDeviceToHost, h->stream));
+            RG_HIP(hipMemcpyAsync(h->pin_send + 16, h->send_items, item_bound * sizeof(rg_send_item), hipMemcpyDeviceToHost,
+                                  h->stream));
+        }
+    }
     u32 n_groups = 0, dup = 0;
     if (upper) {
         RG_HIP(hipMemcpyAsync(h->pin_packed, h->d_packed, RG_PACKED_HDR + upper * sizeof(rg_res_rec), hipMemcpyDeviceToHost,
@@ -1695,6 +1737,20 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     }
     rc = rg_sparse_finish(h, n_groups);
     if (rc) return rc;
+    if (send) {
+        h->send_ready = false; // the stage of this tick has run (or had nothing to walk)
+        h->send_bound = (u64)n_groups * h->P;
+        if (!upper) RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
+        if (!upper) {
+            h->host_items.clear();
+            h->host_items_valid = true;
+        } else if (fetch_items) {
+            const u32 cnt = *reinterpret_cast<const u32 *>(h->pin_send);
+            const rg_send_item *it = reinterpret_cast<const rg_send_item *>(h->pin_send + 16);
+            h->host_items.assign(it, it + cnt);
+            h->host_items_valid = true;
+        }
+    }
     if (dup_out) *dup_out = dup;
     const rg_res_rec *rec = reinterpret_cast<const rg_res_rec *>(h->pin_packed + RG_PACKED_HDR);
     h->host_res_groups.resize(n_groups);
@@ -1709,9 +1765,9 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     return RG_OK;
 }
 
-static int rg_flush_sparse(rg_engine *h) {
+static int rg_flush_sparse(rg_engine *h, const rg_send_req *send) {
     u32 dup = 0;
-    int rc = rg_sparse_roundtrip(h, nullptr, 0, h->q_any_logterm, &dup);
+    int rc = rg_sparse_roundtrip(h, nullptr, 0, h->q_any_logterm, &dup, send);
     if (rc) return rc;
     if (dup) return rg_fail(RG_ERR_STATE, "rg_flush: %u duplicate cells (internal error)", dup);
     return RG_OK;
@@ -1731,8 +1787,7 @@ extern "C" int rg_ingest_tick(rg_engine *h, const rg_wire_msg *records, uint64_t
     return RG_OK;
 }
 
-extern "C" int rg_flush(rg_engine *h) {
-    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
+static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
     int rc;
     if (h->q_dirty.size() * 2 >= h->G) {
@@ -1762,15 +1817,32 @@ extern "C" int rg_flush(rg_engine *h) {
             if (e != hipSuccess) rc = rg_fail(RG_ERR_NO_DEVICE, "rg_flush: %s", hipGetErrorString(e));
             else h->last_sparse_n = n;
         }
+        if (rc == RG_OK && send) rc = rg_send_appends(h, send->max_entries, send->flags); // dense stage, items on request
     } else {
         // few groups have events: ship only their records and tick only them -- ONE host<->device round trip
         // (pinned record staging, five back-to-back launches, one packed D2H copy, one synchronisation)
-        rc = rg_flush_sparse(h);
+        rc = rg_flush_sparse(h, send);
     }
     for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
     h->q_dirty.clear();
     h->q_any_logterm = false;
     return rc;
+}
+
+extern "C" int rg_flush(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
+    return rg_flush_impl(h, nullptr);
+}
+
+extern "C" int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush_send: null engine");
+    if (!h->ins_arena)
+        return rg_fail(RG_ERR_STATE, "rg_flush_send: engine created with max_inflight = 0 (Inflights are the host's)");
+    if (flags & ~RG_SEND_SKIP_BCAST_COMMIT) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush_send: unknown flags %#x", flags);
+    rg_send_req req;
+    req.max_entries = max_entries_per_msg;
+    req.flags = flags;
+    return rg_flush_impl(h, &req);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -163,6 +163,7 @@ SYMBOLS = {
     "rg_ingest_tick": (_i, [_vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_appends": (_i, [_vp, _u64, C.c_uint32]),
+    "rg_flush_send": (_i, [_vp, _u64, C.c_uint32]),
     "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_items_ptr": (_vp, [_vp]),
     "rg_inflights_bytes": (_u64, [_vp, _i]),
@@ -410,6 +411,10 @@ class Engine:
     def send_appends(self, max_entries_per_msg=0, skip_bcast_commit=False):
         """Run the send stage for the tick that just ran (asynchronous)."""
         self._check(self.L.rg_send_appends(self.h, max_entries_per_msg, SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0))
+
+    def flush_send(self, max_entries_per_msg=0, skip_bcast_commit=False):
+        """flush() + send_appends(); one host<->device round trip for small batches."""
+        self._check(self.L.rg_flush_send(self.h, max_entries_per_msg, SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0))
 
     def send_items(self):
         """Work items of the last send stage as a SEND_ITEM_DTYPE array (order unspecified)."""

@@ -176,9 +176,11 @@ def test_send_stage_call_sequence_and_checkpoint(rg):
     eng.close()
 
 
-def test_mirror_steps_with_device_inflights(rg):
+@pytest.mark.parametrize("one_call", [False, True])
+def test_mirror_steps_with_device_inflights(rg, one_call):
     """RawNode::step mirror (rg_step / rg_local_append / rg_flush) followed by the send stage: proposals fill the
-    window of every follower, an ack moves it forward and the backlog goes out in one MsgAppend."""
+    window of every follower, an ack moves it forward and the backlog goes out in one MsgAppend. one_call: the
+    same through rg_flush_send (tick + stage + results + items in one round trip on the sparse path)."""
     G, P, cap = 64, 3, 4
     eng = rg.Engine(G, P, max_inflight=cap)
     st = O.alloc_state(G, P, stride=eng.stride)
@@ -193,8 +195,11 @@ def test_mirror_steps_with_device_inflights(rg):
     for r in range(1, 7):  # six proposals of one entry each
         for g in range(G):
             eng.local_append(g, 10 + r)
-        eng.flush()
-        eng.send_appends()
+        if one_call:
+            eng.flush_send()  # every group is dirty: the dense path
+        else:
+            eng.flush()
+            eng.send_appends()
         items = eng.send_items()
         if r <= cap:
             assert len(items) == G * 2 and (items["prev_index"] == 9 + r).all() and (items["last_index"] == 10 + r).all()
@@ -204,15 +209,25 @@ def test_mirror_steps_with_device_inflights(rg):
     assert (eng.read_column(rg.COL.PFLAGS)[:, 1:3] & rg.PF.INS_FULL).all()
     for g in range(0, G, 2):  # peer 2 of every other group acks index 12
         eng.step(g, from_=2, term=5, index=12)
-    eng.flush()  # < 50 % of the groups: the sparse path
-    eng.send_appends()
+    if one_call:
+        eng.flush_send()  # < 50 % of the groups: the sparse path, one round trip
+        with pytest.raises(rg.EngineError):
+            eng.send_appends()  # the stage of this tick has already run
+    else:
+        eng.flush()
+        eng.send_appends()
     items = eng.send_items()
+    groups, commit, out = eng.ingested_results()
+    assert sorted(groups.tolist()) == list(range(0, G, 2)) and (commit == 10).all()
     assert len(items) == G // 2 and (items["slot"] == 1).all() and (items["group"] % 2 == 0).all()
     assert (items["prev_index"] == 14).all() and (items["last_index"] == 16).all() and (items["n_msgs"] == 1).all()
     meta, ring = eng.read_inflights()
     assert eng.inflights(4, 1, meta, ring) == [13, 14, 16] and eng.inflights(5, 1, meta, ring) == [11, 12, 13, 14]
     nxt = eng.read_column(rg.COL.NEXT)
     assert nxt[1, 4] == 17 and nxt[1, 5] == 15 and nxt[2, 4] == 15
+    if one_call:  # a flush with nothing queued: no groups, no items
+        eng.flush_send()
+        assert len(eng.send_items()) == 0 and len(eng.ingested_results()[0]) == 0
     eng.close()
 
 

@@ -55,9 +55,10 @@ eng.workload_init(rg.WL_MAJORITY)
 L, h = eng.L, eng.h
 for g in range(G):
     L.rg_set_peers(h, g, arr, 5, 4)
-print("with device Inflights: k x rg_step + rg_flush + rg_send_appends + rg_send_items + rg_ingested_results")
+print("with device Inflights: k x rg_step, then rg_flush + rg_send_appends + rg_send_items + rg_ingested_results"
+      " | the same through rg_flush_send")
 for k in (1, 100, 1000):
-    lat = []
+    lat, lat1 = [], []
     for rep in range(30):
         groups = rng.choice(G, size=k, replace=False)
         idx = np.minimum(st["term_hi"][groups], st["match"][1, groups] + rep + 1)
@@ -69,5 +70,15 @@ for k in (1, 100, 1000):
         items = eng.send_items()
         gr, commit, out = eng.ingested_results()
         lat.append(time.perf_counter() - t1)
-    print(f"  k={k:6d}: {float(np.median(lat[5:]))*1e6:8.1f} us ({len(items)} work items in the last round)")
+        groups = rng.choice(G, size=k, replace=False)
+        idx = np.minimum(st["term_hi"][groups], st["match"][2, groups] + rep + 1)
+        for g, i in zip(groups.tolist(), idx.tolist()):
+            eng.step(g, 3, 4, i)
+        t1 = time.perf_counter()
+        eng.flush_send()
+        items = eng.send_items()
+        gr, commit, out = eng.ingested_results()
+        lat1.append(time.perf_counter() - t1)
+    print(f"  k={k:6d}: {float(np.median(lat[5:]))*1e6:8.1f} us | {float(np.median(lat1[5:]))*1e6:8.1f} us "
+          f"({len(items)} work items in the last round)")
 eng.close()
