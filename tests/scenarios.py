@@ -319,6 +319,34 @@ def scenario_send_path_update_state(B):
     assert ld.sent(3) != 0, "Snapshot: update_state panics in the reference -> reported as a fault"
 
 
+def scenario_leader_commit_preceding_entries(B):
+    """test_raft_paper.rs:541-581 test_leader_commit_preceding_entries: committing an entry of the leader's own
+    term (3) commits every preceding entry, including those created by previous leaders."""
+    for i, prev in enumerate(([], [(2, 1)], [(1, 1), (2, 2)], [(1, 1)])):
+        li = len(prev)
+        log = list(prev) + [(3, li + 1), (3, li + 2)]  # become_leader's noop, then the proposal
+        ld = B(1, 3, [1, 2, 3], log=log, committed=0, next_idx=li + 1)
+        ld.set_progress(1, match=0, next=li + 3, state=REPLICATE)
+        ld.persisted(li + 2)
+        assert ld.committed() == 0, f"#{i}: nothing is committed by the leader alone"
+        out = ld.step(2, li + 2)  # accept_and_reply of the MsgAppend
+        assert out["changed"] and ld.committed() == li + 2, f"#{i}: committed = {ld.committed()}, want {li + 2}"
+        ld.step(3, li + 2)
+        assert ld.committed() == li + 2
+
+
+def scenario_leader_increase_next(B):
+    """test_raft.rs:2793-2827 test_leader_increase_next: a proposal optimistically moves next to last_index + 1 for a
+    peer in Replicate (3 previous entries + noop + proposal + 1 = 6) and leaves it alone for a peer in Probe."""
+    for state, next_idx, wnext in ((REPLICATE, 2, 6), (PROBE, 2, 2)):
+        ld = B(1, 2, [1, 2], log=[(1, 1), (1, 2), (1, 3), (2, 4)], committed=0, next_idx=4, max_inflight=256)
+        ld.set_progress(1, match=4, next=5, state=REPLICATE)
+        ld.set_progress(2, match=0, next=next_idx, state=state, paused=False)
+        ms = ld.propose()
+        assert len(ms) == 1 and ms[0][2] == next_idx - 1 and ms[0][3] == 4, ms
+        assert ld.progress(2)["next"] == wnext, f"{state}: next = {ld.progress(2)['next']}, want {wnext}"
+
+
 def _flow_leader(B, cap):
     """new_test_raft(1, [1, 2], ..) after become_candidate + become_leader (noop at index 1), peer 2 forced
     into Replicate (test_raft_flow_control.rs:24-31)."""
@@ -465,7 +493,7 @@ def scenario_skip_bcast_commit(B):
     assert ld.ack(2, 5) == [] and ld.committed() == 5
 
 
-FLOW = [scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+FLOW = [scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
@@ -474,4 +502,4 @@ ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_com
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
        scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
        scenario_commit_after_remove_node, scenario_fast_log_rejection, scenario_progress_committed_index,
-       scenario_send_path_update_state]
+       scenario_send_path_update_state, scenario_leader_commit_preceding_entries]
