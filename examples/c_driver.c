@@ -81,6 +81,47 @@ int main(void) {
         ok = ok && commit[g] == want && ((out[g] & RG_OUT_CHANGED) != 0) == (want == 2);
     }
     rg_destroy(h);
+
+    /* ---- the optional send stage: Inflights (window of 2 messages) on the device, decisions by the engine ---- */
+    cfg.max_inflight = 2;
+    CHECK(rg_create(&cfg, &h));
+    for (int g = 0; g < G; g++)
+        for (int p = 0; p < P; p++) col[p * stride + g] = 2;
+    CHECK(rg_load_column(h, RG_COL_MATCH, col, rg_column_bytes(h, RG_COL_MATCH)));
+    for (int g = 0; g < G; g++)
+        for (int p = 0; p < P; p++) col[p * stride + g] = 3;
+    CHECK(rg_load_column(h, RG_COL_NEXT, col, rg_column_bytes(h, RG_COL_NEXT)));
+    CHECK(rg_load_column(h, RG_COL_PFLAGS, pflags, rg_column_bytes(h, RG_COL_PFLAGS)));
+    CHECK(rg_load_column(h, RG_COL_CFG, cfgw, rg_column_bytes(h, RG_COL_CFG)));
+    for (int g = 0; g < G; g++) per_group[g] = 2;
+    CHECK(rg_load_column(h, RG_COL_COMMIT, per_group, rg_column_bytes(h, RG_COL_COMMIT)));
+    CHECK(rg_load_column(h, RG_COL_TERM_HI, per_group, rg_column_bytes(h, RG_COL_TERM_HI)));
+    for (int g = 0; g < G; g++) per_group[g] = 1;
+    CHECK(rg_load_column(h, RG_COL_TERM_LO, per_group, rg_column_bytes(h, RG_COL_TERM_LO)));
+    rg_send_item items[3 * G * P];
+    for (int round = 1; round <= 3 && ok; round++) { /* three proposals of one entry: the third finds the windows full */
+        for (int g = 0; g < G; g++) {
+            memset(&recs[g], 0, sizeof recs[g]);
+            recs[g].group = (uint64_t)g;
+            recs[g].slot = 0;                    /* the leader's own slot */
+            recs[g].commit = 2u + (uint64_t)round; /* RG_MF_APPEND: new last_index */
+            recs[g].flags = RG_MF_APPEND;
+        }
+        CHECK(rg_ingest_tick(h, recs, G, &touched, &dup));
+        CHECK(rg_send_appends(h, 0, 0));
+        CHECK(rg_send_items(h, items, sizeof items / sizeof items[0], &n));
+        printf("proposal %d: %llu groups ticked, %llu MsgAppend work items\n", round, (unsigned long long)touched,
+               (unsigned long long)n);
+        ok = ok && touched == G && dup == 0 && n == (round <= 2 ? (uint64_t)G * (P - 1) : 0);
+        for (uint64_t i = 0; i < n && ok; i++)
+            ok = items[i].kind == RG_SEND_APPEND && items[i].n_msgs == 1 && items[i].prev_index == 1u + (uint64_t)round &&
+                 items[i].last_index == 2u + (uint64_t)round && items[i].slot >= 1 && items[i].slot < P;
+    }
+    rg_device_info info;
+    CHECK(rg_get_device_info(h, &info));
+    printf("device %s, %u CUs, wave%u, engine holds %llu bytes\n", info.arch, info.compute_units, info.wavefront,
+           (unsigned long long)info.engine_bytes);
+    rg_destroy(h);
     free(col);
     puts(ok ? "C_DRIVER_OK" : "C_DRIVER_FAILED");
     return ok ? 0 : 1;
