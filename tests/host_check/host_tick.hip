@@ -143,3 +143,46 @@ extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long st
     RG_DISPATCH_P(P, n = host_send<N>(st, ins, max_entries, flags, items, items_cap));
     return n;
 }
+
+// RgQuorum (the P x P ">=" bit matrix rank select) and the literal group-commit routine on caller-provided
+// matches / group ids: mci = ProgressTracker::maximal_committed_index over (incoming, outgoing) slot masks.
+// `raise_slot` >= 0: build the matrix on the OLD value of that slot, then apply the incremental update.
+template <int P>
+static u64 host_mci(const u64 *match, const u64 *gid, u32 incoming, u32 outgoing, int use_group_commit, int raise_slot,
+                    u64 old_value, int *used) {
+    u64 v[P], g[P];
+    for (int i = 0; i < P; i++) { v[i] = match[i]; g[i] = gid[i]; }
+    *used = 0;
+    if (use_group_commit) {
+        bool u = false;
+        const u64 r = rg_mci_group<P>(v, g, incoming, outgoing, u);
+        *used = u;
+        return r;
+    }
+    RgQuorum<P> q;
+    if (raise_slot >= 0 && raise_slot < P) {
+        u64 w[P];
+        for (int i = 0; i < P; i++) w[i] = v[i];
+        w[raise_slot] = old_value;
+        q.init(w);
+        switch (raise_slot) { // update<S> is a compile-time slot
+        case 0: if (P > 0) q.template update<0>(v); break;
+        case 1: if (P > 1) q.template update<(P > 1 ? 1 : 0)>(v); break;
+        case 2: if (P > 2) q.template update<(P > 2 ? 2 : 0)>(v); break;
+        case 3: if (P > 3) q.template update<(P > 3 ? 3 : 0)>(v); break;
+        case 4: if (P > 4) q.template update<(P > 4 ? 4 : 0)>(v); break;
+        case 5: if (P > 5) q.template update<(P > 5 ? 5 : 0)>(v); break;
+        case 6: if (P > 6) q.template update<(P > 6 ? 6 : 0)>(v); break;
+        default: if (P > 7) q.template update<(P > 7 ? 7 : 0)>(v); break;
+        }
+    } else {
+        q.init(v);
+    }
+    return q.mci(v, incoming, outgoing);
+}
+
+extern "C" int rg_host_check_mci(unsigned P, const u64 *match, const u64 *gid, unsigned incoming, unsigned outgoing,
+                                 int use_group_commit, int raise_slot, unsigned long old_value, u64 *mci, int *used) {
+    RG_DISPATCH_P(P, *mci = host_mci<N>(match, gid, incoming, outgoing, use_group_commit, raise_slot, old_value, used));
+    return 0;
+}

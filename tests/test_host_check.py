@@ -393,3 +393,69 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
             assert seen["full"] > 0, seen
         if max_entries in (1, 2) and cap > 1:
             assert seen["multi"] > 0, seen
+
+
+# ---- property tests (hypothesis) of the quorum arithmetic over the FULL u64 range --------------------------
+from hypothesis import given, settings, strategies as hst  # noqa: E402
+
+U64 = hst.one_of(hst.integers(0, (1 << 64) - 1), hst.sampled_from([0, 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 2, (1 << 64) - 1]),
+                 hst.integers(0, 6))
+
+
+def _mci_fn():
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_mci
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_ulong,
+                   C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    return fn
+
+
+def _oracle_joint(match, gid, incoming, outgoing, gc):
+    """ProgressTracker::maximal_committed_index through the oracle's majority routine (slot order = voter order)."""
+    res, used = [], []
+    for mask in (incoming, outgoing):
+        pairs = [(match[i], gid[i]) for i in range(len(match)) if (mask >> i) & 1]
+        if not pairs:
+            res.append(O.U64_MAX)  # empty config (majority.rs:71-75)
+            used.append(True)
+            continue
+        v, u = O.committed_index(pairs, gc)
+        res.append(v)
+        used.append(u)
+    return min(res), all(used)
+
+
+@settings(max_examples=400, deadline=None)
+@given(hst.integers(1, 8).flatmap(lambda p: hst.tuples(
+    hst.just(p), hst.lists(U64, min_size=p, max_size=p), hst.integers(0, (1 << p) - 1), hst.integers(0, (1 << p) - 1),
+    hst.integers(-1, p - 1), U64)))
+def test_quorum_bit_matrix_equals_sort_based_reference(case):
+    """RgQuorum (rank select on the >= bit matrix, with and without the incremental row/column update) ==
+    the reference's sort-based committed_index for arbitrary u64 matches and voter masks."""
+    P, match, incoming, outgoing, raise_slot, old = case
+    fn = _mci_fn()
+    m = (C.c_uint64 * P)(*match)
+    g = (C.c_uint64 * P)(*([0] * P))
+    if raise_slot >= 0:
+        old = min(old, match[raise_slot])  # matches only grow
+    out, used = C.c_uint64(0), C.c_int(0)
+    assert fn(P, m, g, incoming, outgoing, 0, raise_slot, old, C.byref(out), C.byref(used)) == 0
+    want, _ = _oracle_joint(match, [0] * P, incoming, outgoing, False)
+    assert out.value == want, (case, out.value, want)
+
+
+@settings(max_examples=400, deadline=None)
+@given(hst.integers(1, 8).flatmap(lambda p: hst.tuples(
+    hst.just(p), hst.lists(U64, min_size=p, max_size=p), hst.lists(hst.integers(0, 3), min_size=p, max_size=p),
+    hst.integers(0, (1 << p) - 1), hst.integers(0, (1 << p) - 1))))
+def test_group_commit_routine_equals_reference(case):
+    """rg_mci_group == majority.rs:99-123 (group commit) composed by joint.rs:47-51, value and flag."""
+    P, match, gid, incoming, outgoing = case
+    fn = _mci_fn()
+    out, used = C.c_uint64(0), C.c_int(0)
+    assert fn(P, (C.c_uint64 * P)(*match), (C.c_uint64 * P)(*gid), incoming, outgoing, 1, -1, 0, C.byref(out),
+              C.byref(used)) == 0
+    want, want_used = _oracle_joint(match, gid, incoming, outgoing, True)
+    assert out.value == want and bool(used.value) == want_used, (case, out.value, used.value, want, want_used)
