@@ -35,6 +35,9 @@
 static thread_local std::string g_last_error;
 
 static int rg_fail(int code, const char *fmt, ...) {
+    // HIP keeps the last error until somebody reads it: a failed hipMalloc must not resurface later as the
+    // "launch error" of an unrelated kernel (every launch site checks hipGetLastError)
+    (void)hipGetLastError();
     char buf[512];
     va_list ap;
     va_start(ap, fmt);

@@ -454,3 +454,23 @@ def test_device_info_is_queried_not_assumed(rg):
     cols = sum(eng.L.rg_column_bytes(eng.h, c) for c in range(17))
     assert cols <= info["engine_bytes"] <= cols + (64 << 10) + 4 * 5 * eng.stride * 8
     eng.close()
+
+
+def test_allocation_failures_are_reported_not_fatal(rg):
+    """A shard or an inflight window that does not fit in HBM comes back as RG_ERR_OUT_OF_MEMORY; the process and
+    the device stay usable."""
+    from raft_rs_amd.engine import EngineError, ERR
+    with pytest.raises(EngineError) as e:
+        rg.Engine(1 << 36, 8)  # 64 G groups x 8 peers: tens of terabytes of columns
+    assert e.value.code == ERR["OUT_OF_MEMORY"]
+    with pytest.raises(EngineError) as e:
+        rg.Engine(4_000_000, 8, max_inflight=65535)  # 16 TB of rings
+    assert e.value.code == ERR["OUT_OF_MEMORY"]
+    with pytest.raises(EngineError) as e:
+        rg.Engine(1000, 5, max_inflight=70000)
+    assert e.value.code == ERR["INVALID_ARG"]
+    eng = rg.Engine(1000, 5)  # still works
+    eng.workload_init(2)
+    eng.recompute()
+    eng.results()
+    eng.close()
