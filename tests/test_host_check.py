@@ -368,7 +368,10 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
     seen = {"items": 0, "multi": 0, "snap": 0, "full": 0}
     for t in range(ticks):
         cl.store_soa(st)
-        fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
+        if t % 5 == 4:  # arbitrary event bytes and values now and then
+            fuzz.garbage_msgs(rng, st, msgs)
+        else:
+            fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
         sendstage.prepare_msgs(msgs)
         host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
