@@ -192,6 +192,19 @@ void *rg_column_ptr(rg_engine *h, int column);
 int rg_checkpoint(rg_engine *h);
 int rg_restore(rg_engine *h);
 
+/* Sparse read-back of whole groups -- what Status / ProgressTracker::get hand out for ONE raft
+ * (src/status.rs:25-52, src/tracker.rs:261-287) without copying 40 MB columns: one record per requested group. */
+typedef struct {
+    uint64_t group;
+    uint64_t commit, term_lo, last_index; /* RaftLog.committed, first index of the leader's term, last_index */
+    uint32_t cfg, out;                    /* RG_CFG_* word, RG_OUT_* word of the last tick */
+    uint64_t match[RG_MAX_SLOTS], next[RG_MAX_SLOTS], pr_commit[RG_MAX_SLOTS];
+    uint64_t pend_snap[RG_MAX_SLOTS], pend_rs[RG_MAX_SLOTS];
+    uint8_t pflags[RG_MAX_SLOTS];         /* RG_PF_* per slot */
+    uint8_t inflights[RG_MAX_SLOTS];      /* Inflights.count per slot, saturated at 255 (0 without device Inflights) */
+} rg_group_status;
+int rg_read_groups(rg_engine *h, const uint64_t *groups, uint64_t n, rg_group_status *host_out);
+
 /* Sparse overwrite of Progress cells between ticks -- the send path and the other host-side
  * writers co-own these cells (Progress::update_state/become_snapshot/reset, heartbeat response,
  * unreachable: src/tracker/progress.rs:82-121,231-243; src/raft.rs:664-712,1791-1798,1945-1947). */

@@ -391,6 +391,40 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
     }
 }
 
+// Status read-back: one thread per requested group gathers its cells into one record.
+__global__ void k_read_groups(RgState st, const u64 *groups, u64 n, u32 P, const u32 *ins_meta, rg_group_status *out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 g = groups[i];
+    rg_group_status r;
+    memset(&r, 0, sizeof(r));
+    r.group = g;
+    if (g < st.G) {
+        r.commit = st.commit[g];
+        r.term_lo = st.lo[g];
+        r.last_index = st.hi[g];
+        r.cfg = st.cfg[g];
+        r.out = st.out[g];
+        const u64 row = st.pflags[g];
+        for (u32 p = 0; p < P; p++) {
+            const u64 o = (u64)p * st.stride + g;
+            r.match[p] = st.match[o];
+            r.next[p] = st.next[o];
+            r.pr_commit[p] = st.prc[o];
+            r.pend_snap[p] = st.psnap[o];
+            r.pend_rs[p] = st.prs[o];
+            r.pflags[p] = (u8)(row >> (8 * p));
+            if (ins_meta) {
+                const u32 c = ins_meta[o] >> 16;
+                r.inflights[p] = (u8)(c > 255u ? 255u : c);
+            }
+        }
+    } else {
+        r.group = ~0ULL; // no such group
+    }
+    out[i] = r;
+}
+
 __global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32 P, u32 *ins_meta) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -862,6 +896,29 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
     hipLaunchKernelGGL(k_write_cells, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->d_cells, (u64)n, h->P,
                        h->ins.meta);
     RG_HIP(hipStreamSynchronize(h->stream)); // the caller's array may be reused after return
+    return RG_OK;
+}
+
+extern "C" int rg_read_groups(rg_engine *h, const uint64_t *groups, uint64_t n, rg_group_status *host_out) {
+    if (!h || (n && (!groups || !host_out))) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_groups: bad argument");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    char *d = nullptr; // [n x u64 group ids | n x rg_group_status]
+    const size_t ids_b = rg_align(n * 8);
+    RG_HIP(hipMalloc(&d, ids_b + n * sizeof(rg_group_status)));
+    hipError_t e = hipMemcpyAsync(d, groups, n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_read_groups, dim3(rg_grid(n, 128)), dim3(128), 0, h->stream, h->st, (const u64 *)d, (u64)n, h->P,
+                           (const u32 *)h->ins.meta, reinterpret_cast<rg_group_status *>(d + ids_b));
+        e = hipMemcpyAsync(host_out, d + ids_b, n * sizeof(rg_group_status), hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_read_groups: %s", hipGetErrorString(e));
+    for (u64 i = 0; i < n; i++)
+        if (host_out[i].group == ~0ULL)
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_read_groups: group %llu does not exist (engine holds %llu)",
+                           (unsigned long long)groups[i], (unsigned long long)h->G);
     return RG_OK;
 }
 

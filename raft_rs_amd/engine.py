@@ -74,6 +74,13 @@ class _Config(C.Structure):
                 ("variant", C.c_uint32), ("max_inflight", C.c_uint32)]
 
 
+GROUP_STATUS_DTYPE = np.dtype([("group", "<u8"), ("commit", "<u8"), ("term_lo", "<u8"), ("last_index", "<u8"),
+                               ("cfg", "<u4"), ("out", "<u4"), ("match", "<u8", 8), ("next", "<u8", 8),
+                               ("pr_commit", "<u8", 8), ("pend_snap", "<u8", 8), ("pend_rs", "<u8", 8),
+                               ("pflags", "u1", 8), ("inflights", "u1", 8)])
+assert GROUP_STATUS_DTYPE.itemsize == 376
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("wavefront", C.c_uint32),
                 ("lds_per_workgroup", C.c_uint64), ("hbm_bytes", C.c_uint64), ("l2_bytes", C.c_uint64),
@@ -144,6 +151,7 @@ SYMBOLS = {
     "rg_column_ptr": (_vp, [_vp, _i]),
     "rg_checkpoint": (_i, [_vp]),
     "rg_restore": (_i, [_vp]),
+    "rg_read_groups": (_i, [_vp, _vp, _u64, _vp]),
     "rg_write_cells": (_i, [_vp, C.POINTER(CellWrite), _u64]),
     "rg_set_config": (_i, [_vp, _u64, C.c_uint32]),
     "rg_tick": (_i, [_vp, C.POINTER(_Msgs)]),
@@ -322,6 +330,14 @@ class Engine:
         for col in range(COL.OUT + 1):
             st[COL.NAMES[col]] = self.read_column(col)
         return st
+
+    def read_groups(self, groups):
+        """Status of whole groups (all Progress cells, commit, log range, cfg, last result word) as a
+        GROUP_STATUS_DTYPE array -- the sparse counterpart of read_state()."""
+        ids = np.ascontiguousarray(groups, dtype=np.uint64)
+        out = np.zeros(len(ids), dtype=GROUP_STATUS_DTYPE)
+        self._check(self.L.rg_read_groups(self.h, ids.ctypes.data, len(ids), out.ctypes.data))
+        return out
 
     def checkpoint(self):
         self._check(self.L.rg_checkpoint(self.h))

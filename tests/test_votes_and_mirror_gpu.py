@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import fuzz
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -159,4 +160,31 @@ def test_heartbeat_commits_match_oracle(rg):
         sel = ((present >> p) & 1) == 1
         assert (hb[p, :G][sel] == want[sel]).all()
         assert (hb[p, :G][~sel] == 0).all()
+    eng.close()
+
+
+def test_read_groups_is_the_sparse_status(rg):
+    """rg_read_groups == the same cells out of the bulk columns (Status / ProgressTracker::get for single rafts)."""
+    rng = np.random.default_rng(12)
+    G, P = 7000, 5
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st)
+    eng = rg.Engine(G, P)
+    eng.load_state(st)
+    eng.recompute()
+    full = eng.read_state()
+    ids = rng.choice(G, size=300, replace=False)
+    s = eng.read_groups(ids)
+    assert (s["group"] == ids).all()
+    for name, col in (("commit", "commit"), ("term_lo", "term_lo"), ("last_index", "term_hi"), ("cfg", "cfg"), ("out", "out")):
+        assert (s[name] == full[col][ids]).all(), name
+    for name in ("match", "next", "pr_commit", "pend_snap", "pend_rs"):
+        assert (s[name][:, :P] == full[name][:, ids].T).all(), name
+        assert (s[name][:, P:] == 0).all()
+    assert (s["pflags"][:, :P] == full["pflags"][ids, :P]).all() and (s["inflights"] == 0).all()
+    with pytest.raises(rg.EngineError) as e:
+        eng.read_groups([3, G])
+    assert e.value.code == -1
+    assert len(eng.read_groups([])) == 0
     eng.close()
