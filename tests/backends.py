@@ -42,6 +42,16 @@ class OracleLeader:
         word = (1 if o.commit_changed else 0) | (int(o.send_append) << (8 + s)) | (int(o.send_more) << (16 + s))
         return self._send(word)
 
+    def reject(self, from_, index, reject_hint=0, commit=0):
+        """step(MsgAppendResponse{reject}) followed by its sends."""
+        o = self.cl.step(0, from_, index, commit, True, reject_hint, ins_full=-1)
+        return self._send(int(o.send_append) << (8 + from_ - 1))
+
+    def become_snapshot(self, pid, snapshot_index):
+        """The host's half of a snapshot send: Progress::become_snapshot (progress.rs:117-121)."""
+        import ctypes as C
+        O.lib().ro_progress_become_snapshot(C.byref(self.cl.pr(0, pid)), snapshot_index)
+
     def heartbeat_response(self, from_, commit=0):
         o = O.Out()
         O.lib().ro_handle_heartbeat_response(self.cl.h, 0, from_, commit, -1, o)
@@ -283,6 +293,20 @@ class EngineLeader:
         self.msgs.m_flags[0, s] = self.rg.MF.VALID
         self._tick()
         return self._send()
+
+    def reject(self, from_, index, reject_hint=0, commit=0):
+        s = from_ - 1
+        self.msgs.m_index[s, 0] = index
+        self.msgs.m_commit[s, 0] = commit
+        self.msgs.m_hint[s, 0] = reject_hint
+        self.msgs.m_flags[0, s] = self.rg.MF.VALID | self.rg.MF.REJECT
+        self._tick()
+        return self._send()
+
+    def become_snapshot(self, pid, snapshot_index):
+        f = int(self.eng.read_column(self.rg.COL.PFLAGS)[0, pid - 1])
+        self.eng.write_cells([{"group": 0, "slot": pid - 1, "pend_snap": snapshot_index,
+                               "pflags": (f & ~0x7) | SNAPSHOT}])
 
     def heartbeat_response(self, from_, commit=0):
         s = from_ - 1

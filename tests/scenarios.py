@@ -347,6 +347,23 @@ def scenario_leader_increase_next(B):
         assert ld.progress(2)["next"] == wnext, f"{state}: next = {ld.progress(2)['next']}, want {wnext}"
 
 
+def scenario_sending_snapshot_set_pending_snapshot(B):
+    """test_raft_snap.rs:27-48 test_sending_snapshot_set_pending_snapshot + :51-65
+    test_pending_snapshot_pause_replication: a reject sends next_idx below first_index, the entries are compacted
+    away, so the append turns into a snapshot (decided on the device, fetched by the host, which applies
+    become_snapshot(11)); replication to that peer then pauses."""
+    ld = B(1, 1, [1, 2], log=[(1, 12)], committed=11, dummy=(11, 11), next_idx=12, max_inflight=256)
+    ld.set_progress(1, match=12, next=13, state=REPLICATE)
+    ld.set_progress(2, match=0, next=12, state=PROBE, paused=False)  # next = first_index: node 2 needs a snapshot
+    ms = ld.reject(2, 11)
+    assert ms == [(2, 2, 0, 0)], f"want one snapshot decision for peer 2, got {ms}"
+    assert ld.progress(2)["next"] == 1 and ld.progress(2)["recent_active"]
+    ld.become_snapshot(2, 11)
+    pr = ld.progress(2)
+    assert pr["pending_snapshot"] == 11 and pr["state"] == SNAPSHOT
+    assert ld.propose() == [], "a pending snapshot pauses replication"
+
+
 def _flow_leader(B, cap):
     """new_test_raft(1, [1, 2], ..) after become_candidate + become_leader (noop at index 1), peer 2 forced
     into Replicate (test_raft_flow_control.rs:24-31)."""
@@ -493,7 +510,7 @@ def scenario_skip_bcast_commit(B):
     assert ld.ack(2, 5) == [] and ld.committed() == 5
 
 
-FLOW = [scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+FLOW = [scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
