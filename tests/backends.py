@@ -42,9 +42,9 @@ class OracleLeader:
         word = (1 if o.commit_changed else 0) | (int(o.send_append) << (8 + s)) | (int(o.send_more) << (16 + s))
         return self._send(word)
 
-    def reject(self, from_, index, reject_hint=0, commit=0):
+    def reject(self, from_, index, reject_hint=0, commit=0, request_snapshot=0):
         """step(MsgAppendResponse{reject}) followed by its sends."""
-        o = self.cl.step(0, from_, index, commit, True, reject_hint, ins_full=-1)
+        o = self.cl.step(0, from_, index, commit, True, reject_hint, request_snapshot, ins_full=-1)
         return self._send(int(o.send_append) << (8 + from_ - 1))
 
     def become_snapshot(self, pid, snapshot_index):
@@ -294,12 +294,13 @@ class EngineLeader:
         self._tick()
         return self._send()
 
-    def reject(self, from_, index, reject_hint=0, commit=0):
+    def reject(self, from_, index, reject_hint=0, commit=0, request_snapshot=0):
         s = from_ - 1
         self.msgs.m_index[s, 0] = index
         self.msgs.m_commit[s, 0] = commit
         self.msgs.m_hint[s, 0] = reject_hint
-        self.msgs.m_flags[0, s] = self.rg.MF.VALID | self.rg.MF.REJECT
+        self.msgs.m_rs[s, 0] = request_snapshot
+        self.msgs.m_flags[0, s] = self.rg.MF.VALID | self.rg.MF.REJECT | (self.rg.MF.HAS_RS if request_snapshot else 0)
         self._tick()
         return self._send()
 

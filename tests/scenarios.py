@@ -364,6 +364,27 @@ def scenario_sending_snapshot_set_pending_snapshot(B):
     assert ld.propose() == [], "a pending snapshot pauses replication"
 
 
+def scenario_request_snapshot_through_send_path(B):
+    """test_raft_snap.rs:155-233 test_request_snapshot with the send decisions made by the stage: the in-order
+    request flips Replicate -> Probe, the re-send becomes a snapshot decision, the host applies become_snapshot;
+    acks and heartbeats do not leave Snapshot."""
+    ld = B(1, 1, [1, 2], log=[(1, 12)], committed=11, dummy=(11, 11), next_idx=12, max_inflight=256)
+    ld.set_progress(1, match=11, next=13, state=REPLICATE)  # snapshot at 11 persisted, the noop (12) not yet
+    ld.set_progress(2, match=0, next=12, state=PROBE, paused=False)
+    assert ld.ack(2, 11) == [(2, 1, 11, 1)] and ld.progress(2)["state"] == REPLICATE  # advance matched
+    assert ld.reject(2, 9, request_snapshot=11) == [], "out of order request snapshot messages are ignored"
+    assert ld.progress(2)["state"] == REPLICATE
+    ms = ld.reject(2, 11, request_snapshot=11)
+    assert ms == [(2, 2, 11, 0)], f"want the snapshot decision, got {ms}"
+    ld.become_snapshot(2, 11)  # the host fetched the snapshot (index 11 = request_snapshot_idx)
+    pr = ld.progress(2)
+    assert (pr["state"], pr["pending_snapshot"], pr["next"]) == (SNAPSHOT, 11, 12)
+    assert ld.ack(2, 11) == [], "append responses do not set the state from snapshot to probe"
+    pr = ld.progress(2)
+    assert (pr["state"], pr["pending_snapshot"], pr["next"]) == (SNAPSHOT, 11, 12)
+    assert ld.heartbeat_response(2) == [] and ld.progress(2)["state"] == SNAPSHOT
+
+
 def _flow_leader(B, cap):
     """new_test_raft(1, [1, 2], ..) after become_candidate + become_leader (noop at index 1), peer 2 forced
     into Replicate (test_raft_flow_control.rs:24-31)."""
@@ -510,7 +531,7 @@ def scenario_skip_bcast_commit(B):
     assert ld.ack(2, 5) == [] and ld.committed() == 5
 
 
-FLOW = [scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+FLOW = [scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
