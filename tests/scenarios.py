@@ -385,6 +385,25 @@ def scenario_request_snapshot_through_send_path(B):
     assert ld.heartbeat_response(2) == [] and ld.progress(2)["state"] == SNAPSHOT
 
 
+def scenario_request_snapshot_unavailable(B):
+    """test_raft.rs:4903-4965 test_request_snapshot_unavailable: while the storage cannot produce the snapshot
+    (SnapshotTemporarilyUnavailable) the peer stays in Probe and every repeated request -- never stale, even though
+    reject != next - 1 -- yields the snapshot decision again; once the host has the snapshot it applies
+    become_snapshot."""
+    ld = B(1, 1, [1, 2], log=[(1, i) for i in range(1, 15)], committed=14, next_idx=15, max_inflight=256)
+    ld.set_progress(1, match=14, next=15, state=REPLICATE)
+    ld.set_progress(2, match=14, next=15, state=REPLICATE, recent_active=True)
+    for attempt in range(3):
+        ms = ld.reject(2, 14, request_snapshot=14)
+        assert ms == [(2, 2, 14, 0)], (attempt, ms)
+        pr = ld.progress(2)
+        assert pr["state"] == PROBE and pr["pending_request_snapshot"] == 14 and pr["next"] == 15, (attempt, pr)
+        # attempts 0 and 1: the host's storage answers SnapshotTemporarilyUnavailable -> nothing is applied
+    ld.become_snapshot(2, 14)
+    pr = ld.progress(2)
+    assert pr["state"] == SNAPSHOT and pr["pending_snapshot"] == 14
+
+
 def _flow_leader(B, cap):
     """new_test_raft(1, [1, 2], ..) after become_candidate + become_leader (noop at index 1), peer 2 forced
     into Replicate (test_raft_flow_control.rs:24-31)."""
@@ -531,7 +550,7 @@ def scenario_skip_bcast_commit(B):
     assert ld.ack(2, 5) == [] and ld.committed() == 5
 
 
-FLOW = [scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+FLOW = [scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
