@@ -281,7 +281,7 @@ typedef struct {
     uint64_t reject_hint;      /* Message.reject_hint (resolved through find_conflict_by_term by the caller when log_term>0) */
     uint64_t request_snapshot; /* Message.request_snapshot */
     uint8_t reject;            /* Message.reject */
-    uint8_t ins_full;          /* caller's Inflights::full() for `from` */
+    uint8_t ins_full;          /* caller's Inflights::full() for `from` (leave 0 when the engine holds the Inflights) */
     uint8_t pad[6];
     uint64_t log_term;         /* Message.log_term: if > 0 on a reject, reject_hint is passed through
                                   find_conflict_by_term ON THE DEVICE (needs RG_COL_RUN_*); 0 = reject_hint is final */
@@ -306,13 +306,14 @@ int rg_flush(rg_engine *h);
  * Call once after every tick. For every group it (1) applies the tick's Inflights effects -- ins.free_to(m.index)
  * for an accepted ack in Replicate, ins.free_first_one() for a heartbeat response on a full window, ins.reset()
  * when the Progress left Replicate -- and (2) serves the tick's send requests in slot order: bcast_append when the
- * commit index moved (RG_OUT_CHANGED) or the leader appended (RG_OUT_APPENDED), send_append(from) and the `while maybe_send_append(from, false)` loop. Each
- * message sent applies Progress::update_state(last) (Replicate: next = last+1, ins.add(last); Probe: paused) in
+ * commit index moved (RG_OUT_CHANGED) or the leader appended (RG_OUT_APPENDED), send_append(from) and the
+ * `while maybe_send_append(from, false)` loop. Each message sent applies Progress::update_state(last) (Replicate: next = last+1, ins.add(last); Probe: paused) in
  * place, so the host writes no RG_MF_SENT events in this mode. Messages are NOT built: the result is one work item
  * per peer that has something to send. `max_entries_per_msg` models Config::max_size_per_msg for equal-sized
  * entries (util::limit_size keeps at least one entry), 0 = NO_LIMIT. A peer whose entries are compacted away
  * (next_idx < first_index = RG_COL_DUMMY_INDEX + 1) or that has a pending snapshot request yields
- * RG_SEND_SNAPSHOT (if recent_active, raft.rs:665-672); the host then fetches the snapshot and applies
+ * RG_SEND_SNAPSHOT (if recent_active, raft.rs:665-672; last_index then carries the requested snapshot index, 0 =
+ * any); the host then fetches the snapshot and applies
  * Progress::become_snapshot with rg_write_cells -- the device leaves that Progress untouched.
  * Sends requested by message k of a tick happen after the whole tick; flush after every step where
  * that matters. Not available for fused launches. Asynchronous. */
