@@ -1172,18 +1172,21 @@ static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_log
                            h->P, h->rhint, (const u64 *)h->list, (const u32 *)h->counters);
     }
     u64 *mf = (u64 *)h->staged.mflags;
+    RgListOut lo; // the tick gathers its own results (one launch less than a separate gather kernel)
+    lo.rl = h->res_list;
+    lo.rc = h->res_commit;
+    lo.ro = h->res_out;
+    lo.packed = packed;
     switch (h->P) {
-    case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    case 2: rg_launch_tick_list_t<2>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    case 3: rg_launch_tick_list_t<3>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    case 4: rg_launch_tick_list_t<4>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    case 5: rg_launch_tick_list_t<5>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    case 6: rg_launch_tick_list_t<6>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    case 7: rg_launch_tick_list_t<7>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
-    default: rg_launch_tick_list_t<8>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf); break;
+    case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    case 2: rg_launch_tick_list_t<2>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    case 3: rg_launch_tick_list_t<3>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    case 4: rg_launch_tick_list_t<4>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    case 5: rg_launch_tick_list_t<5>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    case 6: rg_launch_tick_list_t<6>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    case 7: rg_launch_tick_list_t<7>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
+    default: rg_launch_tick_list_t<8>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
     }
-    hipLaunchKernelGGL(k_gather_results, dim3(rg_grid(upper, 256)), dim3(256), 0, h->stream, h->list, h->counters,
-                       (const u64 *)h->st.commit, (const u32 *)h->st.out, h->res_list, h->res_commit, h->res_out, packed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "sparse tick: launch failed: %s", hipGetErrorString(e));
     return RG_OK;

@@ -95,9 +95,22 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st,
 // Sparse variant: lane i owns group list[i] (the groups an ingest touched). Same arithmetic; accesses
 // are gathers instead of streams, and the consumed event row is cleared so the message columns are
 // all-zero again outside the touched set.
+// The results of the listed groups are gathered on the way out (compact arrays for later device consumers and,
+// when `packed` is given, 24-byte records behind a {groups, duplicates} header for ONE D2H copy).
+struct RgListOut {
+    u64 *rl, *rc; // [n] group, commit
+    u32 *ro;      // [n] result word
+    char *packed; // nullable: u32 n, u32 n_duplicates, 8 B pad, then {u64 group, u64 commit, u32 out, u32 pad}[n]
+};
+
 template <int P, bool GC>
-__global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw) {
+__global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw,
+                                           RgListOut lo) {
     const u64 i = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (lo.packed && i == 0) {
+        reinterpret_cast<u32 *>(lo.packed)[0] = n_ptr[0];
+        reinterpret_cast<u32 *>(lo.packed)[1] = n_ptr[1];
+    }
     if (i >= *n_ptr) return;
     const u64 g = list[i];
     RgGroup<P> r;
@@ -105,6 +118,15 @@ __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *lis
     rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
     rg_store_group<P>(r, st, g);
     mflags_rw[g] = 0;
+    lo.rl[i] = g;
+    lo.rc[i] = r.commit;
+    lo.ro[i] = r.out;
+    if (lo.packed) {
+        u64 *rec = reinterpret_cast<u64 *>(lo.packed + 16 + i * 24);
+        rec[0] = g;
+        rec[1] = r.commit;
+        rec[2] = (u64)r.out;
+    }
 }
 
 // Temporal fusion: T consecutive ticks of a group in ONE launch. A group's tick t+1 depends only on
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
-                           const u32 *n_ptr, u64 n_upper, u64 *mflags_rw);
+                           const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo);
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc);
 
 #ifdef RG_TICK_INSTANTIATE
@@ -264,10 +286,10 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
 }
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
-                           const u32 *n_ptr, u64 n_upper, u64 *mflags_rw) {
+                           const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo) {
     const dim3 grid(rg_grid_for(n_upper, RG_BLOCK)), block(RG_BLOCK);
-    if (gc) hipLaunchKernelGGL((k_tick_list<P, true>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw);
-    else hipLaunchKernelGGL((k_tick_list<P, false>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw);
+    if (gc) hipLaunchKernelGGL((k_tick_list<P, true>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
+    else hipLaunchKernelGGL((k_tick_list<P, false>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
 }
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
@@ -276,27 +298,27 @@ template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &
 }
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *);
+extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 #endif
