@@ -267,6 +267,11 @@ int rg_msg_stats(rg_engine *h, const uint8_t *dev_m_flags, uint64_t counts[4]);
 /* yes/no: u8[G] slot bitmasks of recorded votes (record_vote keeps the first, tracker.rs:307-309);
  * result u8[G]: 0 Pending, 1 Lost, 2 Won. Host buffers. */
 int rg_vote_result(rg_engine *h, const uint8_t *host_yes, const uint8_t *host_no, uint8_t *host_result);
+/* ProgressTracker::tally_votes (src/tracker.rs:313-333): additionally the number of granted / rejected votes among
+ * the current voters (incoming or outgoing; votes of ids that left the configuration do not count) -> u8[G] each.
+ * has_quorum(set) (tracker.rs:367-372) is rg_vote_result(yes = set, no = 0) == 2. */
+int rg_tally_votes(rg_engine *h, const uint8_t *host_yes, const uint8_t *host_no, uint8_t *host_granted,
+                   uint8_t *host_rejected, uint8_t *host_result);
 /* quorum_recently_active for every group: result u8[G] (1 = active quorum); clears recent_active of
  * every other slot and sets the self slot's, exactly as tracker.rs:346-361. */
 int rg_quorum_recently_active(rg_engine *h, uint8_t *host_result);

@@ -645,6 +645,22 @@ int ro_group_vote_result(ro_cluster *c, size_t g, const uint64_t *ids, const uin
     return ro_joint_vote_result(r[0], r[1]);
 }
 
+int ro_group_tally_votes(ro_cluster *c, size_t g, const uint64_t *ids, const uint8_t *votes, size_t n,
+                         size_t *granted, size_t *rejected) { /* tracker.rs:313-333 */
+    ro_group *gr = &c->g[g];
+    *granted = *rejected = 0;
+    for (size_t j = 0; j < n; j++) {
+        if (votes[j] == 0) continue; /* no vote recorded for this id */
+        bool voter = false;          /* self.conf.voters.contains(id): incoming or outgoing (joint.rs:69-72) */
+        for (size_t i = 0; i < gr->incoming.len; i++) voter = voter || gr->incoming.ids[i] == ids[j];
+        for (size_t i = 0; i < gr->outgoing.len; i++) voter = voter || gr->outgoing.ids[i] == ids[j];
+        if (!voter) continue;
+        if (votes[j] == 2) (*granted)++;
+        else (*rejected)++;
+    }
+    return ro_group_vote_result(c, g, ids, votes, n);
+}
+
 bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of) {
     /* tracker.rs:346-361 + has_quorum :367-372 */
     ro_group *gr = &c->g[g];

@@ -177,13 +177,19 @@ RG_D u32 rg_vote_joint(u32 i, u32 o) {
     return 0u;
 }
 
-__global__ __launch_bounds__(RG_BLOCK) void k_vote(RgState st, const u8 *yes, const u8 *no, u8 *res) {
+__global__ __launch_bounds__(RG_BLOCK) void k_vote(RgState st, const u8 *yes, const u8 *no, u8 *res, u8 *granted,
+                                                   u8 *rejected) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
     const u32 cfg = st.cfg[g];
     const u32 y = yes[g], n = no[g] & ~y; // record_vote keeps the first vote (tracker.rs:307-309): yes wins a clash
     res[g] = (u8)rg_vote_joint(rg_vote_majority(RG_CFG_INCOMING(cfg), y, n),
                                rg_vote_majority(RG_CFG_OUTGOING(cfg), y, n));
+    if (granted) { // tally_votes: votes of current voters only (tracker.rs:319-330)
+        const u32 voters = RG_CFG_INCOMING(cfg) | RG_CFG_OUTGOING(cfg);
+        granted[g] = (u8)__builtin_popcount(y & voters);
+        rejected[g] = (u8)__builtin_popcount(n & voters);
+    }
 }
 
 __global__ __launch_bounds__(RG_BLOCK) void k_quorum_active(RgState st, u8 *res) {
@@ -1522,8 +1528,25 @@ extern "C" int rg_vote_result(rg_engine *h, const uint8_t *yes, const uint8_t *n
     RG_HIP(hipMemcpyAsync(d, yes, h->G, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(d + h->stride, no, h->G, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_vote, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, d,
-                       d + h->stride, d + 2 * h->stride);
+                       d + h->stride, d + 2 * h->stride, (u8 *)nullptr, (u8 *)nullptr);
     RG_HIP(hipMemcpyAsync(result, d + 2 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_tally_votes(rg_engine *h, const uint8_t *yes, const uint8_t *no, uint8_t *granted, uint8_t *rejected,
+                              uint8_t *result) {
+    if (!h || !yes || !no || !granted || !rejected || !result)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tally_votes: bad argument");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    u8 *d = reinterpret_cast<u8 *>(h->d_scratch); // 8*stride bytes: yes | no | result | granted | rejected
+    RG_HIP(hipMemcpyAsync(d, yes, h->G, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(d + h->stride, no, h->G, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_vote, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, d,
+                       d + h->stride, d + 2 * h->stride, d + 3 * h->stride, d + 4 * h->stride);
+    RG_HIP(hipMemcpyAsync(result, d + 2 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipMemcpyAsync(granted, d + 3 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipMemcpyAsync(rejected, d + 4 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }

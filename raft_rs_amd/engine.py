@@ -178,6 +178,7 @@ SYMBOLS = {
     "rg_read_inflights": (_i, [_vp, _vp, _vp]),
     "rg_load_inflights": (_i, [_vp, _vp, _vp]),
     "rg_vote_result": (_i, [_vp, _vp, _vp, _vp]),
+    "rg_tally_votes": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "rg_quorum_recently_active": (_i, [_vp, _vp]),
     "rg_set_peers": (_i, [_vp, _u64, C.POINTER(_u64), C.c_uint32, _u64]),
     "rg_step": (_i, [_vp, _u64, C.POINTER(AppendResponse)]),
@@ -503,6 +504,15 @@ class Engine:
         res = np.empty(self.n_groups, dtype=np.uint8)
         self._check(self.L.rg_vote_result(self.h, yes.ctypes.data, no.ctypes.data, res.ctypes.data))
         return res
+
+    def tally_votes(self, yes, no):
+        """ProgressTracker::tally_votes: (granted, rejected, result) per group."""
+        yes = np.ascontiguousarray(yes, dtype=np.uint8)
+        no = np.ascontiguousarray(no, dtype=np.uint8)
+        g, r, res = (np.empty(self.n_groups, dtype=np.uint8) for _ in range(3))
+        self._check(self.L.rg_tally_votes(self.h, yes.ctypes.data, no.ctypes.data, g.ctypes.data, r.ctypes.data,
+                                          res.ctypes.data))
+        return g, r, res
 
     def quorum_recently_active(self):
         res = np.empty(self.n_groups, dtype=np.uint8)

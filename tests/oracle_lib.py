@@ -130,6 +130,7 @@ def lib():
         "ro_heartbeat_commit": (u64, [vp, sz, u64]),
         "ro_group_vote_result": (C.c_int, [vp, sz, C.POINTER(u64), C.POINTER(C.c_uint8), sz]),
         "ro_quorum_recently_active": (C.c_bool, [vp, sz, u64]),
+        "ro_group_tally_votes": (C.c_int, [vp, sz, C.POINTER(u64), C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(sz)]),
         "ro_load_soa": (C.c_int, [vp, C.POINTER(SoaState), u64, sz]),
         "ro_store_soa": (C.c_int, [vp, C.POINTER(SoaState)]),
         "ro_tick_soa": (u64, [vp, C.POINTER(SoaMsgs), vp, sz, sz]),

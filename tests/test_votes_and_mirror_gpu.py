@@ -188,3 +188,35 @@ def test_read_groups_is_the_sparse_status(rg):
     assert e.value.code == -1
     assert len(eng.read_groups([])) == 0
     eng.close()
+
+
+def test_tally_votes_matches_oracle(rg):
+    """ProgressTracker::tally_votes: granted / rejected count the votes of current voters only (learners and ids
+    that left the configuration do not count), the result is vote_result; has_quorum(set) = vote_result(set, 0)."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    G, P = 3000, 7
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P, learner_frac=0.5)
+    fuzz.random_state(rng, st)
+    eng = rg.Engine(G, P)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=3)
+    yes = rng.integers(0, 1 << P, size=G, dtype=np.uint8)
+    no = rng.integers(0, 1 << P, size=G, dtype=np.uint8)
+    granted, rejected, res = eng.tally_votes(yes, no)
+    assert (res == eng.vote_result(yes, no)).all()
+    L = O.lib()
+    for g in range(G):
+        y, n = int(yes[g]), int(no[g]) & ~int(yes[g])  # record_vote keeps the first vote
+        ids = [p + 1 for p in range(P) if ((y | n) >> p) & 1]
+        votes = [2 if (y >> (i - 1)) & 1 else 1 for i in ids]
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        want = L.ro_group_tally_votes(cl.h, g, O.u64arr(ids or [0]), (C.c_uint8 * max(1, len(ids)))(*votes), len(ids),
+                                      C.byref(a), C.byref(b))
+        assert (int(granted[g]), int(rejected[g]), int(res[g])) == (a.value, b.value, want), g
+    # has_quorum(set)
+    has = eng.vote_result(yes, np.zeros(G, dtype=np.uint8)) == 2
+    assert has.any() and not has.all()
+    eng.close()
