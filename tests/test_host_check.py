@@ -399,7 +399,7 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
 
 
 # ---- property tests (hypothesis) of the quorum arithmetic over the FULL u64 range --------------------------
-from hypothesis import given, settings, strategies as hst  # noqa: E402
+from hypothesis import HealthCheck, given, settings, strategies as hst  # noqa: E402
 
 U64 = hst.one_of(hst.integers(0, (1 << 64) - 1), hst.sampled_from([0, 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 2, (1 << 64) - 1]),
                  hst.integers(0, 6))
@@ -430,7 +430,7 @@ def _oracle_joint(match, gid, incoming, outgoing, gc):
     return min(res), all(used)
 
 
-@settings(max_examples=400, deadline=None)
+@settings(max_examples=400, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(hst.integers(1, 8).flatmap(lambda p: hst.tuples(
     hst.just(p), hst.lists(U64, min_size=p, max_size=p), hst.integers(0, (1 << p) - 1), hst.integers(0, (1 << p) - 1),
     hst.integers(-1, p - 1), U64)))
@@ -449,7 +449,7 @@ def test_quorum_bit_matrix_equals_sort_based_reference(case):
     assert out.value == want, (case, out.value, want)
 
 
-@settings(max_examples=400, deadline=None)
+@settings(max_examples=400, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(hst.integers(1, 8).flatmap(lambda p: hst.tuples(
     hst.just(p), hst.lists(U64, min_size=p, max_size=p), hst.lists(hst.integers(0, 3), min_size=p, max_size=p),
     hst.integers(0, (1 << p) - 1), hst.integers(0, (1 << p) - 1))))
