@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--groups G] [--slots P] [--workload 2|3|5]
                     [--fuse T] [--split S] [--variant 0|2] [--publish-every E] [--one-engine] [--no-cpu-baseline]
+                    [--inflights CAP]
 
 One "step" = one tick of the hot path over every raft group of the shard: apply each group's
 AppendResponse slots (Raft::handle_append_response semantics) and re-evaluate + gate the commit

@@ -65,3 +65,20 @@ def test_host_generator_is_deterministic_and_shardable():
     assert (a["match"][:, 256:512] == b["match"][:, :256]).all()
     assert (a["commit"][256:512] == b["commit"][:256]).all()
     assert (a["cfg"][256:512] == b["cfg"][:256]).all()
+
+
+def test_algorithmic_bytes_is_the_survey_formula():
+    """B(P, A, R) = 9 P + 58 A + 8 R + 37; the table's 314 / 448 / 180 B per evaluation."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_bytes(1, 5, 4, 0) == 314
+    assert bench.algorithmic_bytes(1, 7, 6, 0) == 448
+    assert bench.algorithmic_bytes(1, 3, 2, 0) == 180
+    assert bench.algorithmic_bytes(1, 5, 4, 1) == 322
+    # summed over a tick: G groups with S slots, A messages, R rejects in total
+    assert bench.algorithmic_bytes(1000, 5000, 4800, 10) == 9 * 5000 + 58 * 4800 + 8 * 10 + 37 * 1000
+    assert bench.HBM_PEAK_GBS == 8000.0
