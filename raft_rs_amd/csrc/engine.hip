@@ -454,6 +454,23 @@ __global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32
     if (c.field_mask & (1u << RG_COL_PFLAGS)) reinterpret_cast<u8 *>(st.pflags)[c.group * 8 + c.slot] = c.pflags;
 }
 
+// RG_PF_INS_FULL is engine-owned: Inflights::full() of a Replicate peer's device-side ring. Re-derived from the
+// window counts whenever the host loads the windows or the flag column wholesale (rg_load_inflights,
+// rg_load_column(RG_COL_PFLAGS)), so the next tick's is_paused() (progress.rs:210-216) sees the loaded window.
+__global__ __launch_bounds__(RG_BLOCK) void k_fix_ins_full(RgState st, RgIns ins, u32 P) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    const u64 row0 = st.pflags[g];
+    u64 row = row0;
+    for (u32 p = 0; p < P; p++) {
+        const u32 pb = (u32)(row >> (8 * p)) & 0xffu;
+        const bool full = (pb & RG_PF_STATE_MASK) == RG_STATE_REPLICATE && (ins.meta[(u64)p * st.stride + g] >> 16) == ins.cap;
+        const u32 nb = (pb & ~RG_PF_INS_FULL) | (full ? RG_PF_INS_FULL : 0u);
+        row = (row & ~(0xffULL << (8 * p))) | ((u64)nb << (8 * p));
+    }
+    if (row != row0) st.pflags[g] = row;
+}
+
 __global__ __launch_bounds__(RG_BLOCK) void k_count_out(const u32 *out, u64 G, u64 *counts) {
     u64 ch = 0, fl = 0;
     for (u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * RG_BLOCK) {
@@ -539,6 +556,7 @@ struct rg_engine {
     RgState st;
     RgMsgs staged;    // views into msg_arena
     bool ticked;
+    u64 tick_launches; // ticks enqueued so far (rg_flush: did a failed flush already change device state?)
     // sparse path (rg_ingest / rg_tick_ingested)
     char *sparse_arena;       // gmark | list | res_list | res_commit | res_out | counters
     u32 *gmark, *counters, *res_out;
@@ -653,6 +671,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->ckpt = nullptr;
     h->msg_arena = nullptr;
     h->ticked = false;
+    h->tick_launches = 0;
     h->sparse_arena = nullptr;
     h->d_records = nullptr;
     h->d_records_cap = 0;
@@ -823,6 +842,9 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
     }
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(rg_col(h, c), src, bytes, hipMemcpyHostToDevice, h->stream));
+    if (c == RG_COL_PFLAGS && h->ins_arena) // the FULL bit is the engine's: re-derive it from the windows
+        hipLaunchKernelGGL(k_fix_ins_full, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
+                           h->st, h->ins, h->P);
     RG_HIP(hipStreamSynchronize(h->stream));
     if (c == RG_COL_CFG) {
         h->host_cfg_valid = false;
@@ -944,7 +966,26 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
 // ------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------
+static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, const u64 *list, u64 n,
+                           const u32 *n_ptr);
+#define RG_SEND_EFFECTS_ONLY 0x80000000u /* internal: apply the tick's Inflights effects, serve no send request */
+
+// Device Inflights: a tick's result word carries free_to / free_first_one / left-Replicate effects for the rings. If
+// the host skipped rg_send_appends, apply those effects (and nothing else: the send requests are dropped, which
+// is what skipping the stage means) before the next tick overwrites RG_COL_OUT, so no window is left stale.
+static int rg_settle_send(rg_engine *h) {
+    if (!h->ins_arena || !h->send_ready) return RG_OK;
+    const u64 *list = h->out_is_dense ? nullptr : h->res_list;
+    const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;
+    int rc = rg_send_enqueue(h, 0, RG_SEND_EFFECTS_ONLY, list, n, nullptr);
+    h->send_ready = false;
+    h->send_bound = 0;
+    return rc;
+}
+
 static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
+    int src = rg_settle_send(h);
+    if (src) return src;
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
     const u32 variant = h->cfg.variant == RG_VARIANT_LDS ? RG_VARIANT_LDS : RG_VARIANT_LANE;
@@ -960,6 +1001,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
+    h->tick_launches++;
     h->ticked = true;
     h->out_is_dense = true;
     h->send_ready = true;
@@ -1159,6 +1201,8 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
 // Everything of a sparse tick that needs no host round trip: clear the previous results, resolve hints, tick the
 // listed groups, gather their results (also into `packed` when given). `upper` bounds the list length.
 static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm) {
+    int src = rg_settle_send(h); // (walks the PREVIOUS tick's result list, before it is cleared below)
+    if (src) return src;
     // RG_COL_OUT must hold zeros for every group this tick does not touch
     if (h->out_is_dense) {
         RG_HIP(hipMemsetAsync(h->st.out, 0, h->stride * 4, h->stream));
@@ -1195,6 +1239,7 @@ static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_log
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "sparse tick: launch failed: %s", hipGetErrorString(e));
+    h->tick_launches++;
     return RG_OK;
 }
 
@@ -1279,7 +1324,9 @@ template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *
 extern "C" int rg_recompute(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_recompute: null engine");
     RG_HIP(hipSetDevice(h->cfg.device));
-    int rc = rg_recompute_impl<true>(h, nullptr, nullptr);
+    int rc = rg_settle_send(h);
+    if (rc) return rc;
+    rc = rg_recompute_impl<true>(h, nullptr, nullptr);
     if (rc == RG_OK) {
         h->ticked = true;
         h->host_res_valid = false;
@@ -1453,6 +1500,8 @@ extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const 
     RG_HIP(hipMemcpyAsync(h->ins.head, head.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.tail, tail.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.ring, host_ring, rg_inflights_bytes(h, 1), hipMemcpyHostToDevice, h->stream));
+    // Inflights::full() of the loaded windows, for the next tick's is_paused() / free_first_one decisions
+    hipLaunchKernelGGL(k_fix_ins_full, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, h->ins, h->P);
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }
@@ -1602,15 +1651,19 @@ static void rg_touch(rg_engine *h, u64 group) {
 extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m) {
     if (!h || !m || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step: rg_set_peers was never called");
-    // Raft::step term gate (src/raft.rs:1282-1411)
-    if (m->term == 0) return rg_fail(RG_ERR_STEP_LOCAL_MSG, "rg_step: term 0 marks a local message (raw_node.rs:404-406)");
-    if (m->term > h->terms[group])
-        return rg_fail(RG_ERR_HIGHER_TERM, "rg_step: message term %llu > leader term %llu: step down (raft.rs:1284-1348)",
-                       (unsigned long long)m->term, (unsigned long long)h->terms[group]);
-    if (m->term < h->terms[group]) return RG_OK; // stale term: ignored (raft.rs:1349-1411)
+    // RawNode::step (src/raw_node.rs:402-411): MsgAppendResponse is not a local message type; a response from an id
+    // without a Progress is rejected BEFORE Raft::step looks at the term, so a removed peer cannot depose the leader
     const int slot = rg_find_slot(h, group, m->from);
     if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_step: peer %llu not in group %llu (raw_node.rs:407-410)",
                                  (unsigned long long)m->from, (unsigned long long)group);
+    // Raft::step term gate (src/raft.rs:1282-1411); term 0 skips the gate (":1282 local message") and falls
+    // through to step_leader exactly as in the reference
+    if (m->term != 0) {
+        if (m->term > h->terms[group])
+            return rg_fail(RG_ERR_HIGHER_TERM, "rg_step: message term %llu > leader term %llu: step down (raft.rs:1284-1348)",
+                           (unsigned long long)m->term, (unsigned long long)h->terms[group]);
+        if (m->term < h->terms[group]) return RG_OK; // stale term: ignored (raft.rs:1349-1411)
+    }
     u8 &f = h->q_mf[group * 8 + slot];
     if (f & (RG_MF_VALID | RG_MF_HEARTBEAT)) return rg_fail(RG_ERR_SLOT_BUSY, "rg_step: peer %llu already has a message queued; rg_flush first",
                                         (unsigned long long)m->from);
@@ -1631,12 +1684,13 @@ extern "C" int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t
                                           uint8_t ins_full) {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_heartbeat_response: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step_heartbeat_response: rg_set_peers was never called");
-    if (term == 0) return rg_fail(RG_ERR_STEP_LOCAL_MSG, "rg_step_heartbeat_response: term 0 marks a local message");
-    if (term > h->terms[group]) return rg_fail(RG_ERR_HIGHER_TERM, "rg_step_heartbeat_response: higher term: step down");
-    if (term < h->terms[group]) return RG_OK;
-    const int slot = rg_find_slot(h, group, from);
+    const int slot = rg_find_slot(h, group, from); // raw_node.rs:407-410 comes before the term gate
     if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_step_heartbeat_response: peer %llu not in group %llu",
                                  (unsigned long long)from, (unsigned long long)group);
+    if (term != 0) {
+        if (term > h->terms[group]) return rg_fail(RG_ERR_HIGHER_TERM, "rg_step_heartbeat_response: higher term: step down");
+        if (term < h->terms[group]) return RG_OK;
+    }
     u8 &f = h->q_mf[group * 8 + slot];
     if (f & (RG_MF_VALID | RG_MF_HEARTBEAT))
         return rg_fail(RG_ERR_SLOT_BUSY, "rg_step_heartbeat_response: peer %llu already has a message queued", (unsigned long long)from);
@@ -1876,6 +1930,7 @@ extern "C" int rg_ingest_tick(rg_engine *h, const rg_wire_msg *records, uint64_t
 static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
     int rc;
+    const u64 launches0 = h->tick_launches;
     if (h->q_dirty.size() * 2 >= h->G) {
         // most groups have events: stream the whole columns through the dense tick (measured crossover with the
         // 64-B-record path is around 60 % of the groups: profiles/r01_sparse_path_and_recompute.txt, mirror_bench)
@@ -1909,6 +1964,10 @@ static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
         // (pinned record staging, five back-to-back launches, one packed D2H copy, one synchronisation)
         rc = rg_flush_sparse(h, send);
     }
+    // A flush that failed BEFORE its tick was enqueued changed nothing on the device: the queued events stay queued
+    // and the call can be retried. Once the tick is enqueued the events are consumed (a retry would apply them
+    // twice); an error after that point means results could not be fetched, not that the batch was lost.
+    if (rc != RG_OK && h->tick_launches == launches0) return rc;
     for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
     h->q_dirty.clear();
     h->q_any_logterm = false;

@@ -67,8 +67,10 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
     const u32 present = RG_CFG_PRESENT(cfg), self = RG_CFG_SELF(cfg);
     // bcast_append: the leader appended entries (a proposal, raft.rs:2049-2053), or the commit index moved and
     // should_bcast_commit() (raft.rs:1745-1748, :2684-2686: !skip_bcast_commit || has_pending_conf())
-    bool bcast = (out & RG_OUT_APPENDED) != 0;
-    if (out & RG_OUT_CHANGED)
+    // RG_SEND_EFFECTS_ONLY (engine-internal, a skipped stage being settled): only the Inflights effects below
+    const bool serve = !(flags & 0x80000000u);
+    bool bcast = serve && (out & RG_OUT_APPENDED) != 0;
+    if (serve && (out & RG_OUT_CHANGED))
         bcast = bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((st.pflags[g] >> (8 * self)) & RG_PF_PENDING_CONF);
     const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
     it.snap = 0;
@@ -124,8 +126,8 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
         }
 
         // ---- send_append(to) then `while maybe_send_append(to, false)` ----
-        const bool sa = bcast || ((sa_bits >> s) & 1u);
-        const bool sm = (sm_bits >> s) & 1u;
+        const bool sa = bcast || (serve && ((sa_bits >> s) & 1u));
+        const bool sm = serve && ((sm_bits >> s) & 1u);
         if (sa || sm) {
             u64 next = next_v[s];
             const u64 next0 = next;

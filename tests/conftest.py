@@ -13,6 +13,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_available():
+    """True when the HIP engine library loads and sees a device (the gpu-marked tests need both)."""
+    try:
+        import raft_rs_amd
+        return raft_rs_amd.load_library().rg_device_count() > 0
+    except Exception:  # noqa: BLE001 -- library not built / no HIP runtime
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a box without an MI355X skips the gpu-marked tests instead of failing in rg_create.
+    An explicit `-m gpu` run is NOT softened: there a missing device or library must fail loudly."""
+    if "gpu" in (config.getoption("-m") or ""):
+        return
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no MI355X visible (gpu-marked tests run with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

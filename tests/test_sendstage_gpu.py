@@ -251,3 +251,83 @@ def test_send_stage_serves_the_broadcast_after_recompute(rg):
     assert (b["slot"] == 2).all() and (b["prev_index"] == 5).all() and (b["last_index"] == 9).all()
     assert eng.inflights(5, 2) == [9] and eng.inflights(5, 1) == []
     eng.close()
+
+
+def test_loaded_full_window_pauses_and_frees_on_heartbeat(rg):
+    """rg_load_inflights / rg_load_column(PFLAGS) re-derive the engine-owned RG_PF_INS_FULL bit: a Replicate peer whose
+    LOADED window is full must read is_paused() == true in the very next tick (raft.rs:1724, `else if old_paused
+    {send_append}` :1749-1751) and a heartbeat response must free its first inflight (raft.rs:1791-1798)."""
+    G, P, cap = 64, 3, 4
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    st["term_lo"][:] = 60  # entries below 60 are of older terms: a quorum index of 51 does not pass maybe_commit
+    st["term_hi"][:] = 100
+    st["commit"][:] = 50
+    st["match"][0, :G] = 100
+    st["match"][1:, :G] = 50
+    st["next"][0, :G] = 101
+    st["next"][1:, :G] = 59  # four messages of two entries each in flight: 52, 54, 56, 58
+    st["pflags"][:, :P] = 1 | 8  # Replicate, recent_active (no INS_FULL bit: the host does not own it)
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.load_state(st)
+    meta = np.zeros((P, eng.stride), dtype=np.uint32)
+    ring = np.zeros((G, P, cap), dtype=np.uint64)
+    meta[1:, :G] = 1 | (cap << 16)  # start 1, count == cap
+    for k in range(cap):
+        ring[:, 1:, (1 + k) % cap] = 52 + 2 * k
+    eng.load_inflights(meta, ring)
+    assert (eng.read_column(rg.COL.PFLAGS)[:, 1:P] & rg.PF.INS_FULL).all()
+    assert not (eng.read_column(rg.COL.PFLAGS)[:, 0] & rg.PF.INS_FULL).any()
+    # a wholesale flag load (checkpoint restore by columns) may carry garbage in that bit: re-derived again
+    eng.load_column(rg.COL.PFLAGS, st["pflags"])
+    assert (eng.read_column(rg.COL.PFLAGS)[:, 1:P] & rg.PF.INS_FULL).all()
+    mb = rg.MsgBuffers(G, P, eng.stride)
+    mb.m_flags[:, 1] = rg.MF.HEARTBEAT  # peer 2: heartbeat response on a full window -> free_first_one
+    mb.m_commit[1, :G] = 50
+    mb.m_flags[:, 2] = rg.MF.VALID      # peer 3: ack 51 cannot commit (older term); it was paused -> send_append
+    mb.m_index[2, :G] = 51
+    mb.m_commit[2, :G] = 50
+    eng.tick(mb)
+    _, out = eng.results()
+    assert (rg.OUT.free_to(out[0]) & 0b010) and (rg.OUT.send_append(out[0]) & 0b100), hex(int(out[0]))
+    assert (out == out[0]).all()
+    eng.send_appends(2)
+    assert eng.inflights(0, 1)[0] == 54  # 52 was freed (and the window refilled up to the cap)
+    eng.close()
+
+
+def test_skipped_send_stage_is_settled_before_the_next_tick(rg):
+    """A host that skips rg_send_appends after a tick drops that tick's send requests, but the tick's effects on the
+    device Inflights (free_to, reset on leaving Replicate) are applied before RG_COL_OUT is overwritten."""
+    G, P, cap = 32, 3, 4
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    st["term_lo"][:] = 1
+    st["term_hi"][:] = 100
+    st["commit"][:] = 50
+    st["match"][0, :G] = 100
+    st["match"][1:, :G] = 50
+    st["next"][0, :G] = 101
+    st["next"][1:, :G] = 59
+    st["pflags"][:, :P] = 1 | 8
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.load_state(st)
+    meta = np.zeros((P, eng.stride), dtype=np.uint32)
+    ring = np.zeros((G, P, cap), dtype=np.uint64)
+    meta[1:, :G] = cap << 16
+    for k in range(cap):
+        ring[:, 1:, k] = 52 + 2 * k
+    eng.load_inflights(meta, ring)
+    mb = rg.MsgBuffers(G, P, eng.stride)
+    mb.m_flags[:, 1] = rg.MF.VALID  # ack 56 frees 52, 54, 56
+    mb.m_index[1, :G] = 56
+    mb.m_flags[:, 2] = rg.MF.VALID | rg.MF.REJECT  # a real reject: Replicate -> Probe, ins.reset()
+    mb.m_index[2, :G] = 58
+    mb.m_hint[2, :G] = 50
+    eng.tick(mb)          # ... and NO send stage
+    mb.clear()
+    eng.tick(mb)          # an empty tick overwrites RG_COL_OUT
+    assert eng.inflights(0, 1) == [58] and eng.inflights(0, 2) == []
+    assert not (eng.read_column(rg.COL.PFLAGS)[:, 1:P] & rg.PF.INS_FULL).any()
+    assert int(eng.read_column(rg.COL.NEXT)[1, 0]) == 59  # nothing was sent for the skipped stage
+    eng.close()

@@ -220,3 +220,38 @@ def test_tally_votes_matches_oracle(rg):
     has = eng.vote_result(yes, np.zeros(G, dtype=np.uint8)) == 2
     assert has.any() and not has.all()
     eng.close()
+
+
+def test_step_checks_the_peer_before_the_term(rg):
+    """RawNode::step (raw_node.rs:402-411) rejects a response from an id without a Progress BEFORE Raft::step
+    compares terms (raft.rs:1282-1411): a removed peer carrying a higher term must not depose the leader; term 0
+    skips the term gate ("local message", raft.rs:1282) and is stepped like any other response."""
+    from raft_rs_amd.engine import ERR
+    G, P, TERM = 4, 3, 5
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    st["term_lo"][:] = 1
+    st["term_hi"][:] = 10
+    st["match"][0, :G] = 10
+    st["next"][:, :G] = 11
+    st["pflags"][:, :P] = 1
+    eng = rg.Engine(G, P)
+    eng.load_state(st)
+    for g in range(G):
+        eng.set_peers(g, [1, 2, 3], TERM)
+    for step in (lambda **kw: eng.step(0, 9, kw["term"], 5), lambda **kw: eng.step_heartbeat_response(0, 9, kw["term"])):
+        for term in (TERM + 7, TERM, TERM - 1, 0):  # unknown peer: always StepPeerNotFound, whatever the term
+            with pytest.raises(rg.EngineError) as e:
+                step(term=term)
+            assert e.value.code == ERR["STEP_PEER_NOT_FOUND"], term
+    with pytest.raises(rg.EngineError) as e:  # a known peer with a higher term: the leader steps down
+        eng.step(0, 2, TERM + 1, 5)
+    assert e.value.code == ERR["HIGHER_TERM"]
+    eng.step(0, 2, TERM - 1, 9)  # stale term: dropped
+    eng.step(1, 2, 0, 7)         # term 0: no term gate, handled by step_leader
+    eng.step(1, 3, TERM, 7)
+    eng.flush()
+    commit, out = eng.results()
+    assert commit[0] == 0 and commit[1] == 7, commit
+    assert int(eng.read_column(rg.COL.MATCH)[1, 1]) == 7 and int(eng.read_column(rg.COL.MATCH)[1, 0]) == 0
+    eng.close()
