@@ -131,6 +131,70 @@ def soa_cpu_line(n_groups, n_slots, workload, seed, threads):
         return {"soa_note": f"unavailable: {type(e).__name__}: {e}"}
 
 
+def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what):
+    """A second, smaller measurement for the bench line's sub-objects, after the headline region: one engine, W+K
+    recorded ticks replayed from a checkpoint (what == "tick"), or K launches of rg_recompute -- Raft::maybe_commit
+    for every group with no messages, literally BASELINE's "commit-index recomputes" (what == "recompute").
+    Times with HIP events on the engine's stream; returns a dict with its own roofline object."""
+    stream = torch.cuda.current_stream()
+    eng = rg.Engine(n_groups, n_slots, device=torch.cuda.current_device())
+    eng.set_stream(stream.cuda_stream)
+    eng.workload_init(workload, seed=seed)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if what == "recompute":
+        # matches as a run leaves them: a few ticks of the stream first (untimed)
+        cols = [torch.empty((n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+        flags = torch.empty((n_groups, 8), dtype=torch.uint8, device="cuda")
+        for t in range(3):
+            eng.workload_gen(workload, t, *[c.data_ptr() for c in cols], flags.data_ptr(), seed=seed)
+            eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        for _ in range(warmup):
+            eng.recompute()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(steps):
+            eng.recompute()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        nbytes = (8 * n_slots + 37) * n_groups  # SURVEY 8(d): B0(P) = 8 P + 37
+        kernel = "k_recompute"
+    else:
+        T = warmup + steps
+        cols = [torch.empty((T, n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+        flags = torch.empty((T, n_groups, 8), dtype=torch.uint8, device="cuda")
+        eng.checkpoint()
+        alg = []
+        for t in range(T):
+            ptrs = [c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]
+            eng.workload_gen(workload, t, *ptrs, seed=seed)
+            s = eng.msg_stats(flags[t].data_ptr())
+            alg.append(algorithmic_bytes(n_groups, s["slots"], s["valid"], s["rejects"]))
+            eng.tick_device(*ptrs)
+        eng.restore()
+        for t in range(warmup):
+            eng.tick_device(*([c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]))
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for t in range(warmup, T):
+            eng.tick_device(*([c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]))
+        e1.record(stream)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        nbytes = float(np.mean(alg[warmup:]))
+        kernel = "k_tick_lane"
+        n_fault = eng.result_counts()[1]
+        if n_fault:
+            raise SystemExit(f"side measurement raised {n_fault} faults")
+    eng.close()
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"groups": n_groups, "peer_slots": n_slots, "steps": steps, "warmup": warmup, "us_per_launch": us,
+            "value": n_groups / (us * 1e-6), "unit": "group-evals/s" if what == "tick" else "commit-index recomputes/s",
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "kernel": kernel, "algorithmic_bytes_per_launch": nbytes, "bytes_per_eval": nbytes / n_groups,
+                         "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +216,10 @@ def main():
                     help="N > 0: keep the Inflights (cap N) on the device and run the send stage (rg_send_appends: "
                          "maybe_send_append decisions, SURVEY 8f row 3) after every tick, inside the timed region; the "
                          "stream then carries no host SENT events. Not the headline configuration.")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the recompute_only and out_of_cache sub-measurements (N=1 only; they run after the "
+                         "timed region and do not touch `value`)")
+    ap.add_argument("--out-of-cache-groups", type=int, default=8_000_000)
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
@@ -186,6 +254,8 @@ def main():
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
     T = W + K
+    if args.workload == 5 and args.fuse > 1:
+        raise SystemExit("--fuse cannot replay config 5: fused launches do not apply elections (include/raftgroups.h)")
     stream = torch.cuda.current_stream()
 
     # A rank's shard is one engine per replica-set size class. Configs 2-4 have one size; config 5
@@ -223,7 +293,7 @@ def main():
 
     # ---- untimed pass: generate + apply W+K ticks, recording the message columns on the device ----
     alg_bytes = [0] * T
-    census = [dict(valid=0, rejects=0, slots=0) for _ in range(T)]
+    census = [dict(valid=0, rejects=0, slots=0, elections=0) for _ in range(T)]
     for t in range(T):
         for pt in parts:
             pt.eng.workload_gen(args.workload, t, *tick_ptrs(pt, t), seed=args.seed, first_group=pt.first,
@@ -394,13 +464,18 @@ def main():
     achieved = timed_bytes / per_launch_s / 1e9
     A = float(np.mean([c["valid"] for c in census[W:]])) / G
     R = float(np.mean([c["rejects"] for c in census[W:]])) / G
+    EL = float(np.mean([c["elections"] for c in census[W:]])) / G
 
     # HBM traffic per launch: PMC-measured in separate rocprofv3 passes of this same command
     # (tools/summarize_prof.py -> profiles/traffic.json); null for configurations not profiled.
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f).get(f"{args.workload}:{G}:{P}", {}).get("bytes") if (len(parts) == 1 and not args.inflights) else None
+            ent = json.load(f).get(f"{args.workload}:{G}:{P}", {}) if (len(parts) == 1 and not args.inflights) else {}
+        traffic = ent.get("bytes")
+        if traffic is not None:
+            traffic_source = ("profiles/traffic.json: " + ent.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "this command (tools/summarize_prof.py)") + " -- NOT measured inside this run")
     except (OSError, ValueError):
         pass
 
@@ -415,6 +490,10 @@ def main():
                    if (G, P) in ((1_000_000, 5), (1_000_000, 7)) else f"{G} groups x {P} slots, workload {args.workload}",
                    "groups_per_gpu": G, "peer_slots": P, "workload_id": args.workload, "seed": hex(args.seed),
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
+                   **({"elections_per_group": round(EL, 5),
+                       "rollover": "every tick 1/32 of the groups elects a new leader (RG_MF_BECOME_LEADER = Raft::reset + "
+                                   "become_leader): ~10% of the groups are between election and the first commit of the new "
+                                   "term at any time"} if args.workload == 5 else {}),
                    "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
                    "device": {k: v for k, v in parts[0].eng.device_info().items() if k != "engine_bytes"},
@@ -422,7 +501,7 @@ def main():
                    "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks ({'gloo, shared GPU test hook' if share_gpu else 'RCCL'})" if distributed else ""),
                    "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("k_tick_lane" if args.variant != 2 else "k_tick_lds") +
                                (" + k_send_appends" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
@@ -436,13 +515,22 @@ def main():
         **({"send_stage": send_stage_info} if args.inflights else {}),
         "commit_changed_last_tick": int(n_changed),
     }
+    for pt in parts:  # free the headline engines' HBM before the side measurements
+        pt.eng.close()
+        pt.cols = pt.flags = None
+    torch.cuda.empty_cache()
+    if world == 1 and not distributed and not args.no_extras:
+        # the literal BASELINE metric ("commit-index recomputes/sec"): Raft::maybe_commit for every group, no messages
+        result["recompute_only"] = side_measurement(rg, torch, G, P, args.workload if args.workload != 5 else 2,
+                                                    5, 50, args.seed, "recompute")
+        # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
+        result["out_of_cache"] = side_measurement(rg, torch, args.out_of_cache_groups, P, args.workload if args.workload != 5 else 2,
+                                                  3, 12, args.seed, "tick")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_groups, G), P, args.workload,
                                               args.cpu_sample_ticks, args.seed, os.cpu_count() or 1)
     elif rank == 0:
         result["cpu_baseline"] = None
-    for pt in parts:
-        pt.eng.close()
     if distributed:
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio; drain it so the JSON is the LAST line of stdout

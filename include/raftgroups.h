@@ -75,6 +75,18 @@ typedef enum {
 #define RG_MF_HAS_LOGTERM 0x80u /* a reject with Message.log_term > 0 (value in m_logterm): the engine runs
                                 RaftLog::find_conflict_by_term(reject_hint, log_term) (src/raft_log.rs:209-235,
                                 src/raft.rs:1562,1657-1660) against the group's term-run table (RG_COL_RUN_*) */
+#define RG_MF_BECOME_LEADER 0x02u /* leader's OWN slot only (where RG_MF_REJECT has no meaning): this node has just won the
+                                group's election at term m_hint[self slot] -- Raft::reset(term) + Raft::become_leader
+                                (src/raft.rs:942-971,1151-1202) run BEFORE every other event of the tick: every Progress is
+                                reset (Progress::reset(last_index + 1), progress.rs:82-92), the leader's own keeps
+                                matched = persisted, takes committed_index = committed and becomes Replicate, a leader
+                                transfer is aborted, the new leader's empty entry is appended (last_index += 1; the new
+                                term's index range starts there: RG_COL_TERM_LO = RG_COL_TERM_HI = last_index), the old
+                                leader's range becomes one more run of RG_COL_RUN_* and RG_COL_CUR_TERM = the new term.
+                                Result: RG_OUT_BECAME_LEADER | RG_OUT_APPENDED (the bcast_append that follows,
+                                raft.rs:2190-2191). The term must
+                                be above RG_COL_CUR_TERM, else RG_OUT_FAULT and the event is ignored; matched != last_index
+                                on the own slot (raft.rs:1170 asserts persisted == last_index) raises RG_OUT_FAULT too. */
 #define RG_MF_HEARTBEAT 0x40u /* a MsgHeartbeatResponse from this peer (m_commit = Message.commit), handled as
                                 Raft::handle_heartbeat_response (src/raft.rs:1777-1803); exclusive with RG_MF_VALID.
                                 Result bits: RG_OUT_SEND_APPEND(slot) = send_append (matched < last_index or a
@@ -97,6 +109,7 @@ typedef enum {
 #define RG_OUT_FAULT 0x2u       /* a precondition of the path was violated (where the reference panics or input is malformed) */
 #define RG_OUT_TIMEOUT_NOW 0x4u /* send_timeout_now(transferee) (src/raft.rs:1764-1774) */
 #define RG_OUT_APPENDED 0x8u    /* the leader's log grew in this tick (RG_MF_APPEND): the bcast_append that follows a proposal is due (src/raft.rs:2049-2053) */
+#define RG_OUT_BECAME_LEADER 0x10u /* an RG_MF_BECOME_LEADER event was applied in this tick (Raft::become_leader): every Progress was reset, so the send stage empties the group's Inflights before anything else */
 #define RG_OUT_SEND_APPEND(o) (((uint32_t)(o) >> 8) & 0xffu) /* per slot: send_append(from) (raft.rs:1719, :1750) */
 #define RG_OUT_SEND_MORE(o) (((uint32_t)(o) >> 16) & 0xffu)  /* per slot: the maybe_send_append loop (raft.rs:1761) */
 #define RG_OUT_FREE_TO(o) (((uint32_t)(o) >> 24) & 0xffu)    /* per slot: ins.free_to(m.index) (raft.rs:1742) */
@@ -118,8 +131,11 @@ typedef enum {
     /* compact log-term table for find_conflict_by_term: the leader's log is a dummy entry
      * (index, term) = (first_index - 1, snapshot term), then up to RG_TERM_RUNS runs of equal-term entries of
      * OLDER terms (run k covers [run_first[k], run_first[k+1]), the last one up to term_lo - 1; unused runs have
-     * run_first = 0), then the entries [term_lo, term_hi] of the leader's own term RG_COL_CUR_TERM (this last run
-     * grows with every RG_MF_APPEND without touching the table). Only read for rejects with RG_MF_HAS_LOGTERM. */
+     * run_first = 0, used runs come first in ascending order), then the entries [term_lo, term_hi] of the leader's
+     * own term RG_COL_CUR_TERM (this last run grows with every RG_MF_APPEND without touching the table; an
+     * RG_MF_BECOME_LEADER event pushes it into the table -- when all RG_TERM_RUNS runs are in use the boundary between
+     * the two OLDEST runs is forgotten, i.e. history deeper than the table is approximated by the oldest kept term).
+     * Only read for rejects with RG_MF_HAS_LOGTERM and by RG_MF_BECOME_LEADER. */
     RG_COL_RUN_FIRST = 12,   /* u64 [RG_TERM_RUNS][stride] */
     RG_COL_RUN_TERM = 13,    /* u64 [RG_TERM_RUNS][stride] */
     RG_COL_DUMMY_INDEX = 14, /* u64 [G] */
@@ -237,7 +253,10 @@ int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
  * Results are bit-identical to n_ticks calls of rg_tick_device. `dev_out_t` (u32 [n_ticks][G], device,
  * required) receives every tick's RG_OUT_* word, `dev_commit_t` (u64 [n_ticks][G], device, may be NULL) the
  * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. m_logterm must be NULL (hints
- * are not passed through find_conflict_by_term in fused launches: resolve them on the host). Asynchronous. Use it to
+ * are not passed through find_conflict_by_term in fused launches: resolve them on the host), and an
+ * RG_MF_BECOME_LEADER event is NOT applied (it rewrites the group's cells in memory, which a launch that holds them
+ * in registers cannot do): that group-tick reports RG_OUT_FAULT -- elections go through single-tick launches.
+ * Asynchronous. Use it to
  * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
 #define RG_MAX_FUSE 8
 int rg_tick_device_fused(rg_engine *h, const rg_msgs *dev_msgs, uint32_t n_ticks, uint32_t *dev_out_t,
@@ -259,8 +278,9 @@ int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out);
 int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault);
 
 /* Census of a tick's message flags in DEVICE memory: counts[0] = VALID messages, [1] = rejects,
- * [2] = slots with a Progress, [3] = groups with at least one event (bench: algorithmic bytes). */
-int rg_msg_stats(rg_engine *h, const uint8_t *dev_m_flags, uint64_t counts[4]);
+ * [2] = slots with a Progress, [3] = groups with at least one event, [4] = RG_MF_BECOME_LEADER events
+ * (bench: algorithmic bytes, rejects and elections per group). */
+int rg_msg_stats(rg_engine *h, const uint8_t *dev_m_flags, uint64_t counts[5]);
 
 /* ---- vote / quorum-liveness bitmaps (src/quorum/majority.rs:130-154, src/quorum/joint.rs:56-67,
  *      src/tracker.rs:313-372) ---- */
@@ -302,6 +322,10 @@ int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t from, uint
 int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index);
 int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index);
 int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id);
+/* This node won the group's election at `term` (Raft::become_leader, src/raft.rs:1151-1202): queues
+ * RG_MF_BECOME_LEADER for the group -- applied before every other event of the flush -- and moves the group's
+ * term gate (rg_step) to `term`. Errors: RG_ERR_INVALID_ARG when `term` is not above the registered term. */
+int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t term);
 /* Run one tick over everything queued since the last flush and clear the queue. */
 int rg_flush(rg_engine *h);
 

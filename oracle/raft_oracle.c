@@ -450,6 +450,37 @@ void ro_group_append(ro_cluster *c, size_t g, uint64_t n) { /* raft.rs:976-991: 
     gr->last_index += n;
 }
 
+/* Raft::reset(term) (src/raft.rs:942-971) followed by Raft::become_leader (src/raft.rs:1151-1202), reduced to the
+ * fields this model holds. Returns -1 where the reference asserts (last_index != persisted, :1170) -- the state is
+ * changed all the same, like every other "fault" of this restatement. `persisted` is the leader's own matched
+ * (on_persist_entries keeps the two equal, :994-1016). */
+int ro_group_become_leader(ro_cluster *c, size_t g, uint64_t term) {
+    ro_group *gr = &c->g[g];
+    int rc = 0;
+    /* reset(term) */
+    if (gr->term != term) gr->term = term; /* :943-946 (vote is not modelled) */
+    gr->lead_transferee = RO_INVALID_ID;   /* abort_leader_transfer, :953 */
+    /* pending_conf_index / applied stay with the host (has_pending_conf is an input bit of this model) */
+    uint64_t last_index = gr->last_index, committed = gr->committed;
+    ro_progress *self = pmap_get(&gr->progress, gr->id);
+    uint64_t persisted = self ? self->matched : 0;
+    for (size_t i = 0; i < gr->progress.len; i++) { /* :964-970 */
+        uint64_t id = gr->progress.order[i];
+        ro_progress *pr = pmap_get(&gr->progress, id);
+        if (!pr) continue;
+        ro_progress_reset(pr, last_index + 1);
+        if (id == gr->id) {
+            pr->matched = persisted;
+            pr->committed_index = committed;
+        }
+    }
+    /* become_leader */
+    if (last_index != persisted) rc = -1; /* assert_eq!(last_index, self.raft_log.persisted), :1170 */
+    if (self) ro_progress_become_replicate(self); /* :1176-1181 */
+    ro_group_append(c, g, 1); /* append_entry(&mut [Entry::default()]), :1191-1194 */
+    return rc;
+}
+
 ro_progress *ro_group_progress(ro_cluster *c, size_t g, uint64_t id) {
     return pmap_get(&c->g[g].progress, id);
 }
@@ -698,12 +729,14 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_MF_INS_FULL 0x08u
 #define RO_MF_SENT 0x10u
 #define RO_MF_APPEND 0x20u
+#define RO_MF_BECOME_LEADER 0x02u /* on the leader's own slot */
 #define RO_MF_HEARTBEAT 0x40u
 #define RO_MF_HAS_LOGTERM 0x80u
 #define RO_OUT_CHANGED 0x1u
 #define RO_OUT_FAULT 0x2u
 #define RO_OUT_TIMEOUT_NOW 0x4u
 #define RO_OUT_APPENDED 0x8u
+#define RO_OUT_BECAME_LEADER 0x10u
 
 int ro_load_soa(ro_cluster *c, const ro_soa_state *s, uint64_t term, size_t max_inflight) {
     if (s->n_groups > c->n || s->n_slots > 8) return -1;
@@ -806,7 +839,19 @@ int ro_store_soa(ro_cluster *c, ro_soa_state *s) {
         }
         s->commit[g] = gr->committed;
         s->term_hi[g] = gr->last_index;
-        /* term_lo / cfg are inputs only */
+        /* the index range of the leader's term: the log's last run when it carries gr->term, else empty */
+        bool own = gr->n_runs && gr->runs[gr->n_runs - 1].term == gr->term;
+        s->term_lo[g] = own ? gr->runs[gr->n_runs - 1].first : gr->last_index + 1;
+        /* cfg: only the transferee field is state (abort_leader_transfer); the rest is an input */
+        s->cfg[g] = (s->cfg[g] & ~(0xfu << 20)) | (((uint32_t)gr->lead_transferee & 0xfu) << 20);
+        if (s->run_first) {
+            size_t older = gr->n_runs - (own ? 1 : 0);
+            for (size_t k = 0; k < 4; k++) {
+                s->run_first[k * s->stride + g] = k < older ? gr->runs[k].first : 0;
+                s->run_term[k * s->stride + g] = k < older ? gr->runs[k].term : 0;
+            }
+            s->cur_term[g] = gr->term;
+        }
     }
     return 0;
 }
@@ -817,8 +862,27 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
     for (size_t g = g_begin; g < g_end; g++) {
         ro_group *gr = &c->g[g];
         uint32_t out = 0;
-        uint64_t last0 = gr->last_index; /* what the host's send path saw before this tick */
         uint32_t self_slot = (uint32_t)(gr->id - 1);
+        /* RG_MF_BECOME_LEADER on the leader's own slot: the election lands before every message of the tick
+         * (they answer the new leader). Engine contract for malformed input: a term that is not above the current
+         * one raises the fault bit and the event is ignored. */
+        if (self_slot < m->n_slots && (m->m_flags[g * 8 + self_slot] & RO_MF_BECOME_LEADER) &&
+            pmap_get(&gr->progress, gr->id)) {
+            uint64_t new_term = m->m_hint[(size_t)self_slot * m->stride + g];
+            if (new_term > gr->term) {
+                if (ro_group_become_leader(c, g, new_term) != 0) out |= RO_OUT_FAULT;
+                out |= RO_OUT_BECAME_LEADER | RO_OUT_APPENDED; /* bcast_append follows become_leader, raft.rs:2190-2191 */
+                /* engine contract: the term table keeps RG_TERM_RUNS runs of older terms; deeper history loses the
+                 * boundary between its two oldest runs */
+                if (gr->n_runs > 4 + 1) {
+                    memmove(&gr->runs[1], &gr->runs[2], (gr->n_runs - 2) * sizeof(ro_run));
+                    gr->n_runs--;
+                }
+            } else {
+                out |= RO_OUT_FAULT;
+            }
+        }
+        uint64_t last0 = gr->last_index; /* what the host's send path saw before this tick */
         for (uint32_t p = 0; p < m->n_slots; p++) {
             uint8_t f = m->m_flags[g * 8 + p];
             if (!(f & (RO_MF_VALID | RO_MF_SENT | RO_MF_APPEND | RO_MF_HEARTBEAT))) continue;

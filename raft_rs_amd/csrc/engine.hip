@@ -488,14 +488,18 @@ __global__ __launch_bounds__(RG_BLOCK) void k_count_out(const u32 *out, u64 G, u
     }
 }
 
-// message census of a tick: [0] VALID messages, [1] rejects, [2] slots in use (present), [3] groups with >=1 event
+// message census of a tick: [0] VALID messages, [1] rejects, [2] slots in use (present), [3] groups with >=1 event,
+// [4] elections (RG_MF_BECOME_LEADER on the leader's own slot, where the same bit does not mean "reject")
 __global__ __launch_bounds__(RG_BLOCK) void k_msg_stats(const u64 *mflags, const u32 *cfg, u64 G, u64 *counts) {
-    u64 a = 0, r = 0, s = 0, e = 0;
+    u64 a = 0, r = 0, s = 0, e = 0, el = 0;
     for (u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * RG_BLOCK) {
         const u64 mf = mflags[g];
+        const u32 c = cfg[g];
+        const u64 own = 0xffULL << (8 * RG_CFG_SELF(c));
         a += __popcll(mf & 0x0101010101010101ULL);
-        r += __popcll((mf >> 1) & mf & 0x0101010101010101ULL);
-        s += __popc(RG_CFG_PRESENT(cfg[g]));
+        r += __popcll((mf >> 1) & mf & 0x0101010101010101ULL & ~own);
+        el += ((RG_CFG_PRESENT(c) >> RG_CFG_SELF(c)) & 1u) ? __popcll((mf >> 1) & 0x0101010101010101ULL & own) : 0;
+        s += __popc(RG_CFG_PRESENT(c));
         e += mf != 0;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -503,16 +507,18 @@ __global__ __launch_bounds__(RG_BLOCK) void k_msg_stats(const u64 *mflags, const
         r += __shfl_down(r, off, 64);
         s += __shfl_down(s, off, 64);
         e += __shfl_down(e, off, 64);
+        el += __shfl_down(el, off, 64);
     }
-    __shared__ u64 part[4][RG_BLOCK / 64];
+    __shared__ u64 part[5][RG_BLOCK / 64];
     if ((threadIdx.x & 63) == 0) {
         part[0][threadIdx.x >> 6] = a;
         part[1][threadIdx.x >> 6] = r;
         part[2][threadIdx.x >> 6] = s;
         part[3][threadIdx.x >> 6] = e;
+        part[4][threadIdx.x >> 6] = el;
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < 5) {
         u64 t = 0;
         for (int w = 0; w < RG_BLOCK / 64; w++) t += part[threadIdx.x][w];
         atomicAdd((unsigned long long *)&counts[threadIdx.x], (unsigned long long)t);
@@ -525,6 +531,14 @@ __global__ __launch_bounds__(RG_BLOCK) void k_wl_init(RgState st, u64 seed, u32 
     rg_wl_init_group(seed, workload, P, st.stride, g, first + g, st.match, st.next, st.prc, st.psnap,
                      st.prs, st.gid, reinterpret_cast<u8 *>(st.pflags), st.commit, st.lo, st.hi, st.cfg);
     st.out[g] = 0;
+    // the cold log-model columns: nothing compacted, no older runs known, leader term RG_WL_TERM0
+    for (int k = 0; k < RG_TERM_RUNS; k++) {
+        st.run_first[(u64)k * st.stride + g] = 0;
+        st.run_term[(u64)k * st.stride + g] = 0;
+    }
+    st.dummy_idx[g] = 0;
+    st.dummy_term[g] = 0;
+    st.cur_term[g] = RG_WL_TERM0;
 }
 
 __global__ __launch_bounds__(RG_BLOCK) void k_wl_gen(RgState st, u64 seed, u32 workload, u32 P, u64 first,
@@ -532,7 +546,7 @@ __global__ __launch_bounds__(RG_BLOCK) void k_wl_gen(RgState st, u64 seed, u32 w
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
     rg_wl_gen_group(seed, workload, P, st.stride, g, first + g, tick, st.match, st.next,
-                    reinterpret_cast<const u8 *>(st.pflags), st.commit, st.hi, mi, mc, mh, mrs, mf);
+                    reinterpret_cast<const u8 *>(st.pflags), st.commit, st.lo, st.hi, mi, mc, mh, mrs, mf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1555,14 +1569,14 @@ extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_f
     return RG_OK;
 }
 
-extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t counts[4]) {
+extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t counts[5]) {
     if (!h || !d_m_flags || !counts) return rg_fail(RG_ERR_INVALID_ARG, "rg_msg_stats: bad argument");
     RG_HIP(hipSetDevice(h->cfg.device));
-    RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
+    RG_HIP(hipMemsetAsync(h->d_counts, 0, 40, h->stream));
     const unsigned grid = rg_grid(h->G, RG_BLOCK) < 1024 ? rg_grid(h->G, RG_BLOCK) : 1024;
     hipLaunchKernelGGL(k_msg_stats, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u64 *)d_m_flags,
                        (const u32 *)h->st.cfg, h->G, h->d_counts);
-    RG_HIP(hipMemcpyAsync(counts, h->d_counts, 32, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipMemcpyAsync(counts, h->d_counts, 40, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }
@@ -1736,6 +1750,27 @@ extern "C" int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index) 
     rg_touch(h, group);
     h->q_mi[(size_t)slot * h->stride + group] = index;
     f |= RG_MF_VALID;
+    return RG_OK;
+}
+
+extern "C" int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t term) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_become_leader: bad argument");
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_become_leader: rg_set_peers was never called");
+    if (term <= h->terms[group])
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_local_become_leader: term %llu is not above the group's term %llu",
+                       (unsigned long long)term, (unsigned long long)h->terms[group]);
+    u32 slot;
+    int rc = rg_self_slot(h, group, &slot);
+    if (rc) return rc;
+    u64 row = 0;
+    memcpy(&row, &h->q_mf[group * 8], 8);
+    if (row) return rg_fail(RG_ERR_SLOT_BUSY, "rg_local_become_leader: the group already has events queued (they belong "
+                                              "to the old term); rg_flush first");
+    u8 &f = h->q_mf[group * 8 + slot];
+    rg_touch(h, group);
+    h->q_mh[(size_t)slot * h->stride + group] = term;
+    f |= RG_MF_BECOME_LEADER;
+    h->terms[group] = term; // responses of the new term pass the gate from now on
     return RG_OK;
 }
 
@@ -2032,7 +2067,8 @@ extern "C" int rg_workload_gen_host(const rg_workload *w, uint64_t first, uint64
     if (!w || !s || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen_host: bad argument");
     for (u64 g = 0; g < s->n_groups; g++)
         rg_wl_gen_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g, first + g, tick, (const u64 *)s->match,
-                        (const u64 *)s->next, s->pflags, (const u64 *)s->commit, (const u64 *)s->term_hi, (u64 *)mi,
+                        (const u64 *)s->next, s->pflags, (const u64 *)s->commit, (const u64 *)s->term_lo,
+                        (const u64 *)s->term_hi, (u64 *)mi,
                         (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
     return RG_OK;
 }

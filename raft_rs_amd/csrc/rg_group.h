@@ -163,72 +163,185 @@ __host__ __device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (
 // run [term_lo, last_index] of the leader's own term. Rare path (rejects with log_term > 0), so the
 // table is read straight from its cold columns.
 // ---------------------------------------------------------------------------------------------
-RG_HD u64 rg_log_term(const RgState &st, u64 g, u64 lo, u64 last_index, u64 idx) {
+// The leader-side view of the log a message of the tick is evaluated against. Normally [lo, last] is the leader's own
+// run at cur_term and everything below comes from the table; when the tick carries RG_MF_BECOME_LEADER the previous
+// leader run [xlo, lo) has just become an older run of term xterm and is not in the table yet (the tick kernel
+// pushes it), so the pre-pass sees it through these two fields. xlo == lo: no such run.
+struct RgLogView {
+    u64 lo, last, cur_term;
+    u64 xlo, xterm;
+    int skip; // table run whose boundary that election's push forgets (table full: run 1), -1 = none
+};
+
+RG_HD u64 rg_log_term(const RgState &st, u64 g, const RgLogView &v, u64 idx) {
     const u64 dummy = st.dummy_idx[g];
-    if (idx < dummy || idx > last_index) return 0; // outside [dummy, last_index]
-    if (idx >= lo) return st.cur_term[g];          // the leader's own entries (lo <= idx <= last_index)
+    if (idx < dummy || idx > v.last) return 0; // outside [dummy, last_index]
+    if (idx >= v.lo) return v.cur_term;        // the leader's own entries (lo <= idx <= last_index)
+    if (idx >= v.xlo) return v.xterm;          // the previous leader's run (election in this tick)
     if (idx == dummy) return st.dummy_term[g];
     u64 t = 0;
     for (int k = 0; k < RG_TERM_RUNS; k++) {
         const u64 first = st.run_first[(u64)k * st.stride + g];
-        if (first != 0 && first <= idx) t = st.run_term[(u64)k * st.stride + g];
+        if (k != v.skip && first != 0 && first <= idx) t = st.run_term[(u64)k * st.stride + g];
     }
     return t;
 }
 
-RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, u64 lo, u64 last_index, u64 index, u64 term) {
-    if (index > last_index) return index; // "out of range": returned as is (raft_log.rs:214-223)
+RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, const RgLogView &v, u64 index, u64 term) {
+    if (index > v.last) return index; // "out of range": returned as is (raft_log.rs:214-223)
     u64 ci = index;
-    for (;;) { // every iteration leaves a whole run (or the dummy entry) behind: <= RG_TERM_RUNS + 3 rounds
-        const u64 t = rg_log_term(st, g, lo, last_index, ci);
+    for (;;) { // every iteration leaves a whole run (or the dummy entry) behind: <= RG_TERM_RUNS + 4 rounds
+        const u64 t = rg_log_term(st, g, v, ci);
         if (t <= term) return ci;
         // t > term: the reference steps ci -= 1 until the term changes; skip to just below this run
         u64 run_start;
-        if (ci >= lo) {
-            run_start = lo; // inside the leader's own run
+        if (ci >= v.lo) {
+            run_start = v.lo; // inside the leader's own run
+        } else if (ci >= v.xlo) {
+            run_start = v.xlo;
         } else {
             run_start = st.dummy_idx[g]; // ci == dummy: step below it
             for (int k = 0; k < RG_TERM_RUNS; k++) {
                 const u64 first = st.run_first[(u64)k * st.stride + g];
-                if (first != 0 && first <= ci) run_start = first;
+                if (k != v.skip && first != 0 && first <= ci) run_start = first;
             }
         }
         ci = run_start - 1;
     }
 }
 
+// Raft::become_leader as a tick event (RG_MF_BECOME_LEADER on the leader's own slot, new term in m_hint): is the
+// event well-formed? A new leader's term is higher than every term in its log (src/raft.rs:1284-1348: terms only
+// grow); anything else is malformed input: RG_OUT_FAULT and the event is ignored.
+RG_HD bool rg_election_valid(const RgState &st, const RgMsgs &ms, u64 g, u32 self, u64 &new_term) {
+    new_term = ms.mh[(u64)self * st.stride + g];
+    return new_term > st.cur_term[g];
+}
+
 // Pre-pass of a tick for ONE group: for every slot whose event is a reject with RG_MF_HAS_LOGTERM, store
 // find_conflict_by_term(reject_hint, log_term) (or the hint itself when log_term == 0) into `rh`.
-// last_index "at message time" is reproduced exactly: the leader's APPEND lands at its own slot, so slots
-// after it see the grown log (RgTick::slot).
+// last_index "at message time" is reproduced exactly: an election lands before every message of the tick, the
+// leader's APPEND at its own slot, so slots after it see the grown log (RgTick::slot).
 RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u64 *rh) {
     const u64 mf = ms.mflags[g];
+    const u32 cfg = st.cfg[g];
+    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
     bool any = false;
     for (u32 p = 0; p < n_slots; p++) {
         const u32 f = (u32)(mf >> (8 * p)) & 0xffu;
-        any |= (f & (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) == (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM);
+        any |= p != self && (f & (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) == (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM);
     }
     if (!any) return;
-    const u32 cfg = st.cfg[g];
-    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
-    const u64 lo = st.lo[g], hi0 = st.hi[g];
-    u64 hi_after = hi0; // last_index once the leader's own slot has been processed
+    RgLogView v;
+    v.lo = st.lo[g];
+    v.last = st.hi[g];
+    v.cur_term = st.cur_term[g];
+    v.xlo = v.lo;
+    v.xterm = 0;
+    v.skip = -1;
+    u64 hi_after = v.last; // last_index once the leader's own slot has been processed
     if (self < n_slots && ((present >> self) & 1u)) {
         const u32 fs = (u32)(mf >> (8 * self)) & 0xffu;
+        u64 new_term;
+        if ((fs & RG_MF_BECOME_LEADER) && rg_election_valid(st, ms, g, self, new_term)) {
+            const u64 old_lo = v.lo, old_hi = v.last;
+            v.last = old_hi + 1; // the new leader's empty entry (raft.rs:1163-1194)
+            v.lo = v.last;
+            v.xlo = old_lo <= old_hi ? old_lo : v.lo; // the previous leader's entries keep their term
+            v.xterm = v.cur_term;
+            // pushing that run into a FULL table forgets the boundary between the two oldest runs (rg_elect_in_memory)
+            if (old_lo <= old_hi && st.run_first[(u64)(RG_TERM_RUNS - 1) * st.stride + g] != 0) v.skip = 1;
+            v.cur_term = new_term;
+            hi_after = v.last;
+        }
         if (fs & RG_MF_APPEND) {
             const u64 nl = ms.mc[(u64)self * st.stride + g];
-            if (nl > hi0) hi_after = nl;
+            if (nl > hi_after) hi_after = nl;
         }
     }
+    const u64 hi_before = v.last;
     for (u32 p = 0; p < n_slots; p++) {
         const u32 f = (u32)(mf >> (8 * p)) & 0xffu;
+        if (p == self) continue;
         if ((f & (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) != (RG_MF_VALID | RG_MF_REJECT | RG_MF_HAS_LOGTERM)) continue;
         const u64 o = (u64)p * st.stride + g;
         const u64 lt = ms.mlt[o];
         u64 hint = ms.mh[o];
-        if (lt > 0) hint = rg_find_conflict_by_term(st, g, lo, p > self ? hi_after : hi0, hint, lt);
+        v.last = p > self ? hi_after : hi_before;
+        if (lt > 0) hint = rg_find_conflict_by_term(st, g, v, hint, lt);
         rh[o] = hint;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RG_MF_BECOME_LEADER: Raft::reset(term) (src/raft.rs:942-971) + Raft::become_leader (:1151-1202) for one group --
+// what the reference runs when this node wins the group's election -- applied to the group's cells IN MEMORY
+// before the tick loads them (the event precedes every message of the tick: they answer the new leader). Every
+// Progress is reset to Progress::reset(last_index + 1) (progress.rs:82-92: matched 0, Probe, not paused, no pending
+// snapshot / snapshot request, not recently active, empty Inflights; committed_index and commit_group_id survive);
+// the leader's own keeps matched = persisted, takes committed_index = committed and becomes Replicate
+// (:1176-1181); a leader transfer is aborted (:953); the new leader's empty entry is appended at last_index + 1
+// (:1191-1194), which starts the index range of the new term; the previous leader's range becomes one more run of
+// the term table. Rare, so it trades a second round of loads for zero registers in the hot kernel: the caller
+// re-loads the group afterwards. Returns the event's result bits (also left in RG_COL_OUT for the store path).
+// ---------------------------------------------------------------------------------------------
+RG_HD bool rg_has_election(u64 mf, u32 cfg, u32 n_slots) {
+    const u32 self = RG_CFG_SELF(cfg);
+    return self < n_slots && ((RG_CFG_PRESENT(cfg) >> self) & 1u) && ((mf >> (8 * self)) & RG_MF_BECOME_LEADER);
+}
+
+RG_HD u32 rg_elect_in_memory(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u32 cfg) {
+    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
+    u64 new_term;
+    if (!rg_election_valid(st, ms, g, self, new_term)) { // malformed: fault, ignored
+        st.out[g] = RG_OUT_FAULT;
+        return RG_OUT_FAULT;
+    }
+    u32 out = RG_OUT_BECAME_LEADER | RG_OUT_APPENDED; // the caller follows with bcast_append (raft.rs:2190-2191)
+    const u64 old_lo = st.lo[g], old_hi = st.hi[g], old_term = st.cur_term[g], commit = st.commit[g];
+    st.cur_term[g] = new_term;
+    if (old_lo <= old_hi) { // the previous leader's entries become one more run of an older term
+        int k = 0;
+        while (k < RG_TERM_RUNS && st.run_first[(u64)k * st.stride + g] != 0) k++;
+        if (k == RG_TERM_RUNS) { // table full: forget the boundary between the two oldest runs
+            for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
+                st.run_first[(u64)j * st.stride + g] = st.run_first[(u64)(j + 1) * st.stride + g];
+                st.run_term[(u64)j * st.stride + g] = st.run_term[(u64)(j + 1) * st.stride + g];
+            }
+            k = RG_TERM_RUNS - 1;
+        }
+        st.run_first[(u64)k * st.stride + g] = old_lo;
+        st.run_term[(u64)k * st.stride + g] = old_term;
+    }
+    u64 row = st.pflags[g];
+#pragma nounroll
+    for (u32 i = 0; i < n_slots; i++) { // (a rolled loop: this rare path must not cost the tick kernels registers)
+        if (!((present >> i) & 1u)) continue;
+        const u64 o = (u64)i * st.stride + g;
+        const u32 pb = (u32)(row >> (8 * i)) & 0xffu;
+        u32 nb;
+        if (i == self) {
+            // assert_eq!(last_index, self.raft_log.persisted) (raft.rs:1170): matched IS the persisted index
+            const u64 persisted = st.match[o];
+            if (persisted != old_hi) out |= RG_OUT_FAULT;
+            st.prc[o] = commit;
+            st.next[o] = persisted + 1; // become_replicate (progress.rs:111-114)
+            nb = (pb & RG_PF_PENDING_CONF) | RG_STATE_REPLICATE;
+        } else {
+            st.match[o] = 0;
+            st.next[o] = old_hi + 1;
+            nb = RG_STATE_PROBE; // ins.reset(): RG_OUT_BECAME_LEADER tells the send stage to empty the device window
+        }
+        st.psnap[o] = 0;
+        st.prs[o] = 0;
+        row = (row & ~(0xffULL << (8 * i))) | ((u64)nb << (8 * i));
+    }
+    st.pflags[g] = row;
+    if (RG_CFG_TRANSFEREE(cfg)) st.cfg[g] = cfg & ~(0xfu << 20); // abort_leader_transfer (raft.rs:953)
+    st.hi[g] = old_hi + 1; // append_entry(&mut [Entry::default()]) (raft.rs:1191-1194)
+    st.lo[g] = old_hi + 1;
+    st.out[g] = out;
+    return out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,12 +353,15 @@ template <int P> struct RgGroup {
     u64 pf, mf;              // flag rows: RG_PF_* / RG_MF_* byte per slot
     u64 commit, lo, hi;      // RaftLog.committed, current-term index range [lo, hi], hi = last_index
     u32 cfg, out;
-    u32 dirty;               // bit s: mt[s] changed, bit 8+s: nx[s], bit 16+s: pc[s], bit 24: pf, 25: commit, 26: hi
+    u32 dirty;               // bit s: mt[s] changed, bit 8+s: nx[s], bit 16+s: pc[s], bit 24: pf, 25: commit, 26: hi,
+                             // bit 29: an election was applied for this tick
     u32 evm;                 // slots (with a Progress) that had any event since the state was loaded
 };
 #define RG_DIRTY_PF (1u << 24)
 #define RG_DIRTY_COMMIT (1u << 25)
 #define RG_DIRTY_HI (1u << 26)
+#define RG_TICK_ELECTED (1u << 29)  /* not a store bit: RG_MF_BECOME_LEADER was applied to this group for THIS tick
+                                       (rg_elect_in_memory) and RG_COL_OUT holds the event's result bits */
 
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
 // (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
@@ -291,7 +407,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         acc = 0;
         acc_oldp = 0;
         if (!FUSED) {
-            r.dirty = 0;
+            r.dirty &= RG_TICK_ELECTED; // (set by the kernel when it applied an election before loading the group)
             r.evm = 0;
         }
 #pragma unroll

@@ -77,8 +77,9 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
     it.count = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
+    const bool elected = (out & RG_OUT_BECAME_LEADER) != 0; // Raft::reset: every Progress's ins.reset() (progress.rs:82-92)
     u32 work = sa_bits | sm_bits | fr_bits;
-    if (bcast) work |= present;
+    if (bcast || elected) work |= present;
     work &= present & ~(1u << self);
     if (work == 0) return;
 
@@ -116,8 +117,9 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
         u64 tail = tail0;
 
         // ---- what the tick did to this peer's Inflights ----
-        if (state != RG_STATE_REPLICATE) {
-            // Progress::reset_state (progress.rs:75-80) ran when it left Replicate; nothing is added outside it
+        if (state != RG_STATE_REPLICATE || elected) {
+            // Progress::reset_state (progress.rs:75-80) ran when it left Replicate; nothing is added outside it.
+            // After an election the peer may already be back in Replicate (its first ack): the window is new.
             start = 0;
             count = 0;
         } else if ((fr_bits >> s) & 1u) {

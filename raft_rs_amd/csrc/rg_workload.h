@@ -11,14 +11,22 @@
 //    persists them (Raft::append_entry + on_persist_entries, src/raft.rs:976-1016);
 //  * the send path's writes to Progress (Progress::update_state, src/tracker/progress.rs:231-243)
 //    as the RG_MF_SENT event: Replicate => optimistic next = last+1, Probe => paused;
-//  * RG_WL_MIXED: 10% of the groups start right after an election (Raft::reset + become_leader,
-//    src/raft.rs:942-971,1151-1202): followers Probe/match 0/next last+1; the first probe is
-//    rejected with the follower's real last index as hint (maybe_decr_to, progress.rs:186-205), the
-//    second accepted (Probe -> Replicate); plus rare Replicate-state rejects, request_snapshot
-//    rejects and full-inflight acks so every branch of handle_append_response runs.
+//  * RG_WL_MIXED (BASELINE config 5, "leader-term rollover"): 10% of the groups START right after an election
+//    (Raft::reset + become_leader, src/raft.rs:942-971,1151-1202) and, on EVERY tick, a hash-selected 1/32 of all
+//    groups elects a new leader (the RG_MF_BECOME_LEADER event; the old term's in-flight responses are dropped by
+//    the host's term gate, so that group carries no follower messages in its election tick): followers
+//    Probe / match 0 / next = last + 1; the first probe is rejected with the follower's real last index as hint
+//    (maybe_decr_to, progress.rs:186-205), the second accepted (Probe -> Replicate), then the followers catch up
+//    until a quorum holds the new term's first entry and the commit index moves again. In steady state ~10% of
+//    the groups are in that probe / reject / catch-up phase and ~0.1 rejects per group arrive per tick. Plus rare
+//    Replicate-state rejects, request_snapshot rejects and full-inflight acks so every branch of
+//    handle_append_response runs.
 #pragma once
 
 #include "rg_common.h"
+
+#define RG_WL_TERM0 5u          /* leader term of every group when the run starts */
+#define RG_WL_ELECT_ONE_IN 32u  /* RG_WL_MIXED: per tick, one group in 32 elects a new leader */
 
 struct RgWlGroup { // static (tick-independent) facts of a group
     u32 n_peers;   // slots in use (P_g)
@@ -54,9 +62,15 @@ RG_HD RgWlGroup rg_wl_group(u64 seed, u32 workload_word, u32 n_slots, u64 gg) {
     return w;
 }
 
-// follower p's real log end at the start of the run (what a rejected probe reports as hint)
+// follower p's real log end when a leader whose log ends at `last0` is elected (what a rejected probe reports
+// as hint): up to 31 entries behind
 RG_HD u64 rg_wl_follower_last(u64 seed, u64 gg, u32 p, u64 last0) {
-    return last0 - (rg_hash(seed, 0, gg, p) & 31);
+    return last0 - rg_min(last0, rg_hash(seed, 0, gg, p) & 31);
+}
+
+// RG_WL_MIXED: does group gg elect a new leader in tick `tick`?
+RG_HD bool rg_wl_elects(u64 seed, u32 workload_word, u64 gg, u64 tick) {
+    return (workload_word & 0xffu) == RG_WL_MIXED && (rg_hash(seed, tick + 1, gg, 15) % RG_WL_ELECT_ONE_IN) == 0;
 }
 
 // q-th largest of up to 8 values under a mask (generator-side, for the initial commit only)
@@ -92,8 +106,8 @@ RG_HD void rg_wl_init_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64
         u64 m = 0, n = 0;
         u8 f = 0;
         if (p < w.n_peers) {
-            if (p == 0) { // the leader: Replicate, matched = persisted
-                m = w.last0;
+            if (p == 0) { // the leader: Replicate, matched = persisted = last_index (its own empty entry included)
+                m = last;
                 n = m + 1;
                 f = RG_STATE_REPLICATE;
             } else if (w.post_election) { // Progress::reset(last_index + 1) (progress.rs:82-92)
@@ -132,11 +146,12 @@ RG_HD void rg_wl_init_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64
 // Messages of tick `tick` for group g, generated from the group's CURRENT state.
 RG_HD void rg_wl_gen_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64 g, u64 gg, u64 tick,
                            const u64 *match, const u64 *next, const u8 *pflags, const u64 *commit,
-                           const u64 *hi, u64 *m_index, u64 *m_commit, u64 *m_hint, u64 *m_rs,
+                           const u64 *lo, const u64 *hi, u64 *m_index, u64 *m_commit, u64 *m_hint, u64 *m_rs,
                            u8 *m_flags) {
     const RgWlGroup w = rg_wl_group(seed, workload, n_slots, gg);
-    const u64 last = hi[g], cm = commit[g];
+    const u64 last = hi[g], cm = commit[g], tlo = lo[g];
     const bool mixed = (workload & 0xffu) == RG_WL_MIXED; // rejects / snapshot requests / full windows: config 5 only
+    const bool elects = rg_wl_elects(seed, workload, gg, tick);
     for (u32 p = 0; p < 8; p++) {
         u8 f = 0;
         u64 idx = 0, mcm = 0, hint = 0, rs = 0;
@@ -148,6 +163,14 @@ RG_HD void rg_wl_gen_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64 
                 f = RG_MF_APPEND | RG_MF_VALID;
                 idx = last + d;
                 mcm = last + d;
+                if (elects) { // a new leader of this group: its empty entry lands at last + 1, then the d entries
+                    f |= RG_MF_BECOME_LEADER;
+                    hint = 100 + tick; // the new term (strictly increasing per group)
+                    idx += 1;
+                    mcm += 1;
+                }
+            } else if (elects) {
+                // responses to the OLD leader carry the old term: dropped by the term gate (raft.rs:1349-1411)
             } else {
                 const u32 pb = pflags[g * 8 + p];
                 const u32 state = pb & RG_PF_STATE_MASK;
@@ -182,9 +205,11 @@ RG_HD void rg_wl_gen_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64 
                     const bool paused = (pb & RG_PF_PAUSED) != 0;
                     if (!paused) f = RG_MF_SENT; // one probe, then paused (progress.rs:238)
                     if (u < 90 && nx > 0) {
-                        const u64 flast = rg_wl_follower_last(seed, gg, p, w.last0);
+                        // the first probe after an election asks for last_index-at-election = term_lo - 1; the
+                        // follower's real log ends up to 31 entries earlier
+                        const u64 flast = rg_wl_follower_last(seed, gg, p, nx - 1);
                         f |= RG_MF_VALID;
-                        if (mt == 0 && nx - 1 > flast) { // probe beyond the follower's log: reject
+                        if (mt == 0 && nx == tlo && nx - 1 > flast) { // probe beyond the follower's log: reject
                             f |= RG_MF_REJECT;
                             idx = nx - 1;
                             hint = flast;

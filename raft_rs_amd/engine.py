@@ -36,10 +36,11 @@ class PF:
 
 class MF:
     VALID, REJECT, HAS_RS, INS_FULL, SENT, APPEND, HEARTBEAT, HAS_LOGTERM = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80
+    BECOME_LEADER = 0x02  # on the leader's own slot (new term in m_hint)
 
 
 class OUT:
-    CHANGED, FAULT, TIMEOUT_NOW, APPENDED = 0x1, 0x2, 0x4, 0x8
+    CHANGED, FAULT, TIMEOUT_NOW, APPENDED, BECAME_LEADER = 0x1, 0x2, 0x4, 0x8, 0x10
 
     @staticmethod
     def send_append(o):
@@ -163,7 +164,7 @@ SYMBOLS = {
     "rg_heartbeat_commits": (_i, [_vp, _vp, _vp]),
     "rg_step_heartbeat_response": (_i, [_vp, _u64, _u64, _u64, _u64, C.c_uint8]),
     "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
-    "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 4)]),
+    "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 5)]),
     "rg_ingest": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_ingest_device": (_i, [_vp, _vp, _u64]),
     "rg_ingested_duplicates": (_i, [_vp, C.POINTER(_u64)]),
@@ -185,6 +186,7 @@ SYMBOLS = {
     "rg_local_append": (_i, [_vp, _u64, _u64]),
     "rg_local_persisted": (_i, [_vp, _u64, _u64]),
     "rg_mark_sent": (_i, [_vp, _u64, _u64]),
+    "rg_local_become_leader": (_i, [_vp, _u64, _u64]),
     "rg_flush": (_i, [_vp]),
     "rg_workload_init": (_i, [_vp, C.POINTER(_Workload), _u64]),
     "rg_workload_gen": (_i, [_vp, C.POINTER(_Workload), _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
@@ -494,9 +496,9 @@ class Engine:
         return a.value, b.value
 
     def msg_stats(self, dev_m_flags):
-        c = (_u64 * 4)()
+        c = (_u64 * 5)()
         self._check(self.L.rg_msg_stats(self.h, _ptr(dev_m_flags), C.byref(c)))
-        return {"valid": c[0], "rejects": c[1], "slots": c[2], "groups_with_events": c[3]}
+        return {"valid": c[0], "rejects": c[1], "slots": c[2], "groups_with_events": c[3], "elections": c[4]}
 
     def vote_result(self, yes, no):
         yes = np.ascontiguousarray(yes, dtype=np.uint8)
@@ -538,6 +540,10 @@ class Engine:
 
     def mark_sent(self, group, peer_id):
         self._check(self.L.rg_mark_sent(self.h, group, peer_id))
+
+    def local_become_leader(self, group, term):
+        """Raft::become_leader at `term` for one group, queued like the other leader-local events."""
+        self._check(self.L.rg_local_become_leader(self.h, group, term))
 
     def flush(self):
         self._check(self.L.rg_flush(self.h))

@@ -110,6 +110,16 @@ class OracleLeader:
     def append(self, n):
         O.lib().ro_group_append(self.cl.h, 0, n)
 
+    def become_leader(self, term):
+        """become_candidate + become_leader (raft.rs:1113-1202): Raft::reset(term), the leader's own Progress to
+        Replicate, the new leader's empty entry; then bcast_append (raft.rs:2190-2191). Returns the messages sent."""
+        assert O.lib().ro_group_become_leader(self.cl.h, 0, term) == 0
+        self.term = term
+
+    def become_leader_and_bcast(self, term):
+        self.become_leader(term)
+        return self._send(0x18)
+
     def persisted(self, index):
         return O.lib().ro_on_persist_entries(self.cl.h, 0, index)
 
@@ -335,6 +345,23 @@ class EngineLeader:
         self.msgs.m_commit[s, 0] = hi + n
         self.msgs.m_flags[0, s] = self.rg.MF.APPEND
         self._tick()
+        for k in range(hi + 1, hi + n + 1):
+            self.log[k] = self.term
+
+    def become_leader(self, term):
+        """The RG_MF_BECOME_LEADER event on the leader's own slot (new term in m_hint), then the send stage when the
+        engine holds the Inflights."""
+        s = self.self_id - 1
+        self.msgs.m_hint[s, 0] = term
+        self.msgs.m_flags[0, s] = self.rg.MF.BECOME_LEADER
+        out = self._tick()
+        assert out & self.rg.OUT.BECAME_LEADER and out & self.rg.OUT.APPENDED and not out & self.rg.OUT.FAULT, hex(out)
+        self.term = term
+        self.log[int(self.eng.read_column(self.rg.COL.TERM_HI)[0])] = term  # the new leader's empty entry
+
+    def become_leader_and_bcast(self, term):
+        self.become_leader(term)
+        return self._send()
 
     def persisted(self, index):
         s = self.self_id - 1

@@ -101,7 +101,9 @@ def random_term_table(rng, st, term):
 
 
 def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p=0.0, sent_p=0.5, heartbeat_p=0.1,
-                logterm_max=0):
+                logterm_max=0, elect_p=0.0, elect_term=0):
+    """elect_p > 0: that fraction of the groups carries RG_MF_BECOME_LEADER on the leader's slot with the new term
+    `elect_term` in m_hint (well-formed when elect_term is above every group's current term)."""
     """logterm_max > 0: 60% of the rejects carry Message.log_term in [1, logterm_max + 1] (needs a term table)."""
     """One tick of random messages against state `st` (fills an alloc_msgs() dict in place)."""
     G, P = st["n_groups"], st["n_slots"]
@@ -144,8 +146,10 @@ def random_msgs(rng, st, msgs, valid_p=0.7, reject_p=0.15, rs_p=0.1, malformed_p
             msgs["m_logterm"][p, :G] = np.where(has_lt, rng.integers(1, max(2, logterm_max + 2), size=G), 0).astype(np.uint64)
             hint_lt = np.clip(hi.astype(np.int64) - rng.integers(-2, 14, size=G), 0, None).astype(np.uint64)
             msgs["m_hint"][p, :G] = np.where(has_lt, hint_lt, msgs["m_hint"][p, :G])
+        elect = is_self & (rng.random(G) < elect_p)
+        msgs["m_hint"][p, :G] = np.where(elect, elect_term, msgs["m_hint"][p, :G]).astype(np.uint64)
         f = (valid * MF_VALID) | (reject * MF_REJECT) | (has_rs * MF_HAS_RS) | (ins_full * MF_INS_FULL) | \
-            (sent * MF_SENT) | (append * MF_APPEND) | (hb * MF_HEARTBEAT) | (has_lt * 0x80)
+            (sent * MF_SENT) | (append * MF_APPEND) | (hb * MF_HEARTBEAT) | (has_lt * 0x80) | (elect * MF_REJECT)
         msgs["m_flags"][:, p] = f.astype(np.uint8)
     return msgs
 

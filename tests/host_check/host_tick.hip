@@ -40,7 +40,7 @@ template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, b
     }
     for (u64 g = g0; g < g1; g++) {
         RgGroup<P> r;
-        rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
+        rg_load_group_elect<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
         if (gc) rg_group_tick<P, true, RG_LAZY_NEXT>(r, st, ms, g);
         else rg_group_tick<P, false, RG_LAZY_NEXT>(r, st, ms, g);
         rg_store_group<P>(r, st, g);
@@ -59,12 +59,14 @@ template <int P> static void host_fused(const RgState &st, const RgMsgs *ms, u32
         r.dirty = 0; r.evm = 0;
         for (u32 t = 0; t < T; t++) {
             r.mf = ms[t].mflags[g];
+            const u32 efault = rg_has_election(r.mf, r.cfg, P) ? RG_OUT_FAULT : 0u; // as in k_tick_fused
             for (int p = 0; p < P; p++) {
                 const u64 o = (u64)p * st.stride + g;
                 r.mi[p] = ms[t].mi[o]; r.mc[p] = ms[t].mc[o];
             }
             if (gc) rg_group_tick<P, true, true, true>(r, st, ms[t], g);
             else rg_group_tick<P, false, true, true>(r, st, ms[t], g);
+            r.out |= efault;
             out_t[(u64)t * st.G + g] = r.out;
             if (commit_t) commit_t[(u64)t * st.G + g] = r.commit;
         }

@@ -116,6 +116,7 @@ def lib():
         "ro_group_set_transferee": (None, [vp, sz, u64]),
         "ro_group_set_log": (C.c_int, [vp, sz, u64, u64, C.POINTER(u64), C.POINTER(u64), sz, u64, u64]),
         "ro_group_append": (None, [vp, sz, u64]),
+        "ro_group_become_leader": (C.c_int, [vp, sz, u64]),
         "ro_group_progress": (PP, [vp, sz, u64]),
         "ro_group_committed": (u64, [vp, sz]), "ro_group_last_index": (u64, [vp, sz]),
         "ro_group_term": (u64, [vp, sz]),

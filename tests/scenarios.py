@@ -550,7 +550,69 @@ def scenario_skip_bcast_commit(B):
     assert ld.ack(2, 5) == [] and ld.committed() == 5
 
 
-FLOW = [scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+def scenario_progress_leader(B):
+    """test_raft.rs:302-328 test_progress_leader: become_candidate + become_leader on an empty log, persist the
+    no-op entry; through five proposals the leader's own Progress stays Replicate with matched = the persisted index
+    and next = matched + 1."""
+    ld = B(1, 0, [1, 2], log=[], committed=0, next_idx=1)
+    ld.become_leader(1)
+    ld.persisted(1)  # raft.persist(): for the no-op entry
+    ld.set_progress(2, state=REPLICATE)
+    for i in range(5):
+        pr = ld.progress(1)
+        assert pr["state"] == REPLICATE
+        assert pr["match"] == i + 1 and pr["next"] == pr["match"] + 1, (i, pr)
+        ld.append(1)         # step(MsgPropose)
+        ld.persisted(i + 2)  # raft.persist()
+
+
+def scenario_become_leader_resets_every_progress(B):
+    """Raft::reset (raft.rs:942-971) through become_leader (:1151-1202), as test_raft.rs:116-299
+    test_progress_committed_index observes it across its elections: every Progress is Progress::reset(last + 1)
+    (progress.rs:82-92) -- matched 0, Probe, not paused, no pending snapshot / request, not recently active -- and keeps
+    its committed_index; the leader's own keeps matched = persisted, takes committed_index = committed and is
+    Replicate; the new term's range starts with the leader's empty entry, so nothing older commits by counting
+    (raft_log.rs:487-499)."""
+    log = [(1, 1), (1, 2), (1, 3), (2, 4), (2, 5)]
+    ld = B(2, 2, [1, 2, 3], learners=[4], log=log, committed=4)
+    ld.set_progress(2, match=5, next=6, state=REPLICATE, committed_index=4, recent_active=True)
+    ld.set_progress(1, match=5, next=6, state=REPLICATE, committed_index=4, recent_active=True)
+    ld.set_progress(3, match=3, next=6, state=SNAPSHOT, pending_snapshot=5, paused=True, committed_index=3)
+    ld.set_progress(4, match=2, next=3, state=PROBE, paused=True, pending_request_snapshot=7, committed_index=2)
+    ld.set_transferee(3)
+    ld.become_leader(5)
+    for pid, cidx in ((1, 4), (3, 3), (4, 2)):
+        assert ld.progress(pid) == {"match": 0, "next": 6, "state": PROBE, "paused": False, "pending_snapshot": 0,
+                                    "pending_request_snapshot": 0, "recent_active": False, "committed_index": cidx}, pid
+    me = ld.progress(2)
+    assert (me["match"], me["next"], me["state"], me["paused"], me["committed_index"]) == (5, 6, REPLICATE, False, 4)
+    assert ld.committed() == 4
+    ld.persisted(6)  # the leader's own empty entry at index 6, term 5
+    # followers at 5 hold a quorum of the OLD term's entry 5: not committed by counting replicas (raft.rs:893-904)
+    for pid in (1, 3):
+        out = ld.step(pid, 5)
+        assert not out["changed"] and not out["timeout_now"], "the aborted transfer sends no MsgTimeoutNow"
+        assert ld.progress(pid)["state"] == REPLICATE
+    assert ld.committed() == 4
+    assert ld.step(1, 6)["changed"] and ld.committed() == 6, "an entry of the new term commits everything before it"
+
+
+def scenario_leader_start_replication(B):
+    """test_raft_paper.rs:425-465 test_leader_start_replication: after become_leader the no-op goes to both
+    followers (commit_noop_entry :24-46: one MsgAppend each, one empty entry, prev index 0); once it is committed a
+    proposal is sent to both with index = li, one entry, commit = li."""
+    ld = B(1, 0, [1, 2, 3], log=[], committed=0, next_idx=1, max_inflight=256)
+    assert ld.become_leader_and_bcast(1) == [(2, 1, 0, 1), (3, 1, 0, 1)]
+    ld.ack(2, 1)
+    ld.ack(3, 1)
+    ld.persisted(1)
+    li = 1
+    assert ld.committed() == li
+    assert ld.propose() == [(2, 1, li, 1), (3, 1, li, 1)]
+    assert ld.committed() == li
+
+
+FLOW = [scenario_leader_start_replication, scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
@@ -559,4 +621,5 @@ ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_com
        scenario_unconditional_next_bump, scenario_old_paused_resend_and_transfer,
        scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
        scenario_commit_after_remove_node, scenario_fast_log_rejection, scenario_progress_committed_index,
-       scenario_send_path_update_state, scenario_leader_commit_preceding_entries]
+       scenario_send_path_update_state, scenario_leader_commit_preceding_entries, scenario_progress_leader,
+       scenario_become_leader_resets_every_progress]

@@ -204,6 +204,50 @@ def test_fused_ticks_equal_sequential_ticks(host_fused, n_slots, T, gc):
         assert not diffs, (rnd, diffs[:6])
 
 
+@pytest.mark.parametrize("n_slots", [1, 3, 5, 8])
+def test_elections_between_and_inside_ticks(host_tick, n_slots):
+    """RG_MF_BECOME_LEADER (Raft::reset + become_leader, raft.rs:942-971,1151-1202) on ~15% of the groups per tick,
+    several elections per group, together with ordinary traffic of the same tick (acks, rejects with and without
+    Message.log_term, heartbeat responses, appends): every column incl. term_lo and the cfg word's transferee, the
+    result word, and the term-run table (pushed by every election, its two oldest runs merged when full)."""
+    rng = np.random.default_rng(4400 + n_slots)
+    G, TERM = 4000, 9
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05, transfer_frac=0.3)
+    fuzz.random_state(rng, st, small_values=True, probe_frac=0.3)
+    fuzz.random_term_table(rng, st, TERM)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    eng_st = copy_state(st)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    elected = np.zeros(G, dtype=np.int64)
+    for t in range(10):
+        cl.store_soa(st)
+        # stale terms now and then (not above the current one): fault, ignored
+        term_t = TERM + 1 + t if t != 6 else TERM
+        fuzz.random_msgs(rng, st, msgs, reject_p=0.3, logterm_max=TERM + t, elect_p=0.15, elect_term=term_t)
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        for k in ("run_first", "run_term", "cur_term", "dummy_index", "dummy_term"):
+            assert (st[k] == eng_st[k]).all(), (t, k)
+        elected += (out & 0x10) != 0
+        self_slot = (st["cfg"] >> 16) & 7
+        flagged = (msgs["m_flags"][np.arange(G), self_slot] & 2) != 0
+        has_self = ((st["cfg"] >> 24) >> self_slot) & 1 == 1
+        if t == 6:
+            assert ((out[flagged & has_self] & 0x12) == 0x2).all(), "a stale term: fault, no election"
+        else:
+            assert ((out[flagged & has_self] & 0x10) != 0).all() and ((out[~flagged] & 0x10) == 0).all()
+            assert ((st["cfg"][flagged & has_self] >> 20) & 0xf == 0).all(), "abort_leader_transfer"
+    assert (elected >= 3).sum() > 50, "some groups saw three and more elections (table overflow path)"
+
+
 @pytest.mark.parametrize("n_slots", [3, 5, 7])
 def test_find_conflict_by_term_on_the_device_table(host_tick, n_slots):
     """Rejects carrying Message.log_term: the engine resolves the hint with find_conflict_by_term over its

@@ -49,12 +49,42 @@ def test_mixed_stream_exercises_probe_and_reject_paths():
     st, stats, _ = run_stream(E.WL_MIXED, 6000, 7, 5)
     assert stats["reject"] > 100, "post-election groups reject the first probe"
     assert stats["send_append"] > 100
-    # after a few ticks the post-election followers have been probed into Replicate
-    states = st["pflags"] & 3
-    present = (st["cfg"] >> 24) & 0xff
-    n_probe = sum(int(((states[:, p] == 0) & ((present >> p) & 1 == 1)).sum()) for p in range(7))
-    n_slots = sum(int(((present >> p) & 1).sum()) for p in range(7))
-    assert n_probe < 0.02 * n_slots
+    assert stats["fault"] == 0
+
+
+def test_mixed_stream_keeps_ten_percent_of_the_groups_in_term_rollover():
+    """BASELINE config 5: "10% leader-term rollover (maybe_decr_to path)". Every tick 1/32 of the groups elects a
+    new leader (RG_MF_BECOME_LEADER); in steady state ~10% of the groups have not committed an entry of their new
+    term yet, ~8% have a follower in Probe, and ~0.1 rejects per group arrive per tick."""
+    G, P = 12000, 7
+    st = O.alloc_state(G, P)
+    E.workload_init_host(st, E.WL_MIXED)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=5)
+    msgs = E.MsgBuffers(G, P, st["stride"])
+    gout = np.zeros(G, dtype=np.uint32)
+    rej, elect, rollover, probing = [], [], [], []
+    for t in range(14):
+        E.workload_gen_host(st, msgs, E.WL_MIXED, t)
+        f = msgs.m_flags
+        # (the BECOME_LEADER bit of the leader's slot 0 is the REJECT bit of a follower's)
+        rej.append(int(((f[:, 1:] & 3) == 3).sum()) / G)
+        elect.append(int((f[:, 0] & E.MF.BECOME_LEADER != 0).sum()) / G)
+        cl.tick_soa(msgs.as_dict(), gout)
+        cl.store_soa(st)
+        assert ((gout >> 1) & 1).sum() == 0, "the stream is well-formed: no fault"
+        elected = (f[:, 0] & E.MF.BECOME_LEADER) != 0
+        assert ((gout[elected] & E.OUT.BECAME_LEADER) != 0).all() and ((gout[~elected] & E.OUT.BECAME_LEADER) == 0).all()
+        assert (f[elected][:, 1:] == 0).all(), "old-term responses never reach the new leader"
+        rollover.append(float((st["commit"] < st["term_lo"]).mean()))
+        present = (st["cfg"] >> 24) & 0xff
+        states = st["pflags"] & 3
+        probing.append(float(np.any([(states[:, p] == 0) & (((present >> p) & 1) == 1) for p in range(1, P)], axis=0).mean()))
+    steady = slice(6, None)
+    assert 0.025 < np.mean(elect[steady]) < 0.04, elect
+    assert 0.09 < np.mean(rej[steady]) < 0.15, rej
+    assert 0.08 < np.mean(rollover[steady]) < 0.13, rollover
+    assert 0.05 < np.mean(probing[steady]) < 0.12, probing
 
 
 def test_host_generator_is_deterministic_and_shardable():
