@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--groups G] [--slots P] [--workload 2|3|5]
                     [--fuse T] [--split S] [--variant 0|2] [--publish-every E] [--one-engine] [--no-cpu-baseline]
-                    [--inflights CAP]
+                    [--inflights CAP] [--no-extras]
 
 One "step" = one tick of the hot path over every raft group of the shard: apply each group's
 AppendResponse slots (Raft::handle_append_response semantics) and re-evaluate + gate the commit
@@ -11,7 +11,9 @@ index (maybe_commit), i.e. one *evaluation* per group per step (BASELINE.md sect
 
 Workload at N=1: BASELINE.json configs[1] = 1,000,000 groups x 5 peers, majority quorum, synthetic
 AppendResponse stream (seed 0x5EED5EED). Weak scaling: every rank holds its own 1M-group shard
-(disjoint global group ids); the only exchange is the all-gather that publishes commit indices.
+(disjoint global group ids); the only exchange is the publication of commit indices, natively behind the C ABI
+(rg_comm_init / rg_publish_commit: ncclAllGather over xGMI of the ~1 B/group slices the ticks produce), after EVERY
+tick by default. `--gpus N --slots 7` is BASELINE configs[3] (8 M x 7 over 8 GPUs at N = 8).
 
 Procedure: the W+K ticks of messages are generated on the device from the evolving state in an
 untimed pass (generate -> tick -> generate ...), the engine state is restored from a checkpoint,
@@ -37,13 +39,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec), /opt/skills/guides/MI355X_MIC
 def algorithmic_bytes(n_groups, slots_present, valid_msgs, rejects):
     """B = 9*P + 58*A + 8*R + 37 bytes per evaluation, summed over the tick."""
     return 9 * slots_present + 58 * valid_msgs + 8 * rejects + 37 * n_groups
-
-
-class DevCommitView:
-    """Zero-copy torch view of the engine's commit column (CUDA array interface)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
 def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
@@ -206,8 +201,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--publish-every", type=int, default=16,
-                    help="N>1: all-gather the commit column every E ticks (and after the last tick)")
+    ap.add_argument("--publish-every", type=int, default=1,
+                    help="N>1: publish the commit advances every E ticks (and after the last tick); default every tick")
     ap.add_argument("--fuse", type=int, default=1,
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
@@ -247,10 +242,9 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # torch.distributed is the CONTROL plane only (unique-id hand-over, barriers, max-over-ranks): gloo. The data
+        # path -- the commit publication -- is the engine's own RCCL communicator (rg_comm_init), one per engine.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
     T = W + K
@@ -316,39 +310,52 @@ def main():
         if n_fault:
             raise SystemExit(f"stream raised {n_fault} faults: malformed workload")
 
-    # ---- commit publication (N>1): double-buffered snapshot of commit_idx, all-gather on a side stream ----
-    def make_publishers():
-        from raft_rs_amd import sharding
-        return [sharding.CommitPublisher(dist, pt.n, world, "cuda") for pt in parts]
-
-    pubs = None
-    if distributed:
-        for pt in parts:
-            pt.commit_view = torch.as_tensor(DevCommitView(pt.eng.column_ptr(rg.COL.COMMIT), pt.n), device="cuda")
-        pubs = make_publishers()
-
-    # Publishing all commit indices EVERY tick is not physically possible at this tick rate: 8 ranks x
-    # 8 MB gathered per ~60 us tick would be ~1 TB/s of xGMI ingress per GPU (7 links x ~64 GB/s each
-    # way). The exchange therefore runs every E ticks (default 16: ~64 MB per ~1 ms), always including
-    # the last tick of the region so the gathered result can be verified.
+    # ---- commit publication (N>1): natively behind the C ABI ----
+    # Every tick writes, fused into its store path, one byte per group whose commit index advanced (include/raftgroups.h,
+    # "multi-GPU"); rg_publish_commit all-gathers that ~1 B/group slice on the engine's side stream (ncclAllGather over
+    # xGMI) while the next ticks run, and every rank keeps a replica of all commit indices, updated lazily. 1 MB per rank
+    # and tick at 1 M groups instead of the 8 MB column: per-tick publication at 8 ranks moves 7 MB into each GPU per
+    # ~60 us tick (~120 GB/s of its ~450 GB/s xGMI ingress) instead of 56 MB (~930 GB/s: not feasible).
     E = max(1, args.publish_every)
-    n_pub = [0]
+
+    class Dev:  # a device range as a torch tensor (CUDA array interface), for the shared-GPU test transport only
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    def gloo_allgather(dev_send, dev_recv, nbytes, hip_stream):
+        torch.cuda.synchronize()
+        send = torch.as_tensor(Dev(dev_send, nbytes), device="cuda").cpu()
+        out = torch.empty(world * nbytes, dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, send)
+        torch.as_tensor(Dev(dev_recv, world * nbytes), device="cuda").copy_(out)
+        torch.cuda.synchronize()
+        return 0
+
+    if distributed:
+        from raft_rs_amd import engine as E_
+        for pt in parts:
+            if share_gpu:  # RCCL refuses two ranks on one device: gloo moves the slices (test hook)
+                pt.eng.comm_init(rank, world, transport=gloo_allgather)
+            else:
+                box = [E_.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                pt.eng.comm_init(rank, world, unique_id=box[0])
 
     # Size-class engines are independent, so each runs on its own HIP stream (forked from / joined to the
     # main stream around the region): the tail of one engine's launch overlaps the next engine's head.
-    multi = len(parts) > 1 and os.environ.get("BENCH_GRAPH") != "1"
+    multi = len(parts) > 1
     for pt in parts:
         pt.stream = torch.cuda.Stream() if multi else stream
         pt.eng.set_stream(pt.stream.cuda_stream)
 
-    def run_ticks(t0, n, publishers):
+    def run_ticks(t0, n, publish):
         if multi:
             fork = torch.cuda.Event()
             fork.record(stream)
             for pt in parts:
                 pt.stream.wait_event(fork)
         F = 1 if args.inflights else max(1, min(8, args.fuse))
-        if F > 1 and publishers is None:
+        if F > 1 and not publish:
             # temporal fusion: F consecutive recorded ticks per launch (state stays in registers between them)
             for pt in parts:
                 if not hasattr(pt, "out_t"):
@@ -359,76 +366,37 @@ def main():
                     pt.eng.tick_device_fused([tick_ptrs(pt, t0 + i + q) for q in range(k)], pt.out_t.data_ptr())
             n = 0  # nothing left for the per-tick loop below
         for i in range(n):
-            pub_now = publishers is not None and ((i + 1) % E == 0 or i == n - 1)
-            for j, pt in enumerate(parts):
+            pub_now = publish and ((i + 1) % E == 0 or i == n - 1)
+            for pt in parts:
                 pt.eng.tick_device(*tick_ptrs(pt, t0 + i))
                 if args.inflights:
                     pt.eng.send_appends(0)
                 if pub_now:
-                    publishers[j].publish(n_pub[0], pt.commit_view, pt.stream)
-            if pub_now:
-                n_pub[0] += 1
-        if publishers is not None:
-            for j, pt in enumerate(parts):
-                publishers[j].join(pt.stream)
+                    pt.eng.publish_commit()
+        if publish:  # the region ends when every exchange has landed and the replicas are up to date
+            for pt in parts:
+                pt.eng.publish_sync()
         if multi:
             for pt in parts:
                 ev = torch.cuda.Event()
                 ev.record(pt.stream)
                 stream.wait_event(ev)
 
-    def join(publishers):
-        pass  # run_ticks joins its publishers itself
-
-    def set_streams(handle):
-        for pt in parts:
-            pt.eng.set_stream(handle)
-
     # ---- timed region ----
     for pt in parts:
         pt.eng.restore()
-    run_ticks(0, W, pubs)
-    join(pubs)
+        if distributed:
+            pt.eng.publish_commit(full=True)  # the replicas restart from the restored columns (outside the region)
+    run_ticks(0, W, distributed)
     torch.cuda.synchronize()
-    # BENCH_GRAPH=1: capture the K ticks + their all-gathers into ONE HIP graph. Measured at world size 1
-    # (profiles/r01_dist_path_ws1.txt): with the exchange every 8 ticks eager launches are faster (66 vs
-    # 68 us/step; the host stays >4 ticks ahead of the GPU), the graph only wins when every tick publishes
-    # (90 vs 98 us/step), so eager is the default.
-    graph = None
     launch_mode = "eager"
-    if distributed and os.environ.get("BENCH_GRAPH") == "1":
-        try:
-            gpubs = make_publishers()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                cap = torch.cuda.current_stream()
-                for pt in parts:
-                    pt.stream = cap
-                set_streams(cap.cuda_stream)
-                run_ticks(W, K, gpubs)
-            for pt in parts:
-                pt.stream = stream
-            set_streams(stream.cuda_stream)
-            pubs = gpubs
-            launch_mode = "hipGraph"
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches", file=sys.stderr)
-            graph = None
-            for pt in parts:
-                pt.stream = stream
-            set_streams(stream.cuda_stream)
-            torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     wall0 = time.perf_counter()
     e0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        run_ticks(W, K, pubs)
-        join(pubs)
+    run_ticks(W, K, distributed)
     e1.record(stream)
     torch.cuda.synchronize()
     if distributed:
@@ -449,11 +417,16 @@ def main():
         if not (np.array_equal(commit, pt.ref_commit) and np.array_equal(out, pt.ref_out)):
             raise SystemExit("timed replay diverged from the recorded pass")
         if distributed:
-            got = pubs[j].result((n_pub[0] - 1) & 1)[rank].cpu().numpy().view(np.uint64)
-            if not np.array_equal(got, commit):
-                raise SystemExit("all-gathered commit indices do not match this rank's shard")
+            # every rank's replica must hold every rank's shard: compare against the columns themselves
+            rep = pt.eng.published_commit()  # [world][n] out of THIS rank's replica
+            cols_all = [torch.empty(pt.n, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(cols_all, torch.from_numpy(commit.view(np.int64)))
+            for r in range(world):
+                if not np.array_equal(rep[r], cols_all[r].numpy().view(np.uint64)):
+                    raise SystemExit(f"rank {rank}: published commit indices of rank {r} differ from its commit column")
+    pub_stats = parts[0].eng.publish_stats() if distributed else None
     if distributed:
-        tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
 
@@ -484,10 +457,14 @@ def main():
         "value": value, "unit": "group-evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": {2: "1M groups x 5 peers, majority quorum (BASELINE configs[1])",
-                                3: "1M groups x 5 slots, joint {0,1,2}&&{1,2,3} + learner (configs[2])",
-                                5: "1M groups mixed 3/5/7 peers + 10% post-election probe/reject (configs[4])"}[args.workload]
-                   if (G, P) in ((1_000_000, 5), (1_000_000, 7)) else f"{G} groups x {P} slots, workload {args.workload}",
+        "config": {"workload": (f"{world} M groups x 7 peers sharded over {world} GPUs, commit indices published every "
+                                f"{'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3] at 8 GPUs)"
+                                if (args.workload == 2 and (G, P) == (1_000_000, 7) and distributed) else
+                                {2: "1M groups x 5 peers, majority quorum (BASELINE configs[1])",
+                                 3: "1M groups x 5 slots, joint {0,1,2}&&{1,2,3} + learner (configs[2])",
+                                 5: "1M groups mixed 3/5/7 peers + 10% leader-term rollover (configs[4])"}[args.workload]
+                                if (G, P) in ((1_000_000, 5), (1_000_000, 7)) else
+                                f"{G} groups x {P} slots, workload {args.workload}"),
                    "groups_per_gpu": G, "peer_slots": P, "workload_id": args.workload, "seed": hex(args.seed),
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
                    **({"elections_per_group": round(EL, 5),
@@ -498,7 +475,12 @@ def main():
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
                    "device": {k: v for k, v in parts[0].eng.device_info().items() if k != "engine_bytes"},
                    "engine_hbm_bytes": sum(pt.eng.device_info()["engine_bytes"] for pt in parts),
-                   "sharding": f"{world} disjoint group ranges" + (f", commit_idx all-gather every {E} ticks ({'gloo, shared GPU test hook' if share_gpu else 'RCCL'})" if distributed else ""),
+                   "sharding": f"{world} disjoint group ranges" + (
+                       f", commit indices published every {E} tick(s) through rg_publish_commit: "
+                       f"{'gloo transport callback (shared-GPU test hook)' if share_gpu else 'ncclAllGather (RCCL)'} of "
+                       f"{pub_stats['bytes_per_rank_delta']} B/rank delta slices (full column: {pub_stats['bytes_per_rank_full']} B)"
+                       if distributed else ""),
+                   **({"publication": pub_stats} if distributed else {}),
                    "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

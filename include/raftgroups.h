@@ -254,8 +254,8 @@ int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
  * required) receives every tick's RG_OUT_* word, `dev_commit_t` (u64 [n_ticks][G], device, may be NULL) the
  * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. m_logterm must be NULL (hints
  * are not passed through find_conflict_by_term in fused launches: resolve them on the host), and an
- * RG_MF_BECOME_LEADER event is NOT applied (it rewrites the group's cells in memory, which a launch that holds them
- * in registers cannot do): that group-tick reports RG_OUT_FAULT -- elections go through single-tick launches.
+ * RG_MF_BECOME_LEADER event is NOT applied (the rare path would cost the fused kernel a wave of occupancy): that
+ * group-tick reports RG_OUT_FAULT -- elections go through single-tick launches.
  * Asynchronous. Use it to
  * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
 #define RG_MAX_FUSE 8
@@ -407,6 +407,67 @@ int rg_ingest_tick(rg_engine *h, const rg_wire_msg *host_records, uint64_t n, ui
 /* Groups touched by the last rg_tick_ingested with their commit index and result word (host arrays of
  * capacity `cap`; *n receives the number of groups, which may exceed cap: then only cap are written). */
 int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *commit, uint32_t *out, uint64_t cap, uint64_t *n);
+
+/* ---- multi-GPU: disjoint group ranges, one engine per rank, and the ONE exchange of the path -- the publication of
+ *      commit indices. What crosses xGMI is what RawNode::advance_append surfaces per group
+ *      (src/raw_node.rs:643-651, fed by Raft::maybe_commit, src/raft.rs:893-904): the new commit index, which never
+ *      decreases (RaftLog::commit_to, src/raft_log.rs:286-300). The ticks therefore record, per group, how far the index
+ *      ADVANCED since the last publication -- one byte, fused into the tick's store path; advances >= 255 go to a short
+ *      exact-value list -- and rg_publish_commit all-gathers that ~1 B/group slice (ncclAllGather over xGMI, RCCL bound at
+ *      run time) on a side stream instead of the 8 B/group column: every tick can be published at 8 ranks (1 MB instead
+ *      of 8 MB per rank and tick at 1 M groups). Each rank keeps a replica of ALL commit indices [world][stride] u64 in
+ *      HBM; gathered slices are folded into it lazily (when `ring_ticks` publications are buffered, or when it is read).
+ *      A full exact-value list (or rg_restore / a reloaded commit column) marks the rank's slice "lost": all ranks
+ *      see that in the gathered headers and the second publication after it is a full 8 B/group snapshot -- decided
+ *      identically everywhere without another collective. All ranks must hold the same number of groups and call
+ *      rg_comm_init / rg_publish_commit in the same order (they are collectives). ---- */
+#define RG_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 creates the id, the host distributes it to the other ranks (any channel). */
+int rg_comm_unique_id(uint8_t id[RG_COMM_ID_BYTES]);
+/* A host-provided all-gather (MPI, a test harness): gather `bytes_per_rank` bytes from every rank's dev_send into
+ * dev_recv ([world][bytes_per_rank], rank order), enqueued on (or completed before returning from) hip_stream.
+ * Returns 0 on success. */
+typedef int (*rg_allgather_fn)(void *user, const void *dev_send, void *dev_recv, uint64_t bytes_per_rank, void *hip_stream);
+typedef struct {
+    uint32_t rank, world;
+    const uint8_t *unique_id;   /* RG_COMM_ID_BYTES from rg_comm_unique_id (RCCL transport); ignored with `transport` */
+    rg_allgather_fn transport;  /* NULL = RCCL's ncclAllGather; else the exchange goes through this callback */
+    void *transport_user;
+    uint32_t ring_ticks;        /* gathered publications buffered before the replica is updated; 0 = 32, at most 64 */
+    uint32_t overflow_slots;    /* capacity of a slice's exact-value list; 0 = n_groups / 256 + 64 */
+} rg_comm_config;
+/* Collective. Allocates the publication buffers and the replica, creates the communicator and runs one FULL
+ * publication so every replica starts from the actual commit columns. */
+int rg_comm_init(rg_engine *h, const rg_comm_config *cfg);
+int rg_comm_destroy(rg_engine *h);
+/* Collective, asynchronous: publish this rank's commit advances since its previous publication (call it after every
+ * tick for per-tick visibility, or less often: the ticks accumulate). The exchange runs on a side stream and overlaps
+ * the ticks that follow. RG_PUBLISH_FULL forces the 8 B/group snapshot on ALL ranks (pass it on all of them). */
+#define RG_PUBLISH_FULL 0x1u
+int rg_publish_commit(rg_engine *h, uint32_t flags);
+/* Wait for every publication issued so far and bring the replica up to date. */
+int rg_publish_sync(rg_engine *h);
+/* The replica in device memory: commit index of group g of rank r at [r * *stride + g]. Valid after rg_publish_sync. */
+const uint64_t *rg_published_commit_ptr(rg_engine *h, uint64_t *stride);
+/* rg_publish_sync, then groups [first, first + n) of `rank` to host memory. */
+int rg_published_commit(rg_engine *h, uint32_t rank, uint64_t first, uint64_t n, uint64_t *host_commit);
+typedef struct {
+    uint64_t publications, full_publications, replica_updates;
+    uint64_t bytes_per_rank_last;  /* what the last publication moved per rank */
+    uint64_t bytes_per_rank_delta; /* size of a delta slice (header + list + 1 B/group) */
+    uint64_t bytes_per_rank_full;  /* size of a full snapshot (8 B/group) */
+    uint32_t overflow_slots, ring_ticks;
+} rg_publish_stats;
+int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out);
+/* Host twins of the encoding over caller-provided buffers (no GPU involved; CPU-only tests of the N > 1 exchange):
+ * accumulate the advances old_commit -> new_commit into a slice of rg_pub_bytes_per_rank() bytes (zeroed by the caller
+ * at the start of an interval), and add one gathered publication ([world] slices) to a replica [world][stride] with
+ * stride = n_groups rounded up to 256; *lost_ranks = slices that ask for a full resynchronisation. */
+uint64_t rg_pub_bytes_per_rank(uint64_t n_groups, uint32_t overflow_slots);
+int rg_pub_accumulate_host(uint64_t n_groups, uint32_t overflow_slots, const uint64_t *old_commit,
+                           const uint64_t *new_commit, uint8_t *slice);
+int rg_pub_apply_host(uint64_t n_groups, uint32_t overflow_slots, uint32_t world, const uint8_t *gathered,
+                      uint64_t *replica, uint32_t *lost_ranks);
 
 /* ---- synthetic AppendResponse stream; same code on host and device ---- */
 typedef struct {

@@ -86,9 +86,10 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out
     }
     if (COMMIT) {
         u64 commit = st.commit[g];
-        const u64 lo = st.lo[g], hi = st.hi[g];
+        const u64 lo = st.lo[g], hi = st.hi[g], commit0 = commit;
         u32 out = 0;
         if (rg_log_maybe_commit(mci, commit, lo, hi)) { // src/raft.rs:893-904
+            if (st.pub) rg_pub_store(st, g, rg_pub_load(st, g) + (u32)rg_min(commit - commit0, 0x10000ULL), commit);
             st.commit[g] = commit;
             const u32 self = RG_CFG_SELF(cfg);
             if ((present >> self) & 1u) {
@@ -142,8 +143,10 @@ __global__ __launch_bounds__(256) void k_recompute_coop(RgState st, u32 P, u64 *
     const u64 mci = result[0] < result[1] ? result[0] : result[1];
     if (COMMIT) {
         u64 commit = st.commit[g];
+        const u64 commit0 = commit;
         u32 out = 0;
         if (rg_log_maybe_commit(mci, commit, st.lo[g], st.hi[g])) {
+            if (st.pub) rg_pub_store(st, g, rg_pub_load(st, g) + (u32)rg_min(commit - commit0, 0x10000ULL), commit);
             st.commit[g] = commit;
             const u32 self = RG_CFG_SELF(cfg);
             if ((present >> self) & 1u) {
@@ -617,6 +620,63 @@ struct rg_engine {
     std::vector<u32> host_cfg;                 // host copy of RG_COL_CFG for the mirror (self slots)
     bool host_cfg_valid;
     bool host_mirror;
+    struct RgPub *pub; // commit publication across ranks (rg_comm_init), nullptr = single engine
+};
+
+// RCCL is bound lazily (the library is ~0.5 GB; single-GPU users never load it). The types come from its header.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct RgRccl {
+    void *lib;
+    decltype(&ncclGetUniqueId) GetUniqueId;
+    decltype(&ncclCommInitRank) CommInitRank;
+    decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclAllGather) AllGather;
+    decltype(&ncclGetErrorString) GetErrorString;
+};
+static RgRccl g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+static int rg_rccl_load() {
+    if (g_rccl.lib) return RG_OK;
+    static const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return rg_fail(RG_ERR_NO_DEVICE, "rg_comm: cannot load RCCL (librccl.so.1): %s", dlerror());
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(&ncclCommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.AllGather = reinterpret_cast<decltype(&ncclAllGather)>(dlsym(lib, "ncclAllGather"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString) {
+        dlclose(lib);
+        return rg_fail(RG_ERR_NO_DEVICE, "rg_comm: the RCCL library lacks an expected symbol");
+    }
+    g_rccl.lib = lib;
+    return RG_OK;
+}
+
+struct RgPub {
+    u32 rank, world;
+    ncclComm_t comm;          // RCCL transport (nullptr with a custom transport)
+    rg_allgather_fn transport;
+    void *transport_user;
+    RgPubLayout lay;
+    u32 ring;                 // publications buffered before the replica is brought up to date
+    hipStream_t side;         // the exchange runs here; the engine's stream only records / waits events
+    char *send[2];            // this rank's slice under construction (double-buffered), bytes_per_rank each
+    char *ring_buf;           // [ring][world][bytes_per_rank]
+    u64 *replica;             // [world][Gpad]
+    u64 *full_send;           // [Gpad] snapshot of the commit column for a full publication
+    RgPubHdr *pin_hdr;        // pinned host: [3][world] headers of the last publications
+    hipEvent_t ev_tick[2], ev_done[2], ev_hdr[3];
+    bool done_pending[2], hdr_pending[3], hdr_full[3];
+    u64 n_pub;                // publications so far
+    u32 pending;              // ring slots gathered and not yet folded into the replica
+    bool local_lost;          // this rank's deltas no longer describe its commit column (restore / column load)
+    bool lost_announced;      // ... and a slice carrying RG_PUB_LOST has gone out (the full snapshot follows)
+    rg_publish_stats stats;
 };
 
 static size_t rg_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -771,6 +831,10 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.cur_term = (u64 *)rg_col(h, RG_COL_CUR_TERM);
     s.G = h->G;
     s.stride = h->stride;
+    s.pub = nullptr;
+    s.pub_off_delta = 0;
+    s.pub_cap = 0;
+    h->pub = nullptr;
     if (cfg->max_inflight) { // Inflights rings + the send stage's work-item list
         const size_t meta_b = rg_align((size_t)h->P * h->stride * 4) + 2 * rg_align((size_t)h->P * h->stride * 8); // meta | head | tail
         const size_t ring_b = rg_align((size_t)h->G * h->P * cfg->max_inflight * 8);
@@ -799,10 +863,13 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     return RG_OK;
 }
 
+extern "C" int rg_comm_destroy(rg_engine *h);
+
 extern "C" void rg_destroy(rg_engine *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->pub) (void)rg_comm_destroy(h);
     if (h->arena) (void)hipFree(h->arena);
     if (h->ckpt) (void)hipFree(h->ckpt);
     if (h->ins_arena) (void)hipFree(h->ins_arena);
@@ -860,6 +927,7 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
         hipLaunchKernelGGL(k_fix_ins_full, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
                            h->st, h->ins, h->P);
     RG_HIP(hipStreamSynchronize(h->stream));
+    if (c == RG_COL_COMMIT && h->pub) h->pub->local_lost = true;
     if (c == RG_COL_CFG) {
         h->host_cfg_valid = false;
         const u32 *w = static_cast<const u32 *>(src);
@@ -906,6 +974,7 @@ extern "C" int rg_restore(rg_engine *h) {
     RG_HIP(hipSetDevice(h->cfg.device));
     RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
     h->host_res_valid = false;
+    if (h->pub) h->pub->local_lost = true; // the published advances no longer describe this commit column
     h->out_is_dense = true; // RG_COL_OUT is whatever it was at the checkpoint: the next sparse tick clears all of it
     h->host_cfg_valid = false; // RG_COL_CFG came back too: the mirror re-reads its copy
     if (h->ckpt_any_group_commit) h->any_group_commit = true; // ... and so may group-commit configurations
@@ -1050,6 +1119,9 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
     if (h->ins_arena)
         return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: engines with device Inflights (max_inflight > 0) need "
                                      "rg_send_appends after every tick; fused launches are not available");
+    if (h->pub)
+        return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: not available while commit publication is active "
+                                     "(rg_comm_init): the per-tick advance of a fused launch is not recorded");
     RG_HIP(hipSetDevice(h->cfg.device));
     RgFused fm;
     memset(&fm, 0, sizeof(fm));
@@ -2038,6 +2110,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
                        w->workload | (w->reserved << 8), h->P, (u64)first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_init: %s", hipGetErrorString(e));
+    if (h->pub) h->pub->local_lost = true;
     h->host_cfg_valid = false;
     return RG_OK;
 }
@@ -2070,5 +2143,346 @@ extern "C" int rg_workload_gen_host(const rg_workload *w, uint64_t first, uint64
                         (const u64 *)s->next, s->pflags, (const u64 *)s->commit, (const u64 *)s->term_lo,
                         (const u64 *)s->term_hi, (u64 *)mi,
                         (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
+    return RG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: publication of commit indices (encoding and replica kernels in rg_publish.h)
+// ------------------------------------------------------------------------------------------------
+// replica kernels (the arithmetic is rg_pub_apply8 in rg_publish.h, shared with the host twins)
+__global__ __launch_bounds__(256) void k_pub_apply(u64 *replica, RgPubSlots sl, RgPubLayout l, u32 world) {
+    const u64 per_rank = l.Gpad / 8;
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_rank * world) return;
+    rg_pub_apply8(replica, sl, l, (u32)(i / per_rank), (i % per_rank) * 8);
+}
+
+// The exact-value lists of the same publications: one thread per (publication, rank, entry).
+__global__ __launch_bounds__(256) void k_pub_apply_lists(u64 *replica, RgPubSlots sl, RgPubLayout l, u32 world) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 per_slot = (u64)world * l.cap;
+    if (i >= per_slot * sl.n) return;
+    const u32 s = (u32)(i / per_slot), rank = (u32)((i % per_slot) / l.cap), k = (u32)(i % l.cap);
+    const char *base = sl.slice[s] + (u64)rank * l.bytes_per_rank;
+    const RgPubHdr *hdr = reinterpret_cast<const RgPubHdr *>(base);
+    if (k >= hdr->n_overflow) return;
+    const RgPubOvf e = reinterpret_cast<const RgPubOvf *>(base + l.off_list)[k];
+    if (e.group < l.G) atomicAdd((unsigned long long *)&replica[(u64)rank * l.Gpad + e.group], (unsigned long long)e.extra);
+}
+
+static const char *rg_nccl_err(ncclResult_t r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
+
+static int rg_pub_allgather(rg_engine *h, const void *send, void *recv, u64 bytes) {
+    RgPub *p = h->pub;
+    if (p->transport) {
+        const int rc = p->transport(p->transport_user, send, recv, bytes, p->side);
+        if (rc) return rg_fail(RG_ERR_NO_DEVICE, "rg_publish_commit: the custom all-gather transport failed (%d)", rc);
+        return RG_OK;
+    }
+    const ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)bytes, ncclUint8, p->comm, p->side);
+    if (r != ncclSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_publish_commit: ncclAllGather failed: %s", rg_nccl_err(r));
+    return RG_OK;
+}
+
+// point the tick kernels at send buffer `b`
+static void rg_pub_target(rg_engine *h, int b) {
+    h->st.pub = h->pub->send[b];
+    h->st.pub_off_delta = h->pub->lay.off_delta;
+    h->st.pub_cap = h->pub->lay.cap;
+}
+
+// fold the buffered publications into the replica (side stream)
+static int rg_pub_materialize(rg_engine *h) {
+    RgPub *p = h->pub;
+    if (!p->pending) return RG_OK;
+    RgPubSlots sl;
+    sl.n = p->pending;
+    const u64 slot_bytes = (u64)p->world * p->lay.bytes_per_rank;
+    for (u32 j = 0; j < p->pending; j++) // the `pending` most recent delta publications, ring order is irrelevant
+        sl.slice[j] = p->ring_buf + (u64)j * slot_bytes;
+    const u64 words = p->lay.Gpad / 8 * p->world;
+    hipLaunchKernelGGL(k_pub_apply, dim3(rg_grid(words, 256)), dim3(256), 0, p->side, p->replica, sl, p->lay, p->world);
+    const u64 entries = (u64)p->world * p->lay.cap * sl.n;
+    if (entries)
+        hipLaunchKernelGGL(k_pub_apply_lists, dim3(rg_grid(entries, 256)), dim3(256), 0, p->side, p->replica, sl, p->lay,
+                           p->world);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_publish: replica update failed: %s", hipGetErrorString(e));
+    p->pending = 0;
+    p->stats.replica_updates++;
+    return RG_OK;
+}
+
+static int rg_publish_impl(rg_engine *h, bool force_full) {
+    RgPub *p = h->pub;
+    const u64 i = p->n_pub;
+    const int b = (int)(i & 1), hb = (int)(i % 3);
+    // Did any rank lose exactness two publications ago? Every rank reads the same gathered headers, so every rank
+    // takes the same decision without another collective. (Two publications back: that exchange has long finished,
+    // the wait below does not stall the pipeline.)
+    bool full = force_full;
+    if (i >= 2) {
+        const int h2 = (int)((i - 2) % 3);
+        if (p->hdr_pending[h2]) {
+            RG_HIP(hipEventSynchronize(p->ev_hdr[h2]));
+            p->hdr_pending[h2] = false;
+            if (!p->hdr_full[h2])
+                for (u32 r = 0; r < p->world; r++) {
+                    const RgPubHdr &hd = p->pin_hdr[(u64)h2 * p->world + r];
+                    if ((hd.flags & RG_PUB_LOST) || hd.n_overflow > p->lay.cap) full = true;
+                }
+        }
+    }
+    if (p->local_lost && !p->lost_announced && !full) { // tell the other ranks (they act on it two publications from now)
+        static const u32 k_lost = RG_PUB_LOST;
+        RG_HIP(hipMemcpyAsync(p->send[b] + offsetof(RgPubHdr, flags), &k_lost, 4, hipMemcpyHostToDevice, h->stream));
+        p->lost_announced = true;
+    }
+    if (full) // snapshot the column before later ticks move it
+        RG_HIP(hipMemcpyAsync(p->full_send, h->st.commit, h->G * 8, hipMemcpyDeviceToDevice, h->stream));
+    RG_HIP(hipEventRecord(p->ev_tick[b], h->stream));
+    RG_HIP(hipStreamWaitEvent(p->side, p->ev_tick[b], 0));
+    int rc;
+    if (full) {
+        // the snapshot supersedes every buffered delta publication (and this interval's deltas)
+        p->pending = 0;
+        rc = rg_pub_allgather(h, p->full_send, p->replica, p->lay.Gpad * 8);
+        if (rc) return rc;
+        p->hdr_full[hb] = true;
+        p->local_lost = false;
+        p->lost_announced = false;
+        p->stats.full_publications++;
+        p->stats.bytes_per_rank_last = p->lay.Gpad * 8;
+    } else {
+        if (p->pending == p->ring) {
+            rc = rg_pub_materialize(h);
+            if (rc) return rc;
+        }
+        char *slot = p->ring_buf + (u64)p->pending * p->world * p->lay.bytes_per_rank;
+        rc = rg_pub_allgather(h, p->send[b], slot, p->lay.bytes_per_rank);
+        if (rc) return rc;
+        p->pending++;
+        // the gathered headers, for the decision two publications from now
+        RG_HIP(hipMemcpy2DAsync(p->pin_hdr + (u64)hb * p->world, sizeof(RgPubHdr), slot, p->lay.bytes_per_rank,
+                                sizeof(RgPubHdr), p->world, hipMemcpyDeviceToHost, p->side));
+        p->hdr_full[hb] = false;
+        p->stats.bytes_per_rank_last = p->lay.bytes_per_rank;
+    }
+    RG_HIP(hipEventRecord(p->ev_hdr[hb], p->side));
+    p->hdr_pending[hb] = true;
+    // this slice starts its next interval empty
+    RG_HIP(hipMemsetAsync(p->send[b], 0, p->lay.bytes_per_rank, p->side));
+    RG_HIP(hipEventRecord(p->ev_done[b], p->side));
+    p->done_pending[b] = true;
+    // the ticks that follow accumulate into the other slice, once its previous exchange has let go of it
+    const int nb = b ^ 1;
+    if (p->done_pending[nb]) {
+        RG_HIP(hipStreamWaitEvent(h->stream, p->ev_done[nb], 0));
+        p->done_pending[nb] = false;
+    }
+    rg_pub_target(h, nb);
+    p->n_pub++;
+    p->stats.publications++;
+    return RG_OK;
+}
+
+extern "C" int rg_comm_unique_id(uint8_t id[RG_COMM_ID_BYTES]) {
+    if (!id) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_unique_id: null argument");
+    int rc = rg_rccl_load();
+    if (rc) return rc;
+    static_assert(RG_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "RG_COMM_ID_BYTES must match RCCL's unique id");
+    ncclUniqueId u;
+    const ncclResult_t r = g_rccl.GetUniqueId(&u);
+    if (r != ncclSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_comm_unique_id: ncclGetUniqueId failed: %s", rg_nccl_err(r));
+    memcpy(id, u.internal, RG_COMM_ID_BYTES);
+    return RG_OK;
+}
+
+extern "C" int rg_comm_destroy(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_destroy: null engine");
+    RgPub *p = h->pub;
+    if (!p) return RG_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    if (p->side) (void)hipStreamSynchronize(p->side);
+    if (p->comm) (void)g_rccl.CommDestroy(p->comm);
+    for (int k = 0; k < 2; k++) {
+        if (p->send[k]) (void)hipFree(p->send[k]);
+        if (p->ev_tick[k]) (void)hipEventDestroy(p->ev_tick[k]);
+        if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]);
+    }
+    for (int k = 0; k < 3; k++)
+        if (p->ev_hdr[k]) (void)hipEventDestroy(p->ev_hdr[k]);
+    if (p->ring_buf) (void)hipFree(p->ring_buf);
+    if (p->replica) (void)hipFree(p->replica);
+    if (p->full_send) (void)hipFree(p->full_send);
+    if (p->pin_hdr) (void)hipHostFree(p->pin_hdr);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    delete p;
+    h->pub = nullptr;
+    h->st.pub = nullptr;
+    return RG_OK;
+}
+
+extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
+    if (!h || !cfg) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: null argument");
+    if (h->pub) return rg_fail(RG_ERR_STATE, "rg_comm_init: already initialised (rg_comm_destroy first)");
+    if (cfg->world == 0 || cfg->rank >= cfg->world)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: rank %u of %u", cfg->rank, cfg->world);
+    if (!cfg->transport && !cfg->unique_id)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: the RCCL transport needs the unique id of rg_comm_unique_id");
+    if (cfg->ring_ticks > RG_PUB_MAX_RING)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: ring_ticks %u, at most %d", cfg->ring_ticks, RG_PUB_MAX_RING);
+    RG_HIP(hipSetDevice(h->cfg.device));
+    RgPub *p = new (std::nothrow) RgPub();
+    if (!p) return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_comm_init: host allocation failed");
+    memset(p, 0, sizeof(*p));
+    p->rank = cfg->rank;
+    p->world = cfg->world;
+    p->transport = cfg->transport;
+    p->transport_user = cfg->transport_user;
+    p->ring = cfg->ring_ticks ? cfg->ring_ticks : 32;
+    const u32 cap = cfg->overflow_slots ? cfg->overflow_slots : (u32)(h->G / 256 + 64);
+    p->lay = rg_pub_layout(h->G, cap);
+    h->pub = p;
+#define RG_PUB_TRY(expr)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess) {                                                                               \
+            (void)rg_comm_destroy(h);                                                                          \
+            return rg_fail(e__ == hipErrorOutOfMemory ? RG_ERR_OUT_OF_MEMORY : RG_ERR_NO_DEVICE,               \
+                           "rg_comm_init: %s failed: %s", #expr, hipGetErrorString(e__));                      \
+        }                                                                                                      \
+    } while (0)
+    RG_PUB_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        RG_PUB_TRY(hipMalloc(&p->send[k], p->lay.bytes_per_rank));
+        RG_PUB_TRY(hipMemsetAsync(p->send[k], 0, p->lay.bytes_per_rank, h->stream));
+        RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_tick[k], hipEventDisableTiming));
+        RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
+    }
+    for (int k = 0; k < 3; k++) RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_hdr[k], hipEventDisableTiming));
+    RG_PUB_TRY(hipMalloc(&p->ring_buf, (size_t)p->ring * p->world * p->lay.bytes_per_rank));
+    RG_PUB_TRY(hipMalloc(&p->replica, (size_t)p->world * p->lay.Gpad * 8));
+    RG_PUB_TRY(hipMemsetAsync(p->replica, 0, (size_t)p->world * p->lay.Gpad * 8, h->stream));
+    RG_PUB_TRY(hipMalloc(&p->full_send, p->lay.Gpad * 8));
+    RG_PUB_TRY(hipMemsetAsync(p->full_send, 0, p->lay.Gpad * 8, h->stream));
+    RG_PUB_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->pin_hdr), 3 * (size_t)p->world * sizeof(RgPubHdr), hipHostMallocDefault));
+    memset(p->pin_hdr, 0, 3 * (size_t)p->world * sizeof(RgPubHdr));
+    RG_PUB_TRY(hipStreamSynchronize(h->stream));
+#undef RG_PUB_TRY
+    if (!cfg->transport) {
+        int rc = rg_rccl_load();
+        if (rc) {
+            (void)rg_comm_destroy(h);
+            return rc;
+        }
+        ncclUniqueId u;
+        memcpy(u.internal, cfg->unique_id, RG_COMM_ID_BYTES);
+        const ncclResult_t r = g_rccl.CommInitRank(&p->comm, (int)p->world, u, (int)p->rank);
+        if (r != ncclSuccess) {
+            p->comm = nullptr;
+            (void)rg_comm_destroy(h);
+            return rg_fail(RG_ERR_NO_DEVICE, "rg_comm_init: ncclCommInitRank(rank %u of %u) failed: %s", cfg->rank, cfg->world,
+                           rg_nccl_err(r));
+        }
+    }
+    h->dev.engine_bytes += 2 * p->lay.bytes_per_rank + (u64)p->ring * p->world * p->lay.bytes_per_rank +
+                           (u64)p->world * p->lay.Gpad * 8 + p->lay.Gpad * 8;
+    rg_pub_target(h, 0);
+    // every replica starts from the actual columns: one full publication (a collective: all ranks are in here)
+    int rc = rg_publish_impl(h, true);
+    if (rc) {
+        (void)rg_comm_destroy(h);
+        return rc;
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_publish_commit(rg_engine *h, uint32_t flags) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: null engine");
+    if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_commit: rg_comm_init was never called");
+    if (flags & ~RG_PUBLISH_FULL) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: unknown flags %#x", flags);
+    RG_HIP(hipSetDevice(h->cfg.device));
+    return rg_publish_impl(h, (flags & RG_PUBLISH_FULL) != 0);
+}
+
+extern "C" int rg_publish_sync(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_sync: null engine");
+    if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_sync: rg_comm_init was never called");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_pub_materialize(h);
+    if (rc) return rc;
+    RG_HIP(hipStreamSynchronize(h->pub->side));
+    return RG_OK;
+}
+
+extern "C" const uint64_t *rg_published_commit_ptr(rg_engine *h, uint64_t *stride) {
+    if (!h || !h->pub) return nullptr;
+    if (stride) *stride = h->pub->lay.Gpad;
+    return h->pub->replica;
+}
+
+extern "C" int rg_published_commit(rg_engine *h, uint32_t rank, uint64_t first, uint64_t n, uint64_t *host_commit) {
+    if (!h || (n && !host_commit)) return rg_fail(RG_ERR_INVALID_ARG, "rg_published_commit: bad argument");
+    if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_published_commit: rg_comm_init was never called");
+    if (rank >= h->pub->world || first > h->G || n > h->G - first)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_published_commit: rank %u groups [%llu, +%llu) outside %u ranks x %llu groups",
+                       rank, (unsigned long long)first, (unsigned long long)n, h->pub->world, (unsigned long long)h->G);
+    int rc = rg_publish_sync(h);
+    if (rc || !n) return rc;
+    RG_HIP(hipMemcpy(host_commit, h->pub->replica + (u64)rank * h->pub->lay.Gpad + first, n * 8, hipMemcpyDeviceToHost));
+    return RG_OK;
+}
+
+extern "C" int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out) {
+    if (!h || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_stats_get: bad argument");
+    if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_stats_get: rg_comm_init was never called");
+    *out = h->pub->stats;
+    out->bytes_per_rank_delta = h->pub->lay.bytes_per_rank;
+    out->bytes_per_rank_full = h->pub->lay.Gpad * 8;
+    out->overflow_slots = h->pub->lay.cap;
+    out->ring_ticks = h->pub->ring;
+    return RG_OK;
+}
+
+// Host twins of the encoding (no GPU involved): what the tick kernels write and what the replica kernels add, over
+// caller-provided buffers. CPU-only tests run the N > 1 exchange with these under gloo.
+extern "C" uint64_t rg_pub_bytes_per_rank(uint64_t n_groups, uint32_t overflow_slots) {
+    return rg_pub_layout(n_groups, overflow_slots ? overflow_slots : (u32)(n_groups / 256 + 64)).bytes_per_rank;
+}
+
+extern "C" int rg_pub_accumulate_host(uint64_t n_groups, uint32_t overflow_slots, const uint64_t *old_commit,
+                                      const uint64_t *new_commit, uint8_t *slice) {
+    if (!old_commit || !new_commit || !slice) return rg_fail(RG_ERR_INVALID_ARG, "rg_pub_accumulate_host: null argument");
+    const RgPubLayout l = rg_pub_layout(n_groups, overflow_slots ? overflow_slots : (u32)(n_groups / 256 + 64));
+    RgPubHdr *hdr = reinterpret_cast<RgPubHdr *>(slice);
+    RgPubOvf *list = reinterpret_cast<RgPubOvf *>(slice + l.off_list);
+    u8 *dlt = slice + l.off_delta;
+    for (u64 g = 0; g < n_groups; g++) {
+        if (new_commit[g] < old_commit[g]) return rg_fail(RG_ERR_INVALID_ARG, "rg_pub_accumulate_host: group %llu: the commit index decreased", (unsigned long long)g);
+        if (new_commit[g] != old_commit[g]) dlt[g] = (u8)rg_pub_accumulate(dlt[g], old_commit[g], new_commit[g], g, hdr, list, l.cap);
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_pub_apply_host(uint64_t n_groups, uint32_t overflow_slots, uint32_t world, const uint8_t *gathered,
+                                 uint64_t *replica, uint32_t *lost_ranks) {
+    if (!gathered || !replica) return rg_fail(RG_ERR_INVALID_ARG, "rg_pub_apply_host: null argument");
+    const RgPubLayout l = rg_pub_layout(n_groups, overflow_slots ? overflow_slots : (u32)(n_groups / 256 + 64));
+    RgPubSlots sl;
+    sl.n = 1;
+    sl.slice[0] = reinterpret_cast<const char *>(gathered);
+    u32 lost = 0;
+    for (u32 r = 0; r < world; r++) {
+        for (u64 g8 = 0; g8 < l.Gpad; g8 += 8) rg_pub_apply8(replica, sl, l, r, g8);
+        const char *base = sl.slice[0] + (u64)r * l.bytes_per_rank;
+        const RgPubHdr *hdr = reinterpret_cast<const RgPubHdr *>(base);
+        const RgPubOvf *list = reinterpret_cast<const RgPubOvf *>(base + l.off_list);
+        for (u32 k = 0; k < hdr->n_overflow && k < l.cap; k++)
+            if (list[k].group < l.G) replica[(u64)r * l.Gpad + list[k].group] += list[k].extra;
+        if ((hdr->flags & RG_PUB_LOST) || hdr->n_overflow > l.cap) lost++;
+    }
+    if (lost_ranks) *lost_ranks = lost;
     return RG_OK;
 }

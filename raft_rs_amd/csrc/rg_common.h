@@ -25,6 +25,10 @@ struct RgState {
     u64 *run_first, *run_term;                   // [RG_TERM_RUNS][stride] term-run table (cold)
     u64 *dummy_idx, *dummy_term, *cur_term;      // [G] (cold)
     u64 G, stride;
+    // commit publication (rg_publish.h): this rank's slice under construction, nullptr = not publishing
+    char *pub;          // [RgPubHdr | RgPubOvf list[pub_cap] | u8 delta[Gpad]]
+    u64 pub_off_delta;
+    u32 pub_cap;
 };
 
 struct RgMsgs {

@@ -9,6 +9,7 @@
 #pragma once
 
 #include "rg_common.h"
+#include "rg_publish.h"
 
 // compile-time slot sequence (a minimal std::integer_sequence)
 template <int... S> struct rg_seq {};
@@ -273,75 +274,24 @@ RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_sl
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// RG_MF_BECOME_LEADER: Raft::reset(term) (src/raft.rs:942-971) + Raft::become_leader (:1151-1202) for one group --
-// what the reference runs when this node wins the group's election -- applied to the group's cells IN MEMORY
-// before the tick loads them (the event precedes every message of the tick: they answer the new leader). Every
-// Progress is reset to Progress::reset(last_index + 1) (progress.rs:82-92: matched 0, Probe, not paused, no pending
-// snapshot / snapshot request, not recently active, empty Inflights; committed_index and commit_group_id survive);
-// the leader's own keeps matched = persisted, takes committed_index = committed and becomes Replicate
-// (:1176-1181); a leader transfer is aborted (:953); the new leader's empty entry is appended at last_index + 1
-// (:1191-1194), which starts the index range of the new term; the previous leader's range becomes one more run of
-// the term table. Rare, so it trades a second round of loads for zero registers in the hot kernel: the caller
-// re-loads the group afterwards. Returns the event's result bits (also left in RG_COL_OUT for the store path).
-// ---------------------------------------------------------------------------------------------
+// Does this tick carry RG_MF_BECOME_LEADER for the group (the REJECT bit of the leader's OWN slot)?
 RG_HD bool rg_has_election(u64 mf, u32 cfg, u32 n_slots) {
     const u32 self = RG_CFG_SELF(cfg);
     return self < n_slots && ((RG_CFG_PRESENT(cfg) >> self) & 1u) && ((mf >> (8 * self)) & RG_MF_BECOME_LEADER);
 }
 
-RG_HD u32 rg_elect_in_memory(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u32 cfg) {
-    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
-    u64 new_term;
-    if (!rg_election_valid(st, ms, g, self, new_term)) { // malformed: fault, ignored
-        st.out[g] = RG_OUT_FAULT;
-        return RG_OUT_FAULT;
-    }
-    u32 out = RG_OUT_BECAME_LEADER | RG_OUT_APPENDED; // the caller follows with bcast_append (raft.rs:2190-2191)
-    const u64 old_lo = st.lo[g], old_hi = st.hi[g], old_term = st.cur_term[g], commit = st.commit[g];
-    st.cur_term[g] = new_term;
-    if (old_lo <= old_hi) { // the previous leader's entries become one more run of an older term
-        int k = 0;
-        while (k < RG_TERM_RUNS && st.run_first[(u64)k * st.stride + g] != 0) k++;
-        if (k == RG_TERM_RUNS) { // table full: forget the boundary between the two oldest runs
-            for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
-                st.run_first[(u64)j * st.stride + g] = st.run_first[(u64)(j + 1) * st.stride + g];
-                st.run_term[(u64)j * st.stride + g] = st.run_term[(u64)(j + 1) * st.stride + g];
-            }
-            k = RG_TERM_RUNS - 1;
-        }
-        st.run_first[(u64)k * st.stride + g] = old_lo;
-        st.run_term[(u64)k * st.stride + g] = old_term;
-    }
-    u64 row = st.pflags[g];
-#pragma nounroll
-    for (u32 i = 0; i < n_slots; i++) { // (a rolled loop: this rare path must not cost the tick kernels registers)
-        if (!((present >> i) & 1u)) continue;
-        const u64 o = (u64)i * st.stride + g;
-        const u32 pb = (u32)(row >> (8 * i)) & 0xffu;
-        u32 nb;
-        if (i == self) {
-            // assert_eq!(last_index, self.raft_log.persisted) (raft.rs:1170): matched IS the persisted index
-            const u64 persisted = st.match[o];
-            if (persisted != old_hi) out |= RG_OUT_FAULT;
-            st.prc[o] = commit;
-            st.next[o] = persisted + 1; // become_replicate (progress.rs:111-114)
-            nb = (pb & RG_PF_PENDING_CONF) | RG_STATE_REPLICATE;
-        } else {
-            st.match[o] = 0;
-            st.next[o] = old_hi + 1;
-            nb = RG_STATE_PROBE; // ins.reset(): RG_OUT_BECAME_LEADER tells the send stage to empty the device window
-        }
-        st.psnap[o] = 0;
-        st.prs[o] = 0;
-        row = (row & ~(0xffULL << (8 * i))) | ((u64)nb << (8 * i));
-    }
-    st.pflags[g] = row;
-    if (RG_CFG_TRANSFEREE(cfg)) st.cfg[g] = cfg & ~(0xfu << 20); // abort_leader_transfer (raft.rs:953)
-    st.hi[g] = old_hi + 1; // append_entry(&mut [Entry::default()]) (raft.rs:1191-1194)
-    st.lo[g] = old_hi + 1;
-    st.out[g] = out;
-    return out;
+// Commit publication (rg_publish.h): the group's accumulated delta byte is loaded with the group; after the
+// tick `adv` = that byte + the tick's advance. Must run BEFORE the commit column is stored: the exact path
+// re-reads the old commit index and the old byte from memory.
+RG_HD u32 rg_pub_load(const RgState &st, u64 g) {
+    return st.pub ? (u32) reinterpret_cast<const u8 *>(st.pub + st.pub_off_delta)[g] : 0u;
+}
+RG_HD void rg_pub_store(const RgState &st, u64 g, u32 adv, u64 new_commit) {
+    u8 *dlt = reinterpret_cast<u8 *>(st.pub + st.pub_off_delta);
+    if (adv > 255u) // rare: saturated byte, the excess goes to the exact-value list
+        adv = rg_pub_accumulate(dlt[g], st.commit[g], new_commit, g, reinterpret_cast<RgPubHdr *>(st.pub),
+                                reinterpret_cast<RgPubOvf *>(st.pub + sizeof(RgPubHdr)), st.pub_cap);
+    dlt[g] = (u8)adv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -354,14 +304,17 @@ template <int P> struct RgGroup {
     u64 commit, lo, hi;      // RaftLog.committed, current-term index range [lo, hi], hi = last_index
     u32 cfg, out;
     u32 dirty;               // bit s: mt[s] changed, bit 8+s: nx[s], bit 16+s: pc[s], bit 24: pf, 25: commit, 26: hi,
-                             // bit 29: an election was applied for this tick
+                             // 27: lo, 28: cfg; bit 29: an election was applied in this tick
     u32 evm;                 // slots (with a Progress) that had any event since the state was loaded
+    u32 adv;                 // commit publication: the group's delta byte of this interval + this tick's advance
+                             // (values > 255 = "saturated, take the exact path"); 0 when not publishing
 };
 #define RG_DIRTY_PF (1u << 24)
 #define RG_DIRTY_COMMIT (1u << 25)
 #define RG_DIRTY_HI (1u << 26)
-#define RG_TICK_ELECTED (1u << 29)  /* not a store bit: RG_MF_BECOME_LEADER was applied to this group for THIS tick
-                                       (rg_elect_in_memory) and RG_COL_OUT holds the event's result bits */
+#define RG_DIRTY_LO (1u << 27)      /* term_lo changed (an election) */
+#define RG_DIRTY_CFG (1u << 28)     /* the cfg word changed (an election aborts a leader transfer) */
+#define RG_TICK_ELECTED (1u << 29)  /* not a store bit: RG_MF_BECOME_LEADER was applied in THIS tick */
 
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
 // (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
@@ -407,12 +360,18 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         acc = 0;
         acc_oldp = 0;
         if (!FUSED) {
-            r.dirty &= RG_TICK_ELECTED; // (set by the kernel when it applied an election before loading the group)
+            r.dirty = 0;
             r.evm = 0;
         }
 #pragma unroll
         for (int i = 0; i < P; i++) // slots without a Progress ack 0 and are never written back
             if (!((present >> i) & 1u)) r.mt[i] = 0;
+        // An election lands before every message of the tick (they answer the NEW leader). Fused launches do not
+        // apply it (k_tick_fused flags the group-tick instead): with several ticks of state in registers the rare
+        // path would cost that kernel a wave of occupancy.
+#ifndef RG_NO_ELECT /* (measurement builds only: python -m raft_rs_amd.build --exp noelect -DRG_NO_ELECT) */
+        if (!FUSED && rg_has_election(r.mf, r.cfg, P)) become_leader();
+#endif
         if (FUSED) {
 #pragma unroll
             for (int i = 0; i < P; i++) mt_start[i] = r.mt[i];
@@ -432,7 +391,8 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                 // FUSED: a cell fetched or written by an earlier tick of this launch is already current
                 // (bit 8+i of dirty doubles as "r.nx[i] is valid": fetched cells are marked too -- rewriting
                 // an unchanged value is harmless)
-                const bool have = FUSED && ((r.dirty >> (8 + i)) & 1u);
+                // (an election of this tick has just written every present cell: same bit)
+                const bool have = (r.dirty >> (8 + i)) & 1u;
                 const bool need = ((present >> i) & 1u) && f != 0 && !overwritten && !have;
                 if (need) {
                     r.nx[i] = st.next[(u64)i * st.stride + g];
@@ -442,6 +402,83 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                 }
             }
         }
+    }
+
+    // RG_MF_BECOME_LEADER: Raft::reset(term) (src/raft.rs:942-971) + Raft::become_leader (:1151-1202) for this
+    // group -- what the reference runs when this node wins the group's election -- over the group's registers:
+    // every Progress is reset to Progress::reset(last_index + 1) (progress.rs:82-92: matched 0, Probe, not paused,
+    // no pending snapshot / snapshot request, not recently active, empty Inflights; committed_index and
+    // commit_group_id survive); the leader's own keeps matched = persisted, takes committed_index = committed and
+    // becomes Replicate (:1176-1181); a leader transfer is aborted (:953); the new leader's empty entry is appended
+    // at last_index + 1 (:1191-1194), which starts the index range of the new term; the previous leader's range
+    // becomes one more run of the term table. Cold columns are written straight to memory (rare path).
+    // Malformed (term not above RG_COL_CUR_TERM): RG_OUT_FAULT, ignored.
+    RG_HD void become_leader() {
+        u64 new_term;
+        if (!rg_election_valid(st, ms, g, self, new_term)) {
+            out |= RG_OUT_FAULT;
+            return;
+        }
+        const u64 old_lo = r.lo, old_hi = r.hi, old_term = st.cur_term[g];
+        st.cur_term[g] = new_term;
+        if (old_lo <= old_hi) { // the previous leader's entries become one more run of an older term
+            int k = 0;
+            while (k < RG_TERM_RUNS && st.run_first[(u64)k * st.stride + g] != 0) k++;
+            if (k == RG_TERM_RUNS) { // table full: forget the boundary between the two oldest runs
+                for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
+                    st.run_first[(u64)j * st.stride + g] = st.run_first[(u64)(j + 1) * st.stride + g];
+                    st.run_term[(u64)j * st.stride + g] = st.run_term[(u64)(j + 1) * st.stride + g];
+                }
+                k = RG_TERM_RUNS - 1;
+            }
+            st.run_first[(u64)k * st.stride + g] = old_lo;
+            st.run_term[(u64)k * st.stride + g] = old_term;
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            if (!((present >> i) & 1u)) continue;
+            const u64 o = (u64)i * st.stride + g;
+            const u32 pb = (u32)(r.pf >> (8 * i)) & 0xffu;
+            u32 nb;
+            if ((u32)i == self) {
+                // assert_eq!(last_index, self.raft_log.persisted) (raft.rs:1170): matched IS the persisted index
+                if (r.mt[i] != old_hi) out |= RG_OUT_FAULT;
+                if (r.pc[i] != r.commit) {
+                    r.pc[i] = r.commit;
+                    r.dirty |= 1u << (16 + i);
+                }
+                r.nx[i] = r.mt[i] + 1; // become_replicate (progress.rs:111-114)
+                nb = (pb & RG_PF_PENDING_CONF) | RG_STATE_REPLICATE;
+            } else {
+                r.mt[i] = 0;
+                r.nx[i] = old_hi + 1;
+                nb = RG_STATE_PROBE; // ins.reset(): RG_OUT_BECAME_LEADER tells the send stage to empty the device window
+            }
+            r.dirty |= (1u << i) | (1u << (8 + i));
+            st.psnap[o] = 0;
+            st.prs[o] = 0;
+            if (nb != pb) {
+                r.pf = (r.pf & ~(0xffULL << (8 * i))) | ((u64)nb << (8 * i));
+                r.dirty |= RG_DIRTY_PF;
+            }
+        }
+        if (xfer) { // abort_leader_transfer (raft.rs:953)
+            xfer = 0;
+            r.cfg &= ~(0xfu << 20);
+            r.dirty |= RG_DIRTY_CFG;
+        }
+        r.hi = old_hi + 1; // append_entry(&mut [Entry::default()]) (raft.rs:1191-1194)
+        r.lo = r.hi;
+        last0 = r.hi;      // what the send path sees once the election is over
+        r.dirty |= RG_DIRTY_HI | RG_DIRTY_LO | RG_TICK_ELECTED;
+        out |= RG_OUT_BECAME_LEADER | RG_OUT_APPENDED; // the caller follows with bcast_append (raft.rs:2190-2191)
+    }
+
+    // matched of slot S when the tick's messages started: memory still holds it, unless an election of this very
+    // tick reset it first (every Progress but the leader's own to 0)
+    template <int S> RG_HD u64 start_match() {
+        if ((r.dirty & RG_TICK_ELECTED) && (u32)S != self) return 0;
+        return st.match[(u64)S * st.stride + g];
     }
 
     // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v`.
@@ -652,7 +689,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         if (replay) {
             u64 cur[P];
             if (FUSED) ((cur[S] = mt_start[S]), ...);
-            else ((cur[S] = ((acc >> S) & 1u) ? st.match[(u64)S * st.stride + g] : r.mt[S]), ...);
+            else ((cur[S] = ((acc >> S) & 1u) ? start_match<S>() : r.mt[S]), ...);
             qm.init(cur);
             u64 commit = commit0;
             (replay_slot<S>(qm, cur, commit), ...);
@@ -661,6 +698,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         if (r.commit != commit0) {
             r.dirty |= RG_DIRTY_COMMIT;
             (self_committed<S>(), ...);
+            r.adv += (u32)rg_min(r.commit - commit0, 0x10000ULL); // (rg_pub_store: what the other ranks learn)
         }
     }
 

@@ -51,6 +51,7 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64
     r.commit = st.commit[g];
     r.lo = st.lo[g];
     r.hi = st.hi[g];
+    r.adv = rg_pub_load(st, g);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const u64 o = (u64)p * st.stride + g;
@@ -62,7 +63,7 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64
     }
 }
 
-template <int P> RG_HD void rg_store_group(RgGroup<P> &r, const RgState &st, u64 g) {
+template <int P> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
@@ -78,32 +79,23 @@ template <int P> RG_HD void rg_store_group(RgGroup<P> &r, const RgState &st, u64
         if (d & (1u << (16 + p))) st.prc[o] = r.pc[p];
     }
     if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
-    if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
-    if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
-    if (d & RG_TICK_ELECTED) r.out |= st.out[g]; // the election's own result bits (rg_elect_in_memory left them there)
-    st.out[g] = r.out;
-}
-
-// RG_MF_BECOME_LEADER (rare): apply the election to the group's cells in memory, then load the group again. The first
-// round of loads is already in flight when the flag is seen, so the common path pays neither latency nor registers.
-template <int P, bool LOAD_NX>
-RG_HD void rg_load_group_elect(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
-    rg_load_group<P, LOAD_NX>(r, st, ms, g);
-    r.dirty = 0;
-#ifndef RG_NO_ELECT
-    if (rg_has_election(r.mf, r.cfg, P)) {
-        rg_elect_in_memory(st, ms, g, P, r.cfg);
-        rg_load_group<P, LOAD_NX>(r, st, ms, g);
-        r.dirty = RG_TICK_ELECTED;
+    if (d & RG_DIRTY_COMMIT) {
+        if (st.pub) rg_pub_store(st, g, r.adv, r.commit); // commit publication: one byte per advanced group
+        st.commit[g] = r.commit;
     }
-#endif
+    if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
+    if (d & (RG_DIRTY_LO | RG_DIRTY_CFG)) { // an election (rare)
+        if (d & RG_DIRTY_LO) st.lo[g] = r.lo;
+        if (d & RG_DIRTY_CFG) st.cfg[g] = r.cfg;
+    }
+    st.out[g] = r.out;
 }
 
 template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
     RgGroup<P> r;
-    rg_load_group_elect<P, !RG_LAZY_NEXT>(r, st, ms, g);
+    rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
     rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
     rg_store_group<P>(r, st, g);
 }
@@ -130,7 +122,7 @@ __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *lis
     if (i >= *n_ptr) return;
     const u64 g = list[i];
     RgGroup<P> r;
-    rg_load_group_elect<P, !RG_LAZY_NEXT>(r, st, ms, g);
+    rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
     rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
     rg_store_group<P>(r, st, g);
     mflags_rw[g] = 0;
@@ -176,12 +168,13 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st
     }
     r.dirty = 0;
     r.evm = 0;
+    r.adv = 0; // (fused launches are refused while commit publication is active)
     for (u32 t = 0; t < fm.n_ticks; t++) {
         const RgMsgs &ms = fm.m[t];
         r.mf = rg_ld_stream(ms.mflags + g);
-        // RG_MF_BECOME_LEADER rewrites the group's cells in memory (rg_elect_in_memory), which a launch that keeps
-        // the state in registers across ticks cannot do: such a group-tick is flagged RG_OUT_FAULT and the event is
-        // NOT applied (include/raftgroups.h: elections go through single-tick launches)
+        // RG_MF_BECOME_LEADER is not applied by fused launches (the rare path would cost this kernel, which holds
+        // several ticks of state in registers, a wave of occupancy): such a group-tick is flagged RG_OUT_FAULT and
+        // the event is ignored (include/raftgroups.h: elections go through single-tick launches)
         const u32 efault = rg_has_election(r.mf, r.cfg, P) ? RG_OUT_FAULT : 0u;
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -218,15 +211,6 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     u64(*L)[P][RG_LDS_BATCH] = lds[wave];
     const u64 *cols[5] = {st.match, st.next, st.prc, ms.mi, ms.mc};
-    // RG_MF_BECOME_LEADER (rare): applied in memory by the lane that stages the group's cells, before it loads them
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const u64 ge = b0 + 2 * lane + k;
-        if (ge < st.G) {
-            const u32 cfg_e = st.cfg[ge];
-            if (rg_has_election(ms.mflags[ge], cfg_e, P)) rg_elect_in_memory(st, ms, ge, P, cfg_e);
-        }
-    }
     // stage in: 5*P coalesced 16-B loads per lane, all issued before the first LDS write
     u64x2 tmp[5][P];
 #pragma unroll
@@ -254,6 +238,7 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
             r.commit = st.commit[g];
             r.lo = st.lo[g];
             r.hi = st.hi[g];
+            r.adv = rg_pub_load(st, g);
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 r.mt[p] = L[0][p][li];
@@ -262,7 +247,6 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
                 r.mi[p] = L[3][p][li];
                 r.mc[p] = L[4][p][li];
             }
-            r.dirty = rg_has_election(r.mf, r.cfg, P) ? RG_TICK_ELECTED : 0u; // (its result bits wait in RG_COL_OUT)
             rg_group_tick<P, GC, false>(r, st, ms, g);
             const u32 d = r.dirty;
 #pragma unroll
@@ -272,9 +256,14 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
                 if (d & (1u << (16 + p))) L[2][p][li] = r.pc[p];
             }
             if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
-            if (d & RG_DIRTY_COMMIT) st.commit[g] = r.commit;
+            if (d & RG_DIRTY_COMMIT) {
+                if (st.pub) rg_pub_store(st, g, r.adv, r.commit);
+                st.commit[g] = r.commit;
+            }
             if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
-            st.out[g] = (d & RG_TICK_ELECTED) ? (r.out | st.out[g]) : r.out;
+            if (d & RG_DIRTY_LO) st.lo[g] = r.lo;
+            if (d & RG_DIRTY_CFG) st.cfg[g] = r.cfg;
+            st.out[g] = r.out;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

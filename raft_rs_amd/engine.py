@@ -128,6 +128,23 @@ class CellWrite(C.Structure):
                 ("pflags", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class CommConfig(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("unique_id", C.c_void_p), ("transport", ALLGATHER_FN),
+                ("transport_user", C.c_void_p), ("ring_ticks", C.c_uint32), ("overflow_slots", C.c_uint32)]
+
+
+class PublishStats(C.Structure):
+    _fields_ = [("publications", C.c_uint64), ("full_publications", C.c_uint64), ("replica_updates", C.c_uint64),
+                ("bytes_per_rank_last", C.c_uint64), ("bytes_per_rank_delta", C.c_uint64),
+                ("bytes_per_rank_full", C.c_uint64), ("overflow_slots", C.c_uint32), ("ring_ticks", C.c_uint32)]
+
+
+COMM_ID_BYTES = 128
+PUBLISH_FULL = 1
+
 SEND_APPEND, SEND_SNAPSHOT = 1, 2
 SEND_SKIP_BCAST_COMMIT = 1
 SEND_ITEM_DTYPE = np.dtype([("group", "<u8"), ("prev_index", "<u8"), ("last_index", "<u8"), ("slot", "<u4"),
@@ -188,6 +205,17 @@ SYMBOLS = {
     "rg_mark_sent": (_i, [_vp, _u64, _u64]),
     "rg_local_become_leader": (_i, [_vp, _u64, _u64]),
     "rg_flush": (_i, [_vp]),
+    "rg_comm_unique_id": (_i, [_vp]),
+    "rg_comm_init": (_i, [_vp, C.POINTER(CommConfig)]),
+    "rg_comm_destroy": (_i, [_vp]),
+    "rg_publish_commit": (_i, [_vp, C.c_uint32]),
+    "rg_publish_sync": (_i, [_vp]),
+    "rg_published_commit_ptr": (_vp, [_vp, C.POINTER(_u64)]),
+    "rg_published_commit": (_i, [_vp, C.c_uint32, _u64, _u64, _vp]),
+    "rg_publish_stats_get": (_i, [_vp, C.POINTER(PublishStats)]),
+    "rg_pub_bytes_per_rank": (_u64, [_u64, C.c_uint32]),
+    "rg_pub_accumulate_host": (_i, [_u64, C.c_uint32, _vp, _vp, _vp]),
+    "rg_pub_apply_host": (_i, [_u64, C.c_uint32, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "rg_workload_init": (_i, [_vp, C.POINTER(_Workload), _u64]),
     "rg_workload_gen": (_i, [_vp, C.POINTER(_Workload), _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "rg_workload_init_host": (_i, [C.POINTER(_Workload), _u64, C.POINTER(_HostState)]),
@@ -548,6 +576,49 @@ class Engine:
     def flush(self):
         self._check(self.L.rg_flush(self.h))
 
+    # ---- multi-GPU: publication of commit indices ---------------------------------------------------
+    def comm_init(self, rank, world, unique_id=None, transport=None, ring_ticks=0, overflow_slots=0):
+        """rg_comm_init (a collective). unique_id: bytes from comm_unique_id() (RCCL); transport: a Python callable
+        (dev_send, dev_recv, bytes_per_rank, hip_stream) -> 0 standing in for the all-gather (tests, other fabrics)."""
+        self._comm_keep = []
+        cfg = CommConfig(rank, world, None, ALLGATHER_FN(0), None, ring_ticks, overflow_slots)
+        if transport is not None:
+            cb = ALLGATHER_FN(lambda user, s, r, n, st: int(transport(s, r, n, st) or 0))
+            cfg.transport = cb
+            self._comm_keep.append(cb)
+        else:
+            buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+            cfg.unique_id = C.addressof(buf)
+            self._comm_keep.append(buf)
+        self._check(self.L.rg_comm_init(self.h, C.byref(cfg)))
+        self.comm_rank, self.comm_world = rank, world
+
+    def comm_destroy(self):
+        self._check(self.L.rg_comm_destroy(self.h))
+
+    def publish_commit(self, full=False):
+        self._check(self.L.rg_publish_commit(self.h, PUBLISH_FULL if full else 0))
+
+    def publish_sync(self):
+        self._check(self.L.rg_publish_sync(self.h))
+
+    def published_commit(self, rank=None):
+        """The replica of `rank`'s commit indices (all ranks: [world][n_groups]) as a host array."""
+        ranks = range(self.comm_world) if rank is None else [rank]
+        out = np.empty((len(ranks), self.n_groups), dtype=np.uint64)
+        for i, r in enumerate(ranks):
+            self._check(self.L.rg_published_commit(self.h, r, 0, self.n_groups, out[i].ctypes.data))
+        return out if rank is None else out[0]
+
+    def published_commit_ptr(self):
+        stride = _u64(0)
+        return self.L.rg_published_commit_ptr(self.h, C.byref(stride)), stride.value
+
+    def publish_stats(self):
+        st = PublishStats()
+        self._check(self.L.rg_publish_stats_get(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in PublishStats._fields_}
+
     # ---- synthetic stream --------------------------------------------------------------------
     def workload_init(self, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0):
         w = _Workload(seed, workload, fixed_peers)
@@ -585,3 +656,37 @@ def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, 
                                 msgs.m_flags.ctypes.data)
     if rc:
         raise EngineError(rc, L.rg_last_error().decode())
+
+
+def comm_unique_id():
+    """rg_comm_unique_id: the RCCL unique id rank 0 hands to the other ranks (128 bytes)."""
+    L = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = L.rg_comm_unique_id(buf)
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())
+    return bytes(buf)
+
+
+def pub_bytes_per_rank(n_groups, overflow_slots=0):
+    return load_library().rg_pub_bytes_per_rank(n_groups, overflow_slots)
+
+
+def pub_accumulate_host(old_commit, new_commit, slice_, overflow_slots=0):
+    """Host twin of the ticks' publication byte: accumulate old -> new into `slice_` (uint8 array, in place)."""
+    L = load_library()
+    a, b = np.ascontiguousarray(old_commit, dtype=np.uint64), np.ascontiguousarray(new_commit, dtype=np.uint64)
+    rc = L.rg_pub_accumulate_host(len(a), overflow_slots, a.ctypes.data, b.ctypes.data, slice_.ctypes.data)
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())
+
+
+def pub_apply_host(n_groups, world, gathered, replica, overflow_slots=0):
+    """Host twin of the replica update: add one gathered publication to `replica` ([world][stride]). Returns the
+    number of slices that ask for a full resynchronisation."""
+    L = load_library()
+    lost = C.c_uint32(0)
+    rc = L.rg_pub_apply_host(n_groups, overflow_slots, world, gathered.ctypes.data, replica.ctypes.data, C.byref(lost))
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())
+    return lost.value

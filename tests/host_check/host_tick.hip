@@ -16,6 +16,7 @@ static RgState make_state(void *const *p, u64 G, u64 stride) {
     st.run_first = (u64 *)p[12]; st.run_term = (u64 *)p[13]; st.dummy_idx = (u64 *)p[14]; st.dummy_term = (u64 *)p[15];
     st.cur_term = (u64 *)p[16];
     st.G = G; st.stride = stride;
+    st.pub = nullptr; st.pub_off_delta = 0; st.pub_cap = 0;
     return st;
 }
 static RgMsgs make_msgs(const void *const *p) {
@@ -40,7 +41,7 @@ template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, b
     }
     for (u64 g = g0; g < g1; g++) {
         RgGroup<P> r;
-        rg_load_group_elect<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
+        rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
         if (gc) rg_group_tick<P, true, RG_LAZY_NEXT>(r, st, ms, g);
         else rg_group_tick<P, false, RG_LAZY_NEXT>(r, st, ms, g);
         rg_store_group<P>(r, st, g);
@@ -56,7 +57,7 @@ template <int P> static void host_fused(const RgState &st, const RgMsgs *ms, u32
             const u64 o = (u64)p * st.stride + g;
             r.mt[p] = st.match[o]; r.pc[p] = st.prc[o]; r.nx[p] = 0;
         }
-        r.dirty = 0; r.evm = 0;
+        r.dirty = 0; r.evm = 0; r.adv = 0;
         for (u32 t = 0; t < T; t++) {
             r.mf = ms[t].mflags[g];
             const u32 efault = rg_has_election(r.mf, r.cfg, P) ? RG_OUT_FAULT : 0u; // as in k_tick_fused

@@ -1,6 +1,7 @@
 """CPU multi-process test of the N>1 path: 2 ranks over gloo. The per-shard ticks run on the CPU
-oracle here (the HIP engine needs a GPU); what is under test is the product's sharding arithmetic,
-the shard-local stream generation and the commit-index publication (raft_rs_amd/sharding.py)."""
+oracle here (the HIP engine needs a GPU); what is under test is the product's sharding arithmetic
+(raft_rs_amd/sharding.py), the shard-local stream generation and the commit-index publication ENCODING of the C ABI
+(host twins rg_pub_accumulate_host / rg_pub_apply_host; tests/test_publish_gpu.py drives rg_publish_commit itself)."""
 import os
 import subprocess
 import sys
@@ -33,7 +34,7 @@ def run(first, n):
     E.workload_init_host(st, WL, first_group=first)
     cl = O.Cluster(n); cl.load_soa(st, term=4)
     msgs = E.MsgBuffers(n, P, st["stride"]); gout = np.zeros(n, dtype=np.uint32)
-    commits = []
+    commits = [st["commit"].copy()]  # [0] = before the first tick
     for t in range(TICKS):
         E.workload_gen_host(st, msgs, WL, t, first_group=first)
         cl.tick_soa(msgs.as_dict(), gout); cl.store_soa(st)
@@ -41,16 +42,33 @@ def run(first, n):
     return commits
 
 mine = run(sh.first_group, sh.n_groups)
-pub = S.CommitPublisher(dist, G, world, "cpu")
-for t in range(TICKS):
-    b = pub.publish(t, torch.from_numpy(mine[t].view(np.int64)))
-    got = pub.result(b).numpy().view(np.uint64)
-    assert (got[rank] == mine[t]).all()
+init, mine = mine[0], mine[1:]
+
+# The product's publication encoding (include/raftgroups.h "multi-GPU"; the host twins of what the tick kernels write and
+# the replica kernels add), with gloo standing in for ncclAllGather: a full snapshot first, then ~1 B/group per
+# publication -- one publication per tick, then one for two ticks (the ticks accumulate).
+bpr, stride = E.pub_bytes_per_rank(G), (G + 255) // 256 * 256
+replica = np.zeros((world, stride), dtype=np.uint64)
+full = np.zeros(stride, dtype=np.uint64); full[:G] = init
+dist.all_gather_into_tensor(torch.from_numpy(replica.view(np.int64).reshape(-1)), torch.from_numpy(full.view(np.int64)))
+def publish(old, new):
+    sl = np.zeros(bpr, dtype=np.uint8)
+    E.pub_accumulate_host(old, new, sl)
+    gathered = np.zeros(world * bpr, dtype=np.uint8)
+    dist.all_gather_into_tensor(torch.from_numpy(gathered), torch.from_numpy(sl))
+    assert E.pub_apply_host(G, world, gathered, replica) == 0
+    return bpr
+prev = init
+for t in (0, 1):
+    publish(prev, mine[t]); prev = mine[t]
+    assert (replica[rank, :G] == mine[t]).all()
+publish(prev, mine[3])  # ticks 2 and 3 in one publication
+assert bpr < 1.1 * G + 2048, "about one byte per group instead of eight"
 if rank == 0:
     # the union of the shards must equal one unsharded run over all groups
     whole = run(0, world * G)
-    got = pub.result((TICKS - 1) & 1).numpy().view(np.uint64).reshape(-1)
-    assert (got == whole[-1]).all(), "sharded commit indices differ from the unsharded run"
+    got = replica[:, :G].reshape(-1)
+    assert (got == whole[-1]).all(), "sharded, delta-published commit indices differ from the unsharded run"
     print("DIST_OK", world, int(got.sum()))
 dist.barrier()
 dist.destroy_process_group()
@@ -66,3 +84,37 @@ def test_two_ranks_shard_and_publish_commit(tmp_path):
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "DIST_OK 2" in r.stdout, r.stdout[-3000:]
+
+
+def test_publication_encoding_saturation_list_and_loss():
+    """The host twins of the publication encoding: advances accumulate over an interval, a saturated byte spills its
+    excess into the exact-value list (additive, so order never matters), a full list marks the slice lost."""
+    import numpy as np
+    from raft_rs_amd import engine as E
+    G, cap = 1000, 4
+    bpr, stride = E.pub_bytes_per_rank(G, cap), 1024
+    rng = np.random.default_rng(5)
+    c0 = rng.integers(0, 1 << 40, size=G).astype(np.uint64)
+    steps = [c0]
+    for k in range(3):
+        adv = rng.integers(0, 60, size=G).astype(np.uint64)
+        adv[7] = [10, 250, 1 << 33][k]        # saturates in the second step, a huge jump in the third
+        adv[500] = [300, 0, 5][k]             # saturates at once
+        steps.append(steps[-1] + adv)
+    sl = np.zeros(bpr, dtype=np.uint8)
+    for a, b in zip(steps, steps[1:]):        # three ticks, ONE publication
+        E.pub_accumulate_host(a, b, sl, cap)
+    replica = np.zeros((1, stride), dtype=np.uint64)
+    replica[0, :G] = c0
+    assert E.pub_apply_host(G, 1, sl, replica, cap) == 0
+    assert (replica[0, :G] == steps[-1]).all()
+    n_list = int(sl[:4].view(np.uint32)[0])
+    assert 3 <= n_list <= cap, n_list
+    # more saturated groups than the list holds: the slice says so, the receivers resynchronise
+    sl = np.zeros(bpr, dtype=np.uint8)
+    E.pub_accumulate_host(c0, c0 + np.uint64(1000), sl, cap)
+    replica[0, :G] = c0
+    assert E.pub_apply_host(G, 1, sl, replica, cap) == 1
+    import pytest
+    with pytest.raises(E.EngineError):
+        E.pub_accumulate_host(c0 + np.uint64(1), c0, sl, cap)  # a commit index never decreases

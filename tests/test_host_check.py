@@ -24,7 +24,7 @@ def build_lib():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         return None
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h", "rg_send.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("rg_group.h", "rg_common.h", "rg_tick_kernels.h", "rg_send.h", "rg_publish.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         # no -march=native: the built .so travels with gpurun snapshots to hosts with other CPUs
         subprocess.check_call([hipcc, "-O3", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",

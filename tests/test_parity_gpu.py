@@ -445,7 +445,7 @@ def test_bench_two_ranks_sharing_the_gpu(rg, tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
-    assert d["config"]["groups_per_gpu"] == 60000 and "all-gather every 4 ticks" in d["config"]["sharding"]
+    assert d["config"]["groups_per_gpu"] == 60000 and "published every 4 tick(s)" in d["config"]["sharding"] and d["config"]["publication"]["publications"] > 0
 
 
 def test_device_info_is_queried_not_assumed(rg):

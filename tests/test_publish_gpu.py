@@ -1,0 +1,229 @@
+"""GPU: publication of commit indices behind the C ABI (rg_comm_init / rg_publish_commit / rg_published_commit).
+
+The exchange itself is ncclAllGather (RCCL, world size 1 on this single-GPU box) or a host-provided all-gather
+(two / three ranks sharing the GPU, gloo moving the slices): what is under test is everything around it -- the byte
+the tick kernels fuse into their store path, accumulation over several ticks, the exact-value list, the loss ->
+full-snapshot protocol, the lazily updated replica."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _device_msgs(torch, eng, n_slots):
+    cols = [torch.zeros((n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+    flags = torch.zeros((eng.n_groups, 8), dtype=torch.uint8, device="cuda")
+    return cols, flags
+
+
+@pytest.mark.parametrize("workload,n_slots", [(2, 5), (5, 7)])
+def test_rccl_world1_replica_follows_every_tick(rg, workload, n_slots):
+    """ncclAllGather at world size 1: after every tick the replica equals the commit column; the slice is ~1 B/group."""
+    import torch
+    from raft_rs_amd import engine as E
+    G = 50_000 + 3
+    eng = rg.Engine(G, n_slots)
+    eng.workload_init(workload)
+    eng.comm_init(0, 1, unique_id=E.comm_unique_id(), ring_ticks=4)
+    assert np.array_equal(eng.published_commit(0), eng.read_column(rg.COL.COMMIT)), "rg_comm_init publishes a full snapshot"
+    cols, flags = _device_msgs(torch, eng, n_slots)
+    for t in range(11):  # more than two rings' worth
+        eng.workload_gen(workload, t, *[c.data_ptr() for c in cols], flags.data_ptr())
+        eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        eng.publish_commit()
+        if t % 3 == 2 or t == 10:  # reading the replica is allowed at any time, not only when the ring is full
+            assert np.array_equal(eng.published_commit(0), eng.read_column(rg.COL.COMMIT)), t
+    st = eng.publish_stats()
+    assert st["publications"] == 12 and st["full_publications"] == 1
+    assert st["bytes_per_rank_delta"] < 1.1 * G + 4096 and st["bytes_per_rank_full"] >= 8 * G
+    ptr, stride = eng.published_commit_ptr()
+    assert ptr and stride >= G
+    eng.comm_destroy()
+    eng.close()
+
+
+def test_ticks_accumulate_between_publications_and_other_commit_paths(rg):
+    """Any cadence: several dense ticks, a sparse tick (rg_ingest_tick) and rg_recompute between two publications."""
+    import torch
+    from raft_rs_amd import engine as E
+    from raft_rs_amd.engine import WIRE_DTYPE
+    G, P = 20_000, 5
+    eng = rg.Engine(G, P)
+    eng.workload_init(2)
+    eng.comm_init(0, 1, unique_id=E.comm_unique_id())
+    cols, flags = _device_msgs(torch, eng, P)
+    for t in range(5):
+        eng.workload_gen(2, t, *[c.data_ptr() for c in cols], flags.data_ptr())
+        eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        if t == 2:
+            eng.publish_commit()
+    # a sparse tick: the leaders of 100 groups append 40 entries and every follower acks them
+    st = eng.read_state()
+    groups = np.arange(0, G, G // 100)[:100]
+    rec = np.zeros(len(groups) * P, dtype=WIRE_DTYPE)
+    k = 0
+    for g in groups:
+        new_last = int(st["term_hi"][g]) + 40
+        for p in range(P):
+            rec[k] = (g, new_last, new_last if p == 0 else int(st["commit"][g]), 0, 0, 0, p,
+                      (rg.MF.APPEND | rg.MF.VALID) if p == 0 else rg.MF.VALID, 0)
+            k += 1
+    # (the followers' acks of index new_last need the append first: slot 0 is processed before them)
+    n, dup = eng.ingest_tick(rec)
+    assert n == len(groups) and dup == 0
+    # a recompute after a membership change that lowers the quorum: group 1 drops to a single voter
+    eng.set_config(1, rg.cfg_make(0b00001, present=0b11111))
+    eng.recompute()
+    eng.publish_commit()
+    commit = eng.read_column(rg.COL.COMMIT)
+    assert (commit[groups] == st["term_hi"][groups] + 40).all()
+    assert np.array_equal(eng.published_commit(0), commit)
+    with pytest.raises(rg.EngineError):  # fused launches do not record their per-tick advance
+        out_t = torch.zeros((1, G), dtype=torch.int32, device="cuda")
+        eng.tick_device_fused([[c.data_ptr() for c in cols] + [flags.data_ptr()]], out_t.data_ptr())
+    eng.close()  # (rg_destroy tears the communicator down)
+
+
+def test_saturated_bytes_list_overflow_and_rollback_resynchronise(rg):
+    """Advances >= 255 go through the exact-value list; a list too short for them marks the slice lost and the second
+    publication after it is a full snapshot (every rank reads the same headers); rg_restore does the same."""
+    from raft_rs_amd import engine as E
+    G, P, cap = 3000, 3, 8
+    st = O.alloc_state(G, P)
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    st["term_lo"][:] = 1
+    st["term_hi"][:] = 1 << 40
+    st["match"][0, :G] = 1 << 40
+    st["next"][:, :G] = 1
+    st["pflags"][:, :P] = 1
+    eng = rg.Engine(G, P)
+    eng.load_state(st)
+    eng.comm_init(0, 1, unique_id=E.comm_unique_id(), overflow_slots=cap)
+    mb = rg.MsgBuffers(G, P, eng.stride)
+
+    def ack_all(index):  # both followers acknowledge index[g]
+        mb.clear()
+        for p in (1, 2):
+            mb.m_flags[:, p] = rg.MF.VALID
+            mb.m_index[p, :G] = index
+        eng.tick(mb)
+
+    target = np.full(G, 100, dtype=np.uint64)
+    target[:5] = [255, 256, 1000, 1 << 33, 254]  # four saturated bytes (255 itself is exact: 255 + extra 0... no list)
+    ack_all(target)
+    eng.publish_commit()
+    assert np.array_equal(eng.published_commit(0), target)
+    assert eng.publish_stats()["full_publications"] == 1
+    # more saturated groups than the list holds
+    target2 = target + np.uint64(7)
+    target2[100:100 + 3 * cap] += np.uint64(5000)
+    ack_all(target2)
+    eng.publish_commit()                     # publication k: lost
+    eng.publish_sync()
+    assert not np.array_equal(eng.published_commit(0), target2), "the replica is knowingly inexact now"
+    ack_all(target2 + np.uint64(1))
+    eng.publish_commit()                     # k + 1: still deltas
+    ack_all(target2 + np.uint64(2))
+    eng.publish_commit()                     # k + 2: every rank has seen the lost header -> full snapshot
+    assert eng.publish_stats()["full_publications"] == 2
+    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(2))
+    # rollback: the published advances no longer describe the column
+    eng.checkpoint()
+    ack_all(target2 + np.uint64(50))
+    eng.publish_commit()
+    eng.restore()
+    for k in range(3):
+        ack_all(target2 + np.uint64(3 + k))
+        eng.publish_commit()
+    assert eng.publish_stats()["full_publications"] == 3
+    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(5))
+    # an explicit full publication (what a host does after it reloads state)
+    eng.publish_commit(full=True)
+    assert eng.publish_stats()["full_publications"] == 4
+    eng.close()
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["RG_ROOT"]); sys.path.insert(0, os.path.join(os.environ["RG_ROOT"], "tests"))
+import raft_rs_amd as rg
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)  # every rank shares the box's one GPU
+G, P, WL, TICKS = 40_000, 5, rg.WL_MIXED if os.environ.get("RG_WL") == "5" else rg.WL_MAJORITY, 9
+
+class Dev:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+calls = []
+def allgather(dev_send, dev_recv, nbytes, stream):
+    """The host-provided transport of rg_comm_config: gloo moves the slices (RCCL refuses two ranks on one GPU)."""
+    torch.cuda.synchronize()
+    send = torch.as_tensor(Dev(dev_send, nbytes), device="cuda").cpu()
+    out = torch.empty(world * nbytes, dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, send)
+    torch.as_tensor(Dev(dev_recv, world * nbytes), device="cuda").copy_(out)
+    torch.cuda.synchronize()
+    calls.append(nbytes)
+    return 0
+
+eng = rg.Engine(G, P)
+eng.workload_init(WL, first_group=rank * G)
+eng.comm_init(rank, world, transport=allgather, ring_ticks=4)
+cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
+for t in range(TICKS):
+    eng.workload_gen(WL, t, *[c.data_ptr() for c in cols], flags.data_ptr(), first_group=rank * G)
+    eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+    eng.publish_commit()
+mine = eng.read_column(rg.COL.COMMIT)
+rep = eng.published_commit()              # [world][G], from this rank's replica
+assert np.array_equal(rep[rank], mine)
+# every rank's replica holds every rank's column
+allc = [torch.empty(G, dtype=torch.int64) for _ in range(world)]
+dist.all_gather(allc, torch.from_numpy(mine.view(np.int64)))
+for r in range(world):
+    assert np.array_equal(rep[r], allc[r].numpy().view(np.uint64)), (rank, r)
+st = eng.publish_stats()
+assert calls[0] >= 8 * G and all(c == st["bytes_per_rank_delta"] for c in calls[1:]), calls
+assert st["publications"] == TICKS + 1 and st["full_publications"] == 1
+if rank == 0:
+    # ... and equals one unsharded engine over all groups
+    whole = rg.Engine(world * G, P)
+    whole.workload_init(WL)
+    wc = [torch.zeros((P, whole.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+    wf = torch.zeros((world * G, 8), dtype=torch.uint8, device="cuda")
+    for t in range(TICKS):
+        whole.workload_gen(WL, t, *[c.data_ptr() for c in wc], wf.data_ptr())
+        whole.tick_device(*[c.data_ptr() for c in wc], wf.data_ptr())
+    assert np.array_equal(rep.reshape(-1), whole.read_column(rg.COL.COMMIT))
+    print("PUBLISH_OK", world, st["bytes_per_rank_delta"])
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,workload", [(2, "2"), (3, "5")])
+def test_ranks_sharing_the_gpu_publish_through_the_c_entry_point(rg, tmp_path, world, workload):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, RG_ROOT=ROOT, RG_WL=workload)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29560 + world), str(script)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert f"PUBLISH_OK {world}" in r.stdout, r.stdout[-3000:]

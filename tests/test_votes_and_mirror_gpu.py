@@ -91,9 +91,8 @@ def test_host_mirror_steps_like_raw_node(rg):
     with pytest.raises(rg.EngineError) as e:
         eng.step(0, 999, TERM, 5)
     assert e.value.code == -5  # StepPeerNotFound
-    with pytest.raises(rg.EngineError) as e:
-        eng.step(0, 102, 0, 5)
-    assert e.value.code == -4  # StepLocalMsg (term 0 = local message)
+    # (term 0 is not an error: Raft::step skips the term gate for it, raft.rs:1282 -- covered by
+    # test_step_checks_the_peer_before_the_term)
     with pytest.raises(rg.EngineError) as e:
         eng.step(0, 102, TERM + 1, 5)
     assert e.value.code == -7  # higher term: the host must step down
