@@ -126,13 +126,13 @@ def soa_cpu_line(n_groups, n_slots, workload, seed, threads):
         return {"soa_note": f"unavailable: {type(e).__name__}: {e}"}
 
 
-def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what):
+def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what, variant=0):
     """A second, smaller measurement for the bench line's sub-objects, after the headline region: one engine, W+K
     recorded ticks replayed from a checkpoint (what == "tick"), or K launches of rg_recompute -- Raft::maybe_commit
     for every group with no messages, literally BASELINE's "commit-index recomputes" (what == "recompute").
     Times with HIP events on the engine's stream; returns a dict with its own roofline object."""
     stream = torch.cuda.current_stream()
-    eng = rg.Engine(n_groups, n_slots, device=torch.cuda.current_device())
+    eng = rg.Engine(n_groups, n_slots, device=torch.cuda.current_device(), variant=variant)
     eng.set_stream(stream.cuda_stream)
     eng.workload_init(workload, seed=seed)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -153,7 +153,7 @@ def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / steps
         nbytes = (8 * n_slots + 37) * n_groups  # B0(P) = 8 P + 37
-        kernel = "k_recompute"
+        kernel = "k_recompute2 (two groups per lane)" if variant != 1 else "k_recompute (one group per lane)"
     else:
         T = warmup + steps
         cols = [torch.empty((T, n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
@@ -248,6 +248,10 @@ def main():
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
     T = W + K
+    # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
+    # other streams of the process, which serialises the publication's side stream with the ticks
+    # (tools/probe_publish_host.py: 66 vs 43 us per tick + publication at world size 1).
+    torch.cuda.set_stream(torch.cuda.Stream())
     if args.workload == 5 and args.fuse > 1:
         raise SystemExit("--fuse cannot replay config 5: fused launches do not apply elections (include/raftgroups.h)")
     stream = torch.cuda.current_stream()
@@ -348,6 +352,8 @@ def main():
         pt.stream = torch.cuda.Stream() if multi else stream
         pt.eng.set_stream(pt.stream.cuda_stream)
 
+    issued = [0.0]  # when the host had issued the last tick / publication of a run_ticks call
+
     def run_ticks(t0, n, publish):
         if multi:
             fork = torch.cuda.Event()
@@ -373,6 +379,7 @@ def main():
                     pt.eng.send_appends(0)
                 if pub_now:
                     pt.eng.publish_commit()
+        issued[0] = time.perf_counter()
         if publish:  # the region ends when every exchange has landed and the replicas are up to date
             for pt in parts:
                 pt.eng.publish_sync()
@@ -398,6 +405,7 @@ def main():
     e0.record(stream)
     run_ticks(W, K, distributed)
     e1.record(stream)
+    host_issue_s = issued[0] - wall0  # the host's share: how long it took to ISSUE the K steps
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -416,7 +424,7 @@ def main():
         commit, out = pt.eng.results()
         if not (np.array_equal(commit, pt.ref_commit) and np.array_equal(out, pt.ref_out)):
             raise SystemExit("timed replay diverged from the recorded pass")
-        if distributed:
+        if distributed and os.environ.get("BENCH_SKIP_VERIFY") != "1":  # (skipped only by RG_PUB_DEBUG measurement builds)
             # every rank's replica must hold every rank's shard: compare against the columns themselves
             rep = pt.eng.published_commit()  # [world][n] out of THIS rank's replica
             cols_all = [torch.empty(pt.n, dtype=torch.int64) for _ in range(world)]
@@ -481,7 +489,7 @@ def main():
                        f"{pub_stats['bytes_per_rank_delta']} B/rank delta slices (full column: {pub_stats['bytes_per_rank_full']} B)"
                        if distributed else ""),
                    **({"publication": pub_stats} if distributed else {}),
-                   "launch": launch_mode, "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
+                   "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("k_tick_lane" if args.variant != 2 else "k_tick_lds") +
@@ -505,6 +513,8 @@ def main():
         # the literal BASELINE metric ("commit-index recomputes/sec"): Raft::maybe_commit for every group, no messages
         result["recompute_only"] = side_measurement(rg, torch, G, P, args.workload if args.workload != 5 else 2,
                                                     5, 50, args.seed, "recompute")
+        result["recompute_only"]["one_group_per_lane_us"] = side_measurement(
+            rg, torch, G, P, args.workload if args.workload != 5 else 2, 5, 50, args.seed, "recompute", variant=1)["us_per_launch"]
         # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
         result["out_of_cache"] = side_measurement(rg, torch, args.out_of_cache_groups, P, args.workload if args.workload != 5 else 2,
                                                   3, 12, args.seed, "tick")

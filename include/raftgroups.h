@@ -418,8 +418,10 @@ int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *commit, uint32
  *      of 8 MB per rank and tick at 1 M groups). Each rank keeps a replica of ALL commit indices [world][stride] u64 in
  *      HBM; gathered slices are folded into it lazily (when `ring_ticks` publications are buffered, or when it is read).
  *      A full exact-value list (or rg_restore / a reloaded commit column) marks the rank's slice "lost": all ranks
- *      see that in the gathered headers and the second publication after it is a full 8 B/group snapshot -- decided
- *      identically everywhere without another collective. All ranks must hold the same number of groups and call
+ *      see that in the gathered headers when they fold the slices into their replicas, which they all do at the same
+ *      publication numbers (every `ring_ticks`-th), and the check point after that one publishes a full 8 B/group
+ *      snapshot -- decided identically everywhere without another collective (the replica of a lost rank is inexact
+ *      for at most 2 x ring_ticks publications; a host that knows it rolled back passes RG_PUBLISH_FULL). All ranks must hold the same number of groups and call
  *      rg_comm_init / rg_publish_commit in the same order (they are collectives). ---- */
 #define RG_COMM_ID_BYTES 128
 /* ncclGetUniqueId: rank 0 creates the id, the host distributes it to the other ranks (any channel). */
@@ -457,6 +459,7 @@ typedef struct {
     uint64_t bytes_per_rank_delta; /* size of a delta slice (header + list + 1 B/group) */
     uint64_t bytes_per_rank_full;  /* size of a full snapshot (8 B/group) */
     uint32_t overflow_slots, ring_ticks;
+    double host_us_events, host_us_allgather, host_us_memset; /* host time spent inside rg_publish_commit, by part */
 } rg_publish_stats;
 int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out);
 /* Host twins of the encoding over caller-provided buffers (no GPU involved; CPU-only tests of the N > 1 exchange):

@@ -105,6 +105,83 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out
     }
 }
 
+// Two groups per lane: every column access of a lane is one 16-B load (a wave moves 1 KiB per instruction and half as
+// many waves are in flight for the same bytes), which is what a 16-us sweep needs: at 1 M groups the launch ramp and
+// tail of 15 625 single-group waves weigh as much as the streaming itself (profiles/r02_recompute.txt).
+#ifndef RG_RECOMPUTE_X2
+#define RG_RECOMPUTE_X2 1
+#endif
+typedef u64 rg_u64x2 __attribute__((ext_vector_type(2)));
+typedef u32 rg_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int P, bool COMMIT>
+__global__ __launch_bounds__(RG_BLOCK) void k_recompute2(RgState st, u64 *mci_out, u8 *gc_out) {
+    const u64 g0 = ((u64)blockIdx.x * RG_BLOCK + threadIdx.x) * 2;
+    if (g0 >= st.G) return;
+    const bool two = g0 + 1 < st.G; // (the columns are padded to a multiple of 256 groups: the 16-B loads stay in bounds)
+    const rg_u32x2 cfg2 = *reinterpret_cast<const rg_u32x2 *>(st.cfg + g0);
+    rg_u64x2 mt2[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) mt2[p] = *reinterpret_cast<const rg_u64x2 *>(st.match + (u64)p * st.stride + g0);
+    rg_u64x2 commit2, lo2, hi2;
+    if (COMMIT) {
+        commit2 = *reinterpret_cast<const rg_u64x2 *>(st.commit + g0);
+        lo2 = *reinterpret_cast<const rg_u64x2 *>(st.lo + g0);
+        hi2 = *reinterpret_cast<const rg_u64x2 *>(st.hi + g0);
+    }
+    u32 out2[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (k == 1 && !two) break;
+        const u64 g = g0 + k;
+        const u32 cfg = k ? cfg2.y : cfg2.x;
+        const u32 present = RG_CFG_PRESENT(cfg), incoming = RG_CFG_INCOMING(cfg), outgoing = RG_CFG_OUTGOING(cfg);
+        u64 mt[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) mt[p] = ((present >> p) & 1u) ? (k ? mt2[p].y : mt2[p].x) : 0ULL; // majority.rs:80-82
+        u64 mci;
+        bool used = false;
+        if (cfg & RG_CFG_GROUP_COMMIT) {
+            u64 gidv[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) gidv[p] = ((present >> p) & 1u) ? st.gid[(u64)p * st.stride + g] : 0ULL;
+            mci = rg_mci_group<P>(mt, gidv, incoming, outgoing, used);
+        } else {
+            RgQuorum<P> qm;
+            qm.init(mt);
+            mci = qm.mci(mt, incoming, outgoing);
+            used = incoming == 0 && outgoing == 0;
+        }
+        if (COMMIT) {
+            u64 commit = k ? commit2.y : commit2.x;
+            const u64 commit0 = commit;
+            if (rg_log_maybe_commit(mci, commit, k ? lo2.y : lo2.x, k ? hi2.y : hi2.x)) { // src/raft.rs:893-904
+                if (st.pub) rg_pub_store(st, g, rg_pub_load(st, g) + (u32)rg_min(commit - commit0, 0x10000ULL), commit);
+                st.commit[g] = commit;
+                const u32 self = RG_CFG_SELF(cfg);
+                if ((present >> self) & 1u) {
+                    const u64 o = (u64)self * st.stride + g;
+                    if (st.prc[o] < commit) st.prc[o] = commit;
+                }
+                out2[k] = RG_OUT_CHANGED;
+            }
+        } else {
+            mci_out[g] = mci;
+            if (gc_out) gc_out[g] = used ? 1 : 0;
+        }
+    }
+    if (COMMIT) {
+        if (two) {
+            rg_u32x2 o;
+            o.x = out2[0];
+            o.y = out2[1];
+            *reinterpret_cast<rg_u32x2 *>(st.out + g0) = o;
+        } else {
+            st.out[g0] = out2[0];
+        }
+    }
+}
+
 // Wave-cooperative recompute (RG_VARIANT_COOP): 8 lanes per group, lane s holds slot s's matched index;
 // the q-th largest is found by a cross-lane rank select: every lane counts, with 7 xor-shuffles inside
 // its 8-lane group, how many voters are >= its own value, and a 3-step butterfly max picks the largest
@@ -657,6 +734,11 @@ static int rg_rccl_load() {
     return RG_OK;
 }
 
+// Send slices in rotation: the ticks of interval i accumulate into slice i % RG_PUB_SEND while the exchanges of the
+// previous intervals still read theirs. Re-use is gated on the HOST (hipEventSynchronize on the exchange that last
+// read the slice, three publications back: normally long finished), so the engine's stream carries no cross-stream
+// wait -- a barrier packet per tick costs ~5 us of a ~58 us tick (profiles/r02_publish_overhead.txt).
+#define RG_PUB_SEND 4
 struct RgPub {
     u32 rank, world;
     ncclComm_t comm;          // RCCL transport (nullptr with a custom transport)
@@ -665,13 +747,14 @@ struct RgPub {
     RgPubLayout lay;
     u32 ring;                 // publications buffered before the replica is brought up to date
     hipStream_t side;         // the exchange runs here; the engine's stream only records / waits events
-    char *send[2];            // this rank's slice under construction (double-buffered), bytes_per_rank each
+    char *send[RG_PUB_SEND];  // this rank's slice under construction (a small ring), bytes_per_rank each
     char *ring_buf;           // [ring][world][bytes_per_rank]
     u64 *replica;             // [world][Gpad]
     u64 *full_send;           // [Gpad] snapshot of the commit column for a full publication
-    RgPubHdr *pin_hdr;        // pinned host: [3][world] headers of the last publications
-    hipEvent_t ev_tick[2], ev_done[2], ev_hdr[3];
-    bool done_pending[2], hdr_pending[3], hdr_full[3];
+    u32 *d_lost;              // device: some gathered slice asked for a resynchronisation (set by the replica update)
+    u32 *pin_lost;            // pinned host: [2] copies of d_lost taken at the last two check points
+    hipEvent_t ev_tick[RG_PUB_SEND], ev_done[RG_PUB_SEND], ev_chk[2];
+    bool done_pending[RG_PUB_SEND], chk_pending[2];
     u64 n_pub;                // publications so far
     u32 pending;              // ring slots gathered and not yet folded into the replica
     bool local_lost;          // this rank's deltas no longer describe its commit column (restore / column load)
@@ -801,6 +884,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
     }
     e = hipMemset(h->arena, 0, off + 2 * zero_bytes + 256 + rg_align(h->stride * 8));
+    // hipMemset of device memory returns before the fill has run (it is queued on the NULL stream), and a caller's
+    // stream created non-blocking (every torch.cuda.Stream) is not ordered behind the NULL stream: without this wait a
+    // first kernel on such a stream races the fill (seen at 8 M groups: 0.1 % of the groups zeroed again after
+    // rg_workload_init had written them)
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         (void)hipFree(h->arena);
         delete h;
@@ -841,6 +929,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         const size_t items_b = rg_align((size_t)h->G * h->P * sizeof(rg_send_item));
         e = hipMalloc(&h->ins_arena, meta_b + ring_b + items_b + 256);
         if (e == hipSuccess) e = hipMemset(h->ins_arena, 0, meta_b + ring_b + items_b + 256);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // (as above: the fill must have run before rg_create returns)
         if (e != hipSuccess) {
             if (h->ins_arena) (void)hipFree(h->ins_arena);
             (void)hipFree(h->arena);
@@ -1389,6 +1478,22 @@ template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *
         hipLaunchKernelGGL((k_recompute_coop<COMMIT>), dim3(rg_grid(h->G, 32)), dim3(256), 0, h->stream, h->st, h->P, mci, gc);
         hipError_t ce = hipGetLastError();
         if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(ce));
+        return RG_OK;
+    }
+    if (RG_RECOMPUTE_X2 && h->cfg.variant != RG_VARIANT_LANE) { // (variant LANE pins the one-group-per-lane kernel)
+        const dim3 grid2(rg_grid((h->G + 1) / 2, RG_BLOCK)), block2(RG_BLOCK);
+        switch (h->P) {
+        case 1: hipLaunchKernelGGL((k_recompute2<1, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        case 2: hipLaunchKernelGGL((k_recompute2<2, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        case 3: hipLaunchKernelGGL((k_recompute2<3, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        case 4: hipLaunchKernelGGL((k_recompute2<4, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        case 5: hipLaunchKernelGGL((k_recompute2<5, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        case 6: hipLaunchKernelGGL((k_recompute2<6, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        case 7: hipLaunchKernelGGL((k_recompute2<7, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        default: hipLaunchKernelGGL((k_recompute2<8, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
+        }
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(e2));
         return RG_OK;
     }
     const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
@@ -2158,13 +2263,15 @@ __global__ __launch_bounds__(256) void k_pub_apply(u64 *replica, RgPubSlots sl, 
 }
 
 // The exact-value lists of the same publications: one thread per (publication, rank, entry).
-__global__ __launch_bounds__(256) void k_pub_apply_lists(u64 *replica, RgPubSlots sl, RgPubLayout l, u32 world) {
+__global__ __launch_bounds__(256) void k_pub_apply_lists(u64 *replica, RgPubSlots sl, RgPubLayout l, u32 world, u32 *lost) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     const u64 per_slot = (u64)world * l.cap;
     if (i >= per_slot * sl.n) return;
     const u32 s = (u32)(i / per_slot), rank = (u32)((i % per_slot) / l.cap), k = (u32)(i % l.cap);
     const char *base = sl.slice[s] + (u64)rank * l.bytes_per_rank;
     const RgPubHdr *hdr = reinterpret_cast<const RgPubHdr *>(base);
+    // a slice that asks for a resynchronisation (RG_PUB_LOST, or more list entries than fit)
+    if (k == 0 && ((hdr->flags & RG_PUB_LOST) || hdr->n_overflow > l.cap)) atomicOr(lost, 1u);
     if (k >= hdr->n_overflow) return;
     const RgPubOvf e = reinterpret_cast<const RgPubOvf *>(base + l.off_list)[k];
     if (e.group < l.G) atomicAdd((unsigned long long *)&replica[(u64)rank * l.Gpad + e.group], (unsigned long long)e.extra);
@@ -2203,9 +2310,8 @@ static int rg_pub_materialize(rg_engine *h) {
     const u64 words = p->lay.Gpad / 8 * p->world;
     hipLaunchKernelGGL(k_pub_apply, dim3(rg_grid(words, 256)), dim3(256), 0, p->side, p->replica, sl, p->lay, p->world);
     const u64 entries = (u64)p->world * p->lay.cap * sl.n;
-    if (entries)
-        hipLaunchKernelGGL(k_pub_apply_lists, dim3(rg_grid(entries, 256)), dim3(256), 0, p->side, p->replica, sl, p->lay,
-                           p->world);
+    hipLaunchKernelGGL(k_pub_apply_lists, dim3(rg_grid(entries, 256)), dim3(256), 0, p->side, p->replica, sl, p->lay,
+                       p->world, p->d_lost);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_publish: replica update failed: %s", hipGetErrorString(e));
     p->pending = 0;
@@ -2213,27 +2319,41 @@ static int rg_pub_materialize(rg_engine *h) {
     return RG_OK;
 }
 
+static inline double rg_now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 static int rg_publish_impl(rg_engine *h, bool force_full) {
     RgPub *p = h->pub;
     const u64 i = p->n_pub;
-    const int b = (int)(i & 1), hb = (int)(i % 3);
-    // Did any rank lose exactness two publications ago? Every rank reads the same gathered headers, so every rank
-    // takes the same decision without another collective. (Two publications back: that exchange has long finished,
-    // the wait below does not stall the pipeline.)
+    const int b = (int)(i % RG_PUB_SEND);
+    const double t0 = rg_now_us();
+    static const int dbg = getenv("RG_PUB_DEBUG") ? atoi(getenv("RG_PUB_DEBUG")) : 0; // measurement knobs (profiles/)
+
+    // Loss protocol. Every `ring` publications is a CHECK POINT (the same publication numbers on every rank): all
+    // buffered slices are folded into the replica first -- the update kernel raises d_lost for a slice that carries
+    // RG_PUB_LOST or an overfull list -- and d_lost is copied to the host. The copy of the PREVIOUS check point
+    // (finished long ago: no stall) decides whether this publication is a full snapshot. Every rank reads the same
+    // gathered headers at the same publication numbers, so every rank decides the same without another collective.
     bool full = force_full;
-    if (i >= 2) {
-        const int h2 = (int)((i - 2) % 3);
-        if (p->hdr_pending[h2]) {
-            RG_HIP(hipEventSynchronize(p->ev_hdr[h2]));
-            p->hdr_pending[h2] = false;
-            if (!p->hdr_full[h2])
-                for (u32 r = 0; r < p->world; r++) {
-                    const RgPubHdr &hd = p->pin_hdr[(u64)h2 * p->world + r];
-                    if ((hd.flags & RG_PUB_LOST) || hd.n_overflow > p->lay.cap) full = true;
-                }
+    const bool check = (i % p->ring) == 0 && i != 0;
+    if (check) {
+        const int cb = (int)((i / p->ring) & 1), pb = cb ^ 1;
+        if (p->chk_pending[pb]) {
+            RG_HIP(hipEventSynchronize(p->ev_chk[pb]));
+            p->chk_pending[pb] = false;
+            if (p->pin_lost[pb]) full = true;
         }
+        int rc = rg_pub_materialize(h);
+        if (rc) return rc;
+        RG_HIP(hipMemcpyAsync(&p->pin_lost[cb], p->d_lost, 4, hipMemcpyDeviceToHost, p->side));
+        RG_HIP(hipMemsetAsync(p->d_lost, 0, 4, p->side));
+        RG_HIP(hipEventRecord(p->ev_chk[cb], p->side));
+        p->chk_pending[cb] = true;
     }
-    if (p->local_lost && !p->lost_announced && !full) { // tell the other ranks (they act on it two publications from now)
+    if (p->local_lost && !p->lost_announced && !full) { // tell the other ranks (they act on it at a check point)
         static const u32 k_lost = RG_PUB_LOST;
         RG_HIP(hipMemcpyAsync(p->send[b] + offsetof(RgPubHdr, flags), &k_lost, 4, hipMemcpyHostToDevice, h->stream));
         p->lost_announced = true;
@@ -2242,19 +2362,19 @@ static int rg_publish_impl(rg_engine *h, bool force_full) {
         RG_HIP(hipMemcpyAsync(p->full_send, h->st.commit, h->G * 8, hipMemcpyDeviceToDevice, h->stream));
     RG_HIP(hipEventRecord(p->ev_tick[b], h->stream));
     RG_HIP(hipStreamWaitEvent(p->side, p->ev_tick[b], 0));
+    const double t1 = rg_now_us();
     int rc;
     if (full) {
         // the snapshot supersedes every buffered delta publication (and this interval's deltas)
         p->pending = 0;
         rc = rg_pub_allgather(h, p->full_send, p->replica, p->lay.Gpad * 8);
         if (rc) return rc;
-        p->hdr_full[hb] = true;
         p->local_lost = false;
         p->lost_announced = false;
         p->stats.full_publications++;
         p->stats.bytes_per_rank_last = p->lay.Gpad * 8;
     } else {
-        if (p->pending == p->ring) {
+        if (p->pending == p->ring) { // (reads between check points can leave the ring out of step with them)
             rc = rg_pub_materialize(h);
             if (rc) return rc;
         }
@@ -2262,27 +2382,28 @@ static int rg_publish_impl(rg_engine *h, bool force_full) {
         rc = rg_pub_allgather(h, p->send[b], slot, p->lay.bytes_per_rank);
         if (rc) return rc;
         p->pending++;
-        // the gathered headers, for the decision two publications from now
-        RG_HIP(hipMemcpy2DAsync(p->pin_hdr + (u64)hb * p->world, sizeof(RgPubHdr), slot, p->lay.bytes_per_rank,
-                                sizeof(RgPubHdr), p->world, hipMemcpyDeviceToHost, p->side));
-        p->hdr_full[hb] = false;
         p->stats.bytes_per_rank_last = p->lay.bytes_per_rank;
     }
-    RG_HIP(hipEventRecord(p->ev_hdr[hb], p->side));
-    p->hdr_pending[hb] = true;
+    const double t2 = rg_now_us();
     // this slice starts its next interval empty
     RG_HIP(hipMemsetAsync(p->send[b], 0, p->lay.bytes_per_rank, p->side));
+    const double t3 = rg_now_us();
     RG_HIP(hipEventRecord(p->ev_done[b], p->side));
     p->done_pending[b] = true;
-    // the ticks that follow accumulate into the other slice, once its previous exchange has let go of it
-    const int nb = b ^ 1;
+    // the ticks that follow accumulate into the next slice, once the exchange that last read it has let go of it
+    const int nb = (b + 1) % RG_PUB_SEND;
     if (p->done_pending[nb]) {
-        RG_HIP(hipStreamWaitEvent(h->stream, p->ev_done[nb], 0));
+        if (dbg & 1) RG_HIP(hipStreamWaitEvent(h->stream, p->ev_done[nb], 0)); // (the variant that was measured against)
+        else RG_HIP(hipEventSynchronize(p->ev_done[nb]));
         p->done_pending[nb] = false;
     }
     rg_pub_target(h, nb);
     p->n_pub++;
     p->stats.publications++;
+    const double t4 = rg_now_us();
+    p->stats.host_us_events += (t1 - t0) + (t4 - t3);
+    p->stats.host_us_allgather += t2 - t1;
+    p->stats.host_us_memset += t3 - t2;
     return RG_OK;
 }
 
@@ -2306,17 +2427,18 @@ extern "C" int rg_comm_destroy(rg_engine *h) {
     (void)hipStreamSynchronize(h->stream);
     if (p->side) (void)hipStreamSynchronize(p->side);
     if (p->comm) (void)g_rccl.CommDestroy(p->comm);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < RG_PUB_SEND; k++) {
         if (p->send[k]) (void)hipFree(p->send[k]);
         if (p->ev_tick[k]) (void)hipEventDestroy(p->ev_tick[k]);
         if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]);
     }
-    for (int k = 0; k < 3; k++)
-        if (p->ev_hdr[k]) (void)hipEventDestroy(p->ev_hdr[k]);
+    for (int k = 0; k < 2; k++)
+        if (p->ev_chk[k]) (void)hipEventDestroy(p->ev_chk[k]);
     if (p->ring_buf) (void)hipFree(p->ring_buf);
     if (p->replica) (void)hipFree(p->replica);
     if (p->full_send) (void)hipFree(p->full_send);
-    if (p->pin_hdr) (void)hipHostFree(p->pin_hdr);
+    if (p->d_lost) (void)hipFree(p->d_lost);
+    if (p->pin_lost) (void)hipHostFree(p->pin_lost);
     if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
     h->pub = nullptr;
@@ -2355,20 +2477,27 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
         }                                                                                                      \
     } while (0)
     RG_PUB_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
+    // ev_tick orders the tick kernel before the exchange's first kernel ON THIS DEVICE (ncclAllGather reads the slice
+    // with a kernel of this device; a host transport synchronises the device itself), so the system-scope fence a
+    // recorded event normally implies -- an L2 write-back worth ~2 us per tick -- is not needed
+    // (RG_PUB_DEBUG & 4 keeps it, for A/B measurements: profiles/r02_publish_overhead.txt)
+    const unsigned evf = hipEventDisableTiming | ((getenv("RG_PUB_DEBUG") && (atoi(getenv("RG_PUB_DEBUG")) & 4)) ? 0 : hipEventDisableSystemFence);
+    for (int k = 0; k < RG_PUB_SEND; k++) {
         RG_PUB_TRY(hipMalloc(&p->send[k], p->lay.bytes_per_rank));
         RG_PUB_TRY(hipMemsetAsync(p->send[k], 0, p->lay.bytes_per_rank, h->stream));
-        RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_tick[k], hipEventDisableTiming));
+        RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_tick[k], evf));
         RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
     }
-    for (int k = 0; k < 3; k++) RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_hdr[k], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_chk[k], hipEventDisableTiming));
     RG_PUB_TRY(hipMalloc(&p->ring_buf, (size_t)p->ring * p->world * p->lay.bytes_per_rank));
     RG_PUB_TRY(hipMalloc(&p->replica, (size_t)p->world * p->lay.Gpad * 8));
     RG_PUB_TRY(hipMemsetAsync(p->replica, 0, (size_t)p->world * p->lay.Gpad * 8, h->stream));
     RG_PUB_TRY(hipMalloc(&p->full_send, p->lay.Gpad * 8));
     RG_PUB_TRY(hipMemsetAsync(p->full_send, 0, p->lay.Gpad * 8, h->stream));
-    RG_PUB_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->pin_hdr), 3 * (size_t)p->world * sizeof(RgPubHdr), hipHostMallocDefault));
-    memset(p->pin_hdr, 0, 3 * (size_t)p->world * sizeof(RgPubHdr));
+    RG_PUB_TRY(hipMalloc(&p->d_lost, 256));
+    RG_PUB_TRY(hipMemsetAsync(p->d_lost, 0, 256, h->stream));
+    RG_PUB_TRY(hipHostMalloc(reinterpret_cast<void **>(&p->pin_lost), 64, hipHostMallocDefault));
+    memset(p->pin_lost, 0, 64);
     RG_PUB_TRY(hipStreamSynchronize(h->stream));
 #undef RG_PUB_TRY
     if (!cfg->transport) {
@@ -2387,7 +2516,7 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
                            rg_nccl_err(r));
         }
     }
-    h->dev.engine_bytes += 2 * p->lay.bytes_per_rank + (u64)p->ring * p->world * p->lay.bytes_per_rank +
+    h->dev.engine_bytes += RG_PUB_SEND * p->lay.bytes_per_rank + (u64)p->ring * p->world * p->lay.bytes_per_rank +
                            (u64)p->world * p->lay.Gpad * 8 + p->lay.Gpad * 8;
     rg_pub_target(h, 0);
     // every replica starts from the actual columns: one full publication (a collective: all ranks are in here)

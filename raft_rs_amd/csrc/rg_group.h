@@ -414,17 +414,25 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
     // becomes one more run of the term table. Cold columns are written straight to memory (rare path).
     // Malformed (term not above RG_COL_CUR_TERM): RG_OUT_FAULT, ignored.
     RG_HD void become_leader() {
-        u64 new_term;
-        if (!rg_election_valid(st, ms, g, self, new_term)) {
+        // everything this rare path reads from the cold columns is requested at once: ONE memory round trip
+        // (a wave of config 5 almost always has an electing lane, and it waits for that lane)
+        const u64 new_term = ms.mh[(u64)self * st.stride + g];
+        const u64 old_term = st.cur_term[g];
+        u64 rf[RG_TERM_RUNS];
+#pragma unroll
+        for (int k = 0; k < RG_TERM_RUNS; k++) rf[k] = st.run_first[(u64)k * st.stride + g];
+        if (!(new_term > old_term)) { // rg_election_valid
             out |= RG_OUT_FAULT;
             return;
         }
-        const u64 old_lo = r.lo, old_hi = r.hi, old_term = st.cur_term[g];
+        const u64 old_lo = r.lo, old_hi = r.hi;
         st.cur_term[g] = new_term;
         if (old_lo <= old_hi) { // the previous leader's entries become one more run of an older term
             int k = 0;
-            while (k < RG_TERM_RUNS && st.run_first[(u64)k * st.stride + g] != 0) k++;
-            if (k == RG_TERM_RUNS) { // table full: forget the boundary between the two oldest runs
+#pragma unroll
+            for (int j = RG_TERM_RUNS - 1; j >= 0; j--)
+                if (rf[j] == 0) k = j; // first unused run (used runs come first)
+            if (rf[RG_TERM_RUNS - 1] != 0) { // table full: forget the boundary between the two oldest runs
                 for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
                     st.run_first[(u64)j * st.stride + g] = st.run_first[(u64)(j + 1) * st.stride + g];
                     st.run_term[(u64)j * st.stride + g] = st.run_term[(u64)(j + 1) * st.stride + g];
@@ -674,14 +682,25 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         if (acc == 0) return;
         const u64 commit0 = r.commit;
         RgQuorum<P> qm;
-        bool replay = acc_oldp != 0;
-        if (!replay) {
+        bool replay;
+        {
             const u32 last_acc = 31u - (u32)__builtin_clz(acc);
             const u64 hi_last = last_acc < self ? last0 : r.hi;
             qm.init(r.mt);
             const u64 mci = mci_of(qm, r.mt);
             if (mci <= hi_last) {
-                if (rg_log_maybe_commit(mci, r.commit, r.lo, hi_last)) out |= RG_OUT_CHANGED;
+                // the evaluation at the last accepted ack decides the final commit index (above). If it does not
+                // commit, NO earlier one did either (mci_k <= mci_final fails the same `> commit` / `>= term_lo`
+                // test), so every ack from a paused peer takes the `else if old_paused` branch: no replay. That is
+                // the steady state of a group between an election and its first commit in the new term.
+                u64 c = r.commit;
+                const bool changed = rg_log_maybe_commit(mci, c, r.lo, hi_last);
+                replay = changed && acc_oldp != 0; // which of the acks moved it? only the sequence tells
+                if (!replay) {
+                    r.commit = c;
+                    if (changed) out |= RG_OUT_CHANGED;
+                    else out |= acc_oldp << 8; // send_append(from) for each of them (raft.rs:1749-1751)
+                }
             } else {
                 replay = true;
             }

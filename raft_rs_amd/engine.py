@@ -139,7 +139,8 @@ class CommConfig(C.Structure):
 class PublishStats(C.Structure):
     _fields_ = [("publications", C.c_uint64), ("full_publications", C.c_uint64), ("replica_updates", C.c_uint64),
                 ("bytes_per_rank_last", C.c_uint64), ("bytes_per_rank_delta", C.c_uint64),
-                ("bytes_per_rank_full", C.c_uint64), ("overflow_slots", C.c_uint32), ("ring_ticks", C.c_uint32)]
+                ("bytes_per_rank_full", C.c_uint64), ("overflow_slots", C.c_uint32), ("ring_ticks", C.c_uint32),
+                ("host_us_events", C.c_double), ("host_us_allgather", C.c_double), ("host_us_memset", C.c_double)]
 
 
 COMM_ID_BYTES = 128

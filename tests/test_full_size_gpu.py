@@ -115,11 +115,11 @@ def commit_cases():
     return cases
 
 
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 def test_commit_golden_vectors_on_the_gpu(rg, variant):
     """All 16 + 50 + 14 `committed` / `group_committed` cases, one raft group per case, through
-    rg_maximal_committed_index (k_recompute<8, false>; variant 3 = the wave-cooperative rank select for the cases
-    without group commit) and through rg_recompute (Raft::maybe_commit: the same index, gated by the log)."""
+    rg_maximal_committed_index (variant 0: k_recompute2, two groups per lane; 1: k_recompute, one group per lane;
+    3: the wave-cooperative rank select, for the cases without group commit) and through rg_recompute (Raft::maybe_commit: the same index, gated by the log)."""
     cases = commit_cases()
     assert len(cases) == 80
     if variant == 3:

@@ -93,10 +93,11 @@ def test_ticks_accumulate_between_publications_and_other_commit_paths(rg):
 
 
 def test_saturated_bytes_list_overflow_and_rollback_resynchronise(rg):
-    """Advances >= 255 go through the exact-value list; a list too short for them marks the slice lost and the second
-    publication after it is a full snapshot (every rank reads the same headers); rg_restore does the same."""
+    """Advances >= 255 go through the exact-value list; a list too short for them marks the slice lost: the ranks
+    notice when they fold the slices into their replicas (check points: every ring_ticks-th publication, the same
+    numbers everywhere) and the check point after that publishes a full snapshot; rg_restore takes the same road."""
     from raft_rs_amd import engine as E
-    G, P, cap = 3000, 3, 8
+    G, P, cap, ring = 3000, 3, 8, 2
     st = O.alloc_state(G, P)
     st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
     st["term_lo"][:] = 1
@@ -106,10 +107,10 @@ def test_saturated_bytes_list_overflow_and_rollback_resynchronise(rg):
     st["pflags"][:, :P] = 1
     eng = rg.Engine(G, P)
     eng.load_state(st)
-    eng.comm_init(0, 1, unique_id=E.comm_unique_id(), overflow_slots=cap)
+    eng.comm_init(0, 1, unique_id=E.comm_unique_id(), overflow_slots=cap, ring_ticks=ring)   # publication 0 (full)
     mb = rg.MsgBuffers(G, P, eng.stride)
 
-    def ack_all(index):  # both followers acknowledge index[g]
+    def ack_all(index):  # both followers acknowledge index[g]: the commit index of every group becomes index[g]
         mb.clear()
         for p in (1, 2):
             mb.m_flags[:, p] = rg.MF.VALID
@@ -117,37 +118,37 @@ def test_saturated_bytes_list_overflow_and_rollback_resynchronise(rg):
         eng.tick(mb)
 
     target = np.full(G, 100, dtype=np.uint64)
-    target[:5] = [255, 256, 1000, 1 << 33, 254]  # four saturated bytes (255 itself is exact: 255 + extra 0... no list)
+    target[:5] = [255, 256, 1000, 1 << 33, 254]  # 255 still fits the byte; 256, 1000 and 2^33 spill into the list
     ack_all(target)
-    eng.publish_commit()
+    eng.publish_commit()                                                                      # publication 1
     assert np.array_equal(eng.published_commit(0), target)
     assert eng.publish_stats()["full_publications"] == 1
     # more saturated groups than the list holds
     target2 = target + np.uint64(7)
     target2[100:100 + 3 * cap] += np.uint64(5000)
     ack_all(target2)
-    eng.publish_commit()                     # publication k: lost
-    eng.publish_sync()
+    eng.publish_commit()                                                                      # 2: lost
     assert not np.array_equal(eng.published_commit(0), target2), "the replica is knowingly inexact now"
-    ack_all(target2 + np.uint64(1))
-    eng.publish_commit()                     # k + 1: still deltas
-    ack_all(target2 + np.uint64(2))
-    eng.publish_commit()                     # k + 2: every rank has seen the lost header -> full snapshot
+    for k in range(1, 5):                                                                     # 3, 4 (seen), 5, 6 (full)
+        assert eng.publish_stats()["full_publications"] == 1
+        ack_all(target2 + np.uint64(k))
+        eng.publish_commit()
     assert eng.publish_stats()["full_publications"] == 2
-    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(2))
+    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(4))
     # rollback: the published advances no longer describe the column
     eng.checkpoint()
     ack_all(target2 + np.uint64(50))
-    eng.publish_commit()
+    eng.publish_commit()                                                                      # 7
     eng.restore()
-    for k in range(3):
-        ack_all(target2 + np.uint64(3 + k))
+    for k in range(6):                                                                        # 8 (announces) .. 13
+        ack_all(target2 + np.uint64(5 + k))
         eng.publish_commit()
     assert eng.publish_stats()["full_publications"] == 3
-    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(5))
-    # an explicit full publication (what a host does after it reloads state)
+    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(10))
+    # an explicit full publication (what a host does right after it reloads state)
     eng.publish_commit(full=True)
     assert eng.publish_stats()["full_publications"] == 4
+    assert np.array_equal(eng.published_commit(0), target2 + np.uint64(10))
     eng.close()
 
 
