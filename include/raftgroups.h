@@ -367,6 +367,13 @@ int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
  * items (only cap are written if it is larger). Synchronises. rg_send_items_ptr: the same list in device memory. */
 int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n);
 const rg_send_item *rg_send_items_ptr(rg_engine *h);
+/* A stage over EVERY group (after a dense tick) writes its work items as peer-major columns, like every other column of
+ * the engine -- u64 prev_index / last_index [P][stride], u32 n_msgs | kind << 16 [P][stride], 0 = nothing for that peer --
+ * with coalesced stores and no compaction; a device-side consumer (a message builder) reads them in place through
+ * these pointers. rg_send_items / rg_send_items_ptr materialise the compact list from them on request. Stages over a
+ * few touched groups (the sparse path) produce the compact list directly and leave these columns alone. */
+int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, const uint64_t **dev_last_index,
+                    const uint32_t **dev_n_kind);
 /* Inflights in/out (parity, checkpoints): meta u32 [P][stride] = start | count << 16; ring u64 [G][P][cap]. */
 uint64_t rg_inflights_bytes(const rg_engine *h, int ring);
 int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring); /* either may be NULL */

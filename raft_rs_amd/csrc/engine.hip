@@ -58,7 +58,9 @@ static int rg_fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // kernels: Raft::maybe_commit for all groups without messages, and maximal_committed_index
 // ------------------------------------------------------------------------------------------------
-template <int P, bool COMMIT>
+// GC = false compiles the group-commit routine (and the scratch its out-of-line call needs) out: launched unless some
+// group has ProgressTracker.group_commit set, like the tick kernels.
+template <int P, bool COMMIT, bool GC>
 __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out, u8 *gc_out) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out
         if (!((present >> p) & 1u)) mt[p] = 0; // a voter without a Progress acks 0 (majority.rs:80-82)
     u64 mci;
     bool used = false;
-    if (cfg & RG_CFG_GROUP_COMMIT) {
+    if (GC && (cfg & RG_CFG_GROUP_COMMIT)) {
         u64 gidv[P];
 #pragma unroll
         for (int p = 0; p < P; p++) gidv[p] = ((present >> p) & 1u) ? st.gid[(u64)p * st.stride + g] : 0ULL;
@@ -114,7 +116,44 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out
 typedef u64 rg_u64x2 __attribute__((ext_vector_type(2)));
 typedef u32 rg_u32x2 __attribute__((ext_vector_type(2)));
 
-template <int P, bool COMMIT>
+// one group of k_recompute2 (everything it needs already in registers); returns the group's result word
+template <int P, bool COMMIT, bool GC>
+RG_D u32 rg_recompute_one(const RgState &st, u64 g, u32 cfg, u64 (&mt)[P], u64 commit, u64 lo, u64 hi, u64 *mci_out, u8 *gc_out) {
+    const u32 present = RG_CFG_PRESENT(cfg), incoming = RG_CFG_INCOMING(cfg), outgoing = RG_CFG_OUTGOING(cfg);
+#pragma unroll
+    for (int p = 0; p < P; p++)
+        if (!((present >> p) & 1u)) mt[p] = 0; // a voter without a Progress acks 0 (majority.rs:80-82)
+    u64 mci;
+    bool used = false;
+    if (GC && (cfg & RG_CFG_GROUP_COMMIT)) {
+        u64 gidv[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) gidv[p] = ((present >> p) & 1u) ? st.gid[(u64)p * st.stride + g] : 0ULL;
+        mci = rg_mci_group<P>(mt, gidv, incoming, outgoing, used);
+    } else {
+        RgQuorum<P> qm;
+        qm.init(mt);
+        mci = qm.mci(mt, incoming, outgoing);
+        used = incoming == 0 && outgoing == 0;
+    }
+    if (!COMMIT) {
+        mci_out[g] = mci;
+        if (gc_out) gc_out[g] = used ? 1 : 0;
+        return 0;
+    }
+    const u64 commit0 = commit;
+    if (!rg_log_maybe_commit(mci, commit, lo, hi)) return 0; // src/raft.rs:893-904
+    if (st.pub) rg_pub_store(st, g, rg_pub_load(st, g) + (u32)rg_min(commit - commit0, 0x10000ULL), commit);
+    st.commit[g] = commit;
+    const u32 self = RG_CFG_SELF(cfg);
+    if ((present >> self) & 1u) {
+        const u64 o = (u64)self * st.stride + g;
+        if (st.prc[o] < commit) st.prc[o] = commit;
+    }
+    return RG_OUT_CHANGED;
+}
+
+template <int P, bool COMMIT, bool GC>
 __global__ __launch_bounds__(RG_BLOCK) void k_recompute2(RgState st, u64 *mci_out, u8 *gc_out) {
     const u64 g0 = ((u64)blockIdx.x * RG_BLOCK + threadIdx.x) * 2;
     if (g0 >= st.G) return;
@@ -123,61 +162,29 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute2(RgState st, u64 *mci_ou
     rg_u64x2 mt2[P];
 #pragma unroll
     for (int p = 0; p < P; p++) mt2[p] = *reinterpret_cast<const rg_u64x2 *>(st.match + (u64)p * st.stride + g0);
-    rg_u64x2 commit2, lo2, hi2;
+    rg_u64x2 commit2 = {0, 0}, lo2 = {0, 0}, hi2 = {0, 0};
     if (COMMIT) {
         commit2 = *reinterpret_cast<const rg_u64x2 *>(st.commit + g0);
         lo2 = *reinterpret_cast<const rg_u64x2 *>(st.lo + g0);
         hi2 = *reinterpret_cast<const rg_u64x2 *>(st.hi + g0);
     }
-    u32 out2[2] = {0, 0};
+    u64 ma[P], mb[P];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        if (k == 1 && !two) break;
-        const u64 g = g0 + k;
-        const u32 cfg = k ? cfg2.y : cfg2.x;
-        const u32 present = RG_CFG_PRESENT(cfg), incoming = RG_CFG_INCOMING(cfg), outgoing = RG_CFG_OUTGOING(cfg);
-        u64 mt[P];
-#pragma unroll
-        for (int p = 0; p < P; p++) mt[p] = ((present >> p) & 1u) ? (k ? mt2[p].y : mt2[p].x) : 0ULL; // majority.rs:80-82
-        u64 mci;
-        bool used = false;
-        if (cfg & RG_CFG_GROUP_COMMIT) {
-            u64 gidv[P];
-#pragma unroll
-            for (int p = 0; p < P; p++) gidv[p] = ((present >> p) & 1u) ? st.gid[(u64)p * st.stride + g] : 0ULL;
-            mci = rg_mci_group<P>(mt, gidv, incoming, outgoing, used);
-        } else {
-            RgQuorum<P> qm;
-            qm.init(mt);
-            mci = qm.mci(mt, incoming, outgoing);
-            used = incoming == 0 && outgoing == 0;
-        }
-        if (COMMIT) {
-            u64 commit = k ? commit2.y : commit2.x;
-            const u64 commit0 = commit;
-            if (rg_log_maybe_commit(mci, commit, k ? lo2.y : lo2.x, k ? hi2.y : hi2.x)) { // src/raft.rs:893-904
-                if (st.pub) rg_pub_store(st, g, rg_pub_load(st, g) + (u32)rg_min(commit - commit0, 0x10000ULL), commit);
-                st.commit[g] = commit;
-                const u32 self = RG_CFG_SELF(cfg);
-                if ((present >> self) & 1u) {
-                    const u64 o = (u64)self * st.stride + g;
-                    if (st.prc[o] < commit) st.prc[o] = commit;
-                }
-                out2[k] = RG_OUT_CHANGED;
-            }
-        } else {
-            mci_out[g] = mci;
-            if (gc_out) gc_out[g] = used ? 1 : 0;
-        }
+    for (int p = 0; p < P; p++) {
+        ma[p] = mt2[p].x;
+        mb[p] = mt2[p].y;
     }
+    const u32 oa = rg_recompute_one<P, COMMIT, GC>(st, g0, cfg2.x, ma, commit2.x, lo2.x, hi2.x, mci_out, gc_out);
+    u32 ob = 0;
+    if (two) ob = rg_recompute_one<P, COMMIT, GC>(st, g0 + 1, cfg2.y, mb, commit2.y, lo2.y, hi2.y, mci_out, gc_out);
     if (COMMIT) {
         if (two) {
             rg_u32x2 o;
-            o.x = out2[0];
-            o.y = out2[1];
+            o.x = oa;
+            o.y = ob;
             *reinterpret_cast<rg_u32x2 *>(st.out + g0) = o;
         } else {
-            st.out[g0] = out2[0];
+            st.out[g0] = oa;
         }
     }
 }
@@ -477,6 +484,76 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
     }
 }
 
+// The dense stage: every group of the shard, one lane each, work items into the peer-major columns (RgSendCols).
+// A pure streaming kernel like the tick: 64-thread workgroups, no LDS, no atomics, no barrier.
+template <int P>
+__global__ __launch_bounds__(RG_BLOCK) void k_send_dense(RgState st, RgIns ins, u64 max_entries, u32 flags, RgSendCols oc) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    RgSendRegs<P> it;
+    it.count = 0;
+    it.snap = 0;
+#pragma unroll
+    for (int s = 0; s < P; s++) it.n[s] = 0;
+    const u32 out = st.out[g];
+    if (out) rg_group_send<P>(st, ins, g, out, max_entries, flags, it);
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const u64 o = (u64)s * st.stride + g;
+        const bool snap = (it.snap >> s) & 1u;
+        const u32 nk = snap ? (1u | (RG_SEND_SNAPSHOT << 16)) : (it.n[s] ? (it.n[s] | (RG_SEND_APPEND << 16)) : 0u);
+        oc.n[o] = nk; // every cell, every stage: 0 = nothing for this peer
+        if (nk) {
+            oc.prev[o] = it.prev[s];
+            oc.last[o] = it.last[s];
+        }
+    }
+}
+
+// Compact list out of the columns, on request (rg_send_items / rg_send_items_ptr after a dense stage).
+__global__ __launch_bounds__(256) void k_send_compact(RgSendCols oc, u64 G, u64 stride, u32 P, rg_send_item *items, u32 *counter) {
+    __shared__ u32 wave_tot[4];
+    __shared__ u32 block_base;
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    u32 cnt = 0;
+    if (g < G)
+        for (u32 s = 0; s < P; s++) cnt += oc.n[(u64)s * stride + g] != 0;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u32 incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 v = __shfl_up(incl, d, 64);
+        if (lane >= (u32)d) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 total = 0;
+        for (int w = 0; w < 4; w++) {
+            const u32 t = wave_tot[w];
+            wave_tot[w] = total;
+            total += t;
+        }
+        block_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    if (cnt == 0) return;
+    u32 k = block_base + wave_tot[wave] + incl - cnt;
+    for (u32 s = 0; s < P; s++) {
+        const u64 o = (u64)s * stride + g;
+        const u32 nk = oc.n[o];
+        if (!nk) continue;
+        rg_send_item r;
+        r.group = g;
+        r.prev_index = oc.prev[o];
+        r.last_index = oc.last[o];
+        r.slot = s;
+        r.n_msgs = (uint16_t)(nk & 0xffffu);
+        r.kind = (uint16_t)(nk >> 16);
+        items[k++] = r;
+    }
+}
+
 // Status read-back: one thread per requested group gathers its cells into one record.
 __global__ void k_read_groups(RgState st, const u64 *groups, u64 n, u32 P, const u32 *ins_meta, rg_group_status *out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -678,6 +755,9 @@ struct rg_engine {
     RgIns ins;
     rg_send_item *send_items;
     u32 *send_counter;
+    RgSendCols send_cols;  // work items of a dense stage (peer-major columns)
+    bool send_cols_fresh;  // ... hold the last stage's items and the compact list has not been materialised from them
+    bool send_last_dense;  // the last stage was a dense one (the columns are its output)
     u64 send_bound;    // upper bound of the last stage's work items (groups it walked x peers)
     std::vector<rg_send_item> host_items; // items of the last stage when rg_flush_send fetched them
     bool host_items_valid;
@@ -858,6 +938,10 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->ins.cap = 0;
     h->send_items = nullptr;
     h->send_counter = nullptr;
+    h->send_cols.prev = h->send_cols.last = nullptr;
+    h->send_cols.n = nullptr;
+    h->send_cols_fresh = false;
+    h->send_last_dense = false;
     h->send_ready = false;
     h->send_bound = 0;
     h->pin_send = nullptr;
@@ -927,14 +1011,16 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         const size_t meta_b = rg_align((size_t)h->P * h->stride * 4) + 2 * rg_align((size_t)h->P * h->stride * 8); // meta | head | tail
         const size_t ring_b = rg_align((size_t)h->G * h->P * cfg->max_inflight * 8);
         const size_t items_b = rg_align((size_t)h->G * h->P * sizeof(rg_send_item));
-        e = hipMalloc(&h->ins_arena, meta_b + ring_b + items_b + 256);
-        if (e == hipSuccess) e = hipMemset(h->ins_arena, 0, meta_b + ring_b + items_b + 256);
+        const size_t col8_b = rg_align((size_t)h->P * h->stride * 8), col4_b = rg_align((size_t)h->P * h->stride * 4);
+        const size_t cols_b = 2 * col8_b + col4_b; // RgSendCols: prev | last | n
+        e = hipMalloc(&h->ins_arena, meta_b + ring_b + items_b + 256 + cols_b);
+        if (e == hipSuccess) e = hipMemset(h->ins_arena, 0, meta_b + ring_b + items_b + 256 + cols_b);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // (as above: the fill must have run before rg_create returns)
         if (e != hipSuccess) {
             if (h->ins_arena) (void)hipFree(h->ins_arena);
             (void)hipFree(h->arena);
             delete h;
-            return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: %zu bytes of Inflights (cap %u): %s", meta_b + ring_b + items_b,
+            return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: %zu bytes of Inflights (cap %u): %s", meta_b + ring_b + items_b + cols_b,
                            cfg->max_inflight, hipGetErrorString(e));
         }
         h->ins.meta = reinterpret_cast<u32 *>(h->ins_arena);
@@ -946,7 +1032,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         h->ins_state_bytes = meta_b + ring_b;
         h->send_items = reinterpret_cast<rg_send_item *>(h->ins_arena + meta_b + ring_b);
         h->send_counter = reinterpret_cast<u32 *>(h->ins_arena + meta_b + ring_b + items_b);
-        h->dev.engine_bytes += meta_b + ring_b + items_b + 256;
+        char *cols = h->ins_arena + meta_b + ring_b + items_b + 256;
+        h->send_cols.prev = reinterpret_cast<u64 *>(cols);
+        h->send_cols.last = reinterpret_cast<u64 *>(cols + col8_b);
+        h->send_cols.n = reinterpret_cast<u32 *>(cols + 2 * col8_b);
+        h->dev.engine_bytes += meta_b + ring_b + items_b + 256 + cols_b;
     }
     *out = h;
     return RG_OK;
@@ -1473,6 +1563,19 @@ extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *com
     return RG_OK;
 }
 
+template <int P, bool COMMIT> static void rg_launch_recompute_p(rg_engine *h, u64 *mci, u8 *gc, bool x2) {
+    const bool group_commit = h->any_group_commit;
+    if (x2) {
+        const dim3 grid(rg_grid((h->G + 1) / 2, RG_BLOCK)), block(RG_BLOCK);
+        if (group_commit) hipLaunchKernelGGL((k_recompute2<P, COMMIT, true>), grid, block, 0, h->stream, h->st, mci, gc);
+        else hipLaunchKernelGGL((k_recompute2<P, COMMIT, false>), grid, block, 0, h->stream, h->st, mci, gc);
+    } else {
+        const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
+        if (group_commit) hipLaunchKernelGGL((k_recompute<P, COMMIT, true>), grid, block, 0, h->stream, h->st, mci, gc);
+        else hipLaunchKernelGGL((k_recompute<P, COMMIT, false>), grid, block, 0, h->stream, h->st, mci, gc);
+    }
+}
+
 template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *gc) {
     if (h->cfg.variant == RG_VARIANT_COOP && !h->any_group_commit) {
         hipLaunchKernelGGL((k_recompute_coop<COMMIT>), dim3(rg_grid(h->G, 32)), dim3(256), 0, h->stream, h->st, h->P, mci, gc);
@@ -1480,32 +1583,16 @@ template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *
         if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(ce));
         return RG_OK;
     }
-    if (RG_RECOMPUTE_X2 && h->cfg.variant != RG_VARIANT_LANE) { // (variant LANE pins the one-group-per-lane kernel)
-        const dim3 grid2(rg_grid((h->G + 1) / 2, RG_BLOCK)), block2(RG_BLOCK);
-        switch (h->P) {
-        case 1: hipLaunchKernelGGL((k_recompute2<1, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        case 2: hipLaunchKernelGGL((k_recompute2<2, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        case 3: hipLaunchKernelGGL((k_recompute2<3, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        case 4: hipLaunchKernelGGL((k_recompute2<4, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        case 5: hipLaunchKernelGGL((k_recompute2<5, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        case 6: hipLaunchKernelGGL((k_recompute2<6, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        case 7: hipLaunchKernelGGL((k_recompute2<7, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        default: hipLaunchKernelGGL((k_recompute2<8, COMMIT>), grid2, block2, 0, h->stream, h->st, mci, gc); break;
-        }
-        hipError_t e2 = hipGetLastError();
-        if (e2 != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(e2));
-        return RG_OK;
-    }
-    const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
+    const bool x2 = RG_RECOMPUTE_X2 && h->cfg.variant != RG_VARIANT_LANE; // (variant LANE pins one group per lane)
     switch (h->P) {
-    case 1: hipLaunchKernelGGL((k_recompute<1, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    case 2: hipLaunchKernelGGL((k_recompute<2, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    case 3: hipLaunchKernelGGL((k_recompute<3, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    case 4: hipLaunchKernelGGL((k_recompute<4, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    case 5: hipLaunchKernelGGL((k_recompute<5, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    case 6: hipLaunchKernelGGL((k_recompute<6, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    case 7: hipLaunchKernelGGL((k_recompute<7, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
-    default: hipLaunchKernelGGL((k_recompute<8, COMMIT>), grid, block, 0, h->stream, h->st, mci, gc); break;
+    case 1: rg_launch_recompute_p<1, COMMIT>(h, mci, gc, x2); break;
+    case 2: rg_launch_recompute_p<2, COMMIT>(h, mci, gc, x2); break;
+    case 3: rg_launch_recompute_p<3, COMMIT>(h, mci, gc, x2); break;
+    case 4: rg_launch_recompute_p<4, COMMIT>(h, mci, gc, x2); break;
+    case 5: rg_launch_recompute_p<5, COMMIT>(h, mci, gc, x2); break;
+    case 6: rg_launch_recompute_p<6, COMMIT>(h, mci, gc, x2); break;
+    case 7: rg_launch_recompute_p<7, COMMIT>(h, mci, gc, x2); break;
+    default: rg_launch_recompute_p<8, COMMIT>(h, mci, gc, x2); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "recompute launch failed: %s", hipGetErrorString(e));
@@ -1556,6 +1643,27 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
 // `n` only sizes the grid.
 static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, const u64 *list, u64 n,
                            const u32 *n_ptr) {
+    h->send_cols_fresh = false;
+    h->send_last_dense = false;
+    if (!list && !n_ptr && n == h->G) { // every group: work items into the peer-major columns, no list
+        const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
+        switch (h->P) {
+        case 1: hipLaunchKernelGGL(k_send_dense<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 2: hipLaunchKernelGGL(k_send_dense<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 3: hipLaunchKernelGGL(k_send_dense<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 4: hipLaunchKernelGGL(k_send_dense<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 5: hipLaunchKernelGGL(k_send_dense<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 6: hipLaunchKernelGGL(k_send_dense<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 7: hipLaunchKernelGGL(k_send_dense<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        default: hipLaunchKernelGGL(k_send_dense<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "send stage: launch failed: %s", hipGetErrorString(e));
+        h->send_cols_fresh = true;
+        h->send_last_dense = true;
+        h->host_items_valid = false;
+        return RG_OK;
+    }
     RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
     if (n) {
         const dim3 grid(rg_grid(n, RG_SEND_BLOCK)), block(RG_SEND_BLOCK);
@@ -1592,10 +1700,26 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
     return RG_OK;
 }
 
+// After a dense stage the work items live in the columns; the compact list exists once somebody asks for it.
+static int rg_send_materialize(rg_engine *h) {
+    if (!h->send_cols_fresh) return RG_OK;
+    RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
+    hipLaunchKernelGGL(k_send_compact, dim3(rg_grid(h->G, 256)), dim3(256), 0, h->stream, h->send_cols, h->G, h->stride, h->P,
+                       h->send_items, h->send_counter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_send_items: compaction launch failed: %s", hipGetErrorString(e));
+    h->send_cols_fresh = false;
+    return RG_OK;
+}
+
 extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n) {
     if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
     RG_HIP(hipSetDevice(h->cfg.device));
+    {
+        int mrc = rg_send_materialize(h);
+        if (mrc) return mrc;
+    }
     if (h->host_items_valid) { // rg_flush_send already brought them over with the tick's results
         *n = h->host_items.size();
         const u64 k = *n < cap ? *n : cap;
@@ -1629,29 +1753,49 @@ extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t ca
     return RG_OK;
 }
 
-extern "C" const rg_send_item *rg_send_items_ptr(rg_engine *h) { return h ? h->send_items : nullptr; }
+extern "C" const rg_send_item *rg_send_items_ptr(rg_engine *h) {
+    if (!h || !h->ins_arena) return nullptr;
+    if (hipSetDevice(h->cfg.device) != hipSuccess || rg_send_materialize(h) != RG_OK) return nullptr;
+    return h->send_items;
+}
+
+extern "C" int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, const uint64_t **dev_last_index,
+                               const uint32_t **dev_n_kind) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_columns: null engine");
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_columns: engine created with max_inflight = 0");
+    if (!h->send_last_dense)
+        return rg_fail(RG_ERR_STATE, "rg_send_columns: the last send stage was not a dense one (sparse stages produce the "
+                                     "compact list only)");
+    if (dev_prev_index) *dev_prev_index = h->send_cols.prev;
+    if (dev_last_index) *dev_last_index = h->send_cols.last;
+    if (dev_n_kind) *dev_n_kind = h->send_cols.n;
+    return RG_OK;
+}
 
 extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
     if (!h || !h->ins_arena) return 0;
     return ring ? (uint64_t)h->G * h->P * h->ins.cap * 8 : (uint64_t)h->P * h->stride * 4;
 }
 
-// The oldest inflight of a window lives in the `head` column (rg_send.h); to the outside the ring is whole.
+// The oldest and the newest inflight of a window live in the `head` / `tail` columns (rg_send.h); to the outside the
+// ring is whole.
 extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_inflights: null engine");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_read_inflights: engine created with max_inflight = 0");
     RG_HIP(hipSetDevice(h->cfg.device));
     const u64 cells = (u64)h->P * h->stride;
     std::vector<u32> meta_tmp;
-    std::vector<u64> head;
+    std::vector<u64> head, tail;
     u32 *meta = host_meta;
     if (host_ring) {
         head.resize(cells);
+        tail.resize(cells);
         if (!meta) {
             meta_tmp.resize(cells);
             meta = meta_tmp.data();
         }
         RG_HIP(hipMemcpyAsync(head.data(), h->ins.head, cells * 8, hipMemcpyDeviceToHost, h->stream));
+        RG_HIP(hipMemcpyAsync(tail.data(), h->ins.tail, cells * 8, hipMemcpyDeviceToHost, h->stream));
         RG_HIP(hipMemcpyAsync(host_ring, h->ins.ring, rg_inflights_bytes(h, 1), hipMemcpyDeviceToHost, h->stream));
     }
     if (meta) RG_HIP(hipMemcpyAsync(meta, h->ins.meta, cells * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1659,8 +1803,11 @@ extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *ho
     if (host_ring)
         for (u32 p = 0; p < h->P; p++)
             for (u64 g = 0; g < h->G; g++) {
-                const u32 m = meta[(u64)p * h->stride + g];
-                if (m >> 16) host_ring[(g * h->P + p) * h->ins.cap + (m & 0xffffu)] = head[(u64)p * h->stride + g];
+                const u32 m = meta[(u64)p * h->stride + g], start = m & 0xffffu, count = m >> 16;
+                if (!count) continue;
+                u64 *cell = host_ring + (g * h->P + p) * h->ins.cap;
+                cell[start] = head[(u64)p * h->stride + g];
+                cell[(start + count - 1) % h->ins.cap] = tail[(u64)p * h->stride + g];
             }
     return RG_OK;
 }

@@ -18,13 +18,23 @@
 
 struct RgIns {
     u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31)
-    u64 *head; // [P][stride]: Inflights.buffer[start], the oldest inflight. This peer-major column (coalesced
-               // across a wave) is the authoritative copy of that one entry; the ring's own word for position
-               // `start` may be stale. A window of <= 1 message in flight therefore never touches the ring.
-    u64 *tail; // [P][stride]: the newest inflight (copy of the ring's last entry). Entries are the last indices of
-               // consecutive MsgAppends, strictly increasing, so `to >= tail` frees the whole window unread.
+    u64 *head; // [P][stride]: the OLDEST inflight, Inflights.buffer[start]
+    u64 *tail; // [P][stride]: the NEWEST inflight, Inflights.buffer[start + count - 1]
+               // These two peer-major columns (coalesced across a wave) are the authoritative copies of those two
+               // entries; the ring's own words for them may be stale. Entries are the last indices of consecutive
+               // MsgAppends, strictly increasing, so a window of <= 2 messages lives entirely in the columns (87 % of
+               // the windows of the bench stream), `to >= tail` frees a whole window unread, and the ring is only
+               // touched for the MIDDLE entries of windows of three and more.
     u64 *ring; // [(g * P + slot) * cap + i]: Inflights.buffer of that Progress, contiguous per cell
     u32 cap;   // Inflights::cap()
+};
+
+// Work items of a DENSE stage (every group walked): peer-major columns, one cell per (slot, group), so the stage
+// stores them like every other column -- coalesced, no compaction, no atomics, no workgroup barrier. A device-side
+// consumer (a message builder) reads them in place; the compact rg_send_item list is materialised on request.
+struct RgSendCols {
+    u64 *prev, *last; // [P][stride] Message.index of the first message / index of the last entry sent (valid where n != 0)
+    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-31); 0 = nothing to send to this peer
 };
 
 template <int P> struct RgSendRegs {
@@ -34,7 +44,7 @@ template <int P> struct RgSendRegs {
     u32 count;  // items of this group
 };
 
-// Inflights::free_to (inflights.rs:84-110); `head` = buffer[start]
+// Inflights::free_to (inflights.rs:84-110) over (head, middle entries in the ring, tail)
 RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &head, u64 tail, u64 to) {
     if (count == 0 || to < head) return; // out of the left side of the window
     if (to >= tail) {                    // everything in the window is <= tail <= to
@@ -43,20 +53,36 @@ RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u6
         count = 0;
         return;
     }
-    u32 i = 1, idx = start + 1;          // buffer[start] <= to: freed
+    // head <= to < tail, so count >= 2: the new oldest is the first entry > to -- a middle one, or the newest
+    u32 i = 1, idx = start + 1;
     if (idx >= ins.cap) idx -= ins.cap;
-    while (i < count) {
+    u64 nh = tail;
+    while (i + 1 < count) { // middle entries only
         const u64 v = (RG_SEND_EXP & 2) ? ~0ULL : ins.ring[base + idx];
-        if (to < v) { // found the first large inflight: the new oldest
-            head = v;
+        if (to < v) {
+            nh = v;
             break;
         }
         idx++;
         if (idx >= ins.cap) idx -= ins.cap;
         i++;
     }
+    head = nh;
     count -= i;
     start = idx;
+}
+
+// Inflights::add (inflights.rs:65-81): the previous newest becomes a middle entry (only then does it need a ring word)
+RG_HD void rg_ins_add(const RgIns &ins, u64 base, u32 start, u32 &count, u64 &head, u64 &tail, u64 v) {
+    if (count == 0) {
+        head = v;
+    } else if (count >= 2) {
+        u32 pos = start + count - 1;
+        if (pos >= ins.cap) pos -= ins.cap;
+        if (!(RG_SEND_EXP & 2)) ins.ring[base + pos] = tail;
+    }
+    tail = v;
+    count++;
 }
 
 // One group of the send stage. `out` is the group's RG_OUT_* word of the tick that just ran.
@@ -160,16 +186,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
                             if (take) { // Progress::update_state(last) (progress.rs:231-243)
                                 if (state == RG_STATE_REPLICATE) {
                                     next += take; // optimistic_update
-                                    // Inflights::add (inflights.rs:65-81)
-                                    if (count == 0) {
-                                        head = next - 1;
-                                    } else {
-                                        u32 pos = start + count;
-                                        if (pos >= ins.cap) pos -= ins.cap;
-                                        if (!(RG_SEND_EXP & 2)) ins.ring[base + pos] = next - 1;
-                                    }
-                                    tail = next - 1;
-                                    count++;
+                                    rg_ins_add(ins, base, start, count, head, tail, next - 1);
                                 } else {
                                     pb |= RG_PF_PAUSED;
                                 }

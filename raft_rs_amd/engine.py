@@ -193,6 +193,7 @@ SYMBOLS = {
     "rg_flush_send": (_i, [_vp, _u64, C.c_uint32]),
     "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_items_ptr": (_vp, [_vp]),
+    "rg_send_columns": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "rg_inflights_bytes": (_u64, [_vp, _i]),
     "rg_read_inflights": (_i, [_vp, _vp, _vp]),
     "rg_load_inflights": (_i, [_vp, _vp, _vp]),
@@ -473,6 +474,13 @@ class Engine:
             items = np.empty(n.value, dtype=SEND_ITEM_DTYPE)
             self._check(self.L.rg_send_items(self.h, items.ctypes.data, n.value, C.byref(n)))
         return items[:n.value]
+
+    def send_columns(self):
+        """Device pointers (prev_index u64 [P][stride], last_index u64 [P][stride], n_msgs | kind << 16 u32 [P][stride])
+        of the last DENSE stage's work items."""
+        a, b, c = _vp(), _vp(), _vp()
+        self._check(self.L.rg_send_columns(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def read_inflights(self):
         """(meta u32 [P][stride] = start | count << 16, ring u64 [G][P][cap])."""

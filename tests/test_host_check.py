@@ -366,12 +366,14 @@ def host_send():
         n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), meta.ctypes.data, head.ctypes.data,
                tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items))
         assert 0 <= n <= len(items)
-        # what rg_read_inflights does: the oldest entry of a window lives in the head column
+        # what rg_read_inflights does: the oldest and the newest entry of a window live in the head / tail columns
         G, P = st["n_groups"], st["n_slots"]
         for p in range(P):
             m = meta[p, :G]
             live = np.nonzero(m >> 16)[0]
-            ring[live, p, (m[live] & 0xffff)] = head[p, live]
+            start, count = (m[live] & 0xffff).astype(np.int64), (m[live] >> 16).astype(np.int64)
+            ring[live, p, start] = head[p, live]
+            ring[live, p, (start + count - 1) % cap] = tail[p, live]
         return items[:n]
     return send
 

@@ -288,3 +288,20 @@ def test_find_conflict_by_term_example():
     assert L.ro_log_find_conflict_by_term(cl.h, 0, 6, 2) == 1
     assert L.ro_log_find_conflict_by_term(cl.h, 0, 9, 5) == 9
     assert L.ro_log_find_conflict_by_term(cl.h, 0, 12, 5) == 12  # out of range: returned as is (:214-223)
+
+
+def test_committed_golden_files_are_what_the_extractor_produces():
+    """tests/golden/*.json are mechanical extracts of the reference's own vectors: where the reference tree is present
+    (the build container) re-extract and compare byte for byte; elsewhere (the GPU box) there is nothing to check."""
+    import importlib.util
+    if not os.path.isdir("/root/reference/src/quorum/testdata"):
+        pytest.skip("reference tree not present")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = {name: mg.extract_table(path, fn, consts) for name, path, fn, consts in mg.TABLES}
+    with open(os.path.join(HERE, "golden", "reference_tables.json"), encoding="utf-8") as f:
+        assert json.load(f) == want
+    quorum = {name: mg.parse_file(os.path.join(mg.REF, name)) for name in mg.FILES}
+    assert quorum == VEC
+    assert sum(len(v) for v in VEC.values()) == 141 and sum(len(v["rows"]) for v in want.values()) == 82

@@ -331,3 +331,45 @@ def test_skipped_send_stage_is_settled_before_the_next_tick(rg):
     assert not (eng.read_column(rg.COL.PFLAGS)[:, 1:P] & rg.PF.INS_FULL).any()
     assert int(eng.read_column(rg.COL.NEXT)[1, 0]) == 59  # nothing was sent for the skipped stage
     eng.close()
+
+
+def test_dense_stage_work_item_columns_equal_the_compact_list(rg):
+    """A stage over every group writes its work items as peer-major columns (rg_send_columns); the compact list
+    rg_send_items materialises from them holds exactly the non-empty cells. A sparse stage leaves the columns alone."""
+    import torch
+    G, P, cap = 30_000 + 7, 5, 8
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.workload_init(2)
+    cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+    flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
+
+    class Dev:
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+    for t in range(4):
+        eng.workload_gen(2, t, *[c.data_ptr() for c in cols], flags.data_ptr())
+        flags &= 0xEF  # no RG_MF_SENT: the device sends
+        eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        eng.send_appends(2 if t % 2 else 0)
+        pp, pl, pn = eng.send_columns()
+        n_cells = P * eng.stride
+        eng.sync()
+        prev = torch.as_tensor(Dev(pp, n_cells, "<i8"), device="cuda").cpu().numpy().view(np.uint64).reshape(P, -1)
+        last = torch.as_tensor(Dev(pl, n_cells, "<i8"), device="cuda").cpu().numpy().view(np.uint64).reshape(P, -1)
+        nk = torch.as_tensor(Dev(pn, n_cells, "<i4"), device="cuda").cpu().numpy().view(np.uint32).reshape(P, -1)
+        items = eng.send_items()
+        assert len(items) == int((nk[:, :G] != 0).sum()) and len(items) > 3 * G
+        g, s = items["group"].astype(np.int64), items["slot"].astype(np.int64)
+        assert (prev[s, g] == items["prev_index"]).all() and (last[s, g] == items["last_index"]).all()
+        assert ((nk[s, g] & 0xffff) == items["n_msgs"]).all() and ((nk[s, g] >> 16) == items["kind"]).all()
+        assert len(set(zip(g.tolist(), s.tolist()))) == len(items)
+    from raft_rs_amd.engine import EngineError, ERR
+    rec = np.zeros(1, dtype=rg.engine.WIRE_DTYPE)
+    rec[0] = (5, int(eng.read_column(rg.COL.MATCH)[1, 5]), 0, 0, 0, 0, 1, rg.MF.VALID, 0)
+    assert eng.ingest_tick(rec) == (1, 0)
+    eng.send_appends(0)  # a sparse stage: compact list only
+    with pytest.raises(EngineError) as e:
+        eng.send_columns()
+    assert e.value.code == ERR["STATE"]
+    eng.close()

@@ -13,11 +13,12 @@ import raft_rs_amd as rg  # noqa: E402
 G = int(os.environ.get("G", 1_000_000))
 P = int(os.environ.get("P", 5))
 K = 40
+torch.cuda.set_stream(torch.cuda.Stream())
 print(f"send stage after every tick, {G} groups x {P} peers, {K} timed ticks")
 for cap, max_entries in ((8, 0), (256, 0), (256, 4)):
     eng = rg.Engine(G, P, max_inflight=cap)
     eng.workload_init(rg.WL_MAJORITY)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)  # (an explicit stream: set below, before the loop)
     cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
     flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (K + 5))]
@@ -41,7 +42,23 @@ for cap, max_entries in ((8, 0), (256, 0), (256, 4)):
         t_send += b.elapsed_time(c)
     t_tick, t_send = t_tick / K * 1e3, t_send / K * 1e3
     full = int((torch.from_numpy(eng.read_column(rg.COL.PFLAGS)) & 0x10).ne(0).sum())
+    # The stage's own algorithmic bytes: per group out 4 + cfg 4 + last_index 8 + first_index 8 +
+    # flag row 8 r + 8 w = 40; per peer in the work set (a send request, an Inflights effect, or a broadcast): window
+    # meta 4 r + 4 w, oldest / newest inflight 16 r + 16 w, next 8 r + 8 w, pending snapshot request 8 r, matched 8 r
+    # = 72; work items as peer-major columns: the n | kind cell of every peer (4 B) + prev / last index of every item
+    # (16 B). Ring words are not counted (windows of <= 2 never touch the ring).
+    import numpy as np
+    _, out = eng.results()
+    cfg = eng.read_column(rg.COL.CFG)
+    present, self_slot = (cfg >> 24) & 0xff, (cfg >> 16) & 7
+    bcast = (out & 0x9) != 0  # CHANGED (should_bcast_commit: skip_bcast_commit is off here) or APPENDED
+    work = ((out >> 8) | (out >> 16) | (out >> 24)) & 0xff
+    work = np.where(bcast, work | present, work) & present & ~(1 << self_slot)
+    n_work = int(sum(((work >> p) & 1).sum() for p in range(8)))
+    nbytes = 40 * G + 72 * n_work + 4 * P * G + 16 * items  # work items as columns: a 4-B cell per peer + 16 B per item
+    gbs = nbytes / (t_send * 1e-6) / 1e9
     print(f"  cap {cap:3d} max_entries {max_entries}: tick {t_tick:7.1f} us  send stage {t_send:7.1f} us  "
           f"-> {G / (t_tick + t_send):7.1f} M group-evals/s incl. sends; {items} work items in the last stage, "
-          f"{full} full windows")
+          f"{full} full windows; stage byte model {nbytes / 1e6:.0f} MB ({nbytes / G:.0f} B/group) -> {gbs:.0f} GB/s = "
+          f"{gbs / 8000:.3f} of 8 TB/s")
     eng.close()
