@@ -153,7 +153,7 @@ def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / steps
         nbytes = (8 * n_slots + 37) * n_groups  # B0(P) = 8 P + 37
-        kernel = "k_recompute2 (two groups per lane)" if variant != 1 else "k_recompute (one group per lane)"
+        kernel = "k_recompute"
     else:
         T = warmup + steps
         cols = [torch.empty((T, n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
@@ -479,7 +479,7 @@ def main():
                        "rollover": "every tick 1/32 of the groups elects a new leader (RG_MF_BECOME_LEADER = Raft::reset + "
                                    "become_leader): ~10% of the groups are between election and the first commit of the new "
                                    "term at any time"} if args.workload == 5 else {}),
-                   "kernel_variant": {0: "lane", 1: "lane", 2: "lds"}[args.variant],
+                   "kernel_variant": {0: "lane", 1: "lane", 2: "lds", 4: "lds-dma"}[args.variant],
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
                    "device": {k: v for k, v in parts[0].eng.device_info().items() if k != "engine_bytes"},
                    "engine_hbm_bytes": sum(pt.eng.device_info()["engine_bytes"] for pt in parts),
@@ -492,7 +492,7 @@ def main():
                    "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": ("k_tick_lane" if args.variant != 2 else "k_tick_lds") +
+                     "kernel": ("k_tick_lane" if args.variant not in (2, 4) else "k_tick_lds") +
                                (" + k_send_appends" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6,
@@ -513,8 +513,6 @@ def main():
         # the literal BASELINE metric ("commit-index recomputes/sec"): Raft::maybe_commit for every group, no messages
         result["recompute_only"] = side_measurement(rg, torch, G, P, args.workload if args.workload != 5 else 2,
                                                     5, 50, args.seed, "recompute")
-        result["recompute_only"]["one_group_per_lane_us"] = side_measurement(
-            rg, torch, G, P, args.workload if args.workload != 5 else 2, 5, 50, args.seed, "recompute", variant=1)["us_per_launch"]
         # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
         result["out_of_cache"] = side_measurement(rg, torch, args.out_of_cache_groups, P, args.workload if args.workload != 5 else 2,
                                                   3, 12, args.seed, "tick")

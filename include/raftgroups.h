@@ -170,6 +170,8 @@ typedef struct {
 #define RG_VARIANT_DEFAULT 0u
 #define RG_VARIANT_LANE 1u /* one lane per group, columns straight into registers */
 #define RG_VARIANT_LDS 2u  /* one wave per 128-group batch, peer columns staged through LDS */
+#define RG_VARIANT_LDS_DMA 4u /* RG_VARIANT_LDS with the stage-in done by gfx950's LDS-DMA (global_load_lds_dwordx4: global
+                                 memory -> LDS without passing through VGPRs). A measured comparison point, like LDS. */
 #define RG_VARIANT_COOP 3u /* rg_recompute / rg_maximal_committed_index only: 8 lanes per group, one peer per lane,
                               wave-level rank-select of the quorum index with cross-lane shuffles (ticks run the
                               lane kernel). A measured comparison point, not the default. */

@@ -107,11 +107,12 @@ __global__ __launch_bounds__(RG_BLOCK) void k_recompute(RgState st, u64 *mci_out
     }
 }
 
-// Two groups per lane: every column access of a lane is one 16-B load (a wave moves 1 KiB per instruction and half as
-// many waves are in flight for the same bytes), which is what a 16-us sweep needs: at 1 M groups the launch ramp and
-// tail of 15 625 single-group waves weigh as much as the streaming itself (profiles/r02_recompute.txt).
+// Two groups per lane: every column access of a lane is one 16-B load (a wave moves 1 KiB per instruction, half as many
+// waves for the same bytes). Measured (profiles/r02_recompute.txt): 12.0 us against 11.2 us for one group per lane once
+// the group-commit routine -- and the scratch its out-of-line call forced on EVERY wave -- was compiled out of the
+// common kernel (that, not the access width, was what held the sweep at 16.7 us). Kept as a build-time variant.
 #ifndef RG_RECOMPUTE_X2
-#define RG_RECOMPUTE_X2 1
+#define RG_RECOMPUTE_X2 0
 #endif
 typedef u64 rg_u64x2 __attribute__((ext_vector_type(2)));
 typedef u32 rg_u32x2 __attribute__((ext_vector_type(2)));
@@ -877,7 +878,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: n_groups=%llu n_slots=%u out of range",
                        (unsigned long long)cfg->n_groups, cfg->n_slots);
-    if (cfg->variant > RG_VARIANT_COOP) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
+    if (cfg->variant > RG_VARIANT_LDS_DMA) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return rg_fail(RG_ERR_NO_DEVICE, "rg_create: no HIP device visible (this engine has no CPU fallback)");
@@ -1250,7 +1251,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     if (src) return src;
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
-    const u32 variant = h->cfg.variant == RG_VARIANT_LDS ? RG_VARIANT_LDS : RG_VARIANT_LANE;
+    const u32 variant = (h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA) ? h->cfg.variant : RG_VARIANT_LANE;
     switch (h->P) {
     case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
     case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;

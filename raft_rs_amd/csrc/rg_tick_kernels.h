@@ -200,7 +200,12 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st
 #define RG_LDS_WAVES 1
 #define RG_LDS_BATCH 128
 
-template <int P, bool GC>
+// DMA = true (RG_VARIANT_LDS_DMA): the stage-in uses gfx950's LDS-DMA -- global_load_lds_dwordx4, 16 B per lane
+// straight from global memory into LDS (destination = wave-uniform base + lane x 16 B, exactly this layout) without
+// passing through VGPRs. Bytes in flight are then bounded by LDS, not registers: 5 P x 128 x 8 B = 25.6 KB per wave at
+// P = 5, i.e. 6 waves per CU (160 KB) = 154 KB in flight per CU -- against ~254 KB for the lane kernel, whose 16 waves
+// per CU each hold 31 x 512 B of loads in VGPRs. The trial is kept as a measured variant (profiles/r02_lds_dma.txt).
+template <int P, bool GC, bool DMA>
 __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMsgs ms) {
     __shared__ u64 lds[RG_LDS_WAVES][5][P][RG_LDS_BATCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -211,18 +216,30 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     u64(*L)[P][RG_LDS_BATCH] = lds[wave];
     const u64 *cols[5] = {st.match, st.next, st.prc, ms.mi, ms.mc};
-    // stage in: 5*P coalesced 16-B loads per lane, all issued before the first LDS write
-    u64x2 tmp[5][P];
+    if (DMA) {
+        // stage in: 5*P LDS-DMA pieces of 1 KiB per wave, no VGPR in between
 #pragma unroll
-    for (int c = 0; c < 5; c++)
+        for (int c = 0; c < 5; c++)
 #pragma unroll
-        for (int p = 0; p < P; p++)
-            tmp[c][p] = *reinterpret_cast<const u64x2 *>(cols[c] + (u64)p * st.stride + b0 + 2 * lane);
+            for (int p = 0; p < P; p++)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(cols[c] + (u64)p * st.stride + b0 + 2 * lane),
+                    (__attribute__((address_space(3))) void *)&L[c][p][0], 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // an LDS-DMA is a pending LDS write on the VM counter
+    } else {
+        // stage in: 5*P coalesced 16-B loads per lane, all issued before the first LDS write
+        u64x2 tmp[5][P];
 #pragma unroll
-    for (int c = 0; c < 5; c++)
+        for (int c = 0; c < 5; c++)
 #pragma unroll
-        for (int p = 0; p < P; p++)
-            *reinterpret_cast<u64x2 *>(&L[c][p][2 * lane]) = tmp[c][p];
+            for (int p = 0; p < P; p++)
+                tmp[c][p] = *reinterpret_cast<const u64x2 *>(cols[c] + (u64)p * st.stride + b0 + 2 * lane);
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+#pragma unroll
+            for (int p = 0; p < P; p++)
+                *reinterpret_cast<u64x2 *>(&L[c][p][2 * lane]) = tmp[c][p];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -294,7 +311,10 @@ template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &
 #ifdef RG_TICK_INSTANTIATE
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
     if (variant == RG_VARIANT_LDS) {
-        hipLaunchKernelGGL((k_tick_lds<P, GC>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
+        hipLaunchKernelGGL((k_tick_lds<P, GC, false>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
+                           dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
+    } else if (variant == RG_VARIANT_LDS_DMA) {
+        hipLaunchKernelGGL((k_tick_lds<P, GC, true>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
     } else {
         hipLaunchKernelGGL((k_tick_lane<P, GC>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);

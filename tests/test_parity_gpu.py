@@ -30,7 +30,7 @@ def assert_same(eng, cl, st_ref, gout_ref, what):
                            f"{[hex(x) for x in got['out'][bad[:5]]]} oracle {[hex(x) for x in gout_ref[bad[:5]]]}")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (3, 5), (5, 7), (2, 7)])
 def test_workload_stream_matches_oracle(rg, variant, workload, n_slots):
     G, ticks = 20000 + 77, 6
@@ -80,7 +80,7 @@ def test_device_generator_equals_host_generator(rg):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("n_slots", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_streams_match_oracle(rg, variant, n_slots):
     rng = np.random.default_rng(1000 + n_slots)
