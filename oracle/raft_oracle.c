@@ -183,7 +183,9 @@ int ro_progress_update_state(ro_progress *p, uint64_t last) { /* :231-243 */
     switch (p->state) {
     case RO_REPLICATE:
         p->next_idx = last + 1; /* optimistic_update :161 */
-        if (p->ins.cap && !ro_ins_full(&p->ins)) ro_ins_add(&p->ins, last);
+        /* self.ins.add(last): panics on a full window (inflights.rs:66-68) -- reported, like every panic of this
+         * restatement, as -1. (cap == 0: a Progress whose Inflights the caller does not model.) */
+        if (p->ins.cap && ro_ins_add(&p->ins, last) != 0) return -1;
         return 0;
     case RO_PROBE:
         p->paused = true;

@@ -341,11 +341,21 @@ __global__ __launch_bounds__(RG_BLOCK) void k_resolve_hints_list(RgState st, RgM
 // decodes record t and scatters its fields to the peer-major message columns. The event byte of the
 // cell is claimed with a CAS on its 32-bit word; a second record for the same cell is dropped and
 // counted. The first record that touches a group appends it to the tick list.
+struct RgClear { // housekeeping the ingest kernel does on the side, so the small-batch flush needs no extra command:
+    const u64 *list; // result words of the PREVIOUS sparse tick to zero first (n of them, through `out`)
+    u32 *out;
+    u32 n;
+    u32 *zero_ctr;   // the counter pair the NEXT sparse tick will use (the two pairs alternate): reset it
+};
+
 __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(const rg_wire_msg *rec, u64 n, u64 G, u64 stride, u32 P,
                                                             u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u64 *mlt,
                                                             u32 *mflags32, u32 *gmark, u32 epoch, u64 *list,
-                                                            u32 *counters) {
+                                                            u32 *counters, RgClear clr) {
     __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
+    for (u32 k = blockIdx.x * RG_INGEST_BLOCK + threadIdx.x; k < clr.n; k += gridDim.x * RG_INGEST_BLOCK)
+        clr.out[clr.list[k]] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2) clr.zero_ctr[threadIdx.x] = 0;
     const u64 base = (u64)blockIdx.x * RG_INGEST_BLOCK;
     const u32 nrec = (u32)((n - base) < RG_INGEST_BLOCK ? (n - base) : RG_INGEST_BLOCK);
     const uint4 *src = reinterpret_cast<const uint4 *>(rec + base);
@@ -391,6 +401,7 @@ struct rg_res_rec {
 };
 #define RG_PACKED_HDR 16
 #define RG_ROUNDTRIP_MAX 16384 /* records: above this the three-call sequence wins (measured crossover ~20 k) */
+#define RG_ZEROCOPY_MAX 1024   /* groups: up to here the kernels read / write pinned host memory directly */
 
 __global__ void k_gather_results(const u64 *list, const u32 *n_ptr, const u64 *commit, const u32 *out, u64 *rl, u64 *rc,
                                  u32 *ro, char *packed) {
@@ -731,7 +742,7 @@ struct rg_engine {
     u64 tick_launches; // ticks enqueued so far (rg_flush: did a failed flush already change device state?)
     // sparse path (rg_ingest / rg_tick_ingested)
     char *sparse_arena;       // gmark | list | res_list | res_commit | res_out | counters
-    u32 *gmark, *counters, *res_out;
+    u32 *gmark, *counters, *counters_base, *res_out;
     u64 *list, *res_list, *res_commit;
     // single-sync flush of the host mirror: pinned staging for the records, one packed D2H copy of the results
     rg_wire_msg *pin_records; // hipHostMalloc
@@ -1385,6 +1396,11 @@ extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
     return RG_OK;
 }
 
+// Two {touched groups, dropped records} counter pairs take turns: a sparse tick uses one, the ingest kernel of the same
+// window resets the other for the tick after it, rg_ctr_flip switches -- no memset command per tick.
+static u32 *rg_ctr_other(rg_engine *h) { return h->counters == h->counters_base ? h->counters_base + 2 : h->counters_base; }
+static void rg_ctr_flip(rg_engine *h) { h->counters = rg_ctr_other(h); }
+
 static int rg_ensure_sparse(rg_engine *h) {
     if (h->sparse_arena) return RG_OK;
     int rc = rg_ensure_msg_arena(h);
@@ -1399,7 +1415,8 @@ static int rg_ensure_sparse(rg_engine *h) {
     h->res_list = (u64 *)(h->sparse_arena + o_rl);
     h->res_commit = (u64 *)(h->sparse_arena + o_rc);
     h->res_out = (u32 *)(h->sparse_arena + o_ro);
-    h->counters = (u32 *)(h->sparse_arena + o_cnt);
+    h->counters_base = (u32 *)(h->sparse_arena + o_cnt);
+    h->counters = h->counters_base;
     return RG_OK;
 }
 
@@ -1427,7 +1444,7 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
                        h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
                        (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
-                       h->counters);
+                       h->counters, RgClear{nullptr, nullptr, 0u, rg_ctr_other(h)});
     u32 dup = 0;
     RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // the caller's record array may be reused after return
@@ -1445,7 +1462,7 @@ extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, ui
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, dev_records, (u64)n,
                        h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
                        (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
-                       h->counters);
+                       h->counters, RgClear{nullptr, nullptr, 0u, rg_ctr_other(h)});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_ingest_device: %s", hipGetErrorString(e));
     h->ingested_upper += n;
@@ -1466,11 +1483,13 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
 
 // Everything of a sparse tick that needs no host round trip: clear the previous results, resolve hints, tick the
 // listed groups, gather their results (also into `packed` when given). `upper` bounds the list length.
-static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm) {
+static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm, bool out_cleared = false) {
     int src = rg_settle_send(h); // (walks the PREVIOUS tick's result list, before it is cleared below)
     if (src) return src;
     // RG_COL_OUT must hold zeros for every group this tick does not touch
-    if (h->out_is_dense) {
+    if (out_cleared) {
+        // (the ingest kernel of this flush has done it)
+    } else if (h->out_is_dense) {
         RG_HIP(hipMemsetAsync(h->st.out, 0, h->stride * 4, h->stream));
     } else if (h->last_sparse_n) {
         hipLaunchKernelGGL(k_clear_out, dim3(rg_grid(h->last_sparse_n, 256)), dim3(256), 0, h->stream, h->res_list,
@@ -1535,8 +1554,8 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     u32 n = 0;
     if (upper) {
         RG_HIP(hipMemcpyAsync(&n, h->counters, 4, hipMemcpyDeviceToHost, h->stream));
-        RG_HIP(hipMemsetAsync(h->counters, 0, 8, h->stream)); // group count and duplicate count of the window
         RG_HIP(hipStreamSynchronize(h->stream));
+        rg_ctr_flip(h); // (the next window's pair was reset by this window's ingest kernels)
     }
     rc = rg_sparse_finish(h, n);
     if (rc) return rc;
@@ -2201,15 +2220,34 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
                              hipHostMallocDefault));
         h->packed_cap = cap;
     }
+    // Small batches are latency-bound: every HIP call costs the host 3-5 us. The kernels then read the records straight
+    // out of the pinned staging buffer and write the packed results straight into pinned host memory (both are mapped into
+    // the device's address space; a few KB over PCIe inside a kernel cost less than a copy command each way), and the
+    // ingest kernel also zeroes the previous sparse tick's result words: ingest + tick + counter reset + ONE
+    // synchronisation instead of copy, ingest, clear, tick, copy, reset, synchronisation.
+    const bool zero_copy = n && upper <= RG_ZEROCOPY_MAX;
+    bool out_cleared = false;
     if (n) {
-        RG_HIP(hipMemcpyAsync(h->d_records, h->pin_records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
+        RgClear clr = {nullptr, nullptr, 0u, rg_ctr_other(h)};
+        // (with device Inflights and an unconsumed send stage the previous result words are still needed: rg_settle_send)
+        if (zero_copy && !h->out_is_dense && !(h->ins_arena && h->send_ready)) {
+            clr.list = h->res_list;
+            clr.out = h->st.out;
+            clr.n = (u32)h->last_sparse_n;
+            out_cleared = true;
+        }
+        const rg_wire_msg *src = h->pin_records;
+        if (!zero_copy) {
+            RG_HIP(hipMemcpyAsync(h->d_records, h->pin_records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
+            src = h->d_records;
+        }
+        hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, src, (u64)n,
                            h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
                            (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
-                           h->counters);
+                           h->counters, clr);
     }
     // (records ingested on the device in this window may carry log terms the host has not seen)
-    rc = rg_sparse_enqueue(h, upper, h->d_packed, any_logterm || h->ingested_upper != 0);
+    rc = rg_sparse_enqueue(h, upper, zero_copy ? h->pin_packed : h->d_packed, any_logterm || h->ingested_upper != 0, out_cleared);
     if (rc) return rc;
     // the send stage rides along: it walks the gathered list, whose length is still only on the device
     const u64 item_bound = upper * h->P;
@@ -2228,10 +2266,11 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     }
     u32 n_groups = 0, dup = 0;
     if (upper) {
-        RG_HIP(hipMemcpyAsync(h->pin_packed, h->d_packed, RG_PACKED_HDR + upper * sizeof(rg_res_rec), hipMemcpyDeviceToHost,
-                              h->stream));
-        RG_HIP(hipMemsetAsync(h->counters, 0, 8, h->stream));
+        if (!zero_copy)
+            RG_HIP(hipMemcpyAsync(h->pin_packed, h->d_packed, RG_PACKED_HDR + upper * sizeof(rg_res_rec), hipMemcpyDeviceToHost,
+                                  h->stream));
         RG_HIP(hipStreamSynchronize(h->stream));
+        rg_ctr_flip(h); // (the next window's pair was reset by this window's ingest kernel)
         n_groups = reinterpret_cast<const u32 *>(h->pin_packed)[0];
         dup = reinterpret_cast<const u32 *>(h->pin_packed)[1];
     }

@@ -305,3 +305,18 @@ def test_committed_golden_files_are_what_the_extractor_produces():
     quorum = {name: mg.parse_file(os.path.join(mg.REF, name)) for name in mg.FILES}
     assert quorum == VEC
     assert sum(len(v) for v in VEC.values()) == 141 and sum(len(v["rows"]) for v in want.values()) == 82
+
+
+def test_update_state_on_a_full_window_panics_like_the_reference():
+    """Progress::update_state in Replicate calls ins.add(last) (progress.rs:231-243), which panics on a full window
+    ("cannot add into a full inflights", inflights.rs:66-68): the restatement reports it instead of skipping the add."""
+    import ctypes as C
+    L = O.lib()
+    p = O.Progress()
+    L.ro_progress_new(C.byref(p), 1, 2)
+    L.ro_progress_become_replicate(C.byref(p))
+    assert L.ro_progress_update_state(C.byref(p), 5) == 0 and L.ro_progress_update_state(C.byref(p), 6) == 0
+    assert L.ro_ins_full(C.byref(p.ins))
+    assert L.ro_progress_update_state(C.byref(p), 7) == -1 and p.next_idx == 8, "the optimistic next is applied first"
+    assert L.ro_ins_add(C.byref(p.ins), 9) == -1
+    L.ro_progress_destroy(C.byref(p))

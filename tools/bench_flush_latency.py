@@ -28,7 +28,7 @@ for g in range(G):
 print(f"rg_set_peers x {G}: {time.perf_counter()-t0:.2f} s")
 rng = np.random.default_rng(5)
 print("k groups touched: median latency of k x rg_step + rg_flush + rg_ingested_results (host wall clock)")
-for k in (1, 10, 100, 1000, 10000):
+for k in (1, 10, 100, 1000, 4000, 10000):
     lat_step, lat_flush, lat_res = [], [], []
     for rep in range(30):
         groups = rng.choice(G, size=k, replace=False)
