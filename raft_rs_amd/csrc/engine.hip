@@ -336,62 +336,11 @@ __global__ __launch_bounds__(RG_BLOCK) void k_resolve_hints_list(RgState st, RgM
 // ------------------------------------------------------------------------------------------------
 // kernels: ingest (wire-order AoS records -> the slot matrix) and helpers of the sparse path
 // ------------------------------------------------------------------------------------------------
-#define RG_INGEST_BLOCK 256
-// A workgroup stages 256 records (16 KiB) through LDS with fully coalesced 16-B loads, then lane t
-// decodes record t and scatters its fields to the peer-major message columns. The event byte of the
-// cell is claimed with a CAS on its 32-bit word; a second record for the same cell is dropped and
-// counted. The first record that touches a group appends it to the tick list.
-struct RgClear { // housekeeping the ingest kernel does on the side, so the small-batch flush needs no extra command:
-    const u64 *list; // result words of the PREVIOUS sparse tick to zero first (n of them, through `out`)
-    u32 *out;
-    u32 n;
-    u32 *zero_ctr;   // the counter pair the NEXT sparse tick will use (the two pairs alternate): reset it
-};
-
-__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(const rg_wire_msg *rec, u64 n, u64 G, u64 stride, u32 P,
-                                                            u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u64 *mlt,
-                                                            u32 *mflags32, u32 *gmark, u32 epoch, u64 *list,
-                                                            u32 *counters, RgClear clr) {
+// (the ingest arithmetic itself, rg_ingest_block, lives in rg_tick_kernels.h: the one-launch small-batch flush uses it too)
+__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_ingest(RgIngest a) {
     __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
-    for (u32 k = blockIdx.x * RG_INGEST_BLOCK + threadIdx.x; k < clr.n; k += gridDim.x * RG_INGEST_BLOCK)
-        clr.out[clr.list[k]] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < 2) clr.zero_ctr[threadIdx.x] = 0;
-    const u64 base = (u64)blockIdx.x * RG_INGEST_BLOCK;
-    const u32 nrec = (u32)((n - base) < RG_INGEST_BLOCK ? (n - base) : RG_INGEST_BLOCK);
-    const uint4 *src = reinterpret_cast<const uint4 *>(rec + base);
-    for (u32 k = threadIdx.x; k < 4 * nrec; k += RG_INGEST_BLOCK) stage[k] = src[k];
-    __syncthreads();
-    const u32 t = threadIdx.x;
-    if (t >= nrec) return;
-    // record t occupies 4 x 16 B of the staged block
-    const uint4 a = stage[4 * t], b = stage[4 * t + 1], c = stage[4 * t + 2], d = stage[4 * t + 3];
-    const u64 group = (u64)a.x | ((u64)a.y << 32), index = (u64)a.z | ((u64)a.w << 32);
-    const u64 commit = (u64)b.x | ((u64)b.y << 32), hint = (u64)b.z | ((u64)b.w << 32);
-    const u64 rs = (u64)c.x | ((u64)c.y << 32), log_term = (u64)c.z | ((u64)c.w << 32);
-    const u32 slot = d.x, flags = d.y & 0xffu;
-    if (group >= G || slot >= P || flags == 0) { // malformed record: counted with the duplicates
-        atomicAdd(&counters[1], 1u);
-        return;
-    }
-    u32 *word = mflags32 + group * 2 + (slot >> 2);
-    const u32 shift = 8u * (slot & 3u);
-    u32 old = *word;
-    for (;;) {
-        if ((old >> shift) & 0xffu) { // the cell already holds an event of this tick
-            atomicAdd(&counters[1], 1u);
-            return;
-        }
-        const u32 seen = atomicCAS(word, old, old | (flags << shift));
-        if (seen == old) break;
-        old = seen;
-    }
-    const u64 o = (u64)slot * stride + group;
-    mi[o] = index;
-    mc[o] = commit;
-    if (flags & RG_MF_REJECT) mh[o] = hint;
-    if (flags & RG_MF_HAS_RS) mrs[o] = rs;
-    if (flags & RG_MF_HAS_LOGTERM) mlt[o] = log_term;
-    if (atomicExch(&gmark[group], epoch) != epoch) list[atomicAdd(&counters[0], 1u)] = group;
+    rg_ingest_housekeeping(a.clr);
+    rg_ingest_block(a, stage);
 }
 
 // 24-byte result record of the single-copy flush path (header: u32 n_groups, u32 n_duplicates, 8 B pad)
@@ -1396,6 +1345,27 @@ extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
     return RG_OK;
 }
 
+static RgIngest rg_ingest_args(rg_engine *h, const rg_wire_msg *rec, u64 n, const RgClear &clr) {
+    RgIngest a;
+    a.rec = rec;
+    a.n = n;
+    a.G = h->G;
+    a.stride = h->stride;
+    a.P = h->P;
+    a.mi = (u64 *)h->staged.mi;
+    a.mc = (u64 *)h->staged.mc;
+    a.mh = (u64 *)h->staged.mh;
+    a.mrs = (u64 *)h->staged.mrs;
+    a.mlt = (u64 *)h->staged.mlt;
+    a.mflags32 = (u32 *)h->staged.mflags;
+    a.gmark = h->gmark;
+    a.epoch = h->epoch;
+    a.list = h->list;
+    a.counters = h->counters;
+    a.clr = clr;
+    return a;
+}
+
 // Two {touched groups, dropped records} counter pairs take turns: a sparse tick uses one, the ingest kernel of the same
 // window resets the other for the tick after it, rg_ctr_flip switches -- no memset command per tick.
 static u32 *rg_ctr_other(rg_engine *h) { return h->counters == h->counters_base ? h->counters_base + 2 : h->counters_base; }
@@ -1441,10 +1411,8 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     u32 dup0 = 0; // duplicates so far in this tick window (device ingests included)
     RG_HIP(hipMemcpyAsync(&dup0, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipMemcpyAsync(h->d_records, records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, h->d_records, (u64)n,
-                       h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
-                       (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
-                       h->counters, RgClear{nullptr, nullptr, 0u, rg_ctr_other(h)});
+    hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream,
+                       rg_ingest_args(h, h->d_records, n, RgClear{nullptr, nullptr, 0u, rg_ctr_other(h)}));
     u32 dup = 0;
     RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // the caller's record array may be reused after return
@@ -1459,10 +1427,8 @@ extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, ui
     RG_HIP(hipSetDevice(h->cfg.device));
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, dev_records, (u64)n,
-                       h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
-                       (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
-                       h->counters, RgClear{nullptr, nullptr, 0u, rg_ctr_other(h)});
+    hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream,
+                       rg_ingest_args(h, dev_records, n, RgClear{nullptr, nullptr, 0u, rg_ctr_other(h)}));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_ingest_device: %s", hipGetErrorString(e));
     h->ingested_upper += n;
@@ -1483,7 +1449,8 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
 
 // Everything of a sparse tick that needs no host round trip: clear the previous results, resolve hints, tick the
 // listed groups, gather their results (also into `packed` when given). `upper` bounds the list length.
-static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm, bool out_cleared = false) {
+static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm, bool out_cleared = false,
+                             const RgIngest *one_launch = nullptr) {
     int src = rg_settle_send(h); // (walks the PREVIOUS tick's result list, before it is cleared below)
     if (src) return src;
     // RG_COL_OUT must hold zeros for every group this tick does not touch
@@ -1501,17 +1468,34 @@ static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_log
     if (!upper) return RG_OK;
     RgMsgs ms = h->staged;
     ms.mhr = ms.mh;
-    if (any_logterm) { // records may carry log terms: resolve the touched groups' flagged hints first
-        ms.mhr = h->rhint;
-        hipLaunchKernelGGL(k_resolve_hints_list, dim3(rg_grid(upper, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms,
-                           h->P, h->rhint, (const u64 *)h->list, (const u32 *)h->counters);
-    }
     u64 *mf = (u64 *)h->staged.mflags;
     RgListOut lo; // the tick gathers its own results (one launch less than a separate gather kernel)
     lo.rl = h->res_list;
     lo.rc = h->res_commit;
     lo.ro = h->res_out;
     lo.packed = packed;
+    if (one_launch) { // <= 256 records: ingest, hint resolution, tick and results in ONE single-workgroup launch
+        if (any_logterm) ms.mhr = h->rhint;
+        switch (h->P) {
+        case 1: rg_launch_flush_small_t<1>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        case 2: rg_launch_flush_small_t<2>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        case 3: rg_launch_flush_small_t<3>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        case 4: rg_launch_flush_small_t<4>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        case 5: rg_launch_flush_small_t<5>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        case 6: rg_launch_flush_small_t<6>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        case 7: rg_launch_flush_small_t<7>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        default: rg_launch_flush_small_t<8>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo); break;
+        }
+        hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "sparse tick: launch failed: %s", hipGetErrorString(e1));
+        h->tick_launches++;
+        return RG_OK;
+    }
+    if (any_logterm) { // records may carry log terms: resolve the touched groups' flagged hints first
+        ms.mhr = h->rhint;
+        hipLaunchKernelGGL(k_resolve_hints_list, dim3(rg_grid(upper, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms,
+                           h->P, h->rhint, (const u64 *)h->list, (const u32 *)h->counters);
+    }
     switch (h->P) {
     case 1: rg_launch_tick_list_t<1>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
     case 2: rg_launch_tick_list_t<2>(h->stream, h->st, ms, h->any_group_commit, h->list, h->counters, upper, mf, lo); break;
@@ -2226,8 +2210,20 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     // ingest kernel also zeroes the previous sparse tick's result words: ingest + tick + counter reset + ONE
     // synchronisation instead of copy, ingest, clear, tick, copy, reset, synchronisation.
     const bool zero_copy = n && upper <= RG_ZEROCOPY_MAX;
+    // ... and up to one workgroup's worth of records the whole flush is ONE launch (k_flush_small)
+    const bool one_launch = zero_copy && n <= RG_INGEST_BLOCK && !(h->ins_arena && h->send_ready);
     bool out_cleared = false;
-    if (n) {
+    RgIngest fused_args;
+    if (one_launch) {
+        RgClear clr = {nullptr, nullptr, 0u, rg_ctr_other(h)};
+        if (!h->out_is_dense) {
+            clr.list = h->res_list;
+            clr.out = h->st.out;
+            clr.n = (u32)h->last_sparse_n;
+            out_cleared = true;
+        }
+        fused_args = rg_ingest_args(h, h->pin_records, n, clr);
+    } else if (n) {
         RgClear clr = {nullptr, nullptr, 0u, rg_ctr_other(h)};
         // (with device Inflights and an unconsumed send stage the previous result words are still needed: rg_settle_send)
         if (zero_copy && !h->out_is_dense && !(h->ins_arena && h->send_ready)) {
@@ -2241,13 +2237,12 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
             RG_HIP(hipMemcpyAsync(h->d_records, h->pin_records, n * sizeof(rg_wire_msg), hipMemcpyHostToDevice, h->stream));
             src = h->d_records;
         }
-        hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream, src, (u64)n,
-                           h->G, h->stride, h->P, (u64 *)h->staged.mi, (u64 *)h->staged.mc, (u64 *)h->staged.mh,
-                           (u64 *)h->staged.mrs, (u64 *)h->staged.mlt, (u32 *)h->staged.mflags, h->gmark, h->epoch, h->list,
-                           h->counters, clr);
+        hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream,
+                           rg_ingest_args(h, src, n, clr));
     }
     // (records ingested on the device in this window may carry log terms the host has not seen)
-    rc = rg_sparse_enqueue(h, upper, zero_copy ? h->pin_packed : h->d_packed, any_logterm || h->ingested_upper != 0, out_cleared);
+    rc = rg_sparse_enqueue(h, upper, zero_copy ? h->pin_packed : h->d_packed, any_logterm || h->ingested_upper != 0, out_cleared,
+                           one_launch ? &fused_args : nullptr);
     if (rc) return rc;
     // the send stage rides along: it walks the gathered list, whose length is still only on the device
     const u64 item_bound = upper * h->P;

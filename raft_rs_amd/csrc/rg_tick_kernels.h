@@ -111,16 +111,9 @@ struct RgListOut {
     char *packed; // nullable: u32 n, u32 n_duplicates, 8 B pad, then {u64 group, u64 commit, u32 out, u32 pad}[n]
 };
 
+// entry i of the tick list: group g
 template <int P, bool GC>
-__global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw,
-                                           RgListOut lo) {
-    const u64 i = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (lo.packed && i == 0) {
-        reinterpret_cast<u32 *>(lo.packed)[0] = n_ptr[0];
-        reinterpret_cast<u32 *>(lo.packed)[1] = n_ptr[1];
-    }
-    if (i >= *n_ptr) return;
-    const u64 g = list[i];
+RG_D void rg_tick_listed(const RgState &st, const RgMsgs &ms, u64 g, u64 i, u64 *mflags_rw, const RgListOut &lo) {
     RgGroup<P> r;
     rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
     rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
@@ -135,6 +128,115 @@ __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *lis
         rec[1] = r.commit;
         rec[2] = (u64)r.out;
     }
+}
+
+template <int P, bool GC>
+__global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw,
+                                           RgListOut lo) {
+    const u64 i = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (lo.packed && i == 0) {
+        reinterpret_cast<u32 *>(lo.packed)[0] = n_ptr[0];
+        reinterpret_cast<u32 *>(lo.packed)[1] = n_ptr[1];
+    }
+    if (i >= *n_ptr) return;
+    rg_tick_listed<P, GC>(st, ms, list[i], i, mflags_rw, lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest: wire-order AoS records -> the slot matrix (the sparse path's first step)
+// ------------------------------------------------------------------------------------------------
+#define RG_INGEST_BLOCK 256
+struct RgClear { // housekeeping the ingest kernel does on the side, so the small-batch flush needs no extra command:
+    const u64 *list; // result words of the PREVIOUS sparse tick to zero first (n of them, through `out`)
+    u32 *out;
+    u32 n;
+    u32 *zero_ctr;   // the counter pair the NEXT sparse tick will use (the two pairs alternate): reset it
+};
+struct RgIngest {
+    const rg_wire_msg *rec;
+    u64 n, G, stride;
+    u32 P;
+    u64 *mi, *mc, *mh, *mrs, *mlt; // the engine-owned message columns
+    u32 *mflags32;
+    u32 *gmark;
+    u32 epoch;
+    u64 *list;
+    u32 *counters; // [0] groups touched so far in this window, [1] records dropped
+    RgClear clr;
+};
+
+RG_D void rg_ingest_housekeeping(const RgClear &clr) {
+    for (u32 k = blockIdx.x * RG_INGEST_BLOCK + threadIdx.x; k < clr.n; k += gridDim.x * RG_INGEST_BLOCK)
+        clr.out[clr.list[k]] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2) clr.zero_ctr[threadIdx.x] = 0;
+}
+
+// A workgroup stages 256 records (16 KiB) through LDS with fully coalesced 16-B loads, then lane t
+// decodes record t and scatters its fields to the peer-major message columns. The event byte of the
+// cell is claimed with a CAS on its 32-bit word; a second record for the same cell is dropped and
+// counted. The first record that touches a group appends it to the tick list.
+RG_D void rg_ingest_block(const RgIngest &a, uint4 *stage) {
+    const u64 base = (u64)blockIdx.x * RG_INGEST_BLOCK;
+    const u32 nrec = base >= a.n ? 0u : (u32)((a.n - base) < RG_INGEST_BLOCK ? (a.n - base) : RG_INGEST_BLOCK);
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.rec + base);
+    for (u32 k = threadIdx.x; k < 4 * nrec; k += RG_INGEST_BLOCK) stage[k] = src[k];
+    __syncthreads();
+    const u32 t = threadIdx.x;
+    if (t >= nrec) return;
+    // record t occupies 4 x 16 B of the staged block
+    const uint4 ra = stage[4 * t], rb = stage[4 * t + 1], rc = stage[4 * t + 2], rd = stage[4 * t + 3];
+    const u64 group = (u64)ra.x | ((u64)ra.y << 32), index = (u64)ra.z | ((u64)ra.w << 32);
+    const u64 commit = (u64)rb.x | ((u64)rb.y << 32), hint = (u64)rb.z | ((u64)rb.w << 32);
+    const u64 rs = (u64)rc.x | ((u64)rc.y << 32), log_term = (u64)rc.z | ((u64)rc.w << 32);
+    const u32 slot = rd.x, flags = rd.y & 0xffu;
+    if (group >= a.G || slot >= a.P || flags == 0) { // malformed record: counted with the duplicates
+        atomicAdd(&a.counters[1], 1u);
+        return;
+    }
+    u32 *word = a.mflags32 + group * 2 + (slot >> 2);
+    const u32 shift = 8u * (slot & 3u);
+    u32 old = *word;
+    for (;;) {
+        if ((old >> shift) & 0xffu) { // the cell already holds an event of this tick
+            atomicAdd(&a.counters[1], 1u);
+            return;
+        }
+        const u32 seen = atomicCAS(word, old, old | (flags << shift));
+        if (seen == old) break;
+        old = seen;
+    }
+    const u64 o = (u64)slot * a.stride + group;
+    a.mi[o] = index;
+    a.mc[o] = commit;
+    if (flags & RG_MF_REJECT) a.mh[o] = hint;
+    if (flags & RG_MF_HAS_RS) a.mrs[o] = rs;
+    if (flags & RG_MF_HAS_LOGTERM) a.mlt[o] = log_term;
+    if (atomicExch(&a.gmark[group], a.epoch) != a.epoch) a.list[atomicAdd(&a.counters[0], 1u)] = group;
+}
+
+// The whole small-batch flush in ONE launch (<= 256 records, one workgroup): housekeeping, ingest, hint resolution,
+// the tick of the touched groups and the packed results -- what k_ingest, k_resolve_hints_list and k_tick_list do
+// in three. A host that waits for one RawNode::step's worth of results pays one launch latency instead of two or three.
+template <int P, bool GC>
+__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small(RgState st, RgMsgs ms, RgIngest a, u64 *rh, u64 *mflags_rw,
+                                                                 RgListOut lo) {
+    __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
+    rg_ingest_housekeeping(a.clr);
+    rg_ingest_block(a, stage);
+    // the message cells, the tick list and the counters were written by this workgroup: make them visible to all of it
+    __threadfence();
+    __syncthreads();
+    const u32 n_groups = atomicAdd(&a.counters[0], 0u), n_dropped = atomicAdd(&a.counters[1], 0u);
+    if (ms.mhr == rh) { // some record may carry Message.log_term: find_conflict_by_term first (k_resolve_hints_list)
+        for (u32 i = threadIdx.x; i < n_groups; i += RG_INGEST_BLOCK) rg_resolve_hints(st, ms, a.list[i], P, rh);
+        __threadfence();
+        __syncthreads();
+    }
+    if (lo.packed && threadIdx.x == 0) {
+        reinterpret_cast<u32 *>(lo.packed)[0] = n_groups;
+        reinterpret_cast<u32 *>(lo.packed)[1] = n_dropped;
+    }
+    for (u32 i = threadIdx.x; i < n_groups; i += RG_INGEST_BLOCK) rg_tick_listed<P, GC>(st, ms, a.list[i], i, mflags_rw, lo);
 }
 
 // Temporal fusion: T consecutive ticks of a group in ONE launch. A group's tick t+1 depends only on
@@ -307,8 +409,17 @@ template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo);
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc);
+template <int P>
+void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
+                             u64 *mflags_rw, const RgListOut &lo);
 
 #ifdef RG_TICK_INSTANTIATE
+template <int P>
+void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
+                             u64 *mflags_rw, const RgListOut &lo) {
+    if (gc) hipLaunchKernelGGL((k_flush_small<P, true>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a, rh, mflags_rw, lo);
+    else hipLaunchKernelGGL((k_flush_small<P, false>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a, rh, mflags_rw, lo);
+}
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
     if (variant == RG_VARIANT_LDS) {
         hipLaunchKernelGGL((k_tick_lds<P, GC, false>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
@@ -340,25 +451,33 @@ template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_flush_small_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 #endif

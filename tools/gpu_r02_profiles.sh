@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round 2 evidence run: every bench line DESIGN.md quotes + rocprofv3 stats and the two PMC passes of the headline command.
+set -u
+cd "$(dirname "$0")/.."
+R=$PWD
+O=$R/gpurun_out/r02p
+rm -rf $O; mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python bench.py --steps 50 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
+for cfg in "--workload 3" "--slots 7" "--slots 3" "--workload 5" "--workload 5 --slots 7 --one-engine" "--groups 4000000 --steps 20" "--groups 8000000 --steps 20" "--variant 2" "--variant 4" "--split 2" "--fuse 4" "--fuse 8" "--inflights 256"; do
+  timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras $cfg >> $O/bench_other_configs.jsonl 2>> $O/bench_other.err
+done
+for cfg in "" "--slots 7" "--workload 5"; do
+  BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline $cfg >> $O/bench_dist_ws1.jsonl 2>> $O/bench_dist.err
+done
+BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 20 --warmup 3 --groups 500000 --no-cpu-baseline >> $O/bench_dist_share2.jsonl 2>> $O/bench_dist.err
+python tools/bench_send.py > $O/send_stage.txt 2>&1
+python tools/bench_flush_latency.py > $O/flush_latency.txt 2>&1
+cd /tmp
+CMD="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o s -- $CMD > $O/prof_stats.json 2> $O/prof_stats.err
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -o f -- $CMD > /dev/null 2> $O/prof_fetch.err
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_write -o w -- $CMD > /dev/null 2> $O/prof_write.err
+CMD5="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --workload 5"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_c5 -o s -- $CMD5 > /dev/null 2> $O/prof_stats_c5.err
+cd $R
+ls -R $O | head -60
