@@ -117,6 +117,44 @@ int main(void) {
             ok = items[i].kind == RG_SEND_APPEND && items[i].n_msgs == 1 && items[i].prev_index == 1u + (uint64_t)round &&
                  items[i].last_index == 2u + (uint64_t)round && items[i].slot >= 1 && items[i].slot < P;
     }
+    /* ---- multi-GPU entry points from plain C: this rank is the whole world (ncclAllGather at world size 1); with more
+     *      ranks only `rank` / `world` change and rank 0's unique id travels over the host's own channel ---- */
+    if (ok) {
+        uint8_t id[RG_COMM_ID_BYTES];
+        rg_comm_config cc;
+        uint64_t column[G], published[G];
+        uint32_t out2[G];
+        rg_publish_stats ps;
+        memset(&cc, 0, sizeof cc);
+        CHECK(rg_comm_unique_id(id));
+        cc.rank = 0;
+        cc.world = 1;
+        cc.unique_id = id;
+        CHECK(rg_comm_init(h, &cc)); /* collective: communicator + one full publication */
+        for (int g = 0; g < G; g++) { /* every leader persists what it appended; both followers acknowledge index 5 */
+            for (int p = 0; p < P; p++) {
+                rg_wire_msg *r = &recs[g * P + p];
+                memset(r, 0, sizeof *r);
+                r->group = (uint64_t)g;
+                r->slot = (uint32_t)p;
+                r->index = 5;
+                r->commit = 2;
+                r->flags = RG_MF_VALID;
+            }
+        }
+        CHECK(rg_ingest_tick(h, recs, (uint64_t)G * P, &touched, &dup));
+        CHECK(rg_publish_commit(h, 0)); /* asynchronous: the tick's commit advances, one byte per group */
+        CHECK(rg_results(h, column, out2));
+        CHECK(rg_published_commit(h, 0, 0, G, published));
+        CHECK(rg_publish_stats_get(h, &ps));
+        for (int g = 0; g < G; g++) ok = ok && column[g] == 5 && published[g] == column[g];
+        ok = ok && ps.publications == 2 && ps.full_publications == 1 && ps.bytes_per_rank_delta < ps.bytes_per_rank_full;
+        printf("published commit indices: %llu %llu %llu %llu (delta slice %llu B, full column %llu B)\n",
+               (unsigned long long)published[0], (unsigned long long)published[1], (unsigned long long)published[2],
+               (unsigned long long)published[3], (unsigned long long)ps.bytes_per_rank_delta,
+               (unsigned long long)ps.bytes_per_rank_full);
+        CHECK(rg_comm_destroy(h));
+    }
     rg_device_info info;
     CHECK(rg_get_device_info(h, &info));
     printf("device %s, %u CUs, wave%u, engine holds %llu bytes\n", info.arch, info.compute_units, info.wavefront,
