@@ -335,15 +335,35 @@ def main():
         torch.cuda.synchronize()
         return 0
 
+    transport_note = None
     if distributed:
         from raft_rs_amd import engine as E_
         for pt in parts:
             if share_gpu:  # RCCL refuses two ranks on one device: gloo moves the slices (test hook)
                 pt.eng.comm_init(rank, world, transport=gloo_allgather)
-            else:
+                continue
+            err = ""
+            try:
                 box = [E_.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                pt.eng.comm_init(rank, world, unique_id=box[0])
+            except rg.EngineError as e:  # RCCL cannot be loaded on this box
+                box, err = [None], str(e)
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    pt.eng.comm_init(rank, world, unique_id=box[0])
+                except rg.EngineError as e:
+                    err = str(e)
+            # every rank must take the same road: if RCCL failed anywhere, all ranks fall back to the host transport
+            # (gloo moving the slices through host memory: correct, slow, and SAID SO in the JSON line) rather than crash
+            flags = [None] * world
+            dist.all_gather_object(flags, err if box[0] is not None else (err or "no unique id"))
+            if any(flags):
+                transport_note = "RCCL unavailable (" + next(f for f in flags if f)[:200] + "): gloo host transport fallback"
+                try:
+                    pt.eng.comm_destroy()
+                except rg.EngineError:
+                    pass
+                pt.eng.comm_init(rank, world, transport=gloo_allgather)
 
     # Size-class engines are independent, so each runs on its own HIP stream (forked from / joined to the
     # main stream around the region): the tail of one engine's launch overlaps the next engine's head.
@@ -485,7 +505,7 @@ def main():
                    "engine_hbm_bytes": sum(pt.eng.device_info()["engine_bytes"] for pt in parts),
                    "sharding": f"{world} disjoint group ranges" + (
                        f", commit indices published every {E} tick(s) through rg_publish_commit: "
-                       f"{'gloo transport callback (shared-GPU test hook)' if share_gpu else 'ncclAllGather (RCCL)'} of "
+                       f"{'gloo transport callback (shared-GPU test hook)' if share_gpu else (transport_note or 'ncclAllGather (RCCL)')} of "
                        f"{pub_stats['bytes_per_rank_delta']} B/rank delta slices (full column: {pub_stats['bytes_per_rank_full']} B)"
                        if distributed else ""),
                    **({"publication": pub_stats} if distributed else {}),

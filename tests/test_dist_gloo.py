@@ -118,3 +118,39 @@ def test_publication_encoding_saturation_list_and_loss():
     import pytest
     with pytest.raises(E.EngineError):
         E.pub_accumulate_host(c0 + np.uint64(1), c0, sl, cap)  # a commit index never decreases
+
+
+def test_publication_encoding_property():
+    """Hypothesis: whatever the advances, the cadence and the list capacity, accumulate -> gather -> apply reproduces the
+    commit column exactly unless a slice reports itself lost -- and a lost slice is always reported."""
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    from raft_rs_amd import engine as E
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 700), st.integers(1, 40), st.integers(1, 5), st.integers(0, 2 ** 32 - 1),
+           st.sampled_from([3, 60, 300, 70000, 1 << 40]))
+    def run(G, cap, ticks_per_pub, seed, big):
+        rng = np.random.default_rng(seed)
+        stride = (G + 255) // 256 * 256
+        bpr = E.pub_bytes_per_rank(G, cap)
+        commit = rng.integers(0, 1 << 50, size=G).astype(np.uint64)
+        replica = np.zeros((1, stride), dtype=np.uint64)
+        replica[0, :G] = commit
+        for _ in range(4):  # four publications of `ticks_per_pub` ticks each
+            sl = np.zeros(bpr, dtype=np.uint8)
+            for _ in range(ticks_per_pub):
+                adv = rng.integers(0, 90, size=G).astype(np.uint64)
+                jump = rng.random(G) < 0.02
+                adv[jump] = rng.integers(0, big, size=int(jump.sum())).astype(np.uint64)
+                new = commit + adv
+                E.pub_accumulate_host(commit, new, sl, cap)
+                commit = new
+            n_list, flags = sl[:8].view(np.uint32)
+            lost = E.pub_apply_host(G, 1, sl, replica, cap)
+            assert lost == int(n_list > cap or (flags & 1))
+            if lost:
+                replica[0, :G] = commit  # what the full snapshot that follows does
+            assert (replica[0, :G] == commit).all()
+            assert (replica[0, G:] == 0).all()
+    run()
