@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/raftgroups.h"
 
@@ -38,6 +39,16 @@ struct RgMsgs {
     const u64 *mhr;                // [P][stride] hints after find_conflict_by_term (written by the pre-pass;
                                    // == mh when no message of the tick carries a log term)
 };
+
+// Column access with the index type of the caller. IX = u32 (dense lane kernels, engines with P * stride * 8 < 4 GiB):
+// the byte offset is computed in 32 bits and zero-extended onto the column pointer, which is exactly the
+// `SGPR base + 32-bit VGPR offset` form of the global memory instructions -- one VGPR per slot addresses that slot's cell
+// in EVERY column, instead of a 64-bit address pair per (column, slot) kept alive from the load to the store.
+// IX = u64: plain indexing (gathers over arbitrary groups, the host).
+template <typename T, typename IX> RG_HD T &rg_at(T *base, IX i) {
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (IX)(i * (IX)sizeof(T)));
+}
 
 RG_HD u64 rg_min(u64 a, u64 b) { return a < b ? a : b; }
 RG_HD u64 rg_max(u64 a, u64 b) { return a > b ? a : b; }

@@ -283,13 +283,13 @@ RG_HD bool rg_has_election(u64 mf, u32 cfg, u32 n_slots) {
 // Commit publication (rg_publish.h): the group's accumulated delta byte is loaded with the group; after the
 // tick `adv` = that byte + the tick's advance. Must run BEFORE the commit column is stored: the exact path
 // re-reads the old commit index and the old byte from memory.
-RG_HD u32 rg_pub_load(const RgState &st, u64 g) {
+template <typename IX> RG_HD u32 rg_pub_load(const RgState &st, IX g) {
     return st.pub ? (u32) reinterpret_cast<const u8 *>(st.pub + st.pub_off_delta)[g] : 0u;
 }
-RG_HD void rg_pub_store(const RgState &st, u64 g, u32 adv, u64 new_commit) {
+template <typename IX> RG_HD void rg_pub_store(const RgState &st, IX g, u32 adv, u64 new_commit) {
     u8 *dlt = reinterpret_cast<u8 *>(st.pub + st.pub_off_delta);
     if (adv > 255u) // rare: saturated byte, the excess goes to the exact-value list
-        adv = rg_pub_accumulate(dlt[g], st.commit[g], new_commit, g, reinterpret_cast<RgPubHdr *>(st.pub),
+        adv = rg_pub_accumulate(dlt[g], rg_at(st.commit, g), new_commit, g, reinterpret_cast<RgPubHdr *>(st.pub),
                                 reinterpret_cast<RgPubOvf *>(st.pub + sizeof(RgPubHdr)), st.pub_cap);
     dlt[g] = (u8)adv;
 }
@@ -308,13 +308,40 @@ template <int P> struct RgGroup {
     u32 evm;                 // slots (with a Progress) that had any event since the state was loaded
     u32 adv;                 // commit publication: the group's delta byte of this interval + this tick's advance
                              // (values > 255 = "saturated, take the exact path"); 0 when not publishing
+    // Operands of the rare paths, requested TOGETHER WITH the bulk loads by rg_prefetch_rare (NX mode RG_NX_PREFETCH):
+    // reject hints (after find_conflict_by_term where the pre-pass ran) and what an election reads from the cold
+    // columns. A wave then pays one memory round trip however many of its lanes take a rare path.
+    u64 hint[P];
+    u64 el_old;         // an election: the current term (the new one comes in hint[self]) = the term of the previous
+                        // leader's entries, which rg_push_run files in the term-run table after the group's stores
+                        // (RG_TICK_PUSH)
+    u64 push_rf[RG_TERM_RUNS], push_lo; // ... what that needs from memory (the table's first column; the previous
+                        // leader's first index, still in the term_lo column), requested once the slots have been walked
+                        // -- Message.index / .commit are dead by then, so this costs no registers at the kernel's peak,
+                        // and the data is there when the stores have been issued
 };
+// (RgGroup::push_rf: with fewer than 4 slots the dead message registers do not cover the five loads -- P = 3 would lose a
+// wave of occupancy -- so small groups read the table after their stores instead)
+#define RG_PUSH_EARLY(P) ((P) >= 4)
+#if defined(__HIP_DEVICE_COMPILE__)
+// The value stays what it is, but the compiler may not look through: without this it computes `hint + 1` (and the
+// election's term comparison) inside the very branch that issued the prefetch, i.e. waits for the load on the spot.
+#define RG_OPAQUE64(x) asm volatile("" : "+v"(x))
+#else
+#define RG_OPAQUE64(x) (void)(x)
+#endif
+// How a tick gets at Progress.next_idx (and the other rarely needed operands):
+#define RG_NX_LOADED 0   /* the caller loaded r.nx[] for every slot (LDS-staged variants) */
+#define RG_NX_LAZY 1     /* fetched on demand, cell by cell, where the old value can matter (fused launches) */
+#define RG_NX_PREFETCH 2 /* rg_prefetch_rare has requested the needed cells, the reject hints and the election's cold
+                            cells in one batch behind the bulk loads (lane / list kernels) */
 #define RG_DIRTY_PF (1u << 24)
 #define RG_DIRTY_COMMIT (1u << 25)
 #define RG_DIRTY_HI (1u << 26)
 #define RG_DIRTY_LO (1u << 27)      /* term_lo changed (an election) */
 #define RG_DIRTY_CFG (1u << 28)     /* the cfg word changed (an election aborts a leader transfer) */
 #define RG_TICK_ELECTED (1u << 29)  /* not a store bit: RG_MF_BECOME_LEADER was applied in THIS tick */
+#define RG_TICK_PUSH (1u << 30)     /* RG_NX_PREFETCH: ... and the previous leader's run still has to enter the term-run table */
 
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
 // (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
@@ -327,6 +354,69 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
     return false;
 }
 
+// The previous leader's entries [first, ...] of term `term` become one more run of the group's term-run table
+// (RgTick::become_leader). Used runs come first; when all RG_TERM_RUNS are in use the boundary between the two oldest
+// runs is forgotten (include/raftgroups.h: RG_COL_RUN_FIRST).
+template <typename IX> RG_HD void rg_push_run_loaded(const RgState &st, IX g, const u64 (&rf)[RG_TERM_RUNS], u64 first, u64 term);
+template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first, u64 term) {
+    u64 rf[RG_TERM_RUNS];
+#pragma unroll
+    for (int k = 0; k < RG_TERM_RUNS; k++) rf[k] = rg_at(st.run_first, (IX)k * (IX)st.stride + g);
+    rg_push_run_loaded<IX>(st, g, rf, first, term);
+}
+template <typename IX> RG_HD void rg_push_run_loaded(const RgState &st, IX g, const u64 (&rf)[RG_TERM_RUNS], u64 first, u64 term) {
+    int k = 0;
+#pragma unroll
+    for (int j = RG_TERM_RUNS - 1; j >= 0; j--)
+        if (rf[j] == 0) k = j; // first unused run
+    if (rf[RG_TERM_RUNS - 1] != 0) { // table full
+#pragma unroll
+        for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
+            rg_at(st.run_first, (IX)j * (IX)st.stride + g) = rf[j + 1];
+            rg_at(st.run_term, (IX)j * (IX)st.stride + g) = rg_at(st.run_term, (IX)(j + 1) * (IX)st.stride + g);
+        }
+        k = RG_TERM_RUNS - 1;
+    }
+    rg_at(st.run_first, (IX)k * (IX)st.stride + g) = first;
+    rg_at(st.run_term, (IX)k * (IX)st.stride + g) = term;
+}
+
+// RG_NX_PREFETCH: everything a tick may read beyond the bulk columns, decided from the two flag rows and the cfg
+// word alone and requested in ONE batch right behind the bulk loads -- the old `next` of the slots where it can
+// matter (see RgTick: not where SENT on a Replicate peer overwrites it first), the reject hint of every slot whose
+// reject can reach maybe_decr_to's Probe/Snapshot branch (progress.rs:188-203), and the cold cells an election
+// reads (new term, current term; the term-run table is only touched after the group's stores, rg_push_run). On demand, each of these was a dependent
+// memory round trip in the middle of the tick, taken by the WHOLE wave as soon as one lane needed it: under leader-term
+// rollover (BASELINE config 5) practically every wave needed a dozen of them, one after the other.
+// Every destination is written once, before its load is issued, and not touched again until the tick reads it: a
+// later write (even under a disjoint exec mask) would make the compiler wait for the load first.
+template <int P, typename IX> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
+    const u32 cfg = r.cfg;
+    const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
+    const bool elect = rg_has_election(r.mf, cfg, P);
+    r.el_old = 0;
+    if (elect) r.el_old = rg_at(st.cur_term, g); // (the new term arrives in r.hint[self], below)
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const u32 f = (u32)(r.mf >> (8 * i)) & 0xffu, pb = (u32)(r.pf >> (8 * i)) & 0xffu;
+        const IX o = (IX)i * (IX)st.stride + g;
+        const bool here = ((present >> i) & 1u) != 0;
+        const bool repl = (pb & RG_PF_STATE_MASK) == RG_STATE_REPLICATE;
+        // (an election rewrites every present cell of `next` before anything reads it -- but whether the event is
+        // well-formed is only known once its own cells have arrived, so electing groups fetch theirs like the others)
+        const bool overwritten = (u32)i != self && (f & RG_MF_SENT) && repl;
+        r.nx[i] = 0;
+        if (here && f != 0 && !overwritten) r.nx[i] = rg_at(st.next, o);
+        // a reject that is not a heartbeat response reads its hint in maybe_decr_to's Probe / Snapshot branch (unless
+        // it carries a snapshot request: known only with m_rs); after an election every follower is in Probe
+        const u32 rj = RG_MF_VALID | RG_MF_REJECT;
+        // (the leader's own slot has no hint: its register carries the new term of an election, m_hint of that slot)
+        r.hint[i] = 0;
+        if ((u32)i == self ? elect : here && (f & (rj | RG_MF_HEARTBEAT)) == rj && (elect || !repl))
+            r.hint[i] = (f & RG_MF_HAS_LOGTERM) && (u32)i != self ? rg_at(ms.mhr, o) : rg_at(ms.mh, o);
+    }
+}
+
 // Raft::handle_append_response for every slot of one group, in slot order (src/raft.rs:1559-1775),
 // on_persist_entries for the leader's own slot (src/raft.rs:994-1016).
 // Cold columns (pending_snapshot, pending_request_snapshot, commit_group_id, reject_hint,
@@ -334,27 +424,25 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 // GC = false compiles the group-commit path out (the engine launches the GC = true kernel only
 // when some group has ProgressTracker.group_commit set).
 // FUSED: the group's state stays in registers across several ticks (k_tick_fused): `dirty`/`evm`
-// accumulate, `next` cells already fetched or written are not fetched again, and the replay path takes
-// the matches of the tick's start from a register snapshot instead of re-reading memory.
-template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
+// accumulate, and `next` cells already fetched or written are not fetched again.
+template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
+    static constexpr bool LAZY_NX = NXM == RG_NX_LAZY;
+    static constexpr bool PREF = NXM == RG_NX_PREFETCH;
     RgGroup<P> &r;
     const RgState &st;
     const RgMsgs &ms;
-    const u64 g;
+    const IX g;
     u64 last0; // last_index the send path saw before this tick
-    u32 incoming, outgoing, self, present, xfer, out;
-    u64 mt_start[FUSED ? P : 1]; // FUSED: matches at the start of this tick (memory still holds older ones)
+    u32 self, present, out; // (the voter masks and the transferee are extracted from r.cfg where they are used)
+    u64 mc_self;  // m_commit of the leader's own slot
     u32 acc;      // slots whose maybe_update returned true this tick (each is followed by a maybe_commit)
     u32 acc_oldp; // ... of those, the ones that were paused before the ack (raft.rs:1724,1749-1751)
 
-    RG_HD RgTick(RgGroup<P> &r_, const RgState &st_, const RgMsgs &ms_, u64 g_)
+    RG_HD RgTick(RgGroup<P> &r_, const RgState &st_, const RgMsgs &ms_, IX g_)
         : r(r_), st(st_), ms(ms_), g(g_) {
         const u32 cfg = r.cfg;
-        incoming = RG_CFG_INCOMING(cfg);
-        outgoing = RG_CFG_OUTGOING(cfg);
         self = RG_CFG_SELF(cfg);
         present = RG_CFG_PRESENT(cfg);
-        xfer = RG_CFG_TRANSFEREE(cfg);
         last0 = r.hi;
         out = 0;
         acc = 0;
@@ -372,10 +460,6 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
 #ifndef RG_NO_ELECT /* (measurement builds only: python -m raft_rs_amd.build --exp noelect -DRG_NO_ELECT) */
         if (!FUSED && rg_has_election(r.mf, r.cfg, P)) become_leader();
 #endif
-        if (FUSED) {
-#pragma unroll
-            for (int i = 0; i < P; i++) mt_start[i] = r.mt[i];
-        }
 #pragma unroll
         for (int i = 0; i < P; i++)
             if (((r.mf >> (8 * i)) & 0xffULL) && ((present >> i) & 1u)) r.evm |= 1u << i;
@@ -395,7 +479,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                 const bool have = (r.dirty >> (8 + i)) & 1u;
                 const bool need = ((present >> i) & 1u) && f != 0 && !overwritten && !have;
                 if (need) {
-                    r.nx[i] = st.next[(u64)i * st.stride + g];
+                    r.nx[i] = rg_at(st.next, (IX)i * (IX)st.stride + g);
                     if (FUSED) r.dirty |= 1u << (8 + i);
                 } else if (!have) {
                     r.nx[i] = 0ULL;
@@ -416,36 +500,37 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
     RG_HD void become_leader() {
         // everything this rare path reads from the cold columns is requested at once: ONE memory round trip
         // (a wave of config 5 almost always has an electing lane, and it waits for that lane)
-        const u64 new_term = ms.mh[(u64)self * st.stride + g];
-        const u64 old_term = st.cur_term[g];
-        u64 rf[RG_TERM_RUNS];
+        // (RG_NX_PREFETCH: they were requested with the group's bulk loads, rg_prefetch_rare)
+        u64 new_term, old_term;
+        if (PREF) {
+            new_term = 0;
 #pragma unroll
-        for (int k = 0; k < RG_TERM_RUNS; k++) rf[k] = st.run_first[(u64)k * st.stride + g];
+            for (int i = 0; i < P; i++)
+                if ((u32)i == self) new_term = r.hint[i];
+            old_term = r.el_old;
+            RG_OPAQUE64(new_term);
+            RG_OPAQUE64(old_term);
+        } else {
+            new_term = rg_at(ms.mh, (IX)self * (IX)st.stride + g);
+            old_term = rg_at(st.cur_term, g);
+        }
         if (!(new_term > old_term)) { // rg_election_valid
             out |= RG_OUT_FAULT;
             return;
         }
         const u64 old_lo = r.lo, old_hi = r.hi;
-        st.cur_term[g] = new_term;
+        rg_at(st.cur_term, g) = new_term;
         if (old_lo <= old_hi) { // the previous leader's entries become one more run of an older term
-            int k = 0;
-#pragma unroll
-            for (int j = RG_TERM_RUNS - 1; j >= 0; j--)
-                if (rf[j] == 0) k = j; // first unused run (used runs come first)
-            if (rf[RG_TERM_RUNS - 1] != 0) { // table full: forget the boundary between the two oldest runs
-                for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
-                    st.run_first[(u64)j * st.stride + g] = st.run_first[(u64)(j + 1) * st.stride + g];
-                    st.run_term[(u64)j * st.stride + g] = st.run_term[(u64)(j + 1) * st.stride + g];
-                }
-                k = RG_TERM_RUNS - 1;
+            if (PREF) { // nothing in this tick reads the table: filed after the group's stores (rg_store_group)
+                r.dirty |= RG_TICK_PUSH; // (r.el_old is their term; term_lo still holds their first index in memory)
+            } else {
+                rg_push_run<IX>(st, g, old_lo, old_term);
             }
-            st.run_first[(u64)k * st.stride + g] = old_lo;
-            st.run_term[(u64)k * st.stride + g] = old_term;
         }
 #pragma unroll
         for (int i = 0; i < P; i++) {
             if (!((present >> i) & 1u)) continue;
-            const u64 o = (u64)i * st.stride + g;
+            const IX o = (IX)i * (IX)st.stride + g;
             const u32 pb = (u32)(r.pf >> (8 * i)) & 0xffu;
             u32 nb;
             if ((u32)i == self) {
@@ -463,15 +548,14 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                 nb = RG_STATE_PROBE; // ins.reset(): RG_OUT_BECAME_LEADER tells the send stage to empty the device window
             }
             r.dirty |= (1u << i) | (1u << (8 + i));
-            st.psnap[o] = 0;
-            st.prs[o] = 0;
+            rg_at(st.psnap, o) = 0;
+            rg_at(st.prs, o) = 0;
             if (nb != pb) {
                 r.pf = (r.pf & ~(0xffULL << (8 * i))) | ((u64)nb << (8 * i));
                 r.dirty |= RG_DIRTY_PF;
             }
         }
-        if (xfer) { // abort_leader_transfer (raft.rs:953)
-            xfer = 0;
+        if (RG_CFG_TRANSFEREE(r.cfg)) { // abort_leader_transfer (raft.rs:953)
             r.cfg &= ~(0xfu << 20);
             r.dirty |= RG_DIRTY_CFG;
         }
@@ -482,31 +566,24 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         out |= RG_OUT_BECAME_LEADER | RG_OUT_APPENDED; // the caller follows with bcast_append (raft.rs:2190-2191)
     }
 
-    // matched of slot S when the tick's messages started: memory still holds it, unless an election of this very
-    // tick reset it first (every Progress but the leader's own to 0)
-    template <int S> RG_HD u64 start_match() {
-        if ((r.dirty & RG_TICK_ELECTED) && (u32)S != self) return 0;
-        return st.match[(u64)S * st.stride + g];
-    }
-
     // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v`.
     RG_HD u64 mci_of(const RgQuorum<P> &qm, const u64 (&v)[P]) {
         if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
             u64 gidv[P];
 #pragma unroll
             for (int i = 0; i < P; i++)
-                gidv[i] = ((present >> i) & 1u) ? st.gid[(u64)i * st.stride + g] : 0ULL;
+                gidv[i] = ((present >> i) & 1u) ? rg_at(st.gid, (IX)i * (IX)st.stride + g) : 0ULL;
             bool used;
-            return rg_mci_group<P>(v, gidv, incoming, outgoing, used);
+            return rg_mci_group<P>(v, gidv, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg), used);
         }
-        return qm.mci(v, incoming, outgoing);
+        return qm.mci(v, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg));
     }
 
     // Progress::reset_state (progress.rs:75-80): paused=false, pending_snapshot=0, state; the
     // Inflights reset is the host's (it sees the transition through the state column).
-    RG_HD void reset_state(u32 &pb, u32 new_state, u64 o) {
+    RG_HD void reset_state(u32 &pb, u32 new_state, IX o) {
         pb = (pb & ~(RG_PF_PAUSED | RG_PF_STATE_MASK)) | new_state;
-        st.psnap[o] = 0;
+        rg_at(st.psnap, o) = 0;
     }
 
     template <int S> RG_HD void set_next(u64 n) {
@@ -518,6 +595,10 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
     template <int S> RG_HD bool maybe_update(u64 idx, u32 &pb) {
         const bool upd = r.mt[S] < idx;
         if (upd) {
+            // the matched index this ack replaces is parked where the message's index was (r.mi[S] == idx is not read
+            // again): the replay of commit_phase() needs the matches as they were BEFORE each ack, and gets them
+            // without re-reading memory or spending registers on a snapshot
+            r.mi[S] = r.mt[S];
             r.mt[S] = idx;
             r.dirty |= 1u << S;
             pb &= ~RG_PF_PAUSED; // resume()
@@ -527,16 +608,30 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         return upd;
     }
 
+    // Progress::update_committed(m.commit) (progress.rs:153-157) of a follower's AppendResponse (raft.rs:1677) or
+    // HeartbeatResponse (:1781): unconditional once the peer has a Progress, and nothing between the start of the tick and
+    // that line reads pr.committed_index, so it is applied to every slot up front -- Message.commit is then dead before the
+    // slots are walked (registers).
+    template <int S> RG_HD void peer_committed() {
+        const u32 f = (u32)(r.mf >> (8 * S)) & 0xffu;
+        if ((u32)S == self) mc_self = r.mc[S]; // (RG_MF_APPEND: the leader's new last_index)
+        if ((u32)S == self || !((present >> S) & 1u) || !(f & (RG_MF_VALID | RG_MF_HEARTBEAT))) return;
+        if (r.mc[S] > r.pc[S]) {
+            r.pc[S] = r.mc[S];
+            r.dirty |= 1u << (16 + S);
+        }
+    }
+
     template <int S> RG_HD void slot() {
         const u32 f = (u32)(r.mf >> (8 * S)) & 0xffu;
         if (f == 0 || !((present >> S) & 1u)) return; // no event / no Progress (raft.rs:1663-1673)
         const u32 pb0 = (u32)(r.pf >> (8 * S)) & 0xffu;
         u32 pb = pb0;
-        const u64 o = (u64)S * st.stride + g;
+        const IX o = (IX)S * (IX)st.stride + g;
 
         if ((u32)S == self) {
             if (f & RG_MF_APPEND) { // Raft::append_entry (raft.rs:976-991): last_index grows, same term
-                const u64 nl = r.mc[S];
+                const u64 nl = mc_self;
                 if (nl > r.hi) {
                     r.hi = nl;
                     r.dirty |= RG_DIRTY_HI;
@@ -556,32 +651,26 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                 else out |= RG_OUT_FAULT; // the reference panics
             }
             if (f & RG_MF_HEARTBEAT) { // Raft::handle_heartbeat_response (raft.rs:1777-1803)
-                if (r.mc[S] > r.pc[S]) { // update_committed(m.commit)
-                    r.pc[S] = r.mc[S];
-                    r.dirty |= 1u << (16 + S);
-                }
+                // (update_committed(m.commit): peer_committed<S>())
                 pb = (pb | RG_PF_RECENT_ACTIVE) & ~RG_PF_PAUSED; // recent_active = true; resume()
                 if (state == RG_STATE_REPLICATE && ((f & RG_MF_INS_FULL) || (pb0 & RG_PF_INS_FULL)))
                     out |= 1u << (24 + S); // ins.free_first_one()
-                if (r.mt[S] < r.hi || st.prs[o] != 0) out |= 1u << (8 + S); // send_append(m.from)
+                if (r.mt[S] < r.hi || rg_at(st.prs, o) != 0) out |= 1u << (8 + S); // send_append(m.from)
             } else if (f & RG_MF_VALID) {
                 const u64 idx = r.mi[S];
                 const bool reject = (f & RG_MF_REJECT) != 0;
                 if ((idx >> 63) || (!reject && idx > r.hi)) out |= RG_OUT_FAULT;
                 pb |= RG_PF_RECENT_ACTIVE;  // raft.rs:1674
-                if (r.mc[S] > r.pc[S]) {    // update_committed, raft.rs:1677
-                    r.pc[S] = r.mc[S];
-                    r.dirty |= 1u << (16 + S);
-                }
+                // (update_committed, raft.rs:1677: peer_committed<S>())
                 if (reject) {
                     // Progress::maybe_decr_to(m.index, hint, m.request_snapshot) (progress.rs:168-206)
-                    const u64 rs = (f & RG_MF_HAS_RS) ? ms.mrs[o] : 0ULL;
+                    const u64 rs = (f & RG_MF_HAS_RS) ? rg_at(ms.mrs, o) : 0ULL;
                     bool dec = false;
                     if (state == RG_STATE_REPLICATE) {
                         const bool stale = idx < r.mt[S] || (idx == r.mt[S] && rs == 0);
                         if (!stale) {
                             if (rs == 0) set_next<S>(r.mt[S] + 1);
-                            else st.prs[o] = rs;
+                            else rg_at(st.prs, o) = rs;
                             dec = true;
                         }
                     } else {
@@ -591,13 +680,19 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                                 // rejects that carry log_term > 0 read their hint AFTER find_conflict_by_term
                                 // (raft.rs:1562,1657-1660): resolved by rg_resolve_hints in a pre-pass so that
                                 // the walk over the term table costs this kernel no registers
-                                const u64 hint = (f & RG_MF_HAS_LOGTERM) ? ms.mhr[o] : ms.mh[o];
+                                u64 hint;
+                                if (PREF) {
+                                    hint = r.hint[S];
+                                    RG_OPAQUE64(hint);
+                                } else {
+                                    hint = (f & RG_MF_HAS_LOGTERM) ? rg_at(ms.mhr, o) : rg_at(ms.mh, o);
+                                }
                                 const u64 h = hint + 1;
                                 u64 n = idx < h ? idx : h;
                                 if (n < 1) n = 1;
                                 set_next<S>(n);
-                            } else if (st.prs[o] == 0) {
-                                st.prs[o] = rs;
+                            } else if (rg_at(st.prs, o) == 0) {
+                                rg_at(st.prs, o) = rs;
                             }
                             pb &= ~RG_PF_PAUSED; // resume()
                             dec = true;
@@ -622,7 +717,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                             reset_state(pb, RG_STATE_REPLICATE, o);
                             set_next<S>(r.mt[S] + 1);
                         } else if (state == RG_STATE_SNAPSHOT) { // maybe_snapshot_abort (progress.rs:132-134)
-                            const u64 ps = st.psnap[o];
+                            const u64 ps = rg_at(st.psnap, o);
                             if (r.mt[S] >= ps) { // become_probe from Snapshot (progress.rs:99-102)
                                 reset_state(pb, RG_STATE_PROBE, o);
                                 const u64 a = r.mt[S] + 1, b = ps + 1;
@@ -635,7 +730,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
                         // is resolved in commit_phase(), which knows whether THIS ack moved the commit index
                         if (old_paused) acc_oldp |= 1u << S;
                         out |= 1u << (16 + S);                      // raft.rs:1761
-                        if (xfer == (u32)S + 1u && r.mt[S] == r.hi) // raft.rs:1764-1774
+                        if (RG_CFG_TRANSFEREE(r.cfg) == (u32)S + 1u && r.mt[S] == r.hi) // raft.rs:1764-1774
                             out |= RG_OUT_TIMEOUT_NOW;
                     }
                 }
@@ -675,8 +770,8 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
     // returned true" == "the commit index moved". The per-message results are otherwise observable only
     // through `else if old_paused { send_append }` (raft.rs:1749-1751). So: ONE evaluation on the final
     // matches unless an accepted ack came from a paused peer or mci_final > hi* (possible only with
-    // acks beyond last_index), else an exact replay of the sequence (old matches are re-read from
-    // memory: nothing has been stored yet). Both paths are bit-identical to the message-at-a-time
+    // acks beyond last_index), else an exact replay of the sequence (from the old matches
+    // maybe_update parked in r.mi). Both paths are bit-identical to the message-at-a-time
     // reference for ANY state and input.
     template <int... S> RG_HD void commit_phase(rg_seq<S...>) {
         if (acc == 0) return;
@@ -707,8 +802,7 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
         }
         if (replay) {
             u64 cur[P];
-            if (FUSED) ((cur[S] = mt_start[S]), ...);
-            else ((cur[S] = ((acc >> S) & 1u) ? start_match<S>() : r.mt[S]), ...);
+            ((cur[S] = ((acc >> S) & 1u) ? r.mi[S] : r.mt[S]), ...); // (maybe_update parked the old matches)
             qm.init(cur);
             u64 commit = commit0;
             (replay_slot<S>(qm, cur, commit), ...);
@@ -722,15 +816,27 @@ template <int P, bool GC, bool LAZY_NX, bool FUSED> struct RgTick {
     }
 
     template <int... S> RG_HD void run(rg_seq<S...> seq) {
+        mc_self = 0;
+        (peer_committed<S>(), ...);
         (slot<S>(), ...);
+        if (PREF && RG_PUSH_EARLY(P)) { // (rg_store_group's rg_push_run_loaded: see RgGroup::push_rf)
+#pragma unroll
+            for (int k = 0; k < RG_TERM_RUNS; k++) r.push_rf[k] = 0;
+            r.push_lo = 0;
+            if (r.dirty & RG_TICK_PUSH) {
+#pragma unroll
+                for (int k = 0; k < RG_TERM_RUNS; k++) r.push_rf[k] = rg_at(st.run_first, (IX)k * (IX)st.stride + g);
+                r.push_lo = rg_at(st.lo, g);
+            }
+        }
         commit_phase(seq);
         r.out = out;
     }
 };
 
-// LAZY_NX: r.nx is NOT pre-loaded by the caller; the tick fetches the cells it needs (lane/list kernels).
-template <int P, bool GC, bool LAZY_NX, bool FUSED = false>
-RG_HD void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
-    RgTick<P, GC, LAZY_NX, FUSED> t(r, st, ms, g);
+// NXM: RG_NX_* -- who provides r.nx (and, for RG_NX_PREFETCH, r.hint / r.el_*).
+template <int P, bool GC, int NXM, bool FUSED = false, typename IX = u64>
+RG_HD void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
+    RgTick<P, GC, NXM, FUSED, IX> t(r, st, ms, g);
     t.run(typename rg_make_seq<P>::type{});
 }

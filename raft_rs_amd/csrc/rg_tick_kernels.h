@@ -13,8 +13,8 @@
 #define RG_OPT 6 /* measured best on MI355X: gpurun sweep in profiles/r01_tuning_sweep.txt */
 #endif
 #define RG_OPT_NT_MSG (RG_OPT & 1)
-#ifndef RG_LAZY_NEXT /* 1: the lane kernels fetch `next` only where its old value can matter (rg_group.h) */
-#define RG_LAZY_NEXT 1
+#ifndef RG_LANE_NX /* how the lane / list kernels get at `next` and the rare-path operands (rg_group.h: RG_NX_*) */
+#define RG_LANE_NX RG_NX_PREFETCH
 #endif
 #define RG_OPT_UNCOND_ST (RG_OPT & 2)
 #ifdef RG_BLOCK_SIZE /* experiment override */
@@ -43,27 +43,31 @@ template <typename T> RG_HD T rg_ld_stream(const T *p) { // read-once data: keep
 #endif
 }
 
-template <int P, bool LOAD_NX>
-RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, u64 g) {
-    r.mf = rg_ld_stream(ms.mflags + g);
-    r.pf = st.pflags[g];
-    r.cfg = st.cfg[g];
-    r.commit = st.commit[g];
-    r.lo = st.lo[g];
-    r.hi = st.hi[g];
+// The flag rows and the cfg word go first: rg_prefetch_rare decides from them alone, so its loads can be issued
+// while the bulk loads below are still in flight (memory returns a wave's loads in order).
+template <int P, int NXM, typename IX>
+RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
+    constexpr bool LOAD_NX = NXM == RG_NX_LOADED;
+    r.mf = rg_ld_stream(&rg_at(ms.mflags, g));
+    r.pf = rg_at(st.pflags, g);
+    r.cfg = rg_at(st.cfg, g);
+    r.commit = rg_at(st.commit, g);
+    r.lo = rg_at(st.lo, g);
+    r.hi = rg_at(st.hi, g);
     r.adv = rg_pub_load(st, g);
 #pragma unroll
     for (int p = 0; p < P; p++) {
-        const u64 o = (u64)p * st.stride + g;
-        r.mt[p] = st.match[o];
-        if (LOAD_NX) r.nx[p] = st.next[o];
-        r.pc[p] = st.prc[o];
-        r.mi[p] = rg_ld_stream(ms.mi + o);
-        r.mc[p] = rg_ld_stream(ms.mc + o);
+        const IX o = (IX)p * (IX)st.stride + g;
+        r.mt[p] = rg_at(st.match, o);
+        if (LOAD_NX) r.nx[p] = rg_at(st.next, o);
+        r.pc[p] = rg_at(st.prc, o);
+        r.mi[p] = rg_ld_stream(&rg_at(ms.mi, o));
+        r.mc[p] = rg_ld_stream(&rg_at(ms.mc, o));
     }
+    if (NXM == RG_NX_PREFETCH) rg_prefetch_rare<P, IX>(r, st, ms, g);
 }
 
-template <int P> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, u64 g) {
+template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
@@ -73,31 +77,47 @@ template <int P> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &s
 #endif
 #pragma unroll
     for (int p = 0; p < P; p++) {
-        const u64 o = (u64)p * st.stride + g;
-        if (d & (1u << p)) st.match[o] = r.mt[p];
-        if (d & (1u << (8 + p))) st.next[o] = r.nx[p];
-        if (d & (1u << (16 + p))) st.prc[o] = r.pc[p];
+        const IX o = (IX)p * (IX)st.stride + g;
+        if (d & (1u << p)) rg_at(st.match, o) = r.mt[p];
+        if (d & (1u << (8 + p))) rg_at(st.next, o) = r.nx[p];
+        if (d & (1u << (16 + p))) rg_at(st.prc, o) = r.pc[p];
     }
-    if (d & RG_DIRTY_PF) st.pflags[g] = r.pf;
+    if (d & RG_DIRTY_PF) rg_at(st.pflags, g) = r.pf;
     if (d & RG_DIRTY_COMMIT) {
         if (st.pub) rg_pub_store(st, g, r.adv, r.commit); // commit publication: one byte per advanced group
-        st.commit[g] = r.commit;
+        rg_at(st.commit, g) = r.commit;
     }
-    if (d & RG_DIRTY_HI) st.hi[g] = r.hi;
-    if (d & (RG_DIRTY_LO | RG_DIRTY_CFG)) { // an election (rare)
-        if (d & RG_DIRTY_LO) st.lo[g] = r.lo;
-        if (d & RG_DIRTY_CFG) st.cfg[g] = r.cfg;
+    if (d & RG_DIRTY_HI) rg_at(st.hi, g) = r.hi;
+    rg_at(st.out, g) = r.out;
+    if (d & (RG_DIRTY_LO | RG_DIRTY_CFG | RG_TICK_PUSH)) { // an election (rare)
+        // its table update comes last (it reads the table, and nothing else of the wave should wait for that) but before
+        // term_lo is overwritten: the previous leader's first index is taken from there
+        if (!RG_PUSH_EARLY(P)) {
+            if (d & RG_TICK_PUSH) rg_push_run<IX>(st, g, rg_at(st.lo, g), r.el_old);
+        } else if (d & RG_TICK_PUSH) {
+            u64 rf[RG_TERM_RUNS], lo = r.push_lo;
+#pragma unroll
+            for (int k = 0; k < RG_TERM_RUNS; k++) {
+                rf[k] = r.push_rf[k];
+                RG_OPAQUE64(rf[k]);
+            }
+            RG_OPAQUE64(lo);
+            rg_push_run_loaded<IX>(st, g, rf, lo, r.el_old);
+        }
+        if (d & RG_DIRTY_LO) rg_at(st.lo, g) = r.lo;
+        if (d & RG_DIRTY_CFG) rg_at(st.cfg, g) = r.cfg;
     }
-    st.out[g] = r.out;
 }
 
-template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
-    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (g >= st.G) return;
+// IX = u32 when every cell of the engine's columns lies within 4 GiB of its column's start (rg_launch_tick_t decides).
+template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
+    const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g64 >= st.G) return;
+    const IX g = (IX)g64;
     RgGroup<P> r;
-    rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
-    rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
-    rg_store_group<P>(r, st, g);
+    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    rg_store_group<P, IX>(r, st, g);
 }
 
 // Sparse variant: lane i owns group list[i] (the groups an ingest touched). Same arithmetic; accesses
@@ -115,9 +135,9 @@ struct RgListOut {
 template <int P, bool GC>
 RG_D void rg_tick_listed(const RgState &st, const RgMsgs &ms, u64 g, u64 i, u64 *mflags_rw, const RgListOut &lo) {
     RgGroup<P> r;
-    rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g);
-    rg_group_tick<P, GC, RG_LAZY_NEXT>(r, st, ms, g);
-    rg_store_group<P>(r, st, g);
+    rg_load_group<P, RG_LANE_NX, u64>(r, st, ms, g);
+    rg_group_tick<P, GC, RG_LANE_NX, false, u64>(r, st, ms, g);
+    rg_store_group<P, u64>(r, st, g);
     mflags_rw[g] = 0;
     lo.rl[i] = g;
     lo.rc[i] = r.commit;
@@ -284,13 +304,13 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st
             r.mi[p] = rg_ld_stream(ms.mi + o);
             r.mc[p] = rg_ld_stream(ms.mc + o);
         }
-        rg_group_tick<P, GC, true, true>(r, st, ms, g);
+        rg_group_tick<P, GC, RG_NX_LAZY, true>(r, st, ms, g);
         r.out |= efault;
         fm.out_t[(u64)t * st.G + g] = r.out;
         if (fm.commit_t) fm.commit_t[(u64)t * st.G + g] = r.commit;
     }
     // `next` cells that were only fetched (never needed a write) are harmlessly rewritten with their value
-    rg_store_group<P>(r, st, g);
+    rg_store_group<P, u64>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
                 r.mi[p] = L[3][p][li];
                 r.mc[p] = L[4][p][li];
             }
-            rg_group_tick<P, GC, false>(r, st, ms, g);
+            rg_group_tick<P, GC, RG_NX_LOADED>(r, st, ms, g);
             const u32 d = r.dirty;
 #pragma unroll
             for (int p = 0; p < P; p++) {
@@ -428,7 +448,11 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
         hipLaunchKernelGGL((k_tick_lds<P, GC, true>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
     } else {
-        hipLaunchKernelGGL((k_tick_lane<P, GC>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
+        // 32-bit cell offsets when the farthest cell of a column (slot P-1, group stride-1, 8 B each) is below 4 GiB
+        if ((u64)P * st.stride * 8 <= 0xffffffffULL)
+            hipLaunchKernelGGL((k_tick_lane<P, GC, u32>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
+        else
+            hipLaunchKernelGGL((k_tick_lane<P, GC, u64>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
     }
 }
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc) {

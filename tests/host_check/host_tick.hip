@@ -28,6 +28,14 @@ static RgMsgs make_msgs(const void *const *p) {
 }
 
 #include <vector>
+template <int P, typename IX> static void host_one(const RgState &st, const RgMsgs &ms, bool gc, IX g) {
+    RgGroup<P> r;
+    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    if (gc) rg_group_tick<P, true, RG_LANE_NX, false, IX>(r, st, ms, g);
+    else rg_group_tick<P, false, RG_LANE_NX, false, IX>(r, st, ms, g);
+    rg_store_group<P, IX>(r, st, g);
+}
+
 template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, bool gc, u64 g0, u64 g1) {
     // the engine's pre-pass (k_resolve_hints) followed by the tick, group by group
     std::vector<u64> rh;
@@ -39,12 +47,12 @@ template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, b
         for (u64 g = g0; g < g1; g++) rg_resolve_hints(st, ms_in, g, P, rh.data());
         ms.mhr = rh.data();
     }
+    // exactly what k_tick_lane does, with the index type rg_launch_tick_t would pick (odd groups take the other one,
+    // so both instantiations are diffed against the oracle)
+    const bool fits32 = (u64)P * st.stride * 8 <= 0xffffffffULL;
     for (u64 g = g0; g < g1; g++) {
-        RgGroup<P> r;
-        rg_load_group<P, !RG_LAZY_NEXT>(r, st, ms, g); // exactly what k_tick_lane does
-        if (gc) rg_group_tick<P, true, RG_LAZY_NEXT>(r, st, ms, g);
-        else rg_group_tick<P, false, RG_LAZY_NEXT>(r, st, ms, g);
-        rg_store_group<P>(r, st, g);
+        if (fits32 && !(g & 1)) host_one<P, u32>(st, ms, gc, (u32)g);
+        else host_one<P, u64>(st, ms, gc, g);
     }
 }
 
@@ -65,8 +73,8 @@ template <int P> static void host_fused(const RgState &st, const RgMsgs *ms, u32
                 const u64 o = (u64)p * st.stride + g;
                 r.mi[p] = ms[t].mi[o]; r.mc[p] = ms[t].mc[o];
             }
-            if (gc) rg_group_tick<P, true, true, true>(r, st, ms[t], g);
-            else rg_group_tick<P, false, true, true>(r, st, ms[t], g);
+            if (gc) rg_group_tick<P, true, RG_NX_LAZY, true>(r, st, ms[t], g);
+            else rg_group_tick<P, false, RG_NX_LAZY, true>(r, st, ms[t], g);
             r.out |= efault;
             out_t[(u64)t * st.G + g] = r.out;
             if (commit_t) commit_t[(u64)t * st.G + g] = r.commit;
