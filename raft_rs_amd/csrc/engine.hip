@@ -387,6 +387,12 @@ __global__ void k_clear_out(const u64 *list, u64 n, u32 *out) {
 // The send stage (rg_send.h): one lane per group. The work items of a whole 1024-thread workgroup are appended
 // to the compact list with ONE atomic (wave prefix sums by shuffles, the 16 wave totals through LDS): at one
 // atomic per wave the 15.6 K same-address atomics of a 1 M-group launch cost more than everything else together.
+#ifndef RG_SEND_SPEC_LOADS
+#define RG_SEND_SPEC_LOADS 0 /* 1: the dense stage requests the per-peer cells before the work set is known (rg_send.h: SPEC); measured slower (125 vs 112 us: the extra cells cost more than the round trip saves) */
+#endif
+#ifndef RG_SEND_WAVES
+#define RG_SEND_WAVES 4 /* minimum waves per SIMD the dense stage is compiled for */
+#endif
 #define RG_SEND_BLOCK 1024
 #define RG_SEND_SPEC 16384 /* work items copied speculatively with their count (512 KB of pinned memory) */
 template <int P>
@@ -447,28 +453,40 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
 
 // The dense stage: every group of the shard, one lane each, work items into the peer-major columns (RgSendCols).
 // A pure streaming kernel like the tick: 64-thread workgroups, no LDS, no atomics, no barrier.
-template <int P>
-__global__ __launch_bounds__(RG_BLOCK) void k_send_dense(RgState st, RgIns ins, u64 max_entries, u32 flags, RgSendCols oc) {
-    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (g >= st.G) return;
+// IX = u32 when every cell lies within 4 GiB of its column's start (32-bit cell offsets, rg_common.h: rg_at).
+template <int P, typename IX>
+__global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState st, RgIns ins, u64 max_entries, u32 flags, RgSendCols oc) {
+    const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g64 >= st.G) return;
+    const IX g = (IX)g64;
     RgSendRegs<P> it;
     it.count = 0;
     it.snap = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
-    const u32 out = st.out[g];
-    if (out) rg_group_send<P>(st, ins, g, out, max_entries, flags, it);
+    const u32 out = rg_at(st.out, g);
+    rg_group_send<P, IX, RG_SEND_SPEC_LOADS != 0>(st, ins, g, out, max_entries, flags, it); // (unconditional: its loads ride with `out`)
 #pragma unroll
     for (int s = 0; s < P; s++) {
-        const u64 o = (u64)s * st.stride + g;
+        const IX o = (IX)s * (IX)st.stride + g;
         const bool snap = (it.snap >> s) & 1u;
         const u32 nk = snap ? (1u | (RG_SEND_SNAPSHOT << 16)) : (it.n[s] ? (it.n[s] | (RG_SEND_APPEND << 16)) : 0u);
-        oc.n[o] = nk; // every cell, every stage: 0 = nothing for this peer
-        if (nk) {
-            oc.prev[o] = it.prev[s];
-            oc.last[o] = it.last[s];
+        rg_at(oc.n, o) = nk; // every cell, every stage: 0 = nothing for this peer
+        // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
+        // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
+        if (RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0) != 0 : nk != 0) {
+            rg_at(oc.prev, o) = nk ? it.prev[s] : 0ULL;
+            rg_at(oc.last, o) = nk ? it.last[s] : 0ULL;
         }
     }
+}
+template <int P>
+static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
+                                 u32 flags, const RgSendCols &oc) {
+    if ((u64)P * st.stride * 8 <= 0xffffffffULL)
+        hipLaunchKernelGGL((k_send_dense<P, u32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
+    else
+        hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
 }
 
 // Compact list out of the columns, on request (rg_send_items / rg_send_items_ptr after a dense stage).
@@ -1652,14 +1670,14 @@ static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t 
     if (!list && !n_ptr && n == h->G) { // every group: work items into the peer-major columns, no list
         const dim3 grid(rg_grid(h->G, RG_BLOCK)), block(RG_BLOCK);
         switch (h->P) {
-        case 1: hipLaunchKernelGGL(k_send_dense<1>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        case 2: hipLaunchKernelGGL(k_send_dense<2>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        case 3: hipLaunchKernelGGL(k_send_dense<3>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        case 4: hipLaunchKernelGGL(k_send_dense<4>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        case 5: hipLaunchKernelGGL(k_send_dense<5>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        case 6: hipLaunchKernelGGL(k_send_dense<6>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        case 7: hipLaunchKernelGGL(k_send_dense<7>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
-        default: hipLaunchKernelGGL(k_send_dense<8>, grid, block, 0, h->stream, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 1: rg_launch_send_dense<1>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 2: rg_launch_send_dense<2>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 3: rg_launch_send_dense<3>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 4: rg_launch_send_dense<4>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 5: rg_launch_send_dense<5>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 6: rg_launch_send_dense<6>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        case 7: rg_launch_send_dense<7>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
+        default: rg_launch_send_dense<8>(h->stream, grid, block, h->st, h->ins, (u64)max_entries_per_msg, (u32)flags, h->send_cols); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "send stage: launch failed: %s", hipGetErrorString(e));

@@ -15,6 +15,9 @@
 #ifndef RG_SEND_EXP
 #define RG_SEND_EXP 0
 #endif
+#ifndef RG_SEND_WHOLE_LINES
+#define RG_SEND_WHOLE_LINES 1
+#endif
 
 struct RgIns {
     u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31)
@@ -86,10 +89,34 @@ RG_HD void rg_ins_add(const RgIns &ins, u64 base, u32 start, u32 &count, u64 &he
 }
 
 // One group of the send stage. `out` is the group's RG_OUT_* word of the tick that just ran.
-template <int P>
-RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u64 max_entries, u32 flags,
+// IX: index type of the column accesses (rg_common.h: rg_at); the ring is always addressed with 64 bits.
+// SPEC (the dense stage): the per-peer cells of ALL P slots are requested together with the group-level words, before
+// the result word says which peers are in the work set -- one memory round trip like the tick's instead of two, at the
+// price of the cells that turn out not to be needed (the leader's own slot; groups with nothing to do). After a dense
+// tick of a busy shard nearly every follower is in the work set (every commit advance broadcasts).
+template <int P, typename IX = u64, bool SPEC = false>
+RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags,
                          RgSendRegs<P> &it) {
-    const u32 cfg = st.cfg[g];
+    // everything indexed by the group alone is requested at once, before anything is decided: with the result word the
+    // caller loaded that is ONE memory round trip ahead of the per-peer cells (it used to be three: out, cfg, the rest)
+    const u32 cfg = rg_at(st.cfg, g);
+    const u64 row0 = rg_at(st.pflags, g);
+    const u64 hi = rg_at(st.hi, g);                     // last_index
+    const u64 first_index = rg_at(st.dummy_idx, g) + 1; // RaftLog::first_index (dummy entry = first_index - 1)
+    u32 meta_v[P];
+    u64 head_v[P], tail_v[P], next_v[P], prs_v[P], match_v[P];
+    if (SPEC) {
+#pragma unroll
+        for (int s = 0; s < P; s++) {
+            const IX o = (IX)s * (IX)st.stride + g;
+            meta_v[s] = rg_at(ins.meta, o);
+            head_v[s] = rg_at(ins.head, o);
+            tail_v[s] = rg_at(ins.tail, o);
+            next_v[s] = rg_at(st.next, o);
+            prs_v[s] = rg_at(st.prs, o);
+            match_v[s] = rg_at(st.match, o);
+        }
+    }
     const u32 present = RG_CFG_PRESENT(cfg), self = RG_CFG_SELF(cfg);
     // bcast_append: the leader appended entries (a proposal, raft.rs:2049-2053), or the commit index moved and
     // should_bcast_commit() (raft.rs:1745-1748, :2684-2686: !skip_bcast_commit || has_pending_conf())
@@ -97,7 +124,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
     const bool serve = !(flags & 0x80000000u);
     bool bcast = serve && (out & RG_OUT_APPENDED) != 0;
     if (serve && (out & RG_OUT_CHANGED))
-        bcast = bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((st.pflags[g] >> (8 * self)) & RG_PF_PENDING_CONF);
+        bcast = bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((row0 >> (8 * self)) & RG_PF_PENDING_CONF);
     const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
     it.snap = 0;
     it.count = 0;
@@ -109,30 +136,34 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
     work &= present & ~(1u << self);
     if (work == 0) return;
 
-    const u64 hi = st.hi[g];                    // last_index
-    const u64 first_index = st.dummy_idx[g] + 1; // RaftLog::first_index (dummy entry = first_index - 1)
-    const u64 row0 = st.pflags[g];
     u64 row = row0;
     // all column loads of the group are issued before any of the (dependent, scattered) ring accesses
-    u32 meta_v[P];
-    u64 head_v[P], tail_v[P], next_v[P], prs_v[P], match_v[P];
 #pragma unroll
     for (int s = 0; s < P; s++) {
+        if (SPEC) break;
         const bool w = (work >> s) & 1u;
-        const u64 o = (u64)s * st.stride + g;
+        const IX o = (IX)s * (IX)st.stride + g;
         const bool sends = w && (bcast || (((sa_bits | sm_bits) >> s) & 1u));
-        meta_v[s] = w ? ins.meta[o] : 0u;
-        head_v[s] = w ? ins.head[o] : 0ULL;
-        tail_v[s] = w ? ins.tail[o] : 0ULL;
-        next_v[s] = sends ? st.next[o] : 0ULL;
-        prs_v[s] = sends ? st.prs[o] : 0ULL;
-        match_v[s] = (w && ((fr_bits & sm_bits) >> s) & 1u) ? st.match[o] : 0ULL;
+        // (each destination is written once BEFORE its load is issued and not again: `x = w ? load : 0` made the
+        // compiler wait for slot s's loads -- a pending write to the same registers -- before issuing slot s+1's)
+        meta_v[s] = 0u;
+        head_v[s] = tail_v[s] = next_v[s] = prs_v[s] = match_v[s] = 0ULL;
+        if (w) {
+            meta_v[s] = rg_at(ins.meta, o);
+            head_v[s] = rg_at(ins.head, o);
+            tail_v[s] = rg_at(ins.tail, o);
+        }
+        if (sends) {
+            next_v[s] = rg_at(st.next, o);
+            prs_v[s] = rg_at(st.prs, o);
+        }
+        if (w && (((fr_bits & sm_bits) >> s) & 1u)) match_v[s] = rg_at(st.match, o);
     }
 #pragma unroll
     for (int s = 0; s < P; s++) {
         if (!((work >> s) & 1u)) continue;
-        const u64 o = (u64)s * st.stride + g;
-        const u64 base = (g * (u64)P + (u64)s) * ins.cap;
+        const IX o = (IX)s * (IX)st.stride + g;
+        const u64 base = ((u64)g * (u64)P + (u64)s) * ins.cap;
         u32 pb = (u32)(row >> (8 * s)) & 0xffu;
         const u32 state = pb & RG_PF_STATE_MASK;
         const u32 meta0 = meta_v[s];
@@ -159,6 +190,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
         if (sa || sm) {
             u64 next = next_v[s];
             const u64 next0 = next;
+            (void)next0;
             const u64 prs = prs_v[s];
             u32 n = 0;
             bool snap = false;
@@ -212,14 +244,18 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, u64 g, u32 out, u6
             }
             it.n[s] = n;
             if (n || snap) it.count++;
-            if (next != next0) st.next[o] = next;
+            if (RG_SEND_WHOLE_LINES || next != next0) rg_at(st.next, o) = next;
         }
         pb = (pb & ~RG_PF_INS_FULL) | ((state == RG_STATE_REPLICATE && count == ins.cap) ? RG_PF_INS_FULL : 0u);
         row = (row & ~(0xffULL << (8 * s))) | ((u64)pb << (8 * s));
         const u32 meta = start | (count << 16);
-        if (meta != meta0) ins.meta[o] = meta;
-        if (head != head0 && count) ins.head[o] = head;
-        if (tail != tail0 && count) ins.tail[o] = tail;
+        // RG_SEND_WHOLE_LINES: every cell of the work set is rewritten, changed or not -- whole 128-B lines instead of
+        // lane-masked partial ones, which the memory side has to read before it can merge them (the tick kernel's
+        // RG_OPT bit 1, same reason)
+        if (RG_SEND_WHOLE_LINES || meta != meta0) rg_at(ins.meta, o) = meta;
+        // (an empty window's two cells keep whatever they held: rewritten with the value just read)
+        if (RG_SEND_WHOLE_LINES || (head != head0 && count)) rg_at(ins.head, o) = count ? head : head0;
+        if (RG_SEND_WHOLE_LINES || (tail != tail0 && count)) rg_at(ins.tail, o) = count ? tail : tail0;
     }
-    if (row != row0) st.pflags[g] = row;
+    if (row != row0) rg_at(st.pflags, g) = row;
 }

@@ -13,18 +13,20 @@ import raft_rs_amd as rg  # noqa: E402
 G = int(os.environ.get("G", 1_000_000))
 P = int(os.environ.get("P", 5))
 K = 40
+W = int(os.environ.get("WARMUP", 20))  # untimed ticks (clock ramp, first-touch of the ring arena)
 torch.cuda.set_stream(torch.cuda.Stream())
 print(f"send stage after every tick, {G} groups x {P} peers, {K} timed ticks")
-for cap, max_entries in ((8, 0), (256, 0), (256, 4)):
+CONFIGS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("CONFIGS", "8:0,256:0,256:4").split(",")]  # cap:max_entries
+for cap, max_entries in CONFIGS:
     eng = rg.Engine(G, P, max_inflight=cap)
     eng.workload_init(rg.WL_MAJORITY)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)  # (an explicit stream: set below, before the loop)
     cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
     flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (K + 5))]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (K + W))]
     t_tick = t_send = 0.0
     items = 0
-    for t in range(K + 5):
+    for t in range(K + W):
         eng.workload_gen(rg.WL_MAJORITY, t, *[c.data_ptr() for c in cols], flags.data_ptr())
         flags &= 0xEF  # no RG_MF_SENT: the device sends
         a, b, c = ev[3 * t:3 * t + 3]
@@ -33,14 +35,16 @@ for cap, max_entries in ((8, 0), (256, 0), (256, 4)):
         b.record()
         eng.send_appends(max_entries)
         c.record()
-        if t == K + 4:
+        if t == K + W - 1:
             items = len(eng.send_items())
     torch.cuda.synchronize()
-    for t in range(5, K + 5):
+    ticks, sends = [], []
+    for t in range(W, K + W):
         a, b, c = ev[3 * t:3 * t + 3]
-        t_tick += a.elapsed_time(b)
-        t_send += b.elapsed_time(c)
-    t_tick, t_send = t_tick / K * 1e3, t_send / K * 1e3
+        ticks.append(a.elapsed_time(b))
+        sends.append(b.elapsed_time(c))
+    # medians: single ticks are disturbed by the generator's launches in between and by clock changes
+    t_tick, t_send = sorted(ticks)[K // 2] * 1e3, sorted(sends)[K // 2] * 1e3
     full = int((torch.from_numpy(eng.read_column(rg.COL.PFLAGS)) & 0x10).ne(0).sum())
     # The stage's own algorithmic bytes: per group out 4 + cfg 4 + last_index 8 + first_index 8 +
     # flag row 8 r + 8 w = 40; per peer in the work set (a send request, an Inflights effect, or a broadcast): window

@@ -7,7 +7,7 @@ O=$R/gpurun_out/pmc_$TAG
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"
+CMD=${PMC_CMD:-"python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"}
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $O/a -o a -- $CMD > /dev/null 2> $O/a.err
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d $O/b -o b -- $CMD > /dev/null 2> $O/b.err
 python - "$O" "$TAG" "$*" <<'PY' > $R/gpurun_out/pmc_$TAG.txt

@@ -8,7 +8,7 @@ O=$R/gpurun_out/tcc_$TAG
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"
+CMD=${PMC_CMD:-"python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"}
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- $CMD > /dev/null 2> $O/f.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- $CMD > /dev/null 2> $O/w.err
 python - "$O" "$TAG" "$*" <<'PY' > $R/gpurun_out/tcc_$TAG.txt
