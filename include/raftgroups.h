@@ -341,7 +341,8 @@ int rg_flush(rg_engine *h);
  * `while maybe_send_append(from, false)` loop. Each message sent applies Progress::update_state(last) (Replicate: next = last+1, ins.add(last); Probe: paused) in
  * place, so the host writes no RG_MF_SENT events in this mode. Messages are NOT built: the result is one work item
  * per peer that has something to send. `max_entries_per_msg` models Config::max_size_per_msg for equal-sized
- * entries (util::limit_size keeps at least one entry), 0 = NO_LIMIT. A peer whose entries are compacted away
+ * entries (util::limit_size keeps at least one entry), 0 = NO_LIMIT; with RG_SEND_BYTES it IS max_size_per_msg, in
+ * bytes, over the real entry sizes (below). A peer whose entries are compacted away
  * (next_idx < first_index = RG_COL_DUMMY_INDEX + 1) or that has a pending snapshot request yields
  * RG_SEND_SNAPSHOT (if recent_active, raft.rs:665-672; last_index then carries the requested snapshot index, 0 =
  * any); the host then fetches the snapshot and applies
@@ -358,10 +359,51 @@ typedef struct {
 } rg_send_item;
 #define RG_SEND_APPEND 1u
 #define RG_SEND_SNAPSHOT 2u
+#define RG_SEND_HOST 3u /* RG_SEND_BYTES only: the peer needs entries whose sizes have left the device's window
+                           (rg_log_sizes_enable): the host, which owns the log, runs maybe_send_append for it and reports
+                           what it sent with rg_update_state; prev_index = next_idx - 1, last_index = the leader's
+                           last_index, the Progress is untouched */
 #define RG_SEND_SKIP_BCAST_COMMIT 0x1u /* Config::skip_bcast_commit (src/config.rs:87): a commit advance is broadcast
                                           only by groups with a pending conf change -- should_bcast_commit(),
                                           src/raft.rs:2684-2686; RG_PF_PENDING_CONF on the leader's slot */
+#define RG_SEND_BYTES 0x2u /* the limit is Config::max_size_per_msg in BYTES (src/config.rs:58-63), applied as
+                              RaftLog::entries does: util::limit_size over Entry::compute_size() of every entry
+                              (src/util.rs:52-76; UINT64_MAX = NO_LIMIT, 0 = one entry per message). Needs the entry sizes
+                              on the device: rg_log_sizes_enable / rg_log_sizes_write. */
 int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
+
+/* ---- entry sizes for RG_SEND_BYTES (byte-accurate Config::max_size_per_msg) ----
+ * The send decision needs Entry::compute_size() of the entries it is about to attach (util::limit_size keeps the first
+ * entry and then as many as fit `max` bytes). The device keeps, per group, the CUMULATIVE size of its last `window` log
+ * entries (u32 [G][window], 4 * window bytes per group; window a power of two, 8..4096) -- what a leader replicating to
+ * live followers reads. The host writes one record per appended entry (any order, any batch; before the send stage that
+ * may send it): cum_bytes = the total size of the group's entries up to and including `index`, counted from wherever
+ * the host likes (only differences are used, modulo 2^32: a window's total has to stay below 4 GiB). Entries whose
+ * record has left the window (a follower more than window - 1 entries behind) are served by the host: RG_SEND_HOST.
+ * Checkpoints include the table. Asynchronous (engine stream). */
+typedef struct {
+    uint64_t group;
+    uint64_t index;     /* log index of the entry */
+    uint64_t cum_bytes; /* sum of Entry::compute_size() over the group's entries <= index */
+} rg_log_size;
+int rg_log_sizes_enable(rg_engine *h, uint32_t window);
+int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_t n);
+/* Synthetic sizes for the benchmark / tests: every group's window (last_index - window, last_index] is filled from
+ * size(group, index) = min_bytes + hash(seed, group, index) % (spread + 1) (rg_hash of BASELINE.md's generator). */
+int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes, uint32_t spread);
+
+/* The host sent MsgAppends itself (RG_SEND_HOST items; or a host that builds some messages on its own): apply
+ * Progress::update_state(last) (src/tracker/progress.rs:231-243) for each -- Replicate: next_idx = last + 1 and
+ * ins.add(last) on the device window; Probe: paused; Snapshot: RG_ERR_STATE is NOT raised (the reference panics), the
+ * record is ignored. Records are applied in array order; the records of one (group, slot) must be adjacent.
+ * Only for engines with device Inflights. Asynchronous. */
+typedef struct {
+    uint64_t group;
+    uint64_t last;  /* index of the last entry of the message */
+    uint32_t slot;
+    uint32_t reserved;
+} rg_sent_msg;
+int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n);
 /* rg_flush followed by rg_send_appends, and for small batches in the SAME host<->device round trip (the work items
  * come back with the tick's results; rg_send_items / rg_ingested_results then read host memory). */
 int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);

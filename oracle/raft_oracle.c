@@ -8,6 +8,7 @@
 #include "raft_oracle.h"
 
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -314,12 +315,18 @@ typedef struct {
     ro_run *runs;
     size_t n_runs;
     bool configured;
+    /* Entry::compute_size() of the entries [ent_first, ent_first + ent_n) -- what util::limit_size adds up
+     * (src/util.rs:52-76); only present when the caller models Config::max_size_per_msg in bytes */
+    uint32_t *ent_size;
+    uint64_t ent_first;
+    size_t ent_n, ent_cap;
 } ro_group;
 
 struct ro_cluster {
     size_t n;
     ro_group *g;
     bool own_inflights; /* SoA ticks use the Progress's own Inflights instead of the RG_MF_INS_FULL bit */
+    bool limit_bytes;   /* ro_maybe_send_append's limit is Config::max_size_per_msg in BYTES (ro_set_limit_bytes) */
 };
 
 static inline size_t fx_slot(uint64_t id) { /* FxHash: multiply by the Fx seed (src/lib.rs:602-604) */
@@ -366,6 +373,7 @@ static void group_clear(ro_group *gr) {
     for (size_t k = 0; k < RO_MAP_CAP; k++)
         if (gr->progress.keys[k]) ro_progress_destroy(&gr->progress.vals[k]);
     free(gr->runs);
+    free(gr->ent_size);
     memset(gr, 0, sizeof(*gr));
 }
 
@@ -967,6 +975,59 @@ static bool ro_decide_send_snapshot(const ro_progress *pr) {
     return pr->recent_active; /* :665-672 "ignore sending snapshot ... not recently active" */
 }
 
+void ro_set_limit_bytes(ro_cluster *c, bool on) { c->limit_bytes = on; }
+
+void ro_group_append_entry_sizes(ro_cluster *c, size_t g, uint64_t first_index, const uint32_t *sizes, size_t n) {
+    ro_group *gr = &c->g[g];
+    if (gr->ent_n == 0) gr->ent_first = first_index;
+    if (first_index < gr->ent_first || first_index > gr->ent_first + gr->ent_n) {
+        fprintf(stderr, "ro_group_append_entry_sizes: group %zu holds [%llu, %llu), got %llu\n", g,
+                (unsigned long long)gr->ent_first, (unsigned long long)(gr->ent_first + gr->ent_n),
+                (unsigned long long)first_index);
+        abort();
+    }
+    size_t at = (size_t)(first_index - gr->ent_first); /* overwriting a suffix = a truncated-and-rewritten log tail */
+    if (at + n > gr->ent_cap) {
+        size_t cap = gr->ent_cap ? gr->ent_cap : 64;
+        while (cap < at + n) cap *= 2;
+        gr->ent_size = (uint32_t *)realloc(gr->ent_size, cap * sizeof(uint32_t));
+        gr->ent_cap = cap;
+    }
+    memcpy(gr->ent_size + at, sizes, n * sizeof(uint32_t));
+    gr->ent_n = at + n;
+}
+
+static uint64_t ro_entry_size(const ro_group *gr, uint64_t index) {
+    if (index < gr->ent_first || index >= gr->ent_first + gr->ent_n) {
+        fprintf(stderr, "ro_entry_size: no size for entry %llu (have [%llu, %llu))\n", (unsigned long long)index,
+                (unsigned long long)gr->ent_first, (unsigned long long)(gr->ent_first + gr->ent_n));
+        abort();
+    }
+    return gr->ent_size[index - gr->ent_first];
+}
+
+/* util::limit_size (src/util.rs:52-76) over the entries [next, next + n): how many survive `max` bytes. Literal,
+ * including its `size == 0` test: the first entry is always kept -- and so is every entry that follows a prefix of
+ * zero-size entries (Entry::default().compute_size() == 0), whatever `max` says. RaftLog::slice applies it to the
+ * stable part first and to the whole again (raft_log.rs:583-608); a prefix rule, so one pass gives the same count. */
+static uint64_t ro_limit_size(const ro_group *gr, uint64_t next, uint64_t n, uint64_t max) {
+    if (n <= 1) return n;                 /* if entries.len() <= 1 { return; } */
+    if (max == UINT64_MAX) return n;      /* None | Some(NO_LIMIT) => return */
+    uint64_t size = 0, limit = 0;
+    for (uint64_t k = 0; k < n; k++) {    /* take_while */
+        uint64_t e = ro_entry_size(gr, next + k);
+        if (size == 0) {
+            size += e;
+            limit++;
+            continue;
+        }
+        size += e;
+        if (size <= max) limit++;
+        else break;
+    }
+    return limit;
+}
+
 bool ro_maybe_send_append(ro_cluster *c, size_t g, uint64_t to, bool allow_empty, uint64_t max_entries,
                           ro_send_msg *m) {
     ro_group *gr = &c->g[g];
@@ -992,7 +1053,8 @@ bool ro_maybe_send_append(ro_cluster *c, size_t g, uint64_t to, bool allow_empty
             ents_err = true;
         } else {
             n = gr->last_index - pr->next_idx + 1;
-            if (max_entries && n > max_entries) n = max_entries; /* util::limit_size */
+            if (c->limit_bytes) n = ro_limit_size(gr, pr->next_idx, n, max_entries); /* util::limit_size, in bytes */
+            else if (max_entries && n > max_entries) n = max_entries;                /* ... for equal-sized entries */
         }
     }
     if (!allow_empty && (ents_err || n == 0)) return false; /* :797-799 */

@@ -408,6 +408,7 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
     RgSendRegs<P> it;
     it.count = 0;
     it.snap = 0;
+    it.hostm = 0;
     if (active) {
         const u32 out = st.out[g];
         if (out) rg_group_send<P>(st, ins, g, out, max_entries, flags, it);
@@ -437,18 +438,71 @@ __global__ __launch_bounds__(RG_SEND_BLOCK) void k_send_appends(RgState st, RgIn
     u32 k = block_base + wave_tot[wave] + incl - it.count;
 #pragma unroll
     for (int s = 0; s < P; s++) {
-        const bool snap = (it.snap >> s) & 1u;
-        if (it.n[s] == 0 && !snap) continue;
+        const u32 nk = rg_send_nk<P>(it, s);
+        if (!nk) continue;
         rg_send_item r;
         r.group = g;
         r.prev_index = it.prev[s];
         r.last_index = it.last[s];
         r.slot = (u32)s;
-        r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
-        r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
+        r.n_msgs = (uint16_t)(nk & 0xffffu);
+        r.kind = (uint16_t)(nk >> 16);
         if (!(RG_SEND_EXP & 4)) items[k] = r;
         k++;
     }
+}
+
+// ---- entry sizes for RG_SEND_BYTES (include/raftgroups.h: rg_log_sizes_*) ----
+__global__ __launch_bounds__(256) void k_log_sizes_write(const rg_log_size *recs, u64 n, u64 G, u32 *esz, u32 w) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const rg_log_size r = recs[i];
+    if (r.group < G) esz[r.group * w + ((u32)r.index & (w - 1u))] = (u32)r.cum_bytes;
+}
+// synthetic sizes: the window (last_index - w, last_index] of every group, cumulative from its oldest entry
+__global__ __launch_bounds__(RG_BLOCK) void k_wl_sizes(const u64 *hi, u64 G, u32 *esz, u32 w, u64 seed, u32 min_bytes, u32 spread) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= G) return;
+    const u64 last = hi[g];
+    const u64 first = last >= w ? last - w + 1 : 1;
+    u32 acc = 0;
+    for (u64 idx = first; idx <= last; idx++) {
+        acc += min_bytes + (u32)(rg_hash(seed, 0x517eULL, g, idx) % ((u64)spread + 1));
+        esz[g * w + ((u32)idx & (w - 1u))] = acc;
+    }
+}
+// Progress::update_state(last) (src/tracker/progress.rs:231-243) for messages the HOST sent (rg_update_state). Lane i
+// applies the whole run of records of its (group, slot) if it holds the run's first record.
+__global__ __launch_bounds__(256) void k_update_state(RgState st, RgIns ins, const rg_sent_msg *m, u64 n, u32 P) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 g = m[i].group;
+    const u32 s = m[i].slot;
+    if (g >= st.G || s >= P) return;
+    if (i > 0 && m[i - 1].group == g && m[i - 1].slot == s) return;
+    const u64 o = (u64)s * st.stride + g, base = (g * (u64)P + s) * ins.cap;
+    u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + g * 8 + s;
+    u32 pb = *pfb;
+    const u32 state = pb & RG_PF_STATE_MASK;
+    if (state == RG_STATE_SNAPSHOT) return; // (the reference panics: nothing is sent to a peer in Snapshot)
+    if (state == RG_STATE_PROBE) {
+        *pfb = (u8)(pb | RG_PF_PAUSED);
+        return;
+    }
+    const u32 meta0 = ins.meta[o];
+    u32 start = meta0 & 0xffffu, count = meta0 >> 16;
+    u64 head = ins.head[o], tail = ins.tail[o], next = st.next[o];
+    for (u64 j = i; j < n && m[j].group == g && m[j].slot == s; j++) {
+        if (count == ins.cap) break; // Inflights::add on a full window panics in the reference (inflights.rs:66-68)
+        const u64 last = m[j].last;
+        next = last + 1; // optimistic_update
+        rg_ins_add(ins, base, start, count, head, tail, last);
+    }
+    st.next[o] = next;
+    ins.meta[o] = start | (count << 16);
+    ins.head[o] = head;
+    ins.tail[o] = tail;
+    *pfb = (u8)((pb & ~RG_PF_INS_FULL) | (count == ins.cap ? RG_PF_INS_FULL : 0u));
 }
 
 // The dense stage: every group of the shard, one lane each, work items into the peer-major columns (RgSendCols).
@@ -462,6 +516,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
     RgSendRegs<P> it;
     it.count = 0;
     it.snap = 0;
+    it.hostm = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
     const u32 out = rg_at(st.out, g);
@@ -469,8 +524,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
 #pragma unroll
     for (int s = 0; s < P; s++) {
         const IX o = (IX)s * (IX)st.stride + g;
-        const bool snap = (it.snap >> s) & 1u;
-        const u32 nk = snap ? (1u | (RG_SEND_SNAPSHOT << 16)) : (it.n[s] ? (it.n[s] | (RG_SEND_APPEND << 16)) : 0u);
+        const u32 nk = rg_send_nk<P>(it, s);
         rg_at(oc.n, o) = nk; // every cell, every stage: 0 = nothing for this peer
         // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
         // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
@@ -730,6 +784,9 @@ struct rg_engine {
     // send stage (rg_config.max_inflight > 0): Inflights rings, work items
     char *ins_arena;   // meta | head | tail | ring | items | counter
     char *ins_ckpt;    // checkpoint copy of meta | ring (lazy)
+    u32 *esz, *esz_ckpt; // entry sizes for RG_SEND_BYTES (rg_log_sizes_enable), u32 [G][esz_w]; checkpoint copy (lazy)
+    void *d_recs;      // staging for rg_log_sizes_write / rg_update_state records
+    size_t d_recs_cap;
     size_t ins_state_bytes;
     RgIns ins;
     rg_send_item *send_items;
@@ -909,6 +966,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->q_any_logterm = false;
     h->ins_arena = nullptr;
     h->ins_ckpt = nullptr;
+    h->esz = h->esz_ckpt = nullptr;
+    h->d_recs = nullptr;
+    h->d_recs_cap = 0;
+    h->ins.esz = nullptr;
+    h->ins.esz_w = 0;
     h->ins_state_bytes = 0;
     h->ins.meta = nullptr;
     h->ins.head = nullptr;
@@ -1032,6 +1094,9 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->ckpt) (void)hipFree(h->ckpt);
     if (h->ins_arena) (void)hipFree(h->ins_arena);
     if (h->ins_ckpt) (void)hipFree(h->ins_ckpt);
+    if (h->esz) (void)hipFree(h->esz);
+    if (h->esz_ckpt) (void)hipFree(h->esz_ckpt);
+    if (h->d_recs) (void)hipFree(h->d_recs);
     if (h->msg_arena) (void)hipFree(h->msg_arena);
     if (h->sparse_arena) (void)hipFree(h->sparse_arena);
     if (h->d_records) (void)hipFree(h->d_records);
@@ -1123,6 +1188,11 @@ extern "C" int rg_checkpoint(rg_engine *h) {
         RG_HIP(hipMemcpyAsync(h->ins_ckpt, h->ins_arena, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
         h->ckpt_send_ready = h->send_ready;
     }
+    if (h->esz) {
+        const size_t b = (size_t)h->G * h->ins.esz_w * 4;
+        if (!h->esz_ckpt) RG_HIP(hipMalloc(&h->esz_ckpt, b));
+        RG_HIP(hipMemcpyAsync(h->esz_ckpt, h->esz, b, hipMemcpyDeviceToDevice, h->stream));
+    }
     return RG_OK;
 }
 
@@ -1140,6 +1210,8 @@ extern "C" int rg_restore(rg_engine *h) {
         RG_HIP(hipMemcpyAsync(h->ins_arena, h->ins_ckpt, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
         h->send_ready = h->ckpt_send_ready; // RG_COL_OUT is part of the state: the tick's requests are back too
     }
+    if (h->esz && h->esz_ckpt)
+        RG_HIP(hipMemcpyAsync(h->esz, h->esz_ckpt, (size_t)h->G * h->ins.esz_w * 4, hipMemcpyDeviceToDevice, h->stream));
     return RG_OK;
 }
 
@@ -1711,7 +1783,9 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
     if (!h->ins_arena)
         return rg_fail(RG_ERR_STATE, "rg_send_appends: engine created with max_inflight = 0 (Inflights are the host's)");
     if (!h->send_ready) return rg_fail(RG_ERR_STATE, "rg_send_appends: no tick since the last send stage");
-    if (flags & ~RG_SEND_SKIP_BCAST_COMMIT) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: unknown flags %#x", flags);
+    if (flags & ~(RG_SEND_SKIP_BCAST_COMMIT | RG_SEND_BYTES)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: unknown flags %#x", flags);
+    if ((flags & RG_SEND_BYTES) && !h->esz)
+        return rg_fail(RG_ERR_STATE, "rg_send_appends: RG_SEND_BYTES needs the entry sizes (rg_log_sizes_enable)");
     RG_HIP(hipSetDevice(h->cfg.device));
     const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
     const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;
@@ -1719,6 +1793,86 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
     if (rc) return rc;
     h->send_ready = false;
     h->send_bound = n * h->P;
+    return RG_OK;
+}
+
+extern "C" int rg_log_sizes_enable(rg_engine *h, uint32_t window) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_enable: null engine");
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_log_sizes_enable: engine created with max_inflight = 0 (no send stage)");
+    if (window < 8 || window > 4096 || (window & (window - 1)))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_enable: window %u, a power of two in 8..4096", window);
+    if (h->esz) return rg_fail(RG_ERR_STATE, "rg_log_sizes_enable: already enabled (window %u)", h->ins.esz_w);
+    RG_HIP(hipSetDevice(h->cfg.device));
+    const size_t b = (size_t)h->G * window * 4;
+    hipError_t e = hipMalloc(&h->esz, b);
+    if (e != hipSuccess) {
+        h->esz = nullptr;
+        (void)hipGetLastError();
+        return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_log_sizes_enable: hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
+    }
+    RG_HIP(hipMemsetAsync(h->esz, 0, b, h->stream));
+    h->ins.esz = h->esz;
+    h->ins.esz_w = window;
+    return RG_OK;
+}
+
+// host records -> device staging buffer on the engine's stream (grown on demand; the copy is stream-ordered, the host
+// array may be reused once the call returns: pageable copies are staged by the runtime)
+static int rg_stage_records(rg_engine *h, const void *recs, size_t bytes) {
+    if (bytes > h->d_recs_cap) {
+        RG_HIP(hipStreamSynchronize(h->stream)); // (kernels reading the old buffer)
+        if (h->d_recs) (void)hipFree(h->d_recs);
+        h->d_recs = nullptr;
+        h->d_recs_cap = 0;
+        const size_t cap = bytes < 65536 ? 65536 : bytes + bytes / 2;
+        hipError_t e = hipMalloc(&h->d_recs, cap);
+        if (e != hipSuccess) {
+            h->d_recs = nullptr;
+            (void)hipGetLastError();
+            return rg_fail(RG_ERR_OUT_OF_MEMORY, "record staging: hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        }
+        h->d_recs_cap = cap;
+    }
+    RG_HIP(hipMemcpyAsync(h->d_recs, recs, bytes, hipMemcpyHostToDevice, h->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_t n) {
+    if (!h || (!recs && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_write: bad argument");
+    if (!h->esz) return rg_fail(RG_ERR_STATE, "rg_log_sizes_write: rg_log_sizes_enable first");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_stage_records(h, recs, (size_t)n * sizeof(rg_log_size));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_log_sizes_write, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, (const rg_log_size *)h->d_recs, (u64)n,
+                       h->G, h->esz, h->ins.esz_w);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_log_sizes_write: launch failed: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes, uint32_t spread) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_sizes: null engine");
+    if (!h->esz) return rg_fail(RG_ERR_STATE, "rg_workload_sizes: rg_log_sizes_enable first");
+    RG_HIP(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_wl_sizes, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, (const u64 *)h->st.hi, h->G, h->esz,
+                       h->ins.esz_w, (u64)seed, min_bytes, spread);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_sizes: launch failed: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n) {
+    if (!h || (!msgs && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_update_state: bad argument");
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_update_state: engine created with max_inflight = 0 (use RG_MF_SENT events)");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(h->cfg.device));
+    int rc = rg_stage_records(h, msgs, (size_t)n * sizeof(rg_sent_msg));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_update_state, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->ins, (const rg_sent_msg *)h->d_recs,
+                       (u64)n, h->P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_update_state: launch failed: %s", hipGetErrorString(e));
     return RG_OK;
 }
 
@@ -2395,7 +2549,9 @@ extern "C" int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush_send: null engine");
     if (!h->ins_arena)
         return rg_fail(RG_ERR_STATE, "rg_flush_send: engine created with max_inflight = 0 (Inflights are the host's)");
-    if (flags & ~RG_SEND_SKIP_BCAST_COMMIT) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush_send: unknown flags %#x", flags);
+    if (flags & ~(RG_SEND_SKIP_BCAST_COMMIT | RG_SEND_BYTES)) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush_send: unknown flags %#x", flags);
+    if ((flags & RG_SEND_BYTES) && !h->esz)
+        return rg_fail(RG_ERR_STATE, "rg_flush_send: RG_SEND_BYTES needs the entry sizes (rg_log_sizes_enable)");
     rg_send_req req;
     req.max_entries = max_entries_per_msg;
     req.flags = flags;

@@ -30,7 +30,33 @@ struct RgIns {
                // touched for the MIDDLE entries of windows of three and more.
     u64 *ring; // [(g * P + slot) * cap + i]: Inflights.buffer of that Progress, contiguous per cell
     u32 cap;   // Inflights::cap()
+    // Byte-accurate Config::max_size_per_msg (rg_log_sizes_enable; nullptr = off): per group a ring of the cumulative
+    // Entry::compute_size() of its last `esz_w` log entries, esz[g * esz_w + (index & (esz_w - 1))] = bytes of all
+    // entries up to and including `index`, modulo 2^32 (differences inside a window are exact: its total is < 4 GiB).
+    const u32 *esz;
+    u32 esz_w; // power of two
 };
+
+// util::limit_size (src/util.rs:52-76) over the entries [next, next + avail) of one group, from the cumulative sizes:
+// how many of them one MsgAppend of at most `max` bytes carries. C(m) = bytes of the first m entries. The reference
+// keeps entry k if the running size BEFORE it is 0 (so the first entry always, and any entry behind a prefix of
+// zero-size ones) or if the running size including it stays <= max; a prefix rule, so with m* = the largest m with
+// C(m*) <= max the count is m* -- plus one when C(m*) == 0. RaftLog::slice applies it to the stable part and to the
+// whole again (raft_log.rs:583-608): same count. Requires avail < esz_w (caller).
+RG_HD u64 rg_limit_size(const u32 *row, u32 mask, u64 next, u64 avail, u64 max) {
+    if (avail <= 1 || max == ~0ULL) return avail; // `entries.len() <= 1` / NO_LIMIT
+    if (max >= 0xffffffffULL) return avail;       // a window's total is below 4 GiB
+    const u32 base = row[(u32)(next - 1) & mask], mx = (u32)max;
+    if ((u32)(row[(u32)(next - 1 + avail) & mask] - base) <= mx) return avail; // everything fits: the common case
+    u64 lo = 0, hi = avail - 1;
+    while (lo < hi) {
+        const u64 mid = (lo + hi + 1) >> 1;
+        if ((u32)(row[(u32)(next - 1 + mid) & mask] - base) <= mx) lo = mid;
+        else hi = mid - 1;
+    }
+    const u64 n = ((u32)(row[(u32)(next - 1 + lo) & mask] - base) == 0) ? lo + 1 : lo;
+    return n < avail ? n : avail;
+}
 
 // Work items of a DENSE stage (every group walked): peer-major columns, one cell per (slot, group), so the stage
 // stores them like every other column -- coalesced, no compaction, no atomics, no workgroup barrier. A device-side
@@ -44,8 +70,15 @@ template <int P> struct RgSendRegs {
     u64 prev[P], last[P];
     u32 n[P];   // messages per slot, 0 = nothing to send
     u32 snap;   // bit s: slot s needs a snapshot instead (RG_SEND_SNAPSHOT)
+    u32 hostm;  // bit s: slot s is the host's to serve (RG_SEND_HOST: entry sizes outside the device's window)
     u32 count;  // items of this group
 };
+// The work item of slot s as the `n_msgs | kind << 16` word of the item columns (0 = nothing for this peer)
+template <int P> RG_HD u32 rg_send_nk(const RgSendRegs<P> &it, int s) {
+    if ((it.snap >> s) & 1u) return 1u | (RG_SEND_SNAPSHOT << 16);
+    if ((it.hostm >> s) & 1u) return 1u | (RG_SEND_HOST << 16);
+    return it.n[s] ? (it.n[s] | (RG_SEND_APPEND << 16)) : 0u;
+}
 
 // Inflights::free_to (inflights.rs:84-110) over (head, middle entries in the ring, tail)
 RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &head, u64 tail, u64 to) {
@@ -127,6 +160,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
         bcast = bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((row0 >> (8 * self)) & RG_PF_PENDING_CONF);
     const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
     it.snap = 0;
+    it.hostm = 0;
     it.count = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
@@ -193,7 +227,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             (void)next0;
             const u64 prs = prs_v[s];
             u32 n = 0;
-            bool snap = false;
+            bool snap = false, host = false;
             bool first = sa; // the first call is send_append (allow_empty) only if one was requested
             for (;;) {
                 const bool allow_empty = first;
@@ -211,7 +245,19 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                         if (compacted) {
                             if (allow_empty) snap = (pb & RG_PF_RECENT_ACTIVE) != 0; // else: `return false`
                         } else if (avail != 0 || allow_empty) {
-                            const u64 take = (max_entries && avail > max_entries) ? max_entries : avail;
+                            u64 take;
+                            if (flags & RG_SEND_BYTES) {
+                                // Config::max_size_per_msg in bytes: util::limit_size over the group's entry sizes. A peer
+                                // so far behind that the entries it needs have left the window is the host's to serve
+                                // (it owns the log): RG_SEND_HOST, Progress untouched, like a snapshot.
+                                if (avail > 1 && max_entries != ~0ULL && avail >= ins.esz_w) {
+                                    host = true;
+                                    break;
+                                }
+                                take = rg_limit_size(ins.esz + (u64)g * ins.esz_w, ins.esz_w - 1u, next, avail, max_entries);
+                            } else {
+                                take = (max_entries && avail > max_entries) ? max_entries : avail;
+                            }
                             if (n == 0) it.prev[s] = next - 1;
                             it.last[s] = next - 1 + take;
                             n++;
@@ -242,8 +288,13 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                 it.prev[s] = next - 1;
                 it.last[s] = prs; // the requested snapshot index (0 = any)
             }
+            if (host) { // (only ever the first send of a peer: the entries left shrink with every message)
+                it.hostm |= 1u << s;
+                it.prev[s] = next - 1;
+                it.last[s] = hi;
+            }
             it.n[s] = n;
-            if (n || snap) it.count++;
+            if (n || snap || host) it.count++;
             if (RG_SEND_WHOLE_LINES || next != next0) rg_at(st.next, o) = next;
         }
         pb = (pb & ~RG_PF_INS_FULL) | ((state == RG_STATE_REPLICATE && count == ins.cap) ? RG_PF_INS_FULL : 0u);

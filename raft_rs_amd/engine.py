@@ -146,8 +146,12 @@ class PublishStats(C.Structure):
 COMM_ID_BYTES = 128
 PUBLISH_FULL = 1
 
-SEND_APPEND, SEND_SNAPSHOT = 1, 2
+SEND_APPEND, SEND_SNAPSHOT, SEND_HOST = 1, 2, 3
 SEND_SKIP_BCAST_COMMIT = 1
+SEND_BYTES = 2
+NO_LIMIT = (1 << 64) - 1
+LOG_SIZE_DTYPE = np.dtype([("group", "<u8"), ("index", "<u8"), ("cum_bytes", "<u8")])
+SENT_MSG_DTYPE = np.dtype([("group", "<u8"), ("last", "<u8"), ("slot", "<u4"), ("reserved", "<u4")])
 SEND_ITEM_DTYPE = np.dtype([("group", "<u8"), ("prev_index", "<u8"), ("last_index", "<u8"), ("slot", "<u4"),
                             ("n_msgs", "<u2"), ("kind", "<u2")])
 assert SEND_ITEM_DTYPE.itemsize == 32
@@ -191,6 +195,10 @@ SYMBOLS = {
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_appends": (_i, [_vp, _u64, C.c_uint32]),
     "rg_flush_send": (_i, [_vp, _u64, C.c_uint32]),
+    "rg_log_sizes_enable": (_i, [_vp, C.c_uint32]),
+    "rg_log_sizes_write": (_i, [_vp, _vp, _u64]),
+    "rg_workload_sizes": (_i, [_vp, _u64, C.c_uint32, C.c_uint32]),
+    "rg_update_state": (_i, [_vp, _vp, _u64]),
     "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_items_ptr": (_vp, [_vp]),
     "rg_send_columns": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -457,13 +465,37 @@ class Engine:
         self._check(self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t)))
 
     # ---- send stage (device Inflights + maybe_send_append decisions) ------------------------------
-    def send_appends(self, max_entries_per_msg=0, skip_bcast_commit=False):
-        """Run the send stage for the tick that just ran (asynchronous)."""
-        self._check(self.L.rg_send_appends(self.h, max_entries_per_msg, SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0))
+    def send_appends(self, max_entries_per_msg=0, skip_bcast_commit=False, max_bytes=None):
+        """Run the send stage for the tick that just ran (asynchronous). max_bytes: Config::max_size_per_msg in bytes over
+        the entry sizes on the device (RG_SEND_BYTES; NO_LIMIT = no limit) instead of the entries-per-message model."""
+        flags = SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0
+        if max_bytes is not None:
+            max_entries_per_msg, flags = max_bytes, flags | SEND_BYTES
+        self._check(self.L.rg_send_appends(self.h, max_entries_per_msg, flags))
 
-    def flush_send(self, max_entries_per_msg=0, skip_bcast_commit=False):
+    def flush_send(self, max_entries_per_msg=0, skip_bcast_commit=False, max_bytes=None):
         """flush() + send_appends(); one host<->device round trip for small batches."""
-        self._check(self.L.rg_flush_send(self.h, max_entries_per_msg, SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0))
+        flags = SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0
+        if max_bytes is not None:
+            max_entries_per_msg, flags = max_bytes, flags | SEND_BYTES
+        self._check(self.L.rg_flush_send(self.h, max_entries_per_msg, flags))
+
+    def log_sizes_enable(self, window):
+        """Byte-accurate max_size_per_msg: keep the cumulative sizes of every group's last `window` entries on the device."""
+        self._check(self.L.rg_log_sizes_enable(self.h, window))
+
+    def log_sizes_write(self, recs):
+        """recs: LOG_SIZE_DTYPE array, one record per appended entry (cumulative bytes up to and including it)."""
+        recs = np.ascontiguousarray(recs, dtype=LOG_SIZE_DTYPE)
+        self._check(self.L.rg_log_sizes_write(self.h, recs.ctypes.data, len(recs)))
+
+    def workload_sizes(self, seed, min_bytes, spread):
+        self._check(self.L.rg_workload_sizes(self.h, seed, min_bytes, spread))
+
+    def update_state(self, msgs):
+        """msgs: SENT_MSG_DTYPE array of MsgAppends the HOST sent (RG_SEND_HOST items): Progress::update_state(last)."""
+        msgs = np.ascontiguousarray(msgs, dtype=SENT_MSG_DTYPE)
+        self._check(self.L.rg_update_state(self.h, msgs.ctypes.data, len(msgs)))
 
     def send_items(self):
         """Work items of the last send stage as a SEND_ITEM_DTYPE array (order unspecified)."""

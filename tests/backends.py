@@ -14,7 +14,7 @@ class OracleLeader:
     name = "oracle"
 
     def __init__(self, self_id, term, voters, outgoing=(), learners=(), log=(), committed=0, dummy=(0, 0),
-                 next_idx=1, max_inflight=256, max_entries=0):
+                 next_idx=1, max_inflight=256, max_entries=0, max_bytes=None, entry_bytes=None):
         self.cl = O.Cluster(1).config(0, self_id, term, voters, outgoing, learners, next_idx=next_idx,
                                       max_inflight=max_inflight)
         self.cl.set_log(0, list(log), committed=committed, dummy=dummy)
@@ -22,6 +22,19 @@ class OracleLeader:
         self._voters, self._self_id = list(voters), self_id
         self.max_inflight, self.max_entries = max_inflight, max_entries
         self.skip_bcast_commit = False
+        # Config::max_size_per_msg in bytes: entry_bytes(index) = Entry::compute_size() of that entry
+        self.entry_bytes = entry_bytes
+        if max_bytes is not None:
+            self.max_entries = max_bytes
+            self.cl.set_limit_bytes(True)
+            self._sized = dummy[0]
+            self._feed_sizes()
+
+    def _feed_sizes(self):
+        last = self.cl.last_index(0)
+        if last > self._sized:
+            self.cl.append_entry_sizes(0, self._sized + 1, [self.entry_bytes(i) for i in range(self._sized + 1, last + 1)])
+            self._sized = last
 
     # ---- flow control: the Progress's own Inflights + the send decisions (test_raft_flow_control.rs) ----
     def _send(self, out_word):
@@ -109,6 +122,8 @@ class OracleLeader:
 
     def append(self, n):
         O.lib().ro_group_append(self.cl.h, 0, n)
+        if self.entry_bytes:
+            self._feed_sizes()
 
     def become_leader(self, term):
         """become_candidate + become_leader (raft.rs:1113-1202): Raft::reset(term), the leader's own Progress to
@@ -150,7 +165,7 @@ class EngineLeader:
     name = "engine"
 
     def __init__(self, self_id, term, voters, outgoing=(), learners=(), log=(), committed=0, dummy=(0, 0),
-                 next_idx=1, n_slots=None, max_inflight=0, max_entries=0):
+                 next_idx=1, n_slots=None, max_inflight=0, max_entries=0, max_bytes=None, entry_bytes=None):
         import raft_rs_amd as rg
         self.rg = rg
         ids = sorted(set(voters) | set(outgoing) | set(learners))
@@ -200,6 +215,21 @@ class EngineLeader:
         st["cfg"][0] = rg.cfg_make(**self.cfg)
         self.eng.load_state(st)
         self.msgs = rg.MsgBuffers(1, self.P, self.eng.stride)
+        # Config::max_size_per_msg in bytes (RG_SEND_BYTES): the host writes the cumulative size of every entry it appends
+        self.max_bytes, self.entry_bytes = max_bytes, entry_bytes
+        if max_bytes is not None:
+            self.eng.log_sizes_enable(64)
+            self._cum = {dummy[0]: 0}
+            self._write_sizes(hi)
+
+    def _write_sizes(self, last):
+        new = [i for i in range(max(self._cum) + 1, last + 1)]
+        for i in new:
+            self._cum[i] = self._cum[i - 1] + self.entry_bytes(i)
+        recs = np.zeros(len(new) + 1, dtype=self.rg.engine.LOG_SIZE_DTYPE)
+        for k, i in enumerate([min(self._cum)] + new):  # (the base of the sums rides along: harmless)
+            recs[k] = (0, i, self._cum[i])
+        self.eng.log_sizes_write(recs)
 
     def _push_cfg(self):
         self.eng.set_config(0, self.rg.cfg_make(**self.cfg))
@@ -272,7 +302,9 @@ class EngineLeader:
     # ---- flow control: Inflights on the device + the send stage (needs max_inflight > 0) ----
     def _send(self):
         """rg_send_appends for the tick that just ran; the per-peer items expanded to single messages."""
-        self.eng.send_appends(self.max_entries, skip_bcast_commit=self.skip_bcast_commit)
+        if self.max_bytes is not None:
+            self._write_sizes(int(self.eng.read_column(self.rg.COL.TERM_HI)[0]))
+        self.eng.send_appends(self.max_entries, skip_bcast_commit=self.skip_bcast_commit, max_bytes=self.max_bytes)
         msgs = []
         for it in self.eng.send_items():
             to, kind, prev, last, n = int(it["slot"]) + 1, int(it["kind"]), int(it["prev_index"]), int(it["last_index"]), int(it["n_msgs"])
@@ -281,7 +313,17 @@ class EngineLeader:
                 continue
             E = self.max_entries
             for k in range(n):
-                cnt = (last - prev) if not E else min(E, last - prev)
+                if self.max_bytes is not None:
+                    # what the host does when it builds the messages of an item: util::limit_size over its own entries
+                    cnt, size = 0, 0
+                    for i in range(prev + 1, last + 1):
+                        if size == 0 or size + self.entry_bytes(i) <= self.max_bytes:
+                            size += self.entry_bytes(i)
+                            cnt += 1
+                        else:
+                            break
+                else:
+                    cnt = (last - prev) if not E else min(E, last - prev)
                 msgs.append((to, kind, prev, cnt))
                 prev += cnt
             assert prev == last

@@ -129,13 +129,13 @@ static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, u32 
         RgSendRegs<P> it;
         rg_group_send<P>(st, ins, g, out, max_entries, flags, it);
         for (int s = 0; s < P; s++) {
-            const bool snap = (it.snap >> s) & 1u;
-            if (it.n[s] == 0 && !snap) continue;
+            const u32 nk = rg_send_nk<P>(it, s);
+            if (!nk) continue;
             if (k < cap) {
                 rg_send_item r;
                 r.group = g; r.prev_index = it.prev[s]; r.last_index = it.last[s]; r.slot = (u32)s;
-                r.n_msgs = (uint16_t)(snap ? 1u : it.n[s]);
-                r.kind = (uint16_t)(snap ? RG_SEND_SNAPSHOT : RG_SEND_APPEND);
+                r.n_msgs = (uint16_t)(nk & 0xffffu);
+                r.kind = (uint16_t)(nk >> 16);
                 items[k] = r;
             }
             k++;
@@ -146,10 +146,11 @@ static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, u32 
 
 extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long stride, void *const *state, u32 *meta,
                                    u64 *head, u64 *tail, u64 *ring, unsigned cap, unsigned long max_entries, unsigned flags,
-                                   rg_send_item *items, unsigned long items_cap) {
+                                   rg_send_item *items, unsigned long items_cap, const u32 *esz, unsigned esz_w) {
     const RgState st = make_state(state, G, stride);
     RgIns ins;
     ins.meta = meta; ins.head = head; ins.tail = tail; ins.ring = ring; ins.cap = cap;
+    ins.esz = esz; ins.esz_w = esz_w; // entry sizes for RG_SEND_BYTES (NULL / 0 = off)
     long n = -1;
     RG_DISPATCH_P(P, n = host_send<N>(st, ins, max_entries, flags, items, items_cap));
     return n;

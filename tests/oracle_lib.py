@@ -65,7 +65,7 @@ class SendMsg(C.Structure):
 
 SEND_MSG_DTYPE = np.dtype([("group", "<u8"), ("to", "<u8"), ("index", "<u8"), ("n_entries", "<u8"), ("kind", "<u4"),
                            ("pad", "<u4")])
-SEND_APPEND, SEND_SNAPSHOT = 1, 2
+SEND_APPEND, SEND_SNAPSHOT, SEND_HOST = 1, 2, 3
 
 
 class SoaState(C.Structure):
@@ -140,6 +140,8 @@ def lib():
         "ro_set_own_inflights": (None, [vp, C.c_bool]),
         "ro_send_stage_soa": (sz, [vp, vp, u64, C.c_bool, vp, sz, sz, sz]),
         "ro_group_set_pending_conf": (None, [vp, sz, C.c_bool]),
+        "ro_set_limit_bytes": (None, [vp, C.c_bool]),
+        "ro_group_append_entry_sizes": (None, [vp, sz, u64, vp, sz]),
         "ro_ins_contents": (sz, [vp, sz, u64, C.POINTER(u64), sz]),
     }
     for name, (res, args) in sig.items():
@@ -240,6 +242,14 @@ class Cluster:
 
     def set_own_inflights(self, on=True):
         self.L.ro_set_own_inflights(self.h, on)
+
+    def set_limit_bytes(self, on=True):
+        """max_entries of maybe_send_append / send_stage_soa is Config::max_size_per_msg in bytes (literal limit_size)."""
+        self.L.ro_set_limit_bytes(self.h, on)
+
+    def append_entry_sizes(self, g, first_index, sizes):
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        self.L.ro_group_append_entry_sizes(self.h, g, first_index, sizes.ctypes.data, len(sizes))
 
     def maybe_send_append(self, g, to, allow_empty, max_entries=0):
         m = SendMsg()

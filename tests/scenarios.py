@@ -505,6 +505,28 @@ def scenario_progress_flow_control(B):
     assert ld.inflights(2) == [10, 11] and ld.progress(2)["next"] == 12
 
 
+def scenario_progress_flow_control_bytes(B):
+    """test_raft.rs:369-435 test_progress_flow_control with its literal configuration: max_size_per_msg = 2048 BYTES
+    over the real entry sizes (util::limit_size) instead of the two-entries-per-message stand-in: a proposal's entry
+    {term 1, index < 128, 1000-byte data} is 2 + 2 + (1 + 2 + 1000) = 1007 bytes of protobuf, the leader's empty entry
+    {term 1, index 1} is 4 -- so the first message carries the noop AND the first proposal (1011 bytes), later ones
+    two proposals (2014 <= 2048 < 3021)."""
+    size = lambda idx: 4 if idx == 1 else 1007
+    ld = B(1, 1, [1, 2], log=[(1, 1)], committed=0, next_idx=1, max_inflight=3, max_bytes=2048, entry_bytes=size)
+    ld.set_progress(1, match=0, next=2, state=REPLICATE)
+    ld.set_progress(2, match=0, next=1, state=PROBE, paused=False)
+    ms = []
+    for _ in range(10):
+        ms += ld.propose()
+    assert ms == [(2, 1, 0, 2)], "one MsgAppend in Probe: the noop and the first proposal"
+    ms = ld.ack(2, 2)
+    assert ms == [(2, 1, 2, 2), (2, 1, 4, 2), (2, 1, 6, 2)], ms
+    assert ld.ins_full(2) and ld.inflights(2) == [4, 6, 8]
+    ms = ld.ack(2, 8)
+    assert ms == [(2, 1, 8, 2), (2, 1, 10, 1)], ms
+    assert ld.inflights(2) == [10, 11] and ld.progress(2)["next"] == 12
+
+
 def scenario_msg_append_response_wait_reset(B):
     """test_raft.rs:1484-1529 test_msg_append_response_wait_reset: an ack releases a peer from the probe wait;
     a proposal is broadcast only to peers that are not waiting."""
@@ -612,7 +634,7 @@ def scenario_leader_start_replication(B):
     assert ld.committed() == li
 
 
-FLOW = [scenario_leader_start_replication, scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+FLOW = [scenario_leader_start_replication, scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_progress_flow_control_bytes, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,

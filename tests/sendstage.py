@@ -80,3 +80,71 @@ def mark_pending_conf(rng, st, frac=0.15):
     self_slot = ((st["cfg"] >> 16) & 7).astype(np.int64)
     pick = np.nonzero(rng.random(G) < frac)[0]
     st["pflags"][pick, self_slot[pick]] |= 0x20
+
+
+# ---- byte-accurate Config::max_size_per_msg (RG_SEND_BYTES) ------------------------------------------------
+def entry_sizes(rng, G, n_index, zero_frac=0.1, hi=700):
+    """Entry::compute_size() of entry `i` of group g -> sizes[g, i] (index 0 = no entry, size 0); a tenth of the entries are
+    empty (Entry::default(), the case util::limit_size's `size == 0` test special-cases). Returns (sizes u32, cum u64)."""
+    sizes = rng.integers(1, hi, size=(G, n_index), dtype=np.uint32)
+    sizes[rng.random((G, n_index)) < zero_frac] = 0
+    sizes[:, 0] = 0
+    return sizes, np.cumsum(sizes.astype(np.uint64), axis=1)
+
+
+def fill_size_window(esz, cum, last_index):
+    """What the host keeps on the device: the cumulative sizes of (last_index - W, last_index] of every group."""
+    G, W = esz.shape
+    g = np.arange(G)
+    for k in range(W):
+        idx = last_index.astype(np.int64) - k
+        ok = idx >= 0
+        esz[g[ok], idx[ok] & (W - 1)] = (cum[g[ok], idx[ok]] & 0xffffffff).astype(np.uint32)
+
+
+def split_host_items(engine_items, oracle_msgs):
+    """RG_SEND_HOST items (the peer needs entries outside the device's size window): the engine left the Progress alone and
+    the host serves the peer. Returns (engine items without them, oracle messages without those peers, {(g, slot):
+    [last index of every message the reference sent to that peer]})."""
+    host = {(int(it["group"]), int(it["slot"])): it for it in engine_items if int(it["kind"]) == O.SEND_HOST}
+    served = {k: [] for k in host}
+    keep = np.ones(len(oracle_msgs), dtype=bool)
+    for i, m in enumerate(oracle_msgs):
+        key = (int(m["group"]), int(m["to"]) - 1)
+        if key in host:
+            assert int(m["kind"]) == O.SEND_APPEND, (key, m)
+            if not served[key]:
+                assert int(m["index"]) == int(host[key]["prev_index"]), (key, m, host[key])
+            served[key].append(int(m["index"]) + int(m["n_entries"]))
+            keep[i] = False
+    for k, v in served.items():
+        assert v, ("the reference sent nothing to a peer the engine handed to the host", k)
+    rest = engine_items[[int(it["kind"]) != O.SEND_HOST for it in engine_items]] if len(engine_items) else engine_items
+    return rest, oracle_msgs[keep], served
+
+
+def host_update_state(st, meta, head, tail, ring, cap, g, p, lasts):
+    """Progress::update_state(last) for messages the host sent -- what rg_update_state does on the device, over the
+    numpy copies the host_check tests use (Replicate: next = last + 1, ins.add(last); Probe: paused)."""
+    state = int(st["pflags"][g, p]) & 3
+    if state == O.PROBE:
+        st["pflags"][g, p] |= 0x4
+        return
+    assert state == O.REPLICATE
+    m = int(meta[p, g])
+    start, count = m & 0xffff, m >> 16
+    for last in lasts:
+        if count == cap:
+            break
+        st["next"][p, g] = last + 1
+        if count == 0:
+            head[p, g] = last
+        elif count >= 2:
+            ring[g, p, (start + count - 1) % cap] = tail[p, g]
+        tail[p, g] = last
+        count += 1
+    meta[p, g] = start | (count << 16)
+    st["pflags"][g, p] = (int(st["pflags"][g, p]) & ~PF_INS_FULL) | (PF_INS_FULL if count == cap else 0)
+    if count:  # the logical view rg_read_inflights gives: oldest / newest entry from the head / tail columns
+        ring[g, p, start] = head[p, g]
+        ring[g, p, (start + count - 1) % cap] = tail[p, g]

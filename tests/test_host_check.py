@@ -356,15 +356,16 @@ def host_send():
     fn = C.CDLL(LIB).rg_host_check_send
     fn.restype = C.c_long
     fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
-                   C.c_ulong, C.c_uint, C.c_void_p, C.c_ulong]
+                   C.c_ulong, C.c_uint, C.c_void_p, C.c_ulong, C.c_void_p, C.c_uint]
 
-    def send(st, out, meta, head, ring, cap, max_entries, flags=0):
+    def send(st, out, meta, head, ring, cap, max_entries, flags=0, esz=None):
         """meta/ring as rg_read_inflights reports them; `head` = (head, tail), the engine-internal columns of the
         oldest / newest entry of every window."""
         head, tail = head
         items = np.zeros(st["n_groups"] * st["n_slots"], dtype=SEND_ITEM_DTYPE)
         n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), meta.ctypes.data, head.ctypes.data,
-               tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items))
+               tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items),
+               None if esz is None else esz.ctypes.data, 0 if esz is None else esz.shape[1])
         assert 0 <= n <= len(items)
         # what rg_read_inflights does: the oldest and the newest entry of a window live in the head / tail columns
         G, P = st["n_groups"], st["n_slots"]
@@ -442,6 +443,66 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
             assert seen["full"] > 0, seen
         if max_entries in (1, 2) and cap > 1:
             assert seen["multi"] > 0, seen
+
+
+@pytest.mark.parametrize("n_slots,cap,window,max_bytes", [(3, 4, 8, 900), (5, 256, 64, 1500), (5, 3, 16, 0), (7, 8, 32, 2**32 + 5),
+                                                         (5, 16, 64, O.U64_MAX), (8, 5, 8, 300)])
+def test_send_stage_byte_limit_on_host_matches_oracle(host_tick, host_send, n_slots, cap, window, max_bytes):
+    """Config::max_size_per_msg in BYTES (RG_SEND_BYTES): rg_limit_size over the device's window of cumulative entry sizes
+    against util::limit_size restated literally in the oracle, entry sizes random with a tenth of them zero; peers that
+    need entries outside the window come back as RG_SEND_HOST and are served the way rg_update_state does."""
+    rng = np.random.default_rng(9300 + 31 * n_slots + cap + window)
+    G, ticks = 1200, 12
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, term=6)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    cl.set_own_inflights(True)
+    cl.set_limit_bytes(True)
+    n_index = int(st["term_hi"].max()) + 64 * ticks + 64
+    sizes, cum = sendstage.entry_sizes(rng, G, n_index)
+    for g in range(G):
+        cl.append_entry_sizes(g, 1, sizes[g, 1:])
+    eng_st = copy_state(st)
+    meta = np.zeros((n_slots, st["stride"]), dtype=np.uint32)
+    head = (np.zeros((n_slots, st["stride"]), dtype=np.uint64), np.zeros((n_slots, st["stride"]), dtype=np.uint64))
+    ring = np.zeros((G, n_slots, cap), dtype=np.uint64)
+    esz = np.zeros((G, window), dtype=np.uint32)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    seen = {"items": 0, "multi": 0, "host": 0, "limited": 0}
+    for t in range(ticks):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
+        sendstage.prepare_msgs(msgs)
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        assert int(eng_st["term_hi"].max()) < n_index
+        sendstage.fill_size_window(esz, cum, eng_st["term_hi"])
+        items = host_send(eng_st, out, meta, head, ring, cap, max_bytes, 2, esz=esz)  # RG_SEND_BYTES
+        omsgs = cl.send_stage_soa(gout, max_bytes)
+        items, omsgs_dev, served = sendstage.split_host_items(items, omsgs)
+        got = sendstage.compare_items(items, omsgs_dev)
+        for (g, p), lasts in served.items():
+            sendstage.host_update_state(eng_st, meta, head[0], head[1], ring, cap, g, p, lasts)
+        apply_snapshots(rng, got, cl, eng_st, meta)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        sendstage.compare_rings(cl, meta, ring, st, cap)
+        seen["items"] += len(got)
+        seen["multi"] += sum(1 for v in got.values() if v[3] > 1)
+        seen["host"] += len(served)
+        seen["limited"] += sum(1 for m in omsgs if 0 < int(m["n_entries"]))
+    assert seen["items"] > 100, seen
+    if window <= 16:
+        assert seen["host"] > 0, seen
+    if max_bytes < 2000 and cap > 1:
+        assert seen["multi"] > 0, seen
 
 
 # ---- property tests (hypothesis) of the quorum arithmetic over the FULL u64 range --------------------------

@@ -373,3 +373,160 @@ def test_dense_stage_work_item_columns_equal_the_compact_list(rg):
         eng.send_columns()
     assert e.value.code == ERR["STATE"]
     eng.close()
+
+
+# ---- byte-accurate Config::max_size_per_msg (RG_SEND_BYTES) ------------------------------------------------
+def size_records(rg, cum, lo, hi):
+    """One rg_log_size record per entry in (lo[g], hi[g]] of every group: what a host writes when its leaders append."""
+    n = (hi - lo).astype(np.int64)
+    g = np.repeat(np.arange(len(lo), dtype=np.uint64), n)
+    first = np.repeat(lo.astype(np.int64) + 1, n)
+    off = np.arange(int(n.sum()), dtype=np.int64) - np.repeat(np.cumsum(n) - n, n)
+    recs = np.zeros(len(g), dtype=rg.engine.LOG_SIZE_DTYPE)
+    recs["group"], recs["index"] = g, (first + off).astype(np.uint64)
+    recs["cum_bytes"] = cum[g.astype(np.int64), first + off]
+    return recs
+
+
+@pytest.mark.parametrize("n_slots,cap,window,max_bytes", [(3, 4, 8, 900), (5, 256, 64, 1500), (5, 3, 16, 0),
+                                                         (7, 8, 32, 2**32 + 5), (5, 16, 64, O.U64_MAX)])
+def test_send_stage_byte_limit_matches_oracle(rg, n_slots, cap, window, max_bytes):
+    """rg_send_appends(RG_SEND_BYTES): util::limit_size over the entry sizes the host wrote to the device
+    (rg_log_sizes_write) against the oracle's literal restatement; RG_SEND_HOST peers served through rg_update_state."""
+    rng = np.random.default_rng(7900 + 31 * n_slots + cap + window)
+    G = 5000 + 7
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, term=6)
+    eng = rg.Engine(G, n_slots, max_inflight=cap)
+    eng.load_state(st)
+    eng.log_sizes_enable(window)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    cl.set_own_inflights(True)
+    cl.set_limit_bytes(True)
+    ticks = 8
+    n_index = int(st["term_hi"].max()) + 64 * ticks + 64
+    sizes, cum = sendstage.entry_sizes(rng, G, n_index)
+    for g in range(G):
+        cl.append_entry_sizes(g, 1, sizes[g, 1:])
+    # the log as it stands: every entry up to last_index (index 0 = the base of the cumulative sums)
+    written = st["term_hi"].copy()
+    eng.log_sizes_write(size_records(rg, cum, np.maximum(written.astype(np.int64) - window, -1) , written.astype(np.int64)))
+    msgs = O.alloc_msgs(G, n_slots)
+    mb = rg.MsgBuffers(G, n_slots, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    seen = {"items": 0, "multi": 0, "host": 0}
+    for t in range(ticks):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
+        sendstage.prepare_msgs(msgs)
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+            getattr(mb, k)[...] = msgs[k]
+        eng.tick(mb)
+        cl.tick_soa(msgs, gout)
+        _, out = eng.results()
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        cl.store_soa(st)  # (last_index after the tick's appends)
+        hi = st["term_hi"].astype(np.int64)
+        assert int(hi.max()) < n_index
+        eng.log_sizes_write(size_records(rg, cum, written.astype(np.int64), hi))
+        written = st["term_hi"].copy()
+        eng.send_appends(max_bytes=max_bytes)
+        items, omsgs, served = sendstage.split_host_items(eng.send_items(), cl.send_stage_soa(gout, max_bytes))
+        got = sendstage.compare_items(items, omsgs)
+        if served:
+            sent = np.zeros(sum(len(v) for v in served.values()), dtype=rg.engine.SENT_MSG_DTYPE)
+            i = 0
+            for (g, p), lasts in served.items():
+                for last in lasts:
+                    sent[i] = (g, last, p, 0)
+                    i += 1
+            eng.update_state(sent)
+        apply_snapshots(rg, eng, cl, st, got)
+        check(rg, eng, cl, st, cap, f"bytes P={n_slots} cap={cap} W={window} tick {t}")
+        seen["items"] += len(got)
+        seen["multi"] += sum(1 for v in got.values() if v[3] > 1)
+        seen["host"] += len(served)
+    assert seen["items"] > 1000, seen
+    if window <= 16:
+        assert seen["host"] > 0, seen
+    if max_bytes < 2000 and cap > 1:
+        assert seen["multi"] > 0, seen
+    eng.close()
+
+
+def test_workload_sizes_and_dense_byte_stage(rg):
+    """rg_workload_sizes (the benchmark's synthetic entry sizes) is what its formula says -- checked through the dense
+    byte-limited stage against the oracle fed with the same sizes -- and RG_SEND_BYTES needs the table."""
+    G, P, cap, window, seed = 30011, 5, 8, 64, 0x5eed
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.workload_init(rg.WL_MAJORITY)
+    with pytest.raises(rg.EngineError):
+        eng.send_appends(max_bytes=100)
+    eng.log_sizes_enable(window)
+    with pytest.raises(rg.EngineError):
+        eng.log_sizes_enable(window)
+    st = eng.read_state()
+    for col in (rg.COL.RUN_FIRST, rg.COL.RUN_TERM, rg.COL.DUMMY_INDEX, rg.COL.DUMMY_TERM, rg.COL.CUR_TERM):
+        st[rg.COL.NAMES[col]] = eng.read_column(col)  # the log as the generator left it: nothing compacted
+    cl = O.Cluster(G)
+    cl.load_soa(st, max_inflight=cap)
+    cl.set_own_inflights(True)
+    cl.set_limit_bytes(True)
+
+    def splitmix(x):
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+    def sizes_of(g, first, n):  # min_bytes 40, spread 500
+        idx = np.arange(first, first + n, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h = splitmix(np.uint64(seed) ^ (np.uint64(0x517e) << np.uint64(40)) ^ (np.uint64(g) << np.uint64(3)) ^ idx)
+        return (40 + (h % np.uint64(501))).astype(np.uint32)
+
+    import torch
+    cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+    flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
+    msgs = O.alloc_msgs(G, P)
+    gout = np.zeros(G, dtype=np.uint32)
+    fed = np.zeros(G, dtype=np.int64)  # entries the oracle has sizes for, per group
+    for t in range(4):
+        eng.workload_gen(rg.WL_MAJORITY, t, *[c.data_ptr() for c in cols], flags.data_ptr())
+        flags &= 0xEF  # no RG_MF_SENT: the device sends
+        for k, c in zip(("m_index", "m_commit", "m_hint", "m_rs"), cols):
+            msgs[k][...] = c.cpu().numpy().view(np.uint64)[:, :msgs[k].shape[1]]
+        msgs["m_flags"][...] = flags.cpu().numpy()
+        eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        cl.tick_soa(msgs, gout)
+        _, out = eng.results()
+        bad = np.nonzero(out != gout)[0]
+        assert bad.size == 0, (t, bad.size, bad[:4], [hex(x) for x in out[bad[:4]]], [hex(x) for x in gout[bad[:4]]],
+                               msgs["m_flags"][bad[:2]], st["pflags"][bad[:2]])
+        eng.workload_sizes(seed, 40, 500)
+        cl.store_soa(st)
+        hi = st["term_hi"].astype(np.int64)
+        for g in range(G):
+            first = max(1, int(hi[g]) - 4 * window) if fed[g] == 0 else int(fed[g]) + 1  # (followers lag < 40 entries)
+            if fed[g] == 0:
+                cl.append_entry_sizes(g, first, sizes_of(g, first, int(hi[g]) - first + 1))
+            elif int(hi[g]) >= first:
+                cl.append_entry_sizes(g, first, sizes_of(g, first, int(hi[g]) - first + 1))
+            fed[g] = hi[g]
+        eng.send_appends(max_bytes=700)
+        items, omsgs, served = sendstage.split_host_items(eng.send_items(), cl.send_stage_soa(gout, 700))
+        assert not served  # every follower of this stream is within the window
+        try:
+            got = sendstage.compare_items(items, omsgs)
+        except AssertionError as e:
+            g = e.args[0][0][0]
+            raise AssertionError((t, e.args[0], "engine items", [tuple(i) for i in items[items["group"] == g]], "oracle msgs",
+                                  [tuple(m) for m in omsgs[omsgs["group"] == g]], "out", hex(gout[g]), "hi", int(hi[g]),
+                                  "next", st["next"][:, g], "match", st["match"][:, g], "pflags", st["pflags"][g],
+                                  "fed", int(fed[g])))
+        assert sum(1 for v in got.values() if v[3] > 1) > 100  # 700 bytes split most broadcasts into several messages
+        check(rg, eng, cl, st, cap, f"workload sizes tick {t}")
+    eng.close()

@@ -16,33 +16,41 @@ K = 40
 W = int(os.environ.get("WARMUP", 20))  # untimed ticks (clock ramp, first-touch of the ring arena)
 torch.cuda.set_stream(torch.cuda.Stream())
 print(f"send stage after every tick, {G} groups x {P} peers, {K} timed ticks")
-CONFIGS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("CONFIGS", "8:0,256:0,256:4").split(",")]  # cap:max_entries
-for cap, max_entries in CONFIGS:
+# cap:max_entries[:max_bytes] -- a third field switches to RG_SEND_BYTES (byte-accurate max_size_per_msg over synthetic
+# entry sizes of 40..540 bytes kept in a 64-entry window per group)
+CONFIGS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("CONFIGS", "8:0,256:0,256:4,256:0:700").split(",")]
+for cfg_ in CONFIGS:
+    cap, max_entries, max_bytes = cfg_[0], cfg_[1], (cfg_[2] if len(cfg_) > 2 else None)
     eng = rg.Engine(G, P, max_inflight=cap)
+    if max_bytes is not None:
+        eng.log_sizes_enable(64)
     eng.workload_init(rg.WL_MAJORITY)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)  # (an explicit stream: set below, before the loop)
     cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
     flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * (K + W))]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * (K + W))]
     t_tick = t_send = 0.0
     items = 0
     for t in range(K + W):
         eng.workload_gen(rg.WL_MAJORITY, t, *[c.data_ptr() for c in cols], flags.data_ptr())
         flags &= 0xEF  # no RG_MF_SENT: the device sends
-        a, b, c = ev[3 * t:3 * t + 3]
+        a, b, b2, c = ev[4 * t:4 * t + 4]
         a.record()
         eng.tick_device(*[c_.data_ptr() for c_ in cols], flags.data_ptr())
         b.record()
-        eng.send_appends(max_entries)
+        if max_bytes is not None:
+            eng.workload_sizes(0x5eed, 40, 500)  # the sizes of the entries this tick appended (not part of the stage)
+        b2.record()
+        eng.send_appends(max_entries, max_bytes=max_bytes)
         c.record()
         if t == K + W - 1:
             items = len(eng.send_items())
     torch.cuda.synchronize()
     ticks, sends = [], []
     for t in range(W, K + W):
-        a, b, c = ev[3 * t:3 * t + 3]
+        a, b, b2, c = ev[4 * t:4 * t + 4]
         ticks.append(a.elapsed_time(b))
-        sends.append(b.elapsed_time(c))
+        sends.append(b2.elapsed_time(c))
     # medians: single ticks are disturbed by the generator's launches in between and by clock changes
     t_tick, t_send = sorted(ticks)[K // 2] * 1e3, sorted(sends)[K // 2] * 1e3
     full = int((torch.from_numpy(eng.read_column(rg.COL.PFLAGS)) & 0x10).ne(0).sum())
@@ -61,7 +69,8 @@ for cap, max_entries in CONFIGS:
     n_work = int(sum(((work >> p) & 1).sum() for p in range(8)))
     nbytes = 40 * G + 72 * n_work + 4 * P * G + 16 * items  # work items as columns: a 4-B cell per peer + 16 B per item
     gbs = nbytes / (t_send * 1e-6) / 1e9
-    print(f"  cap {cap:3d} max_entries {max_entries}: tick {t_tick:7.1f} us  send stage {t_send:7.1f} us  "
+    lim = f"max_entries {max_entries}" if max_bytes is None else f"max_bytes {max_bytes}"
+    print(f"  cap {cap:3d} {lim}: tick {t_tick:7.1f} us  send stage {t_send:7.1f} us  "
           f"-> {G / (t_tick + t_send):7.1f} M group-evals/s incl. sends; {items} work items in the last stage, "
           f"{full} full windows; stage byte model {nbytes / 1e6:.0f} MB ({nbytes / G:.0f} B/group) -> {gbs:.0f} GB/s = "
           f"{gbs / 8000:.3f} of 8 TB/s")
