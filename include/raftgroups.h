@@ -423,6 +423,20 @@ uint64_t rg_inflights_bytes(const rg_engine *h, int ring);
 int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring); /* either may be NULL */
 int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring); /* both required */
 
+/* ---- resident small-batch path ("mailbox") ----
+ * What one RawNode::step -> ready() costs a host is the round trip of a SMALL flush, and most of that is the HIP runtime:
+ * one launch, one synchronisation, one wake-up (~15 of the ~21 us). With the mailbox on, ONE workgroup stays resident on
+ * the device and serves small flushes (rg_flush / rg_ingest_tick with <= 256 records that follow another sparse tick)
+ * out of pinned host memory: the host writes the records and a request word and spins on the answer word -- no launch, no
+ * stream synchronisation. Same results as the launch path (it runs the same code). The workgroup leaves when any other
+ * entry point needs the engine's stream (automatically), when it has been idle for idle_timeout_us (0 = 2000), or after
+ * 200 ms, and is relaunched by the next small flush. Not with device Inflights or commit publication (those flushes take
+ * the launch path). The caller's thread spins while it waits: meant for a latency-bound host loop. */
+int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us);
+int rg_mailbox_stop(rg_engine *h);
+/* Flushes the resident workgroup has answered so far / how often it was (re)launched (either may be NULL). */
+int rg_mailbox_stats(const rg_engine *h, uint64_t *flushes_served, uint64_t *launches);
+
 /* ---- sparse path: wire-order records -> slot matrix -> tick over the touched groups only ----
  * For realistic traffic (a small fraction of the groups has events in a tick) the dense sweep of rg_tick
  * wastes bandwidth. rg_ingest scatters array-of-structs records (what a transport thread produces from

@@ -55,6 +55,18 @@ static int rg_fail(int code, const char *fmt, ...) {
                            "%s failed: %s", #expr, hipGetErrorString(e__));                        \
     } while (0)
 
+struct rg_engine;
+static int rg_mailbox_quiesce(rg_engine *h);
+// Every entry point that puts work on the engine's stream starts here: select the device and, if the resident mailbox
+// kernel is on the stream (rg_mailbox_start), tell it to leave -- stream order would make the call wait for it anyway
+// (until its idle timeout), this makes the wait a few microseconds.
+#define RG_ENTER(h)                                                                                \
+    do {                                                                                           \
+        RG_HIP(hipSetDevice((h)->cfg.device));                                                     \
+        int rc__ = rg_mailbox_quiesce(h);                                                          \
+        if (rc__) return rc__;                                                                     \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // kernels: Raft::maybe_commit for all groups without messages, and maximal_committed_index
 // ------------------------------------------------------------------------------------------------
@@ -787,6 +799,13 @@ struct rg_engine {
     u32 *esz, *esz_ckpt; // entry sizes for RG_SEND_BYTES (rg_log_sizes_enable), u32 [G][esz_w]; checkpoint copy (lazy)
     void *d_recs;      // staging for rg_log_sizes_write / rg_update_state records
     size_t d_recs_cap;
+    // resident small-batch path (rg_mailbox_start): request / answer block in pinned host memory, whether the feature is
+    // on, whether the host has launched an instance it has not seen leave, the last request number
+    RgMbox *mbox;
+    bool mbox_on, mbox_running;
+    u32 mbox_seq;
+    u64 mbox_idle_ticks;
+    u64 mbox_served, mbox_launches; // flushes the resident workgroup answered / times it was (re)launched
     size_t ins_state_bytes;
     RgIns ins;
     rg_send_item *send_items;
@@ -969,6 +988,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->esz = h->esz_ckpt = nullptr;
     h->d_recs = nullptr;
     h->d_recs_cap = 0;
+    h->mbox = nullptr;
+    h->mbox_on = h->mbox_running = false;
+    h->mbox_seq = 0;
+    h->mbox_idle_ticks = 0;
+    h->mbox_served = h->mbox_launches = 0;
     h->ins.esz = nullptr;
     h->ins.esz_w = 0;
     h->ins_state_bytes = 0;
@@ -1088,7 +1112,9 @@ extern "C" int rg_comm_destroy(rg_engine *h);
 extern "C" void rg_destroy(rg_engine *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
+    (void)rg_mailbox_quiesce(h);
     (void)hipStreamSynchronize(h->stream);
+    if (h->mbox) (void)hipHostFree(h->mbox);
     if (h->pub) (void)rg_comm_destroy(h);
     if (h->arena) (void)hipFree(h->arena);
     if (h->ckpt) (void)hipFree(h->ckpt);
@@ -1124,7 +1150,7 @@ extern "C" int rg_set_stream(rg_engine *h, void *hip_stream) {
 
 extern "C" int rg_sync(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_sync: null engine");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
 }
@@ -1144,7 +1170,7 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
                                (unsigned long long)g, x, h->P);
         }
     }
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemcpyAsync(rg_col(h, c), src, bytes, hipMemcpyHostToDevice, h->stream));
     if (c == RG_COL_PFLAGS && h->ins_arena) // the FULL bit is the engine's: re-derive it from the windows
         hipLaunchKernelGGL(k_fix_ins_full, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
@@ -1166,7 +1192,7 @@ extern "C" int rg_read_column(rg_engine *h, int c, void *dst, uint64_t bytes) {
     if (bytes != rg_column_bytes(h, c))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_read_column(%d): %llu bytes given, %llu expected", c,
                        (unsigned long long)bytes, (unsigned long long)rg_column_bytes(h, c));
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemcpyAsync(dst, rg_col(h, c), bytes, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
@@ -1179,7 +1205,7 @@ extern "C" void *rg_column_ptr(rg_engine *h, int c) {
 
 extern "C" int rg_checkpoint(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_checkpoint: null engine");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     if (!h->ckpt) RG_HIP(hipMalloc(&h->ckpt, h->state_bytes));
     RG_HIP(hipMemcpyAsync(h->ckpt, h->arena, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
     h->ckpt_any_group_commit = h->any_group_commit;
@@ -1199,7 +1225,7 @@ extern "C" int rg_checkpoint(rg_engine *h) {
 extern "C" int rg_restore(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_restore: null engine");
     if (!h->ckpt) return rg_fail(RG_ERR_STATE, "rg_restore: no checkpoint taken");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemcpyAsync(h->arena, h->ckpt, h->state_bytes, hipMemcpyDeviceToDevice, h->stream));
     h->host_res_valid = false;
     if (h->pub) h->pub->local_lost = true; // the published advances no longer describe this commit column
@@ -1220,7 +1246,7 @@ static unsigned rg_grid(u64 n, unsigned per_block) { return (unsigned)((n + per_
 extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n) {
     if (!h || (!cells && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_write_cells: bad argument");
     if (n == 0) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     if (n > h->d_cells_cap) { // engine-owned staging, grown geometrically (this call sits between ticks)
         if (h->d_cells) {
             RG_HIP(hipStreamSynchronize(h->stream));
@@ -1243,7 +1269,7 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
 extern "C" int rg_read_groups(rg_engine *h, const uint64_t *groups, uint64_t n, rg_group_status *host_out) {
     if (!h || (n && (!groups || !host_out))) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_groups: bad argument");
     if (n == 0) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     char *d = nullptr; // [n x u64 group ids | n x rg_group_status]
     const size_t ids_b = rg_align(n * 8);
     RG_HIP(hipMalloc(&d, ids_b + n * sizeof(rg_group_status)));
@@ -1268,7 +1294,7 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
     if (RG_CFG_SELF(cfg_word) >= h->P || (RG_CFG_PRESENT(cfg_word) >> h->P) || (RG_CFG_INCOMING(cfg_word) >> h->P) ||
         (RG_CFG_OUTGOING(cfg_word) >> h->P) || RG_CFG_TRANSFEREE(cfg_word) > h->P)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_set_config: cfg word %#x names a slot >= %u", cfg_word, h->P);
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemcpyAsync(h->st.cfg + group, &cfg_word, 4, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     if (cfg_word & RG_CFG_GROUP_COMMIT) h->any_group_commit = true; // (stays set: the GC kernel is a superset)
@@ -1325,7 +1351,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
 extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
     if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device: m_index, m_commit and m_flags are required");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RgMsgs ms;
     ms.mi = (const u64 *)m->m_index;
     ms.mc = (const u64 *)m->m_commit;
@@ -1352,7 +1378,7 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
     if (h->pub)
         return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: not available while commit publication is active "
                                      "(rg_comm_init): the per-tick advance of a fused launch is not recorded");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RgFused fm;
     memset(&fm, 0, sizeof(fm));
     for (u32 t = 0; t < n_ticks; t++) {
@@ -1407,7 +1433,7 @@ static int rg_ensure_msg_arena(rg_engine *h) {
 extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
     if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick: m_index, m_commit and m_flags are required");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_ensure_msg_arena(h);
     if (rc) return rc;
     const size_t colb = (size_t)h->P * h->stride * 8;
@@ -1484,7 +1510,7 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     if (!h || (!records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest: bad argument");
     if (n_duplicates) *n_duplicates = 0;
     if (n == 0) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     if (n > h->d_records_cap) {
@@ -1514,7 +1540,7 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
 extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, uint64_t n) {
     if (!h || (!dev_records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest_device: bad argument");
     if (n == 0) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream,
@@ -1529,7 +1555,7 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
     if (!h || !n_duplicates) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingested_duplicates: bad argument");
     *n_duplicates = 0;
     if (!h->sparse_arena) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     u32 dup = 0;
     RG_HIP(hipMemcpyAsync(&dup, h->counters + 1, 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
@@ -1619,7 +1645,7 @@ static int rg_sparse_finish(rg_engine *h, u64 n_groups) {
 extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_ingested: null engine");
     if (n_groups) *n_groups = 0;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     const u64 upper = h->ingested_upper < h->G ? h->ingested_upper : h->G;
@@ -1649,7 +1675,7 @@ extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *com
         if (out) memcpy(out, h->host_res_out.data(), k * 4);
         return RG_OK;
     }
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     if (groups) RG_HIP(hipMemcpyAsync(groups, h->res_list, k * 8, hipMemcpyDeviceToHost, h->stream));
     if (commit) RG_HIP(hipMemcpyAsync(commit, h->res_commit, k * 8, hipMemcpyDeviceToHost, h->stream));
     if (out) RG_HIP(hipMemcpyAsync(out, h->res_out, k * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1695,7 +1721,7 @@ template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *
 
 extern "C" int rg_recompute(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_recompute: null engine");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_settle_send(h);
     if (rc) return rc;
     rc = rg_recompute_impl<true>(h, nullptr, nullptr);
@@ -1710,7 +1736,7 @@ extern "C" int rg_recompute(rg_engine *h) {
 
 extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint8_t *host_gc) {
     if (!h || !host_mci) return rg_fail(RG_ERR_INVALID_ARG, "rg_maximal_committed_index: bad argument");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     u64 *d_mci = nullptr;
     u8 *d_gc = nullptr;
     RG_HIP(hipMalloc(&d_mci, h->G * 8));
@@ -1786,7 +1812,7 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
     if (flags & ~(RG_SEND_SKIP_BCAST_COMMIT | RG_SEND_BYTES)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: unknown flags %#x", flags);
     if ((flags & RG_SEND_BYTES) && !h->esz)
         return rg_fail(RG_ERR_STATE, "rg_send_appends: RG_SEND_BYTES needs the entry sizes (rg_log_sizes_enable)");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
     const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;
     int rc = rg_send_enqueue(h, max_entries_per_msg, flags, list, n, nullptr);
@@ -1802,7 +1828,7 @@ extern "C" int rg_log_sizes_enable(rg_engine *h, uint32_t window) {
     if (window < 8 || window > 4096 || (window & (window - 1)))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_enable: window %u, a power of two in 8..4096", window);
     if (h->esz) return rg_fail(RG_ERR_STATE, "rg_log_sizes_enable: already enabled (window %u)", h->ins.esz_w);
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     const size_t b = (size_t)h->G * window * 4;
     hipError_t e = hipMalloc(&h->esz, b);
     if (e != hipSuccess) {
@@ -1841,7 +1867,7 @@ extern "C" int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_
     if (!h || (!recs && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_write: bad argument");
     if (!h->esz) return rg_fail(RG_ERR_STATE, "rg_log_sizes_write: rg_log_sizes_enable first");
     if (n == 0) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_stage_records(h, recs, (size_t)n * sizeof(rg_log_size));
     if (rc) return rc;
     hipLaunchKernelGGL(k_log_sizes_write, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, (const rg_log_size *)h->d_recs, (u64)n,
@@ -1854,7 +1880,7 @@ extern "C" int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_
 extern "C" int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes, uint32_t spread) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_sizes: null engine");
     if (!h->esz) return rg_fail(RG_ERR_STATE, "rg_workload_sizes: rg_log_sizes_enable first");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     hipLaunchKernelGGL(k_wl_sizes, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, (const u64 *)h->st.hi, h->G, h->esz,
                        h->ins.esz_w, (u64)seed, min_bytes, spread);
     hipError_t e = hipGetLastError();
@@ -1866,7 +1892,7 @@ extern "C" int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n
     if (!h || (!msgs && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_update_state: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_update_state: engine created with max_inflight = 0 (use RG_MF_SENT events)");
     if (n == 0) return RG_OK;
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_stage_records(h, msgs, (size_t)n * sizeof(rg_sent_msg));
     if (rc) return rc;
     hipLaunchKernelGGL(k_update_state, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->ins, (const rg_sent_msg *)h->d_recs,
@@ -1891,7 +1917,7 @@ static int rg_send_materialize(rg_engine *h) {
 extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n) {
     if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     {
         int mrc = rg_send_materialize(h);
         if (mrc) return mrc;
@@ -1958,7 +1984,7 @@ extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
 extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_inflights: null engine");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_read_inflights: engine created with max_inflight = 0");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     const u64 cells = (u64)h->P * h->stride;
     std::vector<u32> meta_tmp;
     std::vector<u64> head, tail;
@@ -2009,7 +2035,7 @@ extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const 
                                                        "increasing, oldest first", (unsigned long long)g, p);
             tail[o] = cell[(start + count - 1) % h->ins.cap];
         }
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemcpyAsync(h->ins.meta, host_meta, cells * 4, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.head, head.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.tail, tail.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
@@ -2022,7 +2048,7 @@ extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const 
 
 extern "C" int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb, uint64_t *host_hb) {
     if (!h || (!dev_hb && !host_hb)) return rg_fail(RG_ERR_INVALID_ARG, "rg_heartbeat_commits: no destination");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     u64 *tmp = nullptr;
     u64 *dst = (u64 *)dev_hb;
     const size_t bytes = (size_t)h->P * h->stride * 8;
@@ -2047,7 +2073,7 @@ extern "C" int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb, uint64_t *ho
 extern "C" int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_results: null engine");
     if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_results: no tick has run yet");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     if (host_commit) RG_HIP(hipMemcpyAsync(host_commit, h->st.commit, h->G * 8, hipMemcpyDeviceToHost, h->stream));
     if (host_out) RG_HIP(hipMemcpyAsync(host_out, h->st.out, h->G * 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
@@ -2057,7 +2083,7 @@ extern "C" int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_ou
 extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_result_counts: null engine");
     if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_result_counts: no tick has run yet");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
     const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
     hipLaunchKernelGGL(k_count_out, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u32 *)h->st.out, h->G, h->d_counts);
@@ -2071,7 +2097,7 @@ extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_f
 
 extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t counts[5]) {
     if (!h || !d_m_flags || !counts) return rg_fail(RG_ERR_INVALID_ARG, "rg_msg_stats: bad argument");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RG_HIP(hipMemsetAsync(h->d_counts, 0, 40, h->stream));
     const unsigned grid = rg_grid(h->G, RG_BLOCK) < 1024 ? rg_grid(h->G, RG_BLOCK) : 1024;
     hipLaunchKernelGGL(k_msg_stats, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u64 *)d_m_flags,
@@ -2086,7 +2112,7 @@ extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t cou
 // ------------------------------------------------------------------------------------------------
 extern "C" int rg_vote_result(rg_engine *h, const uint8_t *yes, const uint8_t *no, uint8_t *result) {
     if (!h || !yes || !no || !result) return rg_fail(RG_ERR_INVALID_ARG, "rg_vote_result: bad argument");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     u8 *d = reinterpret_cast<u8 *>(h->d_scratch); // 8*stride bytes: yes | no | result
     RG_HIP(hipMemcpyAsync(d, yes, h->G, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(d + h->stride, no, h->G, hipMemcpyHostToDevice, h->stream));
@@ -2101,7 +2127,7 @@ extern "C" int rg_tally_votes(rg_engine *h, const uint8_t *yes, const uint8_t *n
                               uint8_t *result) {
     if (!h || !yes || !no || !granted || !rejected || !result)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tally_votes: bad argument");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     u8 *d = reinterpret_cast<u8 *>(h->d_scratch); // 8*stride bytes: yes | no | result | granted | rejected
     RG_HIP(hipMemcpyAsync(d, yes, h->G, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(d + h->stride, no, h->G, hipMemcpyHostToDevice, h->stream));
@@ -2116,7 +2142,7 @@ extern "C" int rg_tally_votes(rg_engine *h, const uint8_t *yes, const uint8_t *n
 
 extern "C" int rg_quorum_recently_active(rg_engine *h, uint8_t *result) {
     if (!h || !result) return rg_fail(RG_ERR_INVALID_ARG, "rg_quorum_recently_active: bad argument");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     u8 *d = reinterpret_cast<u8 *>(h->d_scratch);
     hipLaunchKernelGGL(k_quorum_active, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, d);
     RG_HIP(hipMemcpyAsync(result, d, h->G, hipMemcpyDeviceToHost, h->stream));
@@ -2304,9 +2330,10 @@ static int rg_sparse_threecall(rg_engine *h, const rg_wire_msg *recs, u64 n, u32
     return rc;
 }
 
+static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served);
 static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out,
                                const rg_send_req *send = nullptr) {
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_HIP(hipSetDevice(h->cfg.device)); // (not RG_ENTER: this is the one path the resident mailbox kernel serves)
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     if (recs && n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, recs, n, dup_out, send);
@@ -2349,6 +2376,26 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         }
         if (n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, h->pin_records, n, dup_out, send);
     }
+    // the resident mailbox kernel, when it is on: no launch, no synchronisation (rg_mailbox_flush says whether it took it)
+    bool served = false;
+    if (h->mbox_on && !send) {
+        rc = rg_mailbox_flush(h, n, any_logterm, &served);
+        if (rc) return rc;
+    }
+    if (!served) {
+        rc = rg_mailbox_quiesce(h); // this flush goes through launches on the stream
+        if (rc) return rc;
+    }
+    u32 n_groups = 0, dup = 0;
+    u64 upper = 0;
+    bool fetch_items = false;
+    if (served) {
+        h->out_is_dense = false; // (what rg_sparse_enqueue records)
+        h->tick_launches++;
+        rg_ctr_flip(h);
+        n_groups = reinterpret_cast<const u32 *>(h->pin_packed)[0];
+        dup = reinterpret_cast<const u32 *>(h->pin_packed)[1];
+    } else {
     if (n > h->d_records_cap) {
         if (h->d_records) {
             RG_HIP(hipStreamSynchronize(h->stream));
@@ -2361,7 +2408,7 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         h->d_records_cap = cap;
     }
     const u64 upper_all = h->ingested_upper + n; // device ingests of this window count too
-    const u64 upper = upper_all < h->G ? upper_all : h->G;
+    upper = upper_all < h->G ? upper_all : h->G;
     if (upper > h->packed_cap) {
         if (h->d_packed) {
             RG_HIP(hipStreamSynchronize(h->stream));
@@ -2418,7 +2465,7 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     if (rc) return rc;
     // the send stage rides along: it walks the gathered list, whose length is still only on the device
     const u64 item_bound = upper * h->P;
-    const bool fetch_items = send && upper && item_bound <= RG_SEND_SPEC;
+    fetch_items = send && upper && item_bound <= RG_SEND_SPEC;
     if (send && upper) {
         rc = rg_send_enqueue(h, send->max_entries, send->flags, h->res_list, upper, h->counters);
         if (rc) return rc;
@@ -2431,7 +2478,6 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
                                   h->stream));
         }
     }
-    u32 n_groups = 0, dup = 0;
     if (upper) {
         if (!zero_copy)
             RG_HIP(hipMemcpyAsync(h->pin_packed, h->d_packed, RG_PACKED_HDR + upper * sizeof(rg_res_rec), hipMemcpyDeviceToHost,
@@ -2441,6 +2487,7 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         n_groups = reinterpret_cast<const u32 *>(h->pin_packed)[0];
         dup = reinterpret_cast<const u32 *>(h->pin_packed)[1];
     }
+    } // (!served)
     rc = rg_sparse_finish(h, n_groups);
     if (rc) return rc;
     if (send) {
@@ -2468,6 +2515,137 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         h->host_res_out[i] = rec[i].out;
     }
     h->host_res_valid = true;
+    return RG_OK;
+}
+
+// ---- the resident small-batch path (rg_mailbox_start; kernel: k_mailbox in rg_tick_kernels.h) ----
+#define RG_MBOX_TICKS_PER_US 100ull /* wall_clock64(): constant 100 MHz */
+#define RG_MBOX_MAX_US 200000ull    /* one launch never stays longer than this, whatever the host does */
+
+static int rg_mailbox_quiesce(rg_engine *h) {
+    if (!h->mbox_running) return RG_OK;
+    __atomic_store_n(&h->mbox->stop, 1u, __ATOMIC_RELEASE);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    h->mbox_running = false;
+    __atomic_store_n(&h->mbox->stop, 0u, __ATOMIC_RELEASE);
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "mailbox: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+static int rg_mailbox_launch(rg_engine *h) {
+    RgMsgs ms = h->staged;
+    ms.mhr = ms.mh;
+    RgListOut lo;
+    lo.rl = h->res_list;
+    lo.rc = h->res_commit;
+    lo.ro = h->res_out;
+    lo.packed = h->pin_packed;
+    RgClear clr = {h->res_list, h->st.out, 0u, nullptr};
+    const RgIngest a0 = rg_ingest_args(h, h->pin_records, 0, clr);
+    u64 *mf = (u64 *)h->staged.mflags;
+    const u64 max_ticks = RG_MBOX_MAX_US * RG_MBOX_TICKS_PER_US;
+    switch (h->P) {
+    case 1: rg_launch_mailbox_t<1>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 2: rg_launch_mailbox_t<2>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 3: rg_launch_mailbox_t<3>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 4: rg_launch_mailbox_t<4>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 5: rg_launch_mailbox_t<5>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 6: rg_launch_mailbox_t<6>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 7: rg_launch_mailbox_t<7>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    default: rg_launch_mailbox_t<8>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "mailbox: launch failed: %s", hipGetErrorString(e));
+    h->mbox_running = true;
+    h->mbox_launches++;
+    return RG_OK;
+}
+
+// One small flush through the mailbox: the records are in h->pin_records already. Returns RG_OK with *served = false
+// when the request cannot go this way (the caller takes the launch path).
+static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served) {
+    *served = false;
+    // the body clears the PREVIOUS sparse tick's result words itself; a dense predecessor needs a memset on the stream
+    if (!h->mbox_on || h->ins_arena || h->pub || h->out_is_dense || h->ingested_upper || n == 0 || n > RG_INGEST_BLOCK ||
+        h->last_sparse_n > RG_ZEROCOPY_MAX || h->epoch == 0xffffffffu)
+        return RG_OK;
+    RgMbox *mb = h->mbox;
+    if (h->mbox_running && !__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) &&
+        __atomic_load_n(&mb->seq_done, __ATOMIC_ACQUIRE) == h->mbox_seq) {
+        // the instance has left (idle / lifetime): let the stream see it end before the next one goes on
+        int rc = rg_mailbox_quiesce(h);
+        if (rc) return rc;
+    }
+    const u32 s = ++h->mbox_seq;
+    __atomic_store_n(&mb->seq_head, s, __ATOMIC_RELEASE); // (RgMbox: head, fields, tail -- in this order)
+    __atomic_store_n(&mb->n, (u32)n, __ATOMIC_RELAXED);
+    __atomic_store_n(&mb->epoch, h->epoch, __ATOMIC_RELAXED);
+    __atomic_store_n(&mb->clr_n, (u32)h->last_sparse_n, __ATOMIC_RELAXED);
+    __atomic_store_n(&mb->ctr_sel, h->counters == h->counters_base ? 0u : 1u, __ATOMIC_RELAXED);
+    __atomic_store_n(&mb->any_logterm, any_logterm ? 1u : 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(&mb->seq_tail, s, __ATOMIC_RELEASE);
+    if (!h->mbox_running) {
+        int rc = rg_mailbox_launch(h);
+        if (rc) return rc;
+    }
+    // spin on the answer; an instance that left without serving the request (it timed out as the request arrived) is
+    // replaced -- the new one starts from seq_done and finds the request waiting
+    u64 spins = 0;
+    while (__atomic_load_n(&mb->seq_done, __ATOMIC_ACQUIRE) != s) {
+        if ((++spins & 0xfffu) == 0) {
+            if (hipStreamQuery(h->stream) != hipErrorNotReady) { // the kernel is gone (left, or failed)
+                if (__atomic_load_n(&mb->seq_done, __ATOMIC_ACQUIRE) == s) break;
+                h->mbox_running = false;
+                hipError_t e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "mailbox: %s", hipGetErrorString(e));
+                int rc = rg_mailbox_launch(h);
+                if (rc) return rc;
+            }
+            if (spins > (1ull << 33)) return rg_fail(RG_ERR_NO_DEVICE, "mailbox: no answer from the device");
+        }
+        __builtin_ia32_pause();
+    }
+    *served = true;
+    h->mbox_served++;
+    return RG_OK;
+}
+
+extern "C" int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_start: null engine");
+    if (h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_mailbox_start: not with device Inflights (the send stage is a stream of launches)");
+    RG_ENTER(h);
+    int rc = rg_ensure_sparse(h);
+    if (rc) return rc;
+    if (!h->mbox) {
+        RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->mbox), sizeof(RgMbox), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(h->mbox, 0, sizeof(RgMbox));
+    }
+    // the kernel's arguments are fixed at launch: the staging buffers it reads / writes have to exist at their final size
+    if (!h->pin_records) {
+        RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_records), 4096 * sizeof(rg_wire_msg), hipHostMallocDefault));
+        h->pin_records_cap = 4096;
+    }
+    if (!h->pin_packed) {
+        RG_HIP(hipMalloc(&h->d_packed, RG_PACKED_HDR + 4096 * sizeof(rg_res_rec)));
+        RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_packed), RG_PACKED_HDR + 4096 * sizeof(rg_res_rec), hipHostMallocDefault));
+        h->packed_cap = 4096;
+    }
+    h->mbox_idle_ticks = (u64)(idle_timeout_us ? idle_timeout_us : 2000u) * RG_MBOX_TICKS_PER_US;
+    h->mbox_on = true;
+    return RG_OK;
+}
+
+extern "C" int rg_mailbox_stats(const rg_engine *h, uint64_t *flushes_served, uint64_t *launches) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_stats: null engine");
+    if (flushes_served) *flushes_served = h->mbox_served;
+    if (launches) *launches = h->mbox_launches;
+    return RG_OK;
+}
+
+extern "C" int rg_mailbox_stop(rg_engine *h) {
+    if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_stop: null engine");
+    RG_ENTER(h);
+    h->mbox_on = false;
     return RG_OK;
 }
 
@@ -2566,7 +2744,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
     if (w->workload != RG_WL_MAJORITY && w->workload != RG_WL_JOINT && w->workload != RG_WL_MIXED)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: unknown workload %u", w->workload);
     if (w->reserved > 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: fixed replica-set size %u", w->reserved);
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     hipLaunchKernelGGL(k_wl_init, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
                        w->workload | (w->reserved << 8), h->P, (u64)first);
     hipError_t e = hipGetLastError();
@@ -2579,7 +2757,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
 extern "C" int rg_workload_gen(rg_engine *h, const rg_workload *w, uint64_t first, uint64_t tick, uint64_t *mi,
                                uint64_t *mc, uint64_t *mh, uint64_t *mrs, uint8_t *mf) {
     if (!h || !w || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen: bad argument");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     hipLaunchKernelGGL(k_wl_gen, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
                        w->workload | (w->reserved << 8), h->P, (u64)first, (u64)tick, (u64 *)mi, (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);
     hipError_t e = hipGetLastError();
@@ -2811,7 +2989,7 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
         return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: the RCCL transport needs the unique id of rg_comm_unique_id");
     if (cfg->ring_ticks > RG_PUB_MAX_RING)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: ring_ticks %u, at most %d", cfg->ring_ticks, RG_PUB_MAX_RING);
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     RgPub *p = new (std::nothrow) RgPub();
     if (!p) return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_comm_init: host allocation failed");
     memset(p, 0, sizeof(*p));
@@ -2888,14 +3066,14 @@ extern "C" int rg_publish_commit(rg_engine *h, uint32_t flags) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: null engine");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_commit: rg_comm_init was never called");
     if (flags & ~RG_PUBLISH_FULL) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: unknown flags %#x", flags);
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     return rg_publish_impl(h, (flags & RG_PUBLISH_FULL) != 0);
 }
 
 extern "C" int rg_publish_sync(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_sync: null engine");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_sync: rg_comm_init was never called");
-    RG_HIP(hipSetDevice(h->cfg.device));
+    RG_ENTER(h);
     int rc = rg_pub_materialize(h);
     if (rc) return rc;
     RG_HIP(hipStreamSynchronize(h->pub->side));

@@ -238,9 +238,8 @@ RG_D void rg_ingest_block(const RgIngest &a, uint4 *stage) {
 // the tick of the touched groups and the packed results -- what k_ingest, k_resolve_hints_list and k_tick_list do
 // in three. A host that waits for one RawNode::step's worth of results pays one launch latency instead of two or three.
 template <int P, bool GC>
-__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small(RgState st, RgMsgs ms, RgIngest a, u64 *rh, u64 *mflags_rw,
-                                                                 RgListOut lo) {
-    __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
+RG_D void rg_flush_small_body(const RgState &st, const RgMsgs &ms, const RgIngest &a, u64 *rh, u64 *mflags_rw,
+                              const RgListOut &lo, uint4 *stage) {
     rg_ingest_housekeeping(a.clr);
     rg_ingest_block(a, stage);
     // the message cells, the tick list and the counters were written by this workgroup: make them visible to all of it
@@ -257,6 +256,101 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small(RgState st, RgM
         reinterpret_cast<u32 *>(lo.packed)[1] = n_dropped;
     }
     for (u32 i = threadIdx.x; i < n_groups; i += RG_INGEST_BLOCK) rg_tick_listed<P, GC>(st, ms, a.list[i], i, mflags_rw, lo);
+}
+
+template <int P, bool GC>
+__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small(RgState st, RgMsgs ms, RgIngest a, u64 *rh, u64 *mflags_rw,
+                                                                 RgListOut lo) {
+    __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
+    rg_flush_small_body<P, GC>(st, ms, a, rh, mflags_rw, lo, stage);
+}
+
+// The resident small-batch path ("mailbox", rg_mailbox_start): ONE workgroup stays on the device and serves small flushes
+// out of pinned host memory -- the host writes the records and a request block, bumps a sequence word, and spins on the
+// answer; no launch, no stream synchronisation, no wake-up of the HIP runtime (that is ~15 us of the 21 us a one-launch
+// flush costs). Each request runs exactly k_flush_small's body. The workgroup leaves when told to (any other entry point
+// of the engine stops it first), when it has been idle for `idle_ticks`, or after `max_ticks` (a bound on how long one
+// launch can occupy the device whatever the host does); the host relaunches it on the next small flush.
+struct RgMbox {
+    // host -> device: 32 bytes the resident workgroup fetches with ONE read over PCIe per poll (every separate read is a
+    // ~1.5 us round trip). A request is valid when both sequence words carry its number: the host writes seq_head, the
+    // fields, then seq_tail (x86 stores stay in order), so a torn snapshot shows head != tail and is polled again.
+    u32 seq_head;
+    u32 n, epoch, clr_n, ctr_sel, any_logterm;
+    u32 stop;
+    u32 seq_tail;
+    u32 pad0[8];
+    // device -> host
+    u32 seq_done;
+    u32 alive;
+    u32 pad1[14];
+};
+
+template <int P, bool GC>
+__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs ms, RgIngest a0, u32 *ctr_base, u64 *rh,
+                                                             u64 *mflags_rw, RgListOut lo, RgMbox *mb, u64 idle_ticks,
+                                                             u64 max_ticks) {
+    __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
+    __shared__ u32 req[8];
+    const u64 t_start = wall_clock64(); // constant 100 MHz
+    u64 t_last = t_start;
+    u32 seq = 0;
+    if (threadIdx.x == 0) {
+        seq = __hip_atomic_load(&mb->seq_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the last request served
+        __hip_atomic_store(&mb->alive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (;;) {
+        if (threadIdx.x == 0) {
+            u32 leave = 0;
+            uint4 r0, r1; // {seq_head, n, epoch, clr_n}, {ctr_sel, any_logterm, stop, seq_tail}
+            u64 *q = reinterpret_cast<u64 *>(mb);
+            for (;;) {
+                // four relaxed system-scope loads: independent, so they are in flight together (one PCIe round trip);
+                // `volatile` accesses would be waited for one by one
+                const u64 w0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const u64 w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const u64 w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const u64 w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                r0.x = (u32)w0; r0.y = (u32)(w0 >> 32); r0.z = (u32)w1; r0.w = (u32)(w1 >> 32);
+                r1.x = (u32)w2; r1.y = (u32)(w2 >> 32); r1.z = (u32)w3; r1.w = (u32)(w3 >> 32);
+                if (r0.x == r1.w && r0.x != seq) break;
+                const u64 now = wall_clock64();
+                if (r1.z || now - t_last > idle_ticks || now - t_start > max_ticks) {
+                    leave = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            req[0] = r0.x;
+            req[1] = leave;
+            req[2] = r0.y;
+            req[3] = r0.z;
+            req[4] = r0.w;
+            req[5] = r1.x;
+            req[6] = r1.y;
+        }
+        __syncthreads();
+        if (req[1]) break;
+        RgIngest a = a0;
+        a.n = req[2];
+        a.epoch = req[3];
+        a.clr.n = req[4];
+        a.counters = ctr_base + 2 * (req[5] & 1u);
+        a.clr.zero_ctr = ctr_base + 2 * ((req[5] & 1u) ^ 1u);
+        RgMsgs m = ms;
+        m.mhr = req[6] ? rh : ms.mh;
+        const u32 s = req[0];
+        rg_flush_small_body<P, GC>(st, m, a, rh, mflags_rw, lo, stage);
+        __threadfence_system(); // the packed results (pinned host memory) before the sequence word
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&mb->seq_done, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            seq = s;
+            t_last = wall_clock64();
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Temporal fusion: T consecutive ticks of a group in ONE launch. A group's tick t+1 depends only on
@@ -433,7 +527,17 @@ template <int P>
 void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
                              u64 *mflags_rw, const RgListOut &lo);
 
+template <int P>
+void rg_launch_mailbox_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a0, u32 *ctr_base,
+                         u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks);
+
 #ifdef RG_TICK_INSTANTIATE
+template <int P>
+void rg_launch_mailbox_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a0, u32 *ctr_base,
+                         u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks) {
+    if (gc) hipLaunchKernelGGL((k_mailbox<P, true>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a0, ctr_base, rh, mflags_rw, lo, mb, idle_ticks, max_ticks);
+    else hipLaunchKernelGGL((k_mailbox<P, false>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a0, ctr_base, rh, mflags_rw, lo, mb, idle_ticks, max_ticks);
+}
 template <int P>
 void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
                              u64 *mflags_rw, const RgListOut &lo) {
@@ -476,32 +580,40 @@ extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgM
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_flush_small_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_mailbox_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 #endif

@@ -11,3 +11,5 @@ template void rg_launch_tick_list_t<RG_P>(hipStream_t, const RgState &, const Rg
 template void rg_launch_tick_fused_t<RG_P>(hipStream_t, const RgState &, const RgFused &, bool);
 template void rg_launch_flush_small_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *,
                                             const RgListOut &);
+template void rg_launch_mailbox_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *,
+                                        const RgListOut &, RgMbox *, u64, u64);

@@ -195,6 +195,9 @@ SYMBOLS = {
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_appends": (_i, [_vp, _u64, C.c_uint32]),
     "rg_flush_send": (_i, [_vp, _u64, C.c_uint32]),
+    "rg_mailbox_start": (_i, [_vp, C.c_uint32]),
+    "rg_mailbox_stop": (_i, [_vp]),
+    "rg_mailbox_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rg_log_sizes_enable": (_i, [_vp, C.c_uint32]),
     "rg_log_sizes_write": (_i, [_vp, _vp, _u64]),
     "rg_workload_sizes": (_i, [_vp, _u64, C.c_uint32, C.c_uint32]),
@@ -479,6 +482,19 @@ class Engine:
         if max_bytes is not None:
             max_entries_per_msg, flags = max_bytes, flags | SEND_BYTES
         self._check(self.L.rg_flush_send(self.h, max_entries_per_msg, flags))
+
+    def mailbox_start(self, idle_timeout_us=0):
+        """Keep one workgroup resident for small flushes (no launch / synchronisation per flush); see raftgroups.h."""
+        self._check(self.L.rg_mailbox_start(self.h, idle_timeout_us))
+
+    def mailbox_stop(self):
+        self._check(self.L.rg_mailbox_stop(self.h))
+
+    def mailbox_stats(self):
+        """(flushes served by the resident workgroup, times it was launched)"""
+        a, b = _u64(0), _u64(0)
+        self._check(self.L.rg_mailbox_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def log_sizes_enable(self, window):
         """Byte-accurate max_size_per_msg: keep the cumulative sizes of every group's last `window` entries on the device."""

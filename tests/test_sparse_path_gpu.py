@@ -236,3 +236,99 @@ def test_ingest_tick_is_one_round_trip_with_identical_results(rg):
     assert a.ingest_tick(np.zeros(0, dtype=WIRE_DTYPE)) == (0, 0)
     a.close()
     b.close()
+
+
+def test_mailbox_serves_small_flushes_with_identical_results(rg):
+    """rg_mailbox_start: small rg_ingest_tick batches are served by the resident workgroup (no launch per flush) with the
+    results and state of the launch path and of the oracle -- across other entry points cutting in (the mailbox leaves and
+    comes back), large batches (launch path), idle time-outs, log-term rejects, and rg_mailbox_stop."""
+    import time
+    from raft_rs_amd.engine import WIRE_DTYPE
+    rng = np.random.default_rng(912)
+    G, P, TERM = 9000, 5, 6
+    st = O.add_term_table(O.alloc_state(G, P))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, TERM)
+    a, b = rg.Engine(G, P), rg.Engine(G, P)
+    a.load_state(st)
+    b.load_state(st)
+    a.mailbox_start(idle_timeout_us=300)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    msgs = O.alloc_msgs(G, P)
+    gout = np.zeros(G, dtype=np.uint32)
+    sizes = [3, 1, 40, 12, 900, 5, 7, 2, 30, 1, 2500, 4, 9]
+    for t, k in enumerate(sizes):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, logterm_max=TERM if t % 3 == 0 else 0)
+        touched = np.sort(rng.choice(G, size=k, replace=False))
+        keep = np.zeros(G, dtype=bool)
+        keep[touched] = True
+        msgs["m_flags"][~keep] = 0
+        recs = []
+        for g in touched:
+            for p in range(P):
+                f = int(msgs["m_flags"][g, p])
+                if f:
+                    recs.append((g, msgs["m_index"][p, g], msgs["m_commit"][p, g], msgs["m_hint"][p, g],
+                                 msgs["m_rs"][p, g], msgs["m_logterm"][p, g], p, f, 0))
+        recs = np.array(recs, dtype=WIRE_DTYPE)
+        rng.shuffle(recs)
+        n, dup = a.ingest_tick(recs)
+        nb, dupb = b.ingest_tick(recs)
+        assert (n, dup) == (nb, dupb) == (int(msgs["m_flags"].any(axis=1).sum()), 0)
+        cl.tick_soa(msgs, gout)
+        ga, ca, oa = a.ingested_results()
+        gb, cb, ob = b.ingested_results()
+        ia, ib = np.argsort(ga), np.argsort(gb)
+        assert (ga[ia] == gb[ib]).all() and (ca[ia] == cb[ib]).all() and (oa[ia] == ob[ib]).all(), t
+        assert (oa[ia] == gout[ga[ia]]).all(), t
+        if t in (3, 8):    # another entry point cuts in: the resident workgroup leaves, the next flush brings it back
+            sa = a.read_state()
+            cl.store_soa(st)
+            assert not fuzz.diff_states(st, sa, G, P), t
+            assert (sa["out"] == gout).all()
+        if t == 5:         # idle for longer than the time-out: the workgroup has left by itself
+            time.sleep(0.01)
+        if t == 9:
+            a.mailbox_stop()
+            a.mailbox_start()
+    sa, sb = a.read_state(), b.read_state()
+    cl.store_soa(st)
+    assert not fuzz.diff_states(st, sa, G, P) and not fuzz.diff_states(st, sb, G, P)
+    served, launches = a.mailbox_stats()
+    # every batch of <= 256 records that followed a sparse tick went through the mailbox (not the first one -- it follows
+    # the dense load -- nor the ones right after another entry point rewrote the result words densely)
+    assert served >= 6 and 3 <= launches <= served, (served, launches)
+    a.mailbox_stop()
+    n, dup = a.ingest_tick(recs[:0])
+    assert (n, dup) == (0, 0)
+    a.close()
+    b.close()
+
+
+def test_mailbox_with_the_host_mirror(rg):
+    """rg_step ... rg_flush through the mailbox: what a latency-bound RawNode::step loop does."""
+    G, P = 5000, 5
+    a, b = rg.Engine(G, P), rg.Engine(G, P)
+    for e in (a, b):
+        e.workload_init(rg.WL_MAJORITY)
+        for g in range(0, 64):
+            e.set_peers(g, [1, 2, 3, 4, 5], 4)
+    a.mailbox_start()
+    st = a.read_state()
+    for rep in range(12):
+        for e in (a, b):
+            for g in range(rep % 5, 64, 5):
+                e.step(g, 2 + rep % 3, 4, int(min(st["term_hi"][g], st["match"][1 + rep % 3, g] + rep + 1)))
+            e.flush()
+        ga, ca, oa = a.ingested_results()
+        gb, cb, ob = b.ingested_results()
+        ia, ib = np.argsort(ga), np.argsort(gb)
+        assert len(ga) and (ga[ia] == gb[ib]).all() and (ca[ia] == cb[ib]).all() and (oa[ia] == ob[ib]).all(), rep
+    assert a.mailbox_stats()[0] >= 10
+    sa, sb = a.read_state(), b.read_state()
+    assert not fuzz.diff_states(sa, sb, G, P)
+    a.close()
+    b.close()

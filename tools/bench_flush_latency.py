@@ -47,6 +47,27 @@ for k in (1, 10, 100, 1000, 4000, 10000):
         lat_res.append(t3 - t2)
     f = lambda a: float(np.median(a[5:])) * 1e6
     print(f"  k={k:6d}: steps {f(lat_step):9.1f} us (python loop)  flush {f(lat_flush):8.1f} us  results {f(lat_res):7.1f} us")
+# the same loop with the resident mailbox workgroup serving the small flushes (no launch, no synchronisation per flush)
+eng.mailbox_start()
+print("with rg_mailbox_start (flushes of <= 256 records are served by the resident workgroup):")
+for k in (1, 10, 100, 1000):
+    lat_flush, lat_res = [], []
+    for rep in range(60):
+        groups = rng.choice(G, size=k, replace=False)
+        idx = np.minimum(st["term_hi"][groups], st["match"][1, groups] + rep + 40)
+        for g, i in zip(groups.tolist(), idx.tolist()):
+            eng.step(g, 2, 4, i)
+        t1 = time.perf_counter()
+        eng.flush()
+        t2 = time.perf_counter()
+        gr, commit, out = eng.ingested_results()
+        t3 = time.perf_counter()
+        assert len(gr) == k
+        lat_flush.append(t2 - t1)
+        lat_res.append(t3 - t2)
+    f = lambda a: float(np.median(a[10:])) * 1e6
+    print(f"  k={k:6d}: flush {f(lat_flush):8.1f} us  results {f(lat_res):7.1f} us   (p90 flush {float(np.percentile(lat_flush[10:], 90))*1e6:.1f} us)")
+eng.mailbox_stop()
 eng.close()
 
 # the same round trip with the Inflights on the device: + rg_send_appends + rg_send_items
