@@ -54,7 +54,7 @@ int main(void) {
     CHECK(rg_load_column(h, RG_COL_TERM_HI, per_group, rg_column_bytes(h, RG_COL_TERM_HI)));
 
     /* group g receives acks for index 2 from g followers (0, 1 or 2 of them) */
-    rg_wire_msg recs[2 * G];
+    rg_wire_msg recs[G * P];
     uint64_t n = 0, dup = 0, touched = 0;
     for (int g = 0; g < G; g++) {
         for (int k = 0; k < (g < 3 ? g : 2); k++) {
@@ -79,6 +79,27 @@ int main(void) {
         printf("group %d: %d acks -> commit %llu (want %llu) out %#x\n", g, acks, (unsigned long long)commit[g],
                (unsigned long long)want, out[g]);
         ok = ok && commit[g] == want && ((out[g] & RG_OUT_CHANGED) != 0) == (want == 2);
+    }
+    /* ---- the resident small-batch path: one workgroup stays on the device and answers small flushes out of pinned
+     *      memory (no launch, no synchronisation per flush) -- what a latency-bound RawNode::step loop turns on ---- */
+    {
+        uint64_t served = 0, launches = 0;
+        CHECK(rg_mailbox_start(h, 0));
+        for (int round = 0; round < 3 && ok; round++) { /* follower 2 of group 3 acknowledges index 2, thrice (stale twice) */
+            memset(&recs[0], 0, sizeof recs[0]);
+            recs[0].group = 3;
+            recs[0].slot = 2;
+            recs[0].index = 2;
+            recs[0].commit = 2;
+            recs[0].flags = RG_MF_VALID;
+            CHECK(rg_ingest_tick(h, recs, 1, &touched, &dup));
+            ok = ok && touched == 1 && dup == 0;
+        }
+        CHECK(rg_mailbox_stats(h, &served, &launches));
+        CHECK(rg_mailbox_stop(h));
+        printf("mailbox: %llu flushes served by the resident workgroup (%llu launch)\n", (unsigned long long)served,
+               (unsigned long long)launches);
+        ok = ok && served == 3 && launches == 1;
     }
     rg_destroy(h);
 
@@ -116,6 +137,39 @@ int main(void) {
         for (uint64_t i = 0; i < n && ok; i++)
             ok = items[i].kind == RG_SEND_APPEND && items[i].n_msgs == 1 && items[i].prev_index == 1u + (uint64_t)round &&
                  items[i].last_index == 2u + (uint64_t)round && items[i].slot >= 1 && items[i].slot < P;
+    }
+    /* ---- Config::max_size_per_msg in bytes: the host keeps the cumulative entry sizes on the device, the stage applies
+     *      util::limit_size. Both followers acknowledge index 4 (their windows empty), entry 5 is sent: one message ---- */
+    if (ok) {
+        rg_log_size sz[G * 4];
+        uint64_t k = 0;
+        CHECK(rg_log_sizes_enable(h, 8));
+        for (int g = 0; g < G; g++)
+            for (uint64_t idx = 2; idx <= 5; idx++) { /* entries 2..5 of 100 bytes each: cumulative sums */
+                sz[k].group = (uint64_t)g;
+                sz[k].index = idx;
+                sz[k].cum_bytes = 100 * (idx - 1);
+                k++;
+            }
+        CHECK(rg_log_sizes_write(h, sz, k));
+        n = 0;
+        for (int g = 0; g < G; g++)
+            for (int p = 1; p < P; p++) {
+                memset(&recs[n], 0, sizeof recs[n]);
+                recs[n].group = (uint64_t)g;
+                recs[n].slot = (uint32_t)p;
+                recs[n].index = 4;
+                recs[n].commit = 2;
+                recs[n].flags = RG_MF_VALID;
+                n++;
+            }
+        CHECK(rg_ingest_tick(h, recs, n, &touched, &dup));
+        CHECK(rg_send_appends(h, 150, RG_SEND_BYTES)); /* 150 bytes: one 100-byte entry per MsgAppend */
+        CHECK(rg_send_items(h, items, sizeof items / sizeof items[0], &n));
+        printf("byte-limited stage: %llu MsgAppend work items\n", (unsigned long long)n);
+        ok = ok && n == (uint64_t)G * (P - 1);
+        for (uint64_t i = 0; i < n && ok; i++)
+            ok = items[i].kind == RG_SEND_APPEND && items[i].n_msgs == 1 && items[i].prev_index == 4 && items[i].last_index == 5;
     }
     /* ---- multi-GPU entry points from plain C: this rank is the whole world (ncclAllGather at world size 1); with more
      *      ranks only `rank` / `world` change and rank 0's unique id travels over the host's own channel ---- */

@@ -17,6 +17,19 @@
 #define RG_LANE_NX RG_NX_PREFETCH
 #endif
 #define RG_OPT_UNCOND_ST (RG_OPT & 2)
+// bit3: non-temporal stores of the `next` column and the result word -- written every tick, (almost) never read back by
+// the next one, so they need not displace the columns that are; bit4: non-temporal stores of every state column
+#define RG_OPT_NT_NEXT (RG_OPT & 8)
+#define RG_OPT_NT_ALL (RG_OPT & 16)
+template <typename T> RG_HD void rg_st(T &dst, T v, bool nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nt) __builtin_nontemporal_store(v, &dst);
+    else dst = v;
+#else
+    (void)nt;
+    dst = v;
+#endif
+}
 #ifdef RG_BLOCK_SIZE /* experiment override */
 #define RG_BLOCK RG_BLOCK_SIZE
 #elif RG_OPT & 4
@@ -78,9 +91,9 @@ template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, con
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const IX o = (IX)p * (IX)st.stride + g;
-        if (d & (1u << p)) rg_at(st.match, o) = r.mt[p];
-        if (d & (1u << (8 + p))) rg_at(st.next, o) = r.nx[p];
-        if (d & (1u << (16 + p))) rg_at(st.prc, o) = r.pc[p];
+        if (d & (1u << p)) rg_st(rg_at(st.match, o), r.mt[p], RG_OPT_NT_ALL != 0);
+        if (d & (1u << (8 + p))) rg_st(rg_at(st.next, o), r.nx[p], (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
+        if (d & (1u << (16 + p))) rg_st(rg_at(st.prc, o), r.pc[p], RG_OPT_NT_ALL != 0);
     }
     if (d & RG_DIRTY_PF) rg_at(st.pflags, g) = r.pf;
     if (d & RG_DIRTY_COMMIT) {
@@ -88,7 +101,7 @@ template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, con
         rg_at(st.commit, g) = r.commit;
     }
     if (d & RG_DIRTY_HI) rg_at(st.hi, g) = r.hi;
-    rg_at(st.out, g) = r.out;
+    rg_st(rg_at(st.out, g), r.out, (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
     if (d & (RG_DIRTY_LO | RG_DIRTY_CFG | RG_TICK_PUSH)) { // an election (rare)
         // its table update comes last (it reads the table, and nothing else of the wave should wait for that) but before
         // term_lo is overwritten: the previous leader's first index is taken from there
