@@ -379,20 +379,22 @@ struct RgFused {
     u32 n_ticks;
 };
 
-template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st, RgFused fm) {
-    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (g >= st.G) return;
+// IX: index type of the column accesses (rg_common.h: rg_at), u32 where the engine allows it -- like k_tick_lane.
+template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st, RgFused fm) {
+    const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g64 >= st.G) return;
+    const IX g = (IX)g64;
     RgGroup<P> r;
-    r.pf = st.pflags[g];
-    r.cfg = st.cfg[g];
-    r.commit = st.commit[g];
-    r.lo = st.lo[g];
-    r.hi = st.hi[g];
+    r.pf = rg_at(st.pflags, g);
+    r.cfg = rg_at(st.cfg, g);
+    r.commit = rg_at(st.commit, g);
+    r.lo = rg_at(st.lo, g);
+    r.hi = rg_at(st.hi, g);
 #pragma unroll
     for (int p = 0; p < P; p++) {
-        const u64 o = (u64)p * st.stride + g;
-        r.mt[p] = st.match[o];
-        r.pc[p] = st.prc[o];
+        const IX o = (IX)p * (IX)st.stride + g;
+        r.mt[p] = rg_at(st.match, o);
+        r.pc[p] = rg_at(st.prc, o);
         r.nx[p] = 0;
     }
     r.dirty = 0;
@@ -400,24 +402,24 @@ template <int P, bool GC> __global__ RG_TICK_BOUNDS void k_tick_fused(RgState st
     r.adv = 0; // (fused launches are refused while commit publication is active)
     for (u32 t = 0; t < fm.n_ticks; t++) {
         const RgMsgs &ms = fm.m[t];
-        r.mf = rg_ld_stream(ms.mflags + g);
+        r.mf = rg_ld_stream(&rg_at(ms.mflags, g));
         // RG_MF_BECOME_LEADER is not applied by fused launches (the rare path would cost this kernel, which holds
         // several ticks of state in registers, a wave of occupancy): such a group-tick is flagged RG_OUT_FAULT and
         // the event is ignored (include/raftgroups.h: elections go through single-tick launches)
         const u32 efault = rg_has_election(r.mf, r.cfg, P) ? RG_OUT_FAULT : 0u;
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const u64 o = (u64)p * st.stride + g;
-            r.mi[p] = rg_ld_stream(ms.mi + o);
-            r.mc[p] = rg_ld_stream(ms.mc + o);
+            const IX o = (IX)p * (IX)st.stride + g;
+            r.mi[p] = rg_ld_stream(&rg_at(ms.mi, o));
+            r.mc[p] = rg_ld_stream(&rg_at(ms.mc, o));
         }
-        rg_group_tick<P, GC, RG_NX_LAZY, true>(r, st, ms, g);
+        rg_group_tick<P, GC, RG_NX_LAZY, true, IX>(r, st, ms, g);
         r.out |= efault;
-        fm.out_t[(u64)t * st.G + g] = r.out;
-        if (fm.commit_t) fm.commit_t[(u64)t * st.G + g] = r.commit;
+        fm.out_t[(u64)t * st.G + g64] = r.out;
+        if (fm.commit_t) fm.commit_t[(u64)t * st.G + g64] = r.commit;
     }
     // `next` cells that were only fetched (never needed a write) are harmlessly rewritten with their value
-    rg_store_group<P, u64>(r, st, g);
+    rg_store_group<P, IX>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,8 +587,14 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
 }
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
-    if (gc) hipLaunchKernelGGL((k_tick_fused<P, true>), grid, block, 0, stream, st, fm);
-    else hipLaunchKernelGGL((k_tick_fused<P, false>), grid, block, 0, stream, st, fm);
+    const bool ix32 = (u64)P * st.stride * 8 <= 0xffffffffULL; // 32-bit cell offsets (rg_launch_tick_t)
+    if (gc) {
+        if (ix32) hipLaunchKernelGGL((k_tick_fused<P, true, u32>), grid, block, 0, stream, st, fm);
+        else hipLaunchKernelGGL((k_tick_fused<P, true, u64>), grid, block, 0, stream, st, fm);
+    } else {
+        if (ix32) hipLaunchKernelGGL((k_tick_fused<P, false, u32>), grid, block, 0, stream, st, fm);
+        else hipLaunchKernelGGL((k_tick_fused<P, false, u64>), grid, block, 0, stream, st, fm);
+    }
 }
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);

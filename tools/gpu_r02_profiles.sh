@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 2 evidence run: every bench line DESIGN.md quotes + rocprofv3 stats and the two PMC passes of the headline command.
+# Round 2 evidence run: every bench line DESIGN.md quotes + rocprofv3 stats and the PMC passes of the headline command.
 set -u
 cd "$(dirname "$0")/.."
 R=$PWD
@@ -24,4 +24,13 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 CMD5="python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --workload 5"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_c5 -o s -- $CMD5 > /dev/null 2> $O/prof_stats_c5.err
 cd $R
+# SQ instruction mix / wait breakdown and HBM traffic of the steady 7-slot shard against config 5 in one 7-slot engine
+bash tools/pmc_sq.sh c4 --slots 7 > /dev/null 2>&1
+bash tools/pmc_sq.sh c5one --workload 5 --slots 7 --one-engine > /dev/null 2>&1
+bash tools/pmc_tcc.sh c4 --slots 7 > /dev/null 2>&1
+bash tools/pmc_tcc.sh c5one --workload 5 --slots 7 --one-engine > /dev/null 2>&1
+CONFIGS=8:0 PMC_CMD="python $R/tools/bench_send.py" bash tools/pmc_sq.sh send > /dev/null 2>&1
+CONFIGS=8:0 PMC_CMD="python $R/tools/bench_send.py" bash tools/pmc_tcc.sh send > /dev/null 2>&1
+cp gpurun_out/pmc_*.txt gpurun_out/tcc_*.txt $O/ 2>/dev/null
+rm -rf gpurun_out/pmc_c4 gpurun_out/pmc_c5one gpurun_out/pmc_send gpurun_out/tcc_c4 gpurun_out/tcc_c5one gpurun_out/tcc_send
 ls -R $O | head -60
