@@ -468,6 +468,7 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
             // set starts with SENT on a Replicate peer, which overwrites it (optimistic_update,
             // progress.rs:161) before anything reads it. In steady state that is every follower, so the
             // `next` column is written but (except for the leader's own slot) never read.
+            u32 need_mask = 0;
 #pragma unroll
             for (int i = 0; i < P; i++) {
                 const u32 f = (u32)(r.mf >> (8 * i)) & 0xffu, pb = (u32)(r.pf >> (8 * i)) & 0xffu;
@@ -478,11 +479,16 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                 // (an election of this tick has just written every present cell: same bit)
                 const bool have = (r.dirty >> (8 + i)) & 1u;
                 const bool need = ((present >> i) & 1u) && f != 0 && !overwritten && !have;
-                if (need) {
+                // (a register is written BEFORE its load is issued, never after: a write behind a pending load -- even
+                // on the lanes that do not load -- makes the compiler wait for the load, slot by slot)
+                if (!have) r.nx[i] = 0ULL;
+                need_mask |= need ? 1u << i : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                if ((need_mask >> i) & 1u) {
                     r.nx[i] = rg_at(st.next, (IX)i * (IX)st.stride + g);
                     if (FUSED) r.dirty |= 1u << (8 + i);
-                } else if (!have) {
-                    r.nx[i] = 0ULL;
                 }
             }
         }
