@@ -1144,6 +1144,7 @@ extern "C" int rg_get_device_info(const rg_engine *h, rg_device_info *info) {
 
 extern "C" int rg_set_stream(rg_engine *h, void *hip_stream) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_stream: null engine");
+    RG_ENTER(h); // (a resident mailbox workgroup sits on the OLD stream: it has to leave before the engine moves)
     h->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return RG_OK;
 }
@@ -2958,6 +2959,7 @@ extern "C" int rg_comm_destroy(rg_engine *h) {
     RgPub *p = h->pub;
     if (!p) return RG_OK;
     (void)hipSetDevice(h->cfg.device);
+    (void)rg_mailbox_quiesce(h);
     (void)hipStreamSynchronize(h->stream);
     if (p->side) (void)hipStreamSynchronize(p->side);
     if (p->comm) (void)g_rccl.CommDestroy(p->comm);
