@@ -61,6 +61,15 @@ typedef enum {
                                      (src/raft.rs:2684-2686), read by rg_send_appends(RG_SEND_SKIP_BCAST_COMMIT) */
 #define RG_PF_INS_FULL 0x10u      /* engine-owned, only with rg_config.max_inflight > 0: Inflights::full() of the
                                      device-side ring (rg_send_appends maintains it; OR-ed with RG_MF_INS_FULL) */
+#define RG_PF_PEND_SNAP 0x40u     /* engine-owned, exact: this Progress's pending_snapshot (RG_COL_PEND_SNAP) is non-zero */
+#define RG_PF_PEND_RS 0x80u       /* engine-owned, exact: ... its pending_request_snapshot (RG_COL_PEND_RS) is non-zero.
+                                     Both fields are zero almost always; the two bits let the kernels skip the cold
+                                     columns -- Progress::reset's stores on an election, reset_state's, the
+                                     pending_request_snapshot tests of the heartbeat response and of the send decision --
+                                     without reading them. Whatever a caller passes for them is ignored: they are
+                                     re-derived when the flag column or one of the two columns is loaded and when
+                                     rg_write_cells touches the cell; reads report them. */
+#define RG_PF_PENDING (RG_PF_PEND_SNAP | RG_PF_PEND_RS)
 
 /* ---- message flag byte (one per slot per tick) ---- */
 #define RG_MF_VALID 0x01u    /* an AppendResponse from this peer (on the self slot: on_persist_entries(m_index), src/raft.rs:994-1016) */

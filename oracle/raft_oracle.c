@@ -733,6 +733,8 @@ bool ro_quorum_recently_active(ro_cluster *c, size_t g, uint64_t perspective_of)
 #define RO_PF_RECENT_ACTIVE 0x08u
 #define RO_PF_INS_FULL 0x10u
 #define RO_PF_PENDING_CONF 0x20u
+#define RO_PF_PEND_SNAP 0x40u /* the engine's summary bits: pending_snapshot != 0 / pending_request_snapshot != 0 */
+#define RO_PF_PEND_RS 0x80u   /* (derived on store, ignored on load) */
 #define RO_MF_VALID 0x01u
 #define RO_MF_REJECT 0x02u
 #define RO_MF_HAS_RS 0x04u
@@ -846,6 +848,8 @@ int ro_store_soa(ro_cluster *c, ro_soa_state *s) {
             if (c->own_inflights && pr->state == RO_REPLICATE && pr->ins.cap && ro_ins_full(&pr->ins))
                 s->pflags[g * 8 + p] |= RO_PF_INS_FULL;
             if (gr->pending_conf && p + 1 == gr->id) s->pflags[g * 8 + p] |= RO_PF_PENDING_CONF;
+            if (pr->pending_snapshot) s->pflags[g * 8 + p] |= RO_PF_PEND_SNAP;
+            if (pr->pending_request_snapshot) s->pflags[g * 8 + p] |= RO_PF_PEND_RS;
         }
         s->commit[g] = gr->committed;
         s->term_hi[g] = gr->last_index;

@@ -653,7 +653,26 @@ __global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32
     if (c.field_mask & (1u << RG_COL_PEND_SNAP)) st.psnap[o] = c.pend_snap;
     if (c.field_mask & (1u << RG_COL_PEND_RS)) st.prs[o] = c.pend_rs;
     if (c.field_mask & (1u << RG_COL_GID)) st.gid[o] = c.gid;
-    if (c.field_mask & (1u << RG_COL_PFLAGS)) reinterpret_cast<u8 *>(st.pflags)[c.group * 8 + c.slot] = c.pflags;
+    // RG_PF_PEND_SNAP / _RS are the engine's as well: exact for the cell as it now stands
+    u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + c.group * 8 + c.slot;
+    u8 nf = (c.field_mask & (1u << RG_COL_PFLAGS)) ? c.pflags : *pfb;
+    nf = (u8)((nf & ~RG_PF_PENDING) | (st.psnap[o] ? RG_PF_PEND_SNAP : 0u) | (st.prs[o] ? RG_PF_PEND_RS : 0u));
+    *pfb = nf;
+}
+
+// RG_PF_PEND_SNAP / RG_PF_PEND_RS (pending_snapshot / pending_request_snapshot != 0) re-derived for every cell: after the
+// flag column or one of the two columns was loaded wholesale.
+__global__ __launch_bounds__(RG_BLOCK) void k_fix_pending(RgState st, u32 P) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g >= st.G) return;
+    const u64 row0 = st.pflags[g];
+    u64 row = row0;
+    for (u32 p = 0; p < P; p++) {
+        const u64 o = (u64)p * st.stride + g;
+        row &= ~((u64)RG_PF_PENDING << (8 * p));
+        row |= (u64)((st.psnap[o] ? RG_PF_PEND_SNAP : 0u) | (st.prs[o] ? RG_PF_PEND_RS : 0u)) << (8 * p);
+    }
+    if (row != row0) st.pflags[g] = row;
 }
 
 // RG_PF_INS_FULL is engine-owned: Inflights::full() of a Replicate peer's device-side ring. Re-derived from the
@@ -1176,6 +1195,9 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
     if (c == RG_COL_PFLAGS && h->ins_arena) // the FULL bit is the engine's: re-derive it from the windows
         hipLaunchKernelGGL(k_fix_ins_full, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
                            h->st, h->ins, h->P);
+    if (c == RG_COL_PFLAGS || c == RG_COL_PEND_SNAP || c == RG_COL_PEND_RS) // ... and so is RG_PF_PENDING
+        hipLaunchKernelGGL(k_fix_pending, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
+                           h->st, h->P);
     RG_HIP(hipStreamSynchronize(h->stream));
     if (c == RG_COL_COMMIT && h->pub) h->pub->local_lost = true;
     if (c == RG_COL_CFG) {

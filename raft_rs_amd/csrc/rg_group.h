@@ -554,8 +554,9 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                 nb = RG_STATE_PROBE; // ins.reset(): RG_OUT_BECAME_LEADER tells the send stage to empty the device window
             }
             r.dirty |= (1u << i) | (1u << (8 + i));
-            rg_at(st.psnap, o) = 0;
-            rg_at(st.prs, o) = 0;
+            // (RG_PF_PEND_*: almost never -- these were the 2 P cold stores an election used to cost)
+            if (pb & RG_PF_PEND_SNAP) rg_at(st.psnap, o) = 0;
+            if (pb & RG_PF_PEND_RS) rg_at(st.prs, o) = 0;
             if (nb != pb) {
                 r.pf = (r.pf & ~(0xffULL << (8 * i))) | ((u64)nb << (8 * i));
                 r.dirty |= RG_DIRTY_PF;
@@ -589,7 +590,10 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
     // Inflights reset is the host's (it sees the transition through the state column).
     RG_HD void reset_state(u32 &pb, u32 new_state, IX o) {
         pb = (pb & ~(RG_PF_PAUSED | RG_PF_STATE_MASK)) | new_state;
+        // (stored unconditionally: making this one store conditional on RG_PF_PEND_SNAP costs the kernel 4 VGPRs = a wave of
+        // occupancy at P = 5; the election's 2 P stores are the ones worth skipping)
         rg_at(st.psnap, o) = 0;
+        pb &= ~RG_PF_PEND_SNAP;
     }
 
     template <int S> RG_HD void set_next(u64 n) {
@@ -661,7 +665,7 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                 pb = (pb | RG_PF_RECENT_ACTIVE) & ~RG_PF_PAUSED; // recent_active = true; resume()
                 if (state == RG_STATE_REPLICATE && ((f & RG_MF_INS_FULL) || (pb0 & RG_PF_INS_FULL)))
                     out |= 1u << (24 + S); // ins.free_first_one()
-                if (r.mt[S] < r.hi || rg_at(st.prs, o) != 0) out |= 1u << (8 + S); // send_append(m.from)
+                if (r.mt[S] < r.hi || (pb & RG_PF_PEND_RS) /* pending_request_snapshot != 0 */) out |= 1u << (8 + S); // send_append(m.from)
             } else if (f & RG_MF_VALID) {
                 const u64 idx = r.mi[S];
                 const bool reject = (f & RG_MF_REJECT) != 0;
@@ -675,8 +679,12 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                     if (state == RG_STATE_REPLICATE) {
                         const bool stale = idx < r.mt[S] || (idx == r.mt[S] && rs == 0);
                         if (!stale) {
-                            if (rs == 0) set_next<S>(r.mt[S] + 1);
-                            else rg_at(st.prs, o) = rs;
+                            if (rs == 0) {
+                                set_next<S>(r.mt[S] + 1);
+                            } else {
+                                rg_at(st.prs, o) = rs;
+                                pb |= RG_PF_PEND_RS;
+                            }
                             dec = true;
                         }
                     } else {
@@ -697,8 +705,9 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                                 u64 n = idx < h ? idx : h;
                                 if (n < 1) n = 1;
                                 set_next<S>(n);
-                            } else if (rg_at(st.prs, o) == 0) {
+                            } else if (!(pb & RG_PF_PEND_RS)) { // pending_request_snapshot == 0
                                 rg_at(st.prs, o) = rs;
+                                pb |= RG_PF_PEND_RS;
                             }
                             pb &= ~RG_PF_PAUSED; // resume()
                             dec = true;

@@ -146,7 +146,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             head_v[s] = rg_at(ins.head, o);
             tail_v[s] = rg_at(ins.tail, o);
             next_v[s] = rg_at(st.next, o);
-            prs_v[s] = rg_at(st.prs, o);
+            prs_v[s] = 0ULL; // (SPEC: the flag row is not known yet; an experiment-only path)
             match_v[s] = rg_at(st.match, o);
         }
     }
@@ -187,10 +187,10 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             head_v[s] = rg_at(ins.head, o);
             tail_v[s] = rg_at(ins.tail, o);
         }
-        if (sends) {
-            next_v[s] = rg_at(st.next, o);
-            prs_v[s] = rg_at(st.prs, o);
-        }
+        if (sends) next_v[s] = rg_at(st.next, o);
+        // pending_request_snapshot: zero unless the flag byte says otherwise (RG_PF_PEND_RS) -- a column the stage used
+        // to read for every peer it sends to
+        if (sends && ((row0 >> (8 * s)) & RG_PF_PEND_RS)) prs_v[s] = rg_at(st.prs, o);
         if (w && (((fr_bits & sm_bits) >> s) & 1u)) match_v[s] = rg_at(st.match, o);
     }
 #pragma unroll

@@ -19,6 +19,20 @@ static RgState make_state(void *const *p, u64 G, u64 stride) {
     st.pub = nullptr; st.pub_off_delta = 0; st.pub_cap = 0;
     return st;
 }
+// RG_PF_PEND_SNAP / RG_PF_PEND_RS are engine-owned: the library derives it when the columns are loaded (k_fix_pending); the arrays a test hands
+// over may come straight from a generator, so the same derivation runs here on the way in.
+static void derive_pending(const RgState &st, unsigned P) {
+    for (u64 g = 0; g < st.G; g++) {
+        u64 row = st.pflags[g];
+        for (unsigned p = 0; p < P; p++) {
+            const u64 o = (u64)p * st.stride + g;
+            row &= ~((u64)RG_PF_PENDING << (8 * p));
+            row |= (u64)((st.psnap[o] ? RG_PF_PEND_SNAP : 0u) | (st.prs[o] ? RG_PF_PEND_RS : 0u)) << (8 * p);
+        }
+        st.pflags[g] = row;
+    }
+}
+
 static RgMsgs make_msgs(const void *const *p) {
     RgMsgs ms;
     ms.mi = (const u64 *)p[0]; ms.mc = (const u64 *)p[1]; ms.mh = (const u64 *)p[2]; ms.mrs = (const u64 *)p[3];
@@ -100,6 +114,7 @@ extern "C" int rg_host_check_tick(unsigned P, unsigned long G, unsigned long str
                                   const void *const *msg, int group_commit_kernel, unsigned long g_begin,
                                   unsigned long g_end) {
     const RgState st = make_state(state, G, stride);
+    derive_pending(st, P);
     const RgMsgs ms = make_msgs(msg);
     const bool gc = group_commit_kernel != 0;
     const u64 g0 = g_begin, g1 = g_end < G ? g_end : G;
@@ -110,6 +125,7 @@ extern "C" int rg_host_check_tick(unsigned P, unsigned long G, unsigned long str
 extern "C" int rg_host_check_fused(unsigned P, unsigned long G, unsigned long stride, void *const *state, unsigned T,
                                    const void *const *const *msgs, u32 *out_t, u64 *commit_t, int group_commit_kernel) {
     const RgState st = make_state(state, G, stride);
+    derive_pending(st, P);
     RgMsgs ms[RG_MAX_FUSE];
     if (T == 0 || T > RG_MAX_FUSE) return -1;
     for (unsigned t = 0; t < T; t++) ms[t] = make_msgs(msgs[t]);
@@ -148,6 +164,7 @@ extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long st
                                    u64 *head, u64 *tail, u64 *ring, unsigned cap, unsigned long max_entries, unsigned flags,
                                    rg_send_item *items, unsigned long items_cap, const u32 *esz, unsigned esz_w) {
     const RgState st = make_state(state, G, stride);
+    derive_pending(st, P);
     RgIns ins;
     ins.meta = meta; ins.head = head; ins.tail = tail; ins.ring = ring; ins.cap = cap;
     ins.esz = esz; ins.esz_w = esz_w; // entry sizes for RG_SEND_BYTES (NULL / 0 = off)

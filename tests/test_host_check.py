@@ -387,7 +387,8 @@ def apply_snapshots(rng, items, cl, st, meta):
         sidx = int(st["commit"][g])  # what a storage would hand out: a snapshot at the applied index
         pr = cl.pr(g, p + 1)
         cl.L.ro_progress_become_snapshot(C.byref(pr), sidx)
-        st["pflags"][g, p] = (int(st["pflags"][g, p]) & ~(0x3 | 0x4 | 0x10)) | O.SNAPSHOT
+        # (RG_PF_PEND_SNAP 0x40: rg_write_cells re-derives the engine-owned summary bits of the two pending fields)
+        st["pflags"][g, p] = (int(st["pflags"][g, p]) & ~(0x3 | 0x4 | 0x10 | 0x40)) | O.SNAPSHOT | (0x40 if sidx else 0)
         st["pend_snap"][p, g] = sidx
         meta[p, g] = 0  # what rg_write_cells does on a state change
 
