@@ -46,15 +46,39 @@ struct RgIns {
 RG_HD u64 rg_limit_size(const u32 *row, u32 mask, u64 next, u64 avail, u64 max) {
     if (avail <= 1 || max == ~0ULL) return avail; // `entries.len() <= 1` / NO_LIMIT
     if (max >= 0xffffffffULL) return avail;       // a window's total is below 4 GiB
-    const u32 base = row[(u32)(next - 1) & mask], mx = (u32)max;
-    if ((u32)(row[(u32)(next - 1 + avail) & mask] - base) <= mx) return avail; // everything fits: the common case
-    u64 lo = 0, hi = avail - 1;
-    while (lo < hi) {
-        const u64 mid = (lo + hi + 1) >> 1;
-        if ((u32)(row[(u32)(next - 1 + mid) & mask] - base) <= mx) lo = mid;
-        else hi = mid - 1;
+    // the base, the total and the first four candidates are independent cells of one 4 * window-byte row: six loads in
+    // flight together decide most messages (a limit that admits a handful of entries) in ONE round trip; only a longer
+    // message goes on with the binary search, whose loads depend on each other
+    const u32 mx = (u32)max;
+    const u32 base = row[(u32)(next - 1) & mask];
+    const u32 tot = row[(u32)(next - 1 + avail) & mask] - base;
+    u32 c[5];
+    c[0] = 0;
+#pragma unroll
+    for (u32 m = 1; m <= 4; m++) c[m] = row[(u32)(next - 1 + (m <= avail ? m : avail)) & mask] - base;
+    if (tot <= mx) return avail; // everything fits
+    u64 lo = 0;                  // the largest m with C(m) <= max, C = cumulative bytes from `next`
+    u32 c_lo = 0;
+#pragma unroll
+    for (u32 m = 1; m <= 4; m++)
+        if (m <= avail && c[m] <= mx) {
+            lo = m;
+            c_lo = c[m];
+        }
+    if (lo == 4 && avail > 5) { // (C(avail) > max is known: the answer is below avail)
+        u64 hi = avail - 1;
+        while (lo < hi) {
+            const u64 mid = (lo + hi + 1) >> 1;
+            const u32 cm = row[(u32)(next - 1 + mid) & mask] - base;
+            if (cm <= mx) {
+                lo = mid;
+                c_lo = cm;
+            } else {
+                hi = mid - 1;
+            }
+        }
     }
-    const u64 n = ((u32)(row[(u32)(next - 1 + lo) & mask] - base) == 0) ? lo + 1 : lo;
+    const u64 n = c_lo == 0 ? lo + 1 : lo; // the `size == 0` rule (at least one entry: C(0) = 0)
     return n < avail ? n : avail;
 }
 
