@@ -404,7 +404,8 @@ int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes, uint32_t 
 /* The host sent MsgAppends itself (RG_SEND_HOST items; or a host that builds some messages on its own): apply
  * Progress::update_state(last) (src/tracker/progress.rs:231-243) for each -- Replicate: next_idx = last + 1 and
  * ins.add(last) on the device window; Probe: paused; Snapshot: RG_ERR_STATE is NOT raised (the reference panics), the
- * record is ignored. Records are applied in array order; the records of one (group, slot) must be adjacent.
+ * record is ignored; so is a message that no longer fits the peer's window (Inflights::add on a full window panics in the
+ * reference, inflights.rs:66-68). Records are applied in array order; the records of one (group, slot) must be adjacent.
  * Only for engines with device Inflights. Asynchronous. */
 typedef struct {
     uint64_t group;

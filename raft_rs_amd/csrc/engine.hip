@@ -2365,6 +2365,10 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         for (u64 g : h->q_dirty)
             for (u32 p = 0; p < h->P; p++) n += h->q_mf[g * 8 + p] != 0;
     }
+    if (n > RG_INGEST_BLOCK || send) { // not a flush the resident mailbox workgroup can serve: it leaves now, before
+        rc = rg_mailbox_quiesce(h);    // anything below waits for the stream or replaces a buffer it reads
+        if (rc) return rc;
+    }
     if (n > h->pin_records_cap) {
         if (h->pin_records) {
             RG_HIP(hipStreamSynchronize(h->stream));

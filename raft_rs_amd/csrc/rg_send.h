@@ -170,7 +170,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             head_v[s] = rg_at(ins.head, o);
             tail_v[s] = rg_at(ins.tail, o);
             next_v[s] = rg_at(st.next, o);
-            prs_v[s] = 0ULL; // (SPEC: the flag row is not known yet; an experiment-only path)
+            prs_v[s] = rg_at(st.prs, o); // (the flag row is not known yet)
             match_v[s] = rg_at(st.match, o);
         }
     }
