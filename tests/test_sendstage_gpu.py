@@ -530,3 +530,44 @@ def test_workload_sizes_and_dense_byte_stage(rg):
         assert sum(1 for v in got.values() if v[3] > 1) > 100  # 700 bytes split most broadcasts into several messages
         check(rg, eng, cl, st, cap, f"workload sizes tick {t}")
     eng.close()
+
+
+def test_new_entry_points_refuse_what_they_cannot_do(rg):
+    """Error behaviour of the byte-limit / mailbox / update_state entry points: wrong engine mode, bad arguments."""
+    from raft_rs_amd.engine import EngineError, ERR
+    plain = rg.Engine(300, 3)                   # Inflights with the host
+    dev = rg.Engine(300, 3, max_inflight=4)     # Inflights on the device
+    for eng in (plain, dev):
+        eng.workload_init(rg.WL_MAJORITY)
+    with pytest.raises(EngineError) as e:
+        plain.log_sizes_enable(16)              # no send stage without device Inflights
+    assert e.value.code == ERR["STATE"]
+    with pytest.raises(EngineError) as e:
+        plain.update_state(np.zeros(1, dtype=rg.engine.SENT_MSG_DTYPE))
+    assert e.value.code == ERR["STATE"]
+    for bad in (0, 4, 24, 8192):                # a power of two in 8..4096
+        with pytest.raises(EngineError) as e:
+            dev.log_sizes_enable(bad)
+        assert e.value.code == ERR["INVALID_ARG"]
+    with pytest.raises(EngineError) as e:
+        dev.log_sizes_write(np.zeros(1, dtype=rg.engine.LOG_SIZE_DTYPE))  # not enabled yet
+    assert e.value.code == ERR["STATE"]
+    dev.log_sizes_enable(8)
+    dev.log_sizes_write(np.zeros(0, dtype=rg.engine.LOG_SIZE_DTYPE))      # empty batches are fine
+    dev.update_state(np.zeros(0, dtype=rg.engine.SENT_MSG_DTYPE))
+    recs = np.zeros(2, dtype=rg.engine.LOG_SIZE_DTYPE)
+    recs["group"] = [5, 10**9]                  # a record for a group this engine does not hold is ignored
+    dev.log_sizes_write(recs)
+    sent = np.zeros(2, dtype=rg.engine.SENT_MSG_DTYPE)
+    sent["group"], sent["slot"] = [10**9, 3], [1, 99]  # unknown group / slot: ignored
+    dev.update_state(sent)
+    dev.sync()
+    with pytest.raises(EngineError) as e:
+        dev.mailbox_start()                     # the send stage is a stream of launches
+    assert e.value.code == ERR["STATE"]
+    plain.mailbox_start()
+    assert plain.mailbox_stats() == (0, 0)
+    plain.mailbox_stop()
+    plain.mailbox_stop()                        # idempotent
+    plain.close()
+    dev.close()
