@@ -173,6 +173,13 @@ extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long st
     return n;
 }
 
+// rg_limit_size (rg_send.h) on a caller-provided window of cumulative entry sizes: how many of the entries
+// [next, next + avail) one MsgAppend of at most `max` bytes carries.
+extern "C" unsigned long rg_host_check_limit_size(const u32 *row, unsigned window, unsigned long next, unsigned long avail,
+                                                  unsigned long max) {
+    return rg_limit_size(row, window - 1u, next, avail, max);
+}
+
 // RgQuorum (the P x P ">=" bit matrix rank select) and the literal group-commit routine on caller-provided
 // matches / group ids: mci = ProgressTracker::maximal_committed_index over (incoming, outgoing) slot masks.
 // `raise_slot` >= 0: build the matrix on the OLD value of that slot, then apply the incremental update.

@@ -506,6 +506,59 @@ def test_send_stage_byte_limit_on_host_matches_oracle(host_tick, host_send, n_sl
         assert seen["multi"] > 0, seen
 
 
+def _reference_limit_size(sizes, max_bytes):
+    """util::limit_size (src/util.rs:52-76), literally: `entries.len() <= 1` and NO_LIMIT return early; then take_while with
+    the `size == 0` test that keeps the first entry -- and everything behind a prefix of zero-size entries."""
+    if len(sizes) <= 1 or max_bytes == O.U64_MAX:
+        return len(sizes)
+    size, limit = 0, 0
+    for e in sizes:
+        if size == 0:
+            size += e
+            limit += 1
+            continue
+        size += e
+        if size <= max_bytes:
+            limit += 1
+        else:
+            break
+    return limit
+
+
+def test_limit_size_matches_the_reference_rule_property():
+    """rg_limit_size over the device's ring of cumulative u32 sizes == util::limit_size over the entries themselves, for
+    random sizes (many of them zero), ring positions that wrap, cumulative sums that wrap modulo 2^32, and limits from 0 to
+    NO_LIMIT."""
+    from hypothesis import given, settings, strategies as hst
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_limit_size
+    fn.restype = C.c_ulong
+    fn.argtypes = [C.c_void_p, C.c_uint, C.c_ulong, C.c_ulong, C.c_ulong]
+    size = hst.one_of(hst.just(0), hst.integers(0, 3), hst.integers(1, 2000), hst.integers(1, 1 << 20))
+    limit = hst.one_of(hst.sampled_from([0, 1, 100, 2048, (1 << 32) - 1, 1 << 32, O.U64_MAX - 1, O.U64_MAX]),
+                       hst.integers(0, 5000), hst.integers(0, 1 << 24))
+
+    @settings(max_examples=600, deadline=None)
+    @given(hst.sampled_from([8, 16, 64]), hst.data())
+    def check(window, data):
+        avail = data.draw(hst.integers(0, window - 1))
+        sizes = data.draw(hst.lists(size, min_size=avail, max_size=avail))
+        next_idx = data.draw(hst.integers(1, 1 << 40))
+        base = data.draw(hst.one_of(hst.integers(0, 1 << 20), hst.integers((1 << 32) - 3000, (1 << 32) - 1)))  # wrap mod 2^32
+        max_bytes = data.draw(limit)
+        row = np.zeros(window, dtype=np.uint32)
+        cum = base
+        row[(next_idx - 1) & (window - 1)] = cum & 0xffffffff
+        for k, e in enumerate(sizes):
+            cum += e
+            row[(next_idx + k) & (window - 1)] = cum & 0xffffffff
+        got = fn(row.ctypes.data, window, next_idx, avail, max_bytes)
+        assert got == _reference_limit_size(sizes, max_bytes), (window, next_idx, sizes, max_bytes, got)
+
+    check()
+
+
 # ---- property tests (hypothesis) of the quorum arithmetic over the FULL u64 range --------------------------
 from hypothesis import HealthCheck, given, settings, strategies as hst  # noqa: E402
 
