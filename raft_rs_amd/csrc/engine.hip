@@ -549,7 +549,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
 template <int P>
 static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
                                  u32 flags, const RgSendCols &oc) {
-    if ((u64)P * st.stride * 8 <= 0xffffffffULL)
+    if (rg_fits_u32_offsets(P, st.stride))
         hipLaunchKernelGGL((k_send_dense<P, u32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
     else
         hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, st, ins, max_entries, flags, oc);

@@ -45,6 +45,12 @@ struct RgMsgs {
 // `SGPR base + 32-bit VGPR offset` form of the global memory instructions -- one VGPR per slot addresses that slot's cell
 // in EVERY column, instead of a 64-bit address pair per (column, slot) kept alive from the load to the store.
 // IX = u64: plain indexing (gathers over arbitrary groups, the host).
+// 32-bit offsets are usable when the farthest cell any kernel addresses this way -- slot P-1 of a peer-major column, or
+// run RG_TERM_RUNS-1 of the term-run table, group stride-1, 8 bytes each -- lies below 4 GiB.
+static inline bool rg_fits_u32_offsets(u64 n_slots, u64 stride) {
+    const u64 rows = n_slots > RG_TERM_RUNS ? n_slots : RG_TERM_RUNS;
+    return rows * stride * 8 <= 0xffffffffULL;
+}
 template <typename T, typename IX> RG_HD T &rg_at(T *base, IX i) {
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
     return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (IX)(i * (IX)sizeof(T)));

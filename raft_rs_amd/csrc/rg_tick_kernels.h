@@ -567,8 +567,8 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
         hipLaunchKernelGGL((k_tick_lds<P, GC, true>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
     } else {
-        // 32-bit cell offsets when the farthest cell of a column (slot P-1, group stride-1, 8 B each) is below 4 GiB
-        if ((u64)P * st.stride * 8 <= 0xffffffffULL)
+        // 32-bit cell offsets when every cell a lane addresses is below 4 GiB from its column's start
+        if (rg_fits_u32_offsets(P, st.stride))
             hipLaunchKernelGGL((k_tick_lane<P, GC, u32>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
         else
             hipLaunchKernelGGL((k_tick_lane<P, GC, u64>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
@@ -587,7 +587,7 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
 }
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
-    const bool ix32 = (u64)P * st.stride * 8 <= 0xffffffffULL; // 32-bit cell offsets (rg_launch_tick_t)
+    const bool ix32 = rg_fits_u32_offsets(P, st.stride); // 32-bit cell offsets (rg_launch_tick_t)
     if (gc) {
         if (ix32) hipLaunchKernelGGL((k_tick_fused<P, true, u32>), grid, block, 0, stream, st, fm);
         else hipLaunchKernelGGL((k_tick_fused<P, true, u64>), grid, block, 0, stream, st, fm);

@@ -63,7 +63,7 @@ template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, b
     }
     // exactly what k_tick_lane does, with the index type rg_launch_tick_t would pick (odd groups take the other one,
     // so both instantiations are diffed against the oracle)
-    const bool fits32 = (u64)P * st.stride * 8 <= 0xffffffffULL;
+    const bool fits32 = rg_fits_u32_offsets(P, st.stride);
     for (u64 g = g0; g < g1; g++) {
         if (fits32 && !(g & 1)) host_one<P, u32>(st, ms, gc, (u32)g);
         else host_one<P, u64>(st, ms, gc, g);
