@@ -126,6 +126,40 @@ def soa_cpu_line(n_groups, n_slots, workload, seed, threads):
         return {"soa_note": f"unavailable: {type(e).__name__}: {e}"}
 
 
+def small_batch_latency(rg, torch, n_groups, n_slots, seed):
+    """What one RawNode::step -> ready() costs a host: k messages through the host mirror (rg_step), then the wall-clock
+    time of rg_flush (ingest + tick of the touched groups + results back), with kernel launches and with the resident
+    mailbox workgroup (rg_mailbox_start). Medians over 60 flushes each, 10 warm-up flushes dropped; Python caller."""
+    import time
+    eng = rg.Engine(n_groups, n_slots, device=torch.cuda.current_device())
+    eng.workload_init(2, seed=seed)
+    n_mirror = 4096
+    for g in range(n_mirror):
+        eng.set_peers(g, list(range(1, n_slots + 1)), 4)
+    hi = eng.read_column(rg.COL.TERM_HI)
+    match = eng.read_column(rg.COL.MATCH)
+    rng = np.random.default_rng(7)
+    out = {"resident_groups": n_groups, "unit": "us per rg_flush (median)", "caller": "python / ctypes"}
+    for mode in ("launch", "mailbox"):
+        if mode == "mailbox":
+            eng.mailbox_start()
+        for k in (1, 10):
+            lat = []
+            for rep in range(70):
+                groups = rng.choice(n_mirror, size=k, replace=False)
+                for g in groups.tolist():
+                    eng.step(g, 2, 4, int(min(hi[g], match[1, g] + (rep if mode == "launch" else 70 + rep) + 1)))
+                t0 = time.perf_counter()
+                eng.flush()
+                lat.append(time.perf_counter() - t0)
+                assert len(eng.ingested_results()[0]) == k
+            out[f"{mode}_{k}_groups"] = round(float(np.median(lat[10:])) * 1e6, 2)
+    served, launches = eng.mailbox_stats()
+    out["mailbox_flushes_served"], out["mailbox_launches"] = served, launches
+    eng.close()
+    return out
+
+
 def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what, variant=0):
     """A second, smaller measurement for the bench line's sub-objects, after the headline region: one engine, W+K
     recorded ticks replayed from a checkpoint (what == "tick"), or K launches of rg_recompute -- Raft::maybe_commit
@@ -536,6 +570,8 @@ def main():
         # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
         result["out_of_cache"] = side_measurement(rg, torch, args.out_of_cache_groups, P, args.workload if args.workload != 5 else 2,
                                                   3, 12, args.seed, "tick")
+        # the other end of the scale: the round trip of a flush that touches 1 / 10 groups (not a throughput number)
+        result["small_batch_latency"] = small_batch_latency(rg, torch, G, P, args.seed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_groups, G), P, args.workload,
                                               args.cpu_sample_ticks, args.seed, os.cpu_count() or 1)
