@@ -145,13 +145,16 @@ struct RgListOut {
 };
 
 // entry i of the tick list: group g
-template <int P, bool GC>
-RG_D void rg_tick_listed(const RgState &st, const RgMsgs &ms, u64 g, u64 i, u64 *mflags_rw, const RgListOut &lo) {
+// IX: index type of the column accesses -- u32 wherever the engine allows it (rg_fits_u32_offsets: fewer address registers,
+// one more wave per SIMD for these gather-bound kernels), decided per launch like k_tick_lane's.
+template <int P, bool GC, typename IX = u64>
+RG_D void rg_tick_listed(const RgState &st, const RgMsgs &ms, u64 g64, u64 i, u64 *mflags_rw, const RgListOut &lo) {
+    const IX g = (IX)g64;
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, u64>(r, st, ms, g);
-    rg_group_tick<P, GC, RG_LANE_NX, false, u64>(r, st, ms, g);
-    rg_store_group<P, u64>(r, st, g);
-    mflags_rw[g] = 0;
+    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    rg_store_group<P, IX>(r, st, g);
+    rg_at(mflags_rw, g) = 0;
     lo.rl[i] = g;
     lo.rc[i] = r.commit;
     lo.ro[i] = r.out;
@@ -163,7 +166,7 @@ RG_D void rg_tick_listed(const RgState &st, const RgMsgs &ms, u64 g, u64 i, u64 
     }
 }
 
-template <int P, bool GC>
+template <int P, bool GC, typename IX>
 __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw,
                                            RgListOut lo) {
     const u64 i = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
@@ -172,7 +175,7 @@ __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *lis
         reinterpret_cast<u32 *>(lo.packed)[1] = n_ptr[1];
     }
     if (i >= *n_ptr) return;
-    rg_tick_listed<P, GC>(st, ms, list[i], i, mflags_rw, lo);
+    rg_tick_listed<P, GC, IX>(st, ms, list[i], i, mflags_rw, lo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -582,8 +585,14 @@ template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo) {
     const dim3 grid(rg_grid_for(n_upper, RG_BLOCK)), block(RG_BLOCK);
-    if (gc) hipLaunchKernelGGL((k_tick_list<P, true>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
-    else hipLaunchKernelGGL((k_tick_list<P, false>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
+    const bool ix32 = rg_fits_u32_offsets(P, st.stride);
+    if (gc) {
+        if (ix32) hipLaunchKernelGGL((k_tick_list<P, true, u32>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
+        else hipLaunchKernelGGL((k_tick_list<P, true, u64>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
+    } else {
+        if (ix32) hipLaunchKernelGGL((k_tick_list<P, false, u32>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
+        else hipLaunchKernelGGL((k_tick_list<P, false, u64>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
+    }
 }
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
