@@ -68,3 +68,19 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+
+
+def test_oracle_flag_bits_are_the_headers():
+    """The oracle's SoA adapter speaks the engine's flag byte: every RO_PF_* / RO_MF_* / RO_OUT_* constant of
+    oracle/raft_oracle.c that has an RG_* namesake in include/raftgroups.h carries the same value."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "raftgroups.h")).read()
+    src = open(os.path.join(root, "oracle", "raft_oracle.c")).read() + open(os.path.join(root, "oracle", "raft_oracle.h")).read()
+    rg = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define RG_((?:PF|MF|OUT)_\w+)\s+(0x[0-9a-fA-F]+)u", hdr)}
+    ro = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define RO_((?:PF|MF|OUT)_\w+)\s+(0x[0-9a-fA-F]+)u", src)}
+    common = sorted(set(rg) & set(ro))
+    assert len(common) >= 12, common
+    assert {"PF_PEND_SNAP", "PF_PEND_RS", "PF_INS_FULL", "PF_PAUSED"} <= set(common)
+    for k in common:
+        assert rg[k] == ro[k], (k, hex(rg[k]), hex(ro[k]))
