@@ -533,7 +533,7 @@ def main():
                        "rollover": "every tick 1/32 of the groups elects a new leader (RG_MF_BECOME_LEADER = Raft::reset + "
                                    "become_leader): ~10% of the groups are between election and the first commit of the new "
                                    "term at any time"} if args.workload == 5 else {}),
-                   "kernel_variant": {0: "lane", 1: "lane", 2: "lds", 4: "lds-dma"}[args.variant],
+                   "kernel_variant": {0: "lane", 1: "lane", 2: "lds", 4: "lds-dma", 5: "compact"}[args.variant],
                    "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
                    "device": {k: v for k, v in parts[0].eng.device_info().items() if k != "engine_bytes"},
                    "engine_hbm_bytes": sum(pt.eng.device_info()["engine_bytes"] for pt in parts),
@@ -546,7 +546,7 @@ def main():
                    "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": ("k_tick_lane" if args.variant not in (2, 4) else "k_tick_lds") +
+                     "kernel": ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_lane")) +
                                (" + k_send_appends" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6,

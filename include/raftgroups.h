@@ -181,6 +181,12 @@ typedef struct {
 #define RG_VARIANT_LDS 2u  /* one wave per 128-group batch, peer columns staged through LDS */
 #define RG_VARIANT_LDS_DMA 4u /* RG_VARIANT_LDS with the stage-in done by gfx950's LDS-DMA (global_load_lds_dwordx4: global
                                  memory -> LDS without passing through VGPRs). A measured comparison point, like LDS. */
+#define RG_VARIANT_COMPACT 5u /* the lane kernel in 256-thread workgroups that, after the loads, gather the groups about to
+                                 leave the steady path (an election, a reject, a Probe / Snapshot transition, a full window)
+                                 into ONE wave per workgroup -- the loaded registers travel through LDS -- so that the other
+                                 waves execute the steady path only. For streams with leader-term rollover (BASELINE config
+                                 5), where the lane kernel is instruction-bound; same results, a few per cent slower than
+                                 RG_VARIANT_LANE on a steady stream. */
 #define RG_VARIANT_COOP 3u /* rg_recompute / rg_maximal_committed_index only: 8 lanes per group, one peer per lane,
                               wave-level rank-select of the quorum index with cross-lane shuffles (ticks run the
                               lane kernel). A measured comparison point, not the default. */

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "rg_group.h"
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
 template <int P>
 static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
                                  u32 flags, const RgSendCols &oc) {
-    if (rg_fits_u32_offsets(P, st.stride))
+    if (rg_ix32(P, st.stride))
         hipLaunchKernelGGL((k_send_dense<P, u32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
     else
         hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
@@ -848,6 +849,8 @@ struct rg_engine {
     std::vector<u64> q_dirty;                  // groups touched since the last flush
     std::vector<rg_wire_msg> q_records;        // flush staging (wire-order records of the dirty groups)
     bool q_any_logterm;                        // some queued message carries Message.log_term
+    struct RgQueuedElection { u64 group, old_term; };
+    std::vector<RgQueuedElection> q_elections; // rg_local_become_leader calls of the pending flush: group, the term its gate had
     std::vector<u32> host_cfg;                 // host copy of RG_COL_CFG for the mirror (self slots)
     bool host_cfg_valid;
     bool host_mirror;
@@ -951,7 +954,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: n_groups=%llu n_slots=%u out of range",
                        (unsigned long long)cfg->n_groups, cfg->n_slots);
-    if (cfg->variant > RG_VARIANT_LDS_DMA) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
+    if (cfg->variant > RG_VARIANT_COMPACT) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return rg_fail(RG_ERR_NO_DEVICE, "rg_create: no HIP device visible (this engine has no CPU fallback)");
@@ -1350,7 +1353,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     if (src) return src;
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
-    const u32 variant = (h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA) ? h->cfg.variant : RG_VARIANT_LANE;
+    const u32 variant = (h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
+                            ? h->cfg.variant : RG_VARIANT_LANE;
     switch (h->P) {
     case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
     case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;
@@ -2211,6 +2215,22 @@ static void rg_touch(rg_engine *h, u64 group) {
     if (row == 0) h->q_dirty.push_back(group);
 }
 
+static int rg_self_slot(rg_engine *h, u64 group, u32 *slot);
+
+// A response whose `from` is the leader's OWN id. No follower sends one; the reference would run it against the leader's
+// own Progress, where a well-formed one changes nothing (matched = persisted = last_index: a reject is stale, an accept at
+// or below matched is a no-op). Here the leader's slot carries the LOCAL events of the tick -- VALID is
+// on_persist_entries, and the REJECT bit is RG_MF_BECOME_LEADER, whose m_hint is the new TERM: a spoofed or misrouted
+// reject would run Raft::reset + become_leader with reject_hint as the term. So the mirror drops such a message (RG_OK,
+// nothing queued); local events enter through rg_local_* only.
+static int rg_from_self(rg_engine *h, u64 group, int slot, bool *is_self) {
+    u32 self;
+    int rc = rg_self_slot(h, group, &self);
+    if (rc) return rc;
+    *is_self = (u32)slot == self;
+    return RG_OK;
+}
+
 extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m) {
     if (!h || !m || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step: rg_set_peers was never called");
@@ -2227,6 +2247,10 @@ extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m
                            (unsigned long long)m->term, (unsigned long long)h->terms[group]);
         if (m->term < h->terms[group]) return RG_OK; // stale term: ignored (raft.rs:1349-1411)
     }
+    bool from_self;
+    int src = rg_from_self(h, group, slot, &from_self);
+    if (src) return src;
+    if (from_self) return RG_OK; // (dropped: see rg_from_self)
     u8 &f = h->q_mf[group * 8 + slot];
     if (f & (RG_MF_VALID | RG_MF_HEARTBEAT)) return rg_fail(RG_ERR_SLOT_BUSY, "rg_step: peer %llu already has a message queued; rg_flush first",
                                         (unsigned long long)m->from);
@@ -2254,6 +2278,10 @@ extern "C" int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t
         if (term > h->terms[group]) return rg_fail(RG_ERR_HIGHER_TERM, "rg_step_heartbeat_response: higher term: step down");
         if (term < h->terms[group]) return RG_OK;
     }
+    bool from_self;
+    int src = rg_from_self(h, group, slot, &from_self);
+    if (src) return src;
+    if (from_self) return RG_OK; // (dropped: see rg_from_self)
     u8 &f = h->q_mf[group * 8 + slot];
     if (f & (RG_MF_VALID | RG_MF_HEARTBEAT))
         return rg_fail(RG_ERR_SLOT_BUSY, "rg_step_heartbeat_response: peer %llu already has a message queued", (unsigned long long)from);
@@ -2267,6 +2295,9 @@ static int rg_self_slot(rg_engine *h, u64 group, u32 *slot) {
     // the self slot lives in the device cfg word; the mirror keeps a host copy of the column, refreshed
     // whenever the column may have changed (rg_load_column / rg_set_config / rg_workload_init)
     if (!h->host_cfg_valid) {
+        // (a resident mailbox workgroup sits on the stream: without this the copy below waits for its idle time-out)
+        int qrc = rg_mailbox_quiesce(h);
+        if (qrc) return qrc;
         h->host_cfg.resize(h->G);
         RG_HIP(hipMemcpyAsync(h->host_cfg.data(), h->st.cfg, h->G * 4, hipMemcpyDeviceToHost, h->stream));
         RG_HIP(hipStreamSynchronize(h->stream));
@@ -2319,7 +2350,10 @@ extern "C" int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t ter
     rg_touch(h, group);
     h->q_mh[(size_t)slot * h->stride + group] = term;
     f |= RG_MF_BECOME_LEADER;
-    h->terms[group] = term; // responses of the new term pass the gate from now on
+    // responses of the new term pass the gate from now on (they may be queued behind the election in this very flush);
+    // the flush checks the device's verdict and moves the gate BACK if the event was refused there (rg_settle_elections)
+    h->q_elections.push_back({group, h->terms[group]});
+    h->terms[group] = term;
     return RG_OK;
 }
 
@@ -2329,6 +2363,10 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
     const int slot = rg_find_slot(h, group, peer_id);
     if (slot < 0) return rg_fail(RG_ERR_STEP_PEER_NOT_FOUND, "rg_mark_sent: peer %llu not in group %llu",
                                  (unsigned long long)peer_id, (unsigned long long)group);
+    bool to_self;
+    int src = rg_from_self(h, group, slot, &to_self);
+    if (src) return src;
+    if (to_self) return RG_OK; // the leader sends itself nothing (and SENT has no meaning on its slot)
     rg_touch(h, group);
     h->q_mf[group * 8 + slot] |= RG_MF_SENT;
     return RG_OK;
@@ -2604,13 +2642,11 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served)
         if (rc) return rc;
     }
     const u32 s = ++h->mbox_seq;
-    __atomic_store_n(&mb->seq_head, s, __ATOMIC_RELEASE); // (RgMbox: head, fields, tail -- in this order)
-    __atomic_store_n(&mb->n, (u32)n, __ATOMIC_RELAXED);
-    __atomic_store_n(&mb->epoch, h->epoch, __ATOMIC_RELAXED);
-    __atomic_store_n(&mb->clr_n, (u32)h->last_sparse_n, __ATOMIC_RELAXED);
-    __atomic_store_n(&mb->ctr_sel, h->counters == h->counters_base ? 0u : 1u, __ATOMIC_RELAXED);
-    __atomic_store_n(&mb->any_logterm, any_logterm ? 1u : 0u, __ATOMIC_RELAXED);
-    __atomic_store_n(&mb->seq_tail, s, __ATOMIC_RELEASE);
+    // (RgMbox: three self-validating words, one 8-byte store each; the records in pin_records are older stores)
+    const u32 w0 = (u32)n | ((h->counters == h->counters_base ? 0u : 1u) << 16) | ((any_logterm ? 1u : 0u) << 17);
+    __atomic_store_n(&mb->w[0], rg_mbox_word(s, w0), __ATOMIC_RELEASE);
+    __atomic_store_n(&mb->w[1], rg_mbox_word(s, h->epoch), __ATOMIC_RELEASE);
+    __atomic_store_n(&mb->w[2], rg_mbox_word(s, (u32)h->last_sparse_n), __ATOMIC_RELEASE);
     if (!h->mbox_running) {
         int rc = rg_mailbox_launch(h);
         if (rc) return rc;
@@ -2698,6 +2734,37 @@ extern "C" int rg_ingest_tick(rg_engine *h, const rg_wire_msg *records, uint64_t
     return RG_OK;
 }
 
+// The device is the judge of an RG_MF_BECOME_LEADER event: it validates the new term against RG_COL_CUR_TERM (which the
+// host may have reloaded or restored since rg_set_peers registered a term) and answers RG_OUT_BECAME_LEADER, or
+// RG_OUT_FAULT with the event ignored. rg_local_become_leader had to move the host's term gate when the event was QUEUED
+// (responses of the new term may follow in the same flush); where the device refused, the gate goes back to the old term --
+// otherwise responses of the old term would be dropped and those of the new one applied to a Progress set that was never
+// reset. RG_COL_CUR_TERM and the registered term of a group belong together: load one, register the other.
+static int rg_settle_elections(rg_engine *h, bool results_available) {
+    int rc = RG_OK;
+    if (results_available && h->last_sparse_n) {
+        const u64 n = h->last_sparse_n;
+        std::vector<u64> groups(n);
+        std::vector<u32> out(n);
+        u64 got = 0;
+        rc = rg_ingested_results(h, groups.data(), nullptr, out.data(), n, &got);
+        if (rc == RG_OK) {
+            std::unordered_map<u64, bool> became; // election groups of this flush -> did the device apply the event?
+            for (const auto &e : h->q_elections) became[e.group] = false;
+            for (u64 i = 0; i < n; i++) {
+                auto it = became.find(groups[i]);
+                if (it != became.end() && (out[i] & RG_OUT_BECAME_LEADER)) it->second = true;
+            }
+            for (const auto &e : h->q_elections)
+                if (!became[e.group]) h->terms[e.group] = e.old_term;
+        }
+    } else {
+        for (const auto &e : h->q_elections) h->terms[e.group] = e.old_term; // no verdict: the conservative side
+    }
+    h->q_elections.clear();
+    return rc;
+}
+
 static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_flush: rg_set_peers was never called");
     int rc;
@@ -2742,6 +2809,10 @@ static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
     for (u64 g : h->q_dirty) memset(&h->q_mf[g * 8], 0, 8);
     h->q_dirty.clear();
     h->q_any_logterm = false;
+    if (!h->q_elections.empty()) {
+        const int erc = rg_settle_elections(h, rc == RG_OK);
+        if (rc == RG_OK) rc = erc;
+    }
     return rc;
 }
 

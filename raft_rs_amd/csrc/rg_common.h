@@ -51,6 +51,15 @@ static inline bool rg_fits_u32_offsets(u64 n_slots, u64 stride) {
     const u64 rows = n_slots > RG_TERM_RUNS ? n_slots : RG_TERM_RUNS;
     return rows * stride * 8 <= 0xffffffffULL;
 }
+// What the launchers ask: 32-bit cell offsets unless the engine is too large -- or RG_FORCE_IX64=1 is set in the
+// environment, a TEST hook that makes every launch take the 64-bit-offset instantiations (k_tick_lane / _list / _fused /
+// _compact <..., u64>, k_send_dense<..., u64>), which no engine a test can afford to build would otherwise reach on a GPU.
+#include <stdlib.h>
+static inline bool rg_ix32(u64 n_slots, u64 stride) {
+    const char *e = getenv("RG_FORCE_IX64"); // (read per launch: a test flips it inside one process)
+    const bool forced64 = e && e[0] && e[0] != '0';
+    return !forced64 && rg_fits_u32_offsets(n_slots, stride);
+}
 template <typename T, typename IX> RG_HD T &rg_at(T *base, IX i) {
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
     return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (IX)(i * (IX)sizeof(T)));

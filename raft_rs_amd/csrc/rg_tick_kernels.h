@@ -122,14 +122,152 @@ template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, con
     }
 }
 
+template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u64 &cfg_adv, F &&f);
 // IX = u32 when every cell of the engine's columns lies within 4 GiB of its column's start (rg_launch_tick_t decides).
 template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
+#if defined(RG_LANE_LDS_PAD) && defined(__HIP_DEVICE_COMPILE__) /* experiment: steer the scheduler's occupancy target with an LDS allocation */
+    __shared__ u64 occ_pad[RG_LANE_LDS_PAD / 8];
+    asm volatile("" ::"v"((u32)(uintptr_t)&occ_pad[threadIdx.x]));
+#endif
     RgGroup<P> r;
     rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+#if defined(RG_LANE_FENCE) && defined(__HIP_DEVICE_COMPILE__) /* experiment: keep the compiler from interleaving the tick with the loads */
+#if RG_LANE_FENCE == 1
+    asm volatile("" ::: "memory");
+#elif RG_LANE_FENCE == 3
+    {
+        u64 g64b = g64, ca = (u64)r.cfg | ((u64)r.adv << 32);
+        rg_cpt_fields<P>(r, g64b, ca, [&](int, u64 &x) { RG_OPAQUE64(x); });
+        r.cfg = (u32)ca;
+        r.adv = (u32)(ca >> 32);
+    }
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#endif
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    rg_store_group<P, IX>(r, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick with rare-lane compaction (RG_VARIANT_COMPACT) -- for streams with leader-term rollover
+// ------------------------------------------------------------------------------------------------
+// Under BASELINE config 5 (elections, rejected probes, Probe -> Replicate) ~12 % of the groups leave the steady path in
+// every tick, spread evenly: practically every 64-lane wave of k_tick_lane holds such a lane and executes the UNION of
+// the rare paths (2 089 instead of 1 095 VALU per wave at P = 7, profiles/r02_pmc_sq_c5_one_engine.txt) -- the kernel
+// is instruction-bound there. This variant runs 256-thread workgroups and, after the loads, trades the rare groups of
+// three of the block's four waves for steady groups of the fourth (the "designated" wave, rotating with the block
+// index so that the long waves spread over a CU's four SIMDs): the loaded REGISTERS of both travel through LDS -- the
+// operands go with the group, nothing is re-read from memory -- so that one wave per block executes the rare paths and
+// the other three only the steady one. Stores are addressed by the group a lane ends up holding. The classification
+// (rg_is_rare) is a performance hint only: every lane runs the same complete tick code on whatever group it holds, so
+// results do not depend on it (the parity suite runs this variant like the others).
+#define RG_CPT_BLOCK 256
+#ifndef RG_CPT_CAP
+#define RG_CPT_CAP 48 /* swap pairs per block (LDS: 2 x (6 P + 8) x 8 B each); more rare lanes stay where they are */
+#endif
+
+// Can this group leave the steady path in this tick? Decided from the two flag rows and the cfg word, byte-parallel:
+// an election; a heartbeat response; an AppendResponse that is a reject, comes from a peer outside Replicate (Probe /
+// Snapshot transitions) or from one whose window is full (`old_paused`: the exact replay of commit_phase).
+RG_HD bool rg_is_rare(u64 mf, u64 pf, u32 cfg, u32 n_slots) {
+    const u64 L = 0x0101010101010101ULL;
+    const u64 valid = mf & L, reject = (mf >> 1) & L, hb = (mf >> 6) & L;
+    const u64 full = ((mf >> 3) | (pf >> 4)) & L;
+    const u64 nonrepl = ((pf & L) ^ L) | ((pf >> 1) & L); // state != Replicate (1)
+    return ((hb | (valid & (reject | nonrepl | full))) != 0) || rg_has_election(mf, cfg, n_slots);
+}
+
+// Every input of a tick, as rg_load_group leaves it, in a fixed field order: f(i, x) for field i.
+template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u64 &cfg_adv, F &&f) {
+    int i = 0;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        f(i++, r.mt[p]);
+        f(i++, r.pc[p]);
+        f(i++, r.mi[p]);
+        f(i++, r.mc[p]);
+        f(i++, r.nx[p]);
+        f(i++, r.hint[p]);
+    }
+    f(i++, r.mf);
+    f(i++, r.pf);
+    f(i++, r.commit);
+    f(i++, r.lo);
+    f(i++, r.hi);
+    f(i++, r.el_old);
+    f(i++, cfg_adv);
+    f(i++, g64);
+}
+
+// LDS-only barrier: the global loads of the block stay in flight across it (a __syncthreads() fences global memory
+// too, i.e. waits for every outstanding load of the wave first).
+RG_D void rg_lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <int P, bool GC, typename IX>
+__global__ __launch_bounds__(RG_CPT_BLOCK) void k_tick_compact(RgState st, RgMsgs ms) {
+    constexpr int NF = 6 * P + 8;
+    __shared__ u64 x_rare[NF][RG_CPT_CAP];  // rare groups handed over by the natural waves
+    __shared__ u64 x_disp[NF][RG_CPT_CAP];  // steady groups the designated wave gives away in exchange
+    __shared__ u32 cnt[2];                  // [0] rare lanes of the natural waves, [1] steady lanes of the designated wave
+    const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+#ifdef RG_CPT_FIXED_WD /* experiment: the designated wave does not rotate */
+    const u32 wd = 0;
+#else
+    const u32 wd = blockIdx.x & 3u;
+#endif
+    u64 g64 = (u64)blockIdx.x * RG_CPT_BLOCK + tid;
+    const bool valid = g64 < st.G; // (whole groups travel, so a lane that is valid stays valid)
+    if (tid < 2) cnt[tid] = 0;
+    RgGroup<P> r;
+    r.mf = 0;
+    r.pf = 0;
+    r.cfg = 0;
+    if (valid) rg_load_group<P, RG_NX_PREFETCH, IX>(r, st, ms, (IX)g64);
+    rg_lds_barrier(); // the counters are zero
+    const bool rare = valid && rg_is_rare(r.mf, r.pf, r.cfg, P);
+    const bool cand = wave == wd ? (valid && !rare) : rare;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 bal = __ballot(cand);
+    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+    const u32 n_w = (u32)__builtin_popcountll(bal);
+    u32 base = 0;
+    if (wave == wd) {
+        if (lane == 0) cnt[1] = n_w;
+    } else if (n_w) {
+        if (lane == 0) base = atomicAdd(&cnt[0], n_w);
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    const u32 k = base + rank;
+    rg_lds_barrier();
+    u32 n_swap = cnt[0] < cnt[1] ? cnt[0] : cnt[1];
+    if (n_swap > RG_CPT_CAP) n_swap = RG_CPT_CAP;
+    if (n_swap) { // (uniform over the block)
+        const bool sw = cand && k < n_swap;
+        u64 cfg_adv = (u64)r.cfg | ((u64)r.adv << 32);
+        u64(*mine)[RG_CPT_CAP] = wave == wd ? x_disp : x_rare;
+        u64(*theirs)[RG_CPT_CAP] = wave == wd ? x_rare : x_disp;
+        if (sw) rg_cpt_fields<P>(r, g64, cfg_adv, [&](int i, u64 &x) { mine[i][k] = x; });
+        rg_lds_barrier();
+        if (sw) {
+            rg_cpt_fields<P>(r, g64, cfg_adv, [&](int i, u64 &x) { x = theirs[i][k]; });
+            r.cfg = (u32)cfg_adv;
+            r.adv = (u32)(cfg_adv >> 32);
+        }
+    }
+#else
+    (void)x_rare; (void)x_disp; (void)cnt; (void)wave; (void)lane; (void)wd;
+#endif
+    if (!valid) return;
+    const IX g = (IX)g64;
+    rg_group_tick<P, GC, RG_NX_PREFETCH, false, IX>(r, st, ms, g);
     rg_store_group<P, IX>(r, st, g);
 }
 
@@ -288,19 +426,23 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small(RgState st, RgM
 // of the engine stops it first), when it has been idle for `idle_ticks`, or after `max_ticks` (a bound on how long one
 // launch can occupy the device whatever the host does); the host relaunches it on the next small flush.
 struct RgMbox {
-    // host -> device: 32 bytes the resident workgroup fetches with ONE read over PCIe per poll (every separate read is a
-    // ~1.5 us round trip). A request is valid when both sequence words carry its number: the host writes seq_head, the
-    // fields, then seq_tail (x86 stores stay in order), so a torn snapshot shows head != tail and is polled again.
-    u32 seq_head;
-    u32 n, epoch, clr_n, ctr_sel, any_logterm;
-    u32 stop;
-    u32 seq_tail;
+    // host -> device: 32 bytes the resident workgroup fetches with four independent 8-byte reads over PCIe per poll (in
+    // flight together: one round trip). Every request word is SELF-VALIDATING: its upper half carries the request number,
+    // its lower half a payload, and the host writes each word with ONE 8-byte store -- a word can never be torn, and a
+    // request is accepted only when all three words carry the same new number, whatever order the four reads were
+    // sampled in. (Round 2 bracketed plain fields with a head and a tail sequence word; the head is written first and
+    // read first, the tail written last and read last, so a poll could see head = tail = s around fields of request
+    // s - 1.)
+    u64 w[3];  // w[0] = n (16 bits) | ctr_sel << 16 | any_logterm << 17, w[1] = epoch, w[2] = clr_n; each | seq << 32
+    u32 stop;  // written on its own by rg_mailbox_quiesce: not part of a request
+    u32 pad_stop;
     u32 pad0[8];
     // device -> host
     u32 seq_done;
     u32 alive;
     u32 pad1[14];
 };
+RG_HD u64 rg_mbox_word(u32 seq, u32 payload) { return ((u64)seq << 32) | payload; }
 
 template <int P, bool GC>
 __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs ms, RgIngest a0, u32 *ctr_base, u64 *rh,
@@ -318,33 +460,32 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs 
     for (;;) {
         if (threadIdx.x == 0) {
             u32 leave = 0;
-            uint4 r0, r1; // {seq_head, n, epoch, clr_n}, {ctr_sel, any_logterm, stop, seq_tail}
+            u64 w0, w1, w2, w3;
             u64 *q = reinterpret_cast<u64 *>(mb);
             for (;;) {
                 // four relaxed system-scope loads: independent, so they are in flight together (one PCIe round trip);
                 // `volatile` accesses would be waited for one by one
-                const u64 w0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const u64 w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const u64 w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const u64 w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                r0.x = (u32)w0; r0.y = (u32)(w0 >> 32); r0.z = (u32)w1; r0.w = (u32)(w1 >> 32);
-                r1.x = (u32)w2; r1.y = (u32)(w2 >> 32); r1.z = (u32)w3; r1.w = (u32)(w3 >> 32);
-                if (r0.x == r1.w && r0.x != seq) break;
+                w0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const u32 s0 = (u32)(w0 >> 32);
+                if (s0 != seq && (u32)(w1 >> 32) == s0 && (u32)(w2 >> 32) == s0) break; // all three words of ONE new request
                 const u64 now = wall_clock64();
-                if (r1.z || now - t_last > idle_ticks || now - t_start > max_ticks) {
+                if ((u32)w3 /* stop */ || now - t_last > idle_ticks || now - t_start > max_ticks) {
                     leave = 1;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            req[0] = r0.x;
+            req[0] = (u32)(w0 >> 32);          // request number
             req[1] = leave;
-            req[2] = r0.y;
-            req[3] = r0.z;
-            req[4] = r0.w;
-            req[5] = r1.x;
-            req[6] = r1.y;
+            req[2] = (u32)w0 & 0xffffu;        // n
+            req[3] = (u32)w1;                  // epoch
+            req[4] = (u32)w2;                  // clr_n
+            req[5] = ((u32)w0 >> 16) & 1u;     // ctr_sel
+            req[6] = ((u32)w0 >> 17) & 1u;     // any_logterm
         }
         __syncthreads();
         if (req[1]) break;
@@ -569,9 +710,13 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
     } else if (variant == RG_VARIANT_LDS_DMA) {
         hipLaunchKernelGGL((k_tick_lds<P, GC, true>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
+    } else if (variant == RG_VARIANT_COMPACT) {
+        const dim3 grid(rg_grid_for(st.G, RG_CPT_BLOCK)), block(RG_CPT_BLOCK);
+        if (rg_ix32(P, st.stride)) hipLaunchKernelGGL((k_tick_compact<P, GC, u32>), grid, block, 0, stream, st, ms);
+        else hipLaunchKernelGGL((k_tick_compact<P, GC, u64>), grid, block, 0, stream, st, ms);
     } else {
         // 32-bit cell offsets when every cell a lane addresses is below 4 GiB from its column's start
-        if (rg_fits_u32_offsets(P, st.stride))
+        if (rg_ix32(P, st.stride))
             hipLaunchKernelGGL((k_tick_lane<P, GC, u32>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
         else
             hipLaunchKernelGGL((k_tick_lane<P, GC, u64>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
@@ -585,7 +730,7 @@ template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo) {
     const dim3 grid(rg_grid_for(n_upper, RG_BLOCK)), block(RG_BLOCK);
-    const bool ix32 = rg_fits_u32_offsets(P, st.stride);
+    const bool ix32 = rg_ix32(P, st.stride);
     if (gc) {
         if (ix32) hipLaunchKernelGGL((k_tick_list<P, true, u32>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
         else hipLaunchKernelGGL((k_tick_list<P, true, u64>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
@@ -596,7 +741,7 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
 }
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
-    const bool ix32 = rg_fits_u32_offsets(P, st.stride); // 32-bit cell offsets (rg_launch_tick_t)
+    const bool ix32 = rg_ix32(P, st.stride); // 32-bit cell offsets (rg_launch_tick_t)
     if (gc) {
         if (ix32) hipLaunchKernelGGL((k_tick_fused<P, true, u32>), grid, block, 0, stream, st, fm);
         else hipLaunchKernelGGL((k_tick_fused<P, true, u64>), grid, block, 0, stream, st, fm);

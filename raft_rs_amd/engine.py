@@ -59,7 +59,7 @@ ERR = {"INVALID_ARG": -1, "NO_DEVICE": -2, "OUT_OF_MEMORY": -3, "STEP_LOCAL_MSG"
        "STEP_PEER_NOT_FOUND": -5, "SLOT_BUSY": -6, "HIGHER_TERM": -7, "STATE": -8}
 
 WL_MAJORITY, WL_JOINT, WL_MIXED = 2, 3, 5
-VARIANT_DEFAULT, VARIANT_LANE, VARIANT_LDS, VARIANT_COOP, VARIANT_LDS_DMA = 0, 1, 2, 3, 4
+VARIANT_DEFAULT, VARIANT_LANE, VARIANT_LDS, VARIANT_COOP, VARIANT_LDS_DMA, VARIANT_COMPACT = 0, 1, 2, 3, 4, 5
 
 
 def cfg_make(incoming, outgoing=0, self_slot=0, group_commit=False, transferee_plus1=0, present=None):

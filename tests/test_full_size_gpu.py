@@ -94,6 +94,28 @@ def test_config5_size_class_engines_match_the_oracle(rg):
     assert total["elections"] > 5 * G / 32 * 0.9 and total["rejects"] > 300_000, total
 
 
+@pytest.mark.parametrize("layout", ["one-engine", "size-classes"])
+def test_config5_compact_variant_full_size(rg, layout):
+    """RG_VARIANT_COMPACT (rare groups gathered into one wave per workgroup through LDS) over config 5 at full size:
+    the groups change lanes inside the kernel, the results must not."""
+    G = 1_000_000
+    if layout == "one-engine":
+        seen = _run_full_size(rg, 5, G, 7, ticks=4, variant=5)
+    else:
+        first, seen = 0, {"elections": 0, "rejects": 0}
+        for slots, n in ((3, G // 3), (5, G // 3), (7, G - 2 * (G // 3))):
+            part = _run_full_size(rg, 5, n, slots, ticks=4, first_group=first, fixed_peers=slots, variant=5)
+            first += n
+            for k in seen:
+                seen[k] += part[k]
+    assert seen["elections"] > 4 * G / 32 * 0.9 and seen["rejects"] > 200_000, seen
+
+
+def test_config2_compact_variant_full_size(rg):
+    """... and over the steady stream, where no group changes lanes."""
+    _run_full_size(rg, 2, 1_000_000, 5, ticks=2, variant=5)
+
+
 def test_config2_lds_variant_full_size(rg):
     """The LDS-staged kernel over the same 1 M x 5 stream (two ticks)."""
     _run_full_size(rg, 2, 1_000_000, 5, ticks=2, variant=2)

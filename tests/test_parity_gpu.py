@@ -3,6 +3,8 @@
 Every comparison is over ALL state columns (match, next, pr_commit, pending_snapshot,
 pending_request_snapshot, pflags, commit, term_hi) and the per-group result word.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -30,7 +32,7 @@ def assert_same(eng, cl, st_ref, gout_ref, what):
                            f"{[hex(x) for x in got['out'][bad[:5]]]} oracle {[hex(x) for x in gout_ref[bad[:5]]]}")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5])
 @pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (3, 5), (5, 7), (2, 7)])
 def test_workload_stream_matches_oracle(rg, variant, workload, n_slots):
     G, ticks = 20000 + 77, 6
@@ -80,7 +82,7 @@ def test_device_generator_equals_host_generator(rg):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5])
 @pytest.mark.parametrize("n_slots", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_streams_match_oracle(rg, variant, n_slots):
     rng = np.random.default_rng(1000 + n_slots)
@@ -110,7 +112,7 @@ def test_tiny_and_ragged_group_counts(rg, n_groups, n_slots):
     """Edge sizes: a single group, one short of / exactly / one past a wave, one past a 256 tile; indices
     near the top of the u64 range."""
     rng = np.random.default_rng(n_groups * 10 + n_slots)
-    for variant in (1, 2):
+    for variant in (1, 2, 5):
         st = O.alloc_state(n_groups, n_slots)
         st["cfg"][:] = fuzz.random_cfg(rng, n_groups, n_slots)
         fuzz.random_state(rng, st, small_values=True, base=2 ** 62)
@@ -506,3 +508,36 @@ def test_fused_launch_flags_elections_instead_of_applying_them(rg):
     st = eng.read_state()
     assert (st["term_lo"][::2] == before["term_hi"][::2] + 1).all() and (st["match"][1:, :G:2] == 0).all()
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the 64-bit-offset instantiations (k_tick_lane / _list / _fused / _compact <..., u64>): engines beyond 4 GiB per column
+# run them; RG_FORCE_IX64=1 (rg_common.h: rg_ix32) makes every launch of a small engine take them, so the device code
+# objects that ship are the ones that are tested
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def force_ix64():
+    os.environ["RG_FORCE_IX64"] = "1"
+    yield
+    os.environ.pop("RG_FORCE_IX64", None)
+
+
+@pytest.mark.parametrize("variant", [1, 5])
+@pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (5, 7)])
+def test_workload_stream_matches_oracle_with_64bit_offsets(rg, force_ix64, variant, workload, n_slots):
+    test_workload_stream_matches_oracle(rg, variant, workload, n_slots)
+
+
+@pytest.mark.parametrize("n_slots", [3, 5, 7, 8])
+def test_random_streams_match_oracle_with_64bit_offsets(rg, force_ix64, n_slots):
+    test_random_streams_match_oracle(rg, 1, n_slots)
+    test_random_streams_match_oracle(rg, 5, n_slots)
+
+
+def test_fused_and_sparse_kernels_with_64bit_offsets(rg, force_ix64):
+    """k_tick_fused<..., u64> and k_tick_list<..., u64> on the GPU."""
+    test_fused_launch_equals_sequential_ticks(rg, 2, 5, 4)
+    test_fused_launch_equals_sequential_ticks(rg, 5, 7, 8)
+    import test_sparse_path_gpu as S
+    S.test_sparse_ticks_match_oracle(rg, 5)
+    S.test_sparse_ticks_match_oracle(rg, 7)
