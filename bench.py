@@ -2,8 +2,12 @@
 """bench.py -- raft-group progress+commit evaluations per second on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--groups G] [--slots P] [--workload 2|3|5]
-                    [--fuse T] [--split S] [--variant 0|2] [--publish-every E] [--one-engine] [--no-cpu-baseline]
-                    [--inflights CAP] [--no-extras]
+                    [--fuse T] [--split S] [--variant 0|2|4|5] [--publish-every E] [--one-engine] [--no-cpu-baseline]
+                    [--inflights CAP] [--no-extras] [--c5-variant V]
+
+The default (N = 1) line also carries, as sub-objects with their own `roofline` (each labelled with its memory regime):
+`recompute_only` (+ `_out_of_cache`), `out_of_cache`, `other_configs` (every other BASELINE configuration that fits one
+GPU, and the headline with the send stage), `small_batch_latency`, `cpu_baseline`.
 
 One "step" = one tick of the hot path over every raft group of the shard: apply each group's
 AppendResponse slots (Raft::handle_append_response semantics) and re-evaluate + gate the commit
@@ -33,6 +37,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+C5_VARIANT = 0  # RG_VARIANT_* the config-5 sub-measurements run (set from the measured comparison, profiles/r03_*)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec), /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -71,7 +76,7 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
         elapsed[nthreads] += time.perf_counter() - t0
         evals[nthreads] += n_groups
         cl.store_soa(st)
-    soa = soa_cpu_line(n_groups, n_slots, workload, seed, min(threads, 128))  # Python thread pool: 128 is its sweet spot
+    soa = soa_cpu_line(n_groups, n_slots, workload, seed, threads)
     out = {"value": evals[threads] / elapsed[threads] if elapsed[threads] else None, "unit": "group-evals/s",
            "cores": threads, "kind": "port",
            "sample": f"{n_groups} groups x {n_slots} peers, {sample_ticks} ticks of the same stream "
@@ -80,50 +85,82 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
            "value_1core": evals[1] / elapsed[1] if elapsed[1] else None,
            "host_cores": os.cpu_count()}
     out.update(soa)
+    out["config1"] = cpu_config1(seed, min(threads, 16))
     return out
 
 
 def soa_cpu_line(n_groups, n_slots, workload, seed, threads):
     """Second CPU line: the engine's own struct-of-arrays arithmetic compiled for the host
     (tests/host_check/, test infrastructure) -- a best-effort CPU implementation of the same algorithm,
-    next to the reference-shaped (hash-map, message-at-a-time) port above."""
+    next to the reference-shaped (hash-map, message-at-a-time) port above. Threads are std::threads INSIDE the
+    library (rg_host_check_tick_mt: contiguous group ranges), as the C port's are pthreads inside its own."""
     import ctypes as C
-    from concurrent.futures import ThreadPoolExecutor
     try:
         import test_host_check as H
         import oracle_lib as O
         from raft_rs_amd import engine as E
         if H.build_lib() is None:
             return {}
-        fn = C.CDLL(H.LIB).rg_host_check_tick
+        fn = C.CDLL(H.LIB).rg_host_check_tick_mt
         fn.restype = C.c_int
-        fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_int, C.c_ulong, C.c_ulong]
+        fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
         st = O.alloc_state(n_groups, n_slots)
         E.workload_init_host(st, workload, seed=seed)
         msgs = E.MsgBuffers(n_groups, n_slots, st["stride"])
         out = np.zeros(n_groups, dtype=np.uint32)
         sp, mp = H.state_ptrs(st, out), H.msg_ptrs(msgs.as_dict())
-
-        def run(a, b):
-            fn(n_slots, n_groups, st["stride"], sp, mp, 0, a, b)
-
         res = {}
-        pool = ThreadPoolExecutor(max_workers=threads)
         for nthreads in (1, threads):
             total, el = 0, 0.0
             for t in range(6):
                 E.workload_gen_host(st, msgs, workload, t if nthreads == 1 else t + 6, seed=seed)
-                bounds = [(i * n_groups // nthreads, (i + 1) * n_groups // nthreads) for i in range(nthreads)]
                 t0 = time.perf_counter()
-                list(pool.map(lambda ab: run(*ab), bounds))
+                if fn(n_slots, n_groups, st["stride"], sp, mp, 0, nthreads) != 0:
+                    raise RuntimeError("rg_host_check_tick_mt failed")
                 el += time.perf_counter() - t0
                 total += n_groups
             res[nthreads] = total / el
-        pool.shutdown()
         return {"soa_value_1core": res[1], "soa_value": res[threads], "soa_cores": threads,
-                "soa_note": "engine arithmetic (rg_group.h) compiled for the host over the same SoA columns"}
+                "soa_note": "engine arithmetic (rg_group.h) compiled for the host over the same SoA columns, std::threads "
+                            "inside the library over contiguous group ranges"}
     except Exception as e:  # noqa: BLE001
         return {"soa_note": f"unavailable: {type(e).__name__}: {e}"}
+
+
+def cpu_config1(seed, threads):
+    """BASELINE.json configs[0]: 1 000 raft groups x 3 peers, the synthetic AppendResponse stream, on the CPU -- the exact
+    workload bench_reference_rust/benches/append_response.rs drives through real RawNode<MemStorage> leaders (shape of
+    the reference's own Criterion bench, /root/reference/benches/suites/raw_node.rs:35-79). The Rust side cannot run here
+    (no cargo); this is the C port (oracle/raft_oracle.c) on the same stream, so whoever runs cargo has the matched number."""
+    import oracle_lib as O
+    from raft_rs_amd import engine as E
+    G, P, ticks = 1000, 3, 2000
+    st = O.alloc_state(G, P)
+    E.workload_init_host(st, 2, seed=seed)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=5)
+    msgs = E.MsgBuffers(G, P, st["stride"])
+    gout = np.zeros(G, dtype=np.uint32)
+    md = msgs.as_dict()
+    el = {1: 0.0, threads: 0.0}
+    n = {1: 0, threads: 0}
+    for t in range(ticks):
+        nt = 1 if t % 2 == 0 else threads
+        E.workload_gen_host(st, msgs, 2, t, seed=seed)
+        t0 = time.perf_counter()
+        if nt == 1:
+            cl.tick_soa(md, gout, 0, G)
+        else:
+            cl.tick_soa_mt(md, gout, nt)
+        el[nt] += time.perf_counter() - t0
+        n[nt] += G
+        cl.store_soa(st)
+    return {"workload": "1 000 groups x 3 peers, synthetic AppendResponse stream (BASELINE configs[0])", "ticks": ticks,
+            "value_1core": n[1] / el[1], "value": n[threads] / el[threads], "cores": threads, "unit": "group-evals/s",
+            "kind": "port",
+            "note": "C oracle (message-at-a-time, per-group hash map); at 1 000 groups a tick is ~0.5 ms of work, so the "
+                    "all-cores figure is dominated by thread start-up -- the 1-core figure is the one to put next to "
+                    "`cargo bench` of bench_reference_rust/ (unrun: no Rust toolchain in this image)"}
 
 
 def small_batch_latency(rg, torch, n_groups, n_slots, seed):
@@ -160,68 +197,229 @@ def small_batch_latency(rg, torch, n_groups, n_slots, seed):
     return out
 
 
-def side_measurement(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what, variant=0):
-    """A second, smaller measurement for the bench line's sub-objects, after the headline region: one engine, W+K
-    recorded ticks replayed from a checkpoint (what == "tick"), or K launches of rg_recompute -- Raft::maybe_commit
-    for every group with no messages, literally BASELINE's "commit-index recomputes" (what == "recompute").
-    Times with HIP events on the engine's stream; returns a dict with its own roofline object."""
-    stream = torch.cuda.current_stream()
-    eng = rg.Engine(n_groups, n_slots, device=torch.cuda.current_device(), variant=variant)
-    eng.set_stream(stream.cuda_stream)
-    eng.workload_init(workload, seed=seed)
+MALL_BYTES = 256 << 20  # Infinity Cache (MALL) of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def regime_of(hot_bytes):
+    """Which memory regime a measurement runs in: the columns a kernel touches on EVERY launch (state, not the
+    read-once message columns) either fit the 256 MB Infinity Cache -- then part of the traffic never reaches HBM and the
+    fraction is not a pure HBM efficiency -- or they do not."""
+    return "infinity-cache" if hot_bytes <= MALL_BYTES else "hbm"
+
+
+def hot_state_bytes(n_groups, n_slots, inflights=False):
+    """Bytes of engine state a tick touches every launch: match / next / pr_commit (24 P), flag row, commit, term_lo,
+    term_hi, cfg, out (40); with device Inflights also window meta / head / tail (20 P) and the work-item columns (20 P)."""
+    return n_groups * (24 * n_slots + 40 + (40 * n_slots if inflights else 0))
+
+
+def traffic_lookup(key):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), or (None, None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            ent = json.load(f).get(key, {})
+    except (OSError, ValueError):
+        return None, None
+    if ent.get("bytes") is None:
+        return None, None
+    return ent["bytes"], ("profiles/traffic.json[" + key + "]: " + ent.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") +
+                          " -- NOT measured inside this run")
+
+
+def workload_label(workload, n_groups, n_slots, one_engine=False):
+    m = n_groups // 1_000_000 if n_groups % 1_000_000 == 0 else None
+    size = f"{m}M" if m else str(n_groups)
+    if workload == 2 and n_slots == 5:
+        return f"{size} groups x 5 peers, majority quorum" + (" (BASELINE configs[1])" if n_groups == 1_000_000 else "")
+    if workload == 2 and n_slots == 7:
+        return f"{size} groups x 7 peers, majority quorum" + (": ONE rank's shard of BASELINE configs[3] (8M x 7 over 8 GPUs), "
+                                                               "no publication" if n_groups == 1_000_000 else "")
+    if workload == 3:
+        return f"{size} groups x {n_slots} slots, joint {{0,1,2}}&&{{1,2,3}} + learner" + (" (BASELINE configs[2])" if (n_groups, n_slots) == (1_000_000, 5) else "")
+    if workload == 5:
+        return (f"{size} groups mixed 3/5/7 peers + 10% leader-term rollover" + (" (BASELINE configs[4])" if n_groups == 1_000_000 else "") +
+                (f", sizes interleaved in one {n_slots}-slot engine" if one_engine else ", one engine per replica-set size"))
+    return f"{n_groups} groups x {n_slots} slots, workload {workload}"
+
+
+def send_stage_bytes(rg, eng, n_items):
+    """The send stage's own algorithmic bytes for the LAST tick: per group out 4 + cfg 4 +
+    last_index 8 + first_index 8 + flag row 8 r + 8 w = 40; per peer in the work set (a send request, an Inflights effect,
+    or a broadcast) window meta 4 r + 4 w, oldest / newest inflight 16 r + 16 w, next 8 r + 8 w, pending snapshot request
+    8 r, matched 8 r = 72; work items as peer-major columns: 4 B per (slot, group) cell + 16 B per item."""
+    _, out = eng.results()
+    cfg = eng.read_column(rg.COL.CFG)
+    present, self_slot = (cfg >> 24) & 0xff, (cfg >> 16) & 7
+    bcast = (out & 0x9) != 0  # CHANGED (skip_bcast_commit off) or APPENDED
+    work = ((out >> 8) | (out >> 16) | (out >> 24)) & 0xff
+    work = np.where(bcast, work | present, work) & present & ~(1 << self_slot)
+    n_work = int(sum(((work >> p) & 1).sum() for p in range(8)))
+    return 40 * eng.n_groups + 72 * n_work + 4 * eng.n_slots * eng.n_groups + 16 * n_items
+
+
+def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
+               inflights=0):
+    """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
+    headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
+    synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
+    checkpoint, and the K recorded ticks are replayed back to back between two HIP events on the engines' streams.
+      what == "tick":      the hot path; config 5 runs one engine per replica-set size on its own stream unless one_engine;
+                           inflights > 0 adds the send stage (rg_send_appends) after every tick, timed per launch too
+      what == "recompute": K launches of rg_recompute -- Raft::maybe_commit for every group with no messages, literally
+                           BASELINE's "commit-index recomputes"
+    Returns a dict with its own `roofline` object (bound, regime, achieved, peak, frac, traffic...)."""
+    main_stream = torch.cuda.current_stream()
+    if workload == 5 and not one_engine:
+        sizes = [(3, n_groups // 3), (5, n_groups // 3), (7, n_groups - 2 * (n_groups // 3))]
+    else:
+        sizes = [(n_slots, n_groups)]
+    T = warmup + steps
+
+    class Part:
+        pass
+
+    parts, first = [], 0
+    for slots, n in sizes:
+        pt = Part()
+        pt.n, pt.slots, pt.first = n, slots, first
+        pt.fixed = slots if (workload == 5 and not one_engine) else 0
+        pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights)
+        pt.eng.set_stream(main_stream.cuda_stream)
+        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed)
+        first += n
+        parts.append(pt)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    extra = {}
     if what == "recompute":
-        # matches as a run leaves them: a few ticks of the stream first (untimed)
-        cols = [torch.empty((n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+        pt = parts[0]
+        cols = [torch.empty((n_slots, pt.eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
         flags = torch.empty((n_groups, 8), dtype=torch.uint8, device="cuda")
-        for t in range(3):
-            eng.workload_gen(workload, t, *[c.data_ptr() for c in cols], flags.data_ptr(), seed=seed)
-            eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        for t in range(3):  # matches as a run leaves them: a few ticks of the stream first (untimed)
+            pt.eng.workload_gen(workload, t, *[c.data_ptr() for c in cols], flags.data_ptr(), seed=seed)
+            pt.eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
         for _ in range(warmup):
-            eng.recompute()
+            pt.eng.recompute()
         torch.cuda.synchronize()
-        e0.record(stream)
+        e0.record(main_stream)
         for _ in range(steps):
-            eng.recompute()
-        e1.record(stream)
+            pt.eng.recompute()
+        e1.record(main_stream)
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / steps
         nbytes = (8 * n_slots + 37) * n_groups  # SURVEY 8(d): B0(P) = 8 P + 37
-        kernel = "k_recompute"
+        hot = nbytes  # every byte it reads is re-read by the next launch
+        kernel, unit = "k_recompute", "commit-index recomputes/s"
+        key = f"recompute:{n_groups}:{n_slots}"
     else:
-        T = warmup + steps
-        cols = [torch.empty((T, n_slots, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
-        flags = torch.empty((T, n_groups, 8), dtype=torch.uint8, device="cuda")
-        eng.checkpoint()
-        alg = []
+        for pt in parts:
+            pt.cols = [torch.empty((T, pt.slots, pt.eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+            pt.flags = torch.empty((T, pt.n, 8), dtype=torch.uint8, device="cuda")
+            pt.eng.checkpoint()
+
+        def ptrs(pt, t):
+            return [c[t].data_ptr() for c in pt.cols] + [pt.flags[t].data_ptr()]
+
+        alg = [0] * T
+        census = dict(valid=0, rejects=0, elections=0)
         for t in range(T):
-            ptrs = [c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]
-            eng.workload_gen(workload, t, *ptrs, seed=seed)
-            s = eng.msg_stats(flags[t].data_ptr())
-            alg.append(algorithmic_bytes(n_groups, s["slots"], s["valid"], s["rejects"]))
-            eng.tick_device(*ptrs)
-        eng.restore()
-        for t in range(warmup):
-            eng.tick_device(*([c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]))
+            for pt in parts:
+                pt.eng.workload_gen(workload, t, *ptrs(pt, t), seed=seed, first_group=pt.first, fixed_peers=pt.fixed)
+                if inflights:
+                    pt.flags[t] &= 0xE7  # no RG_MF_SENT / RG_MF_INS_FULL: the device owns the send path
+                s = pt.eng.msg_stats(pt.flags[t].data_ptr())
+                alg[t] += algorithmic_bytes(pt.n, s["slots"], s["valid"], s["rejects"])
+                if t >= warmup:
+                    for k in census:
+                        census[k] += s[k]
+                pt.eng.tick_device(*ptrs(pt, t))
+                if inflights:
+                    pt.eng.send_appends(0)
+        for pt in parts:
+            pt.eng.sync()
+            pt.ref = pt.eng.results()
+            if pt.eng.result_counts()[1]:
+                raise SystemExit("side measurement: the stream raised faults")
+            pt.eng.restore()
+        multi = len(parts) > 1
+        for pt in parts:  # size-class engines are independent: one HIP stream each
+            pt.stream = torch.cuda.Stream() if multi else main_stream
+            pt.eng.set_stream(pt.stream.cuda_stream)
+        per_launch = []  # (tick start, tick end / stage start, stage end) events of every timed step (inflights only)
+
+        def replay(t0, n, record):
+            if multi:
+                fork = torch.cuda.Event()
+                fork.record(main_stream)
+                for pt in parts:
+                    pt.stream.wait_event(fork)
+            for i in range(n):
+                for pt in parts:
+                    if record and inflights:
+                        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                        ev[0].record(pt.stream)
+                    pt.eng.tick_device(*ptrs(pt, t0 + i))
+                    if inflights:
+                        if record:
+                            ev[1].record(pt.stream)
+                        pt.eng.send_appends(0)
+                        if record:
+                            ev[2].record(pt.stream)
+                            per_launch.append(ev)
+            if multi:
+                for pt in parts:
+                    ev_ = torch.cuda.Event()
+                    ev_.record(pt.stream)
+                    main_stream.wait_event(ev_)
+
+        replay(0, warmup, False)
         torch.cuda.synchronize()
-        e0.record(stream)
-        for t in range(warmup, T):
-            eng.tick_device(*([c[t].data_ptr() for c in cols] + [flags[t].data_ptr()]))
-        e1.record(stream)
+        e0.record(main_stream)
+        replay(warmup, steps, True)
+        e1.record(main_stream)
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / steps
+        for pt in parts:  # replay determinism
+            c, o = pt.eng.results()
+            if not (np.array_equal(c, pt.ref[0]) and np.array_equal(o, pt.ref[1])):
+                raise SystemExit("side measurement: the timed replay diverged from the recorded pass")
         nbytes = float(np.mean(alg[warmup:]))
-        kernel = "k_tick_lane"
-        n_fault = eng.result_counts()[1]
-        if n_fault:
-            raise SystemExit(f"side measurement raised {n_fault} faults")
-    eng.close()
+        hot = sum(hot_state_bytes(pt.n, pt.slots, bool(inflights)) for pt in parts)
+        kernel = {2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(variant, "k_tick_lane")
+        unit = "group-evals/s"
+        key = f"{workload}:{n_groups}:{n_slots}" + (":one-engine" if (workload == 5 and one_engine) else "") + (f":v{variant}" if variant else "")
+        denom = float(n_groups * steps)
+        extra = {"acks_per_group": round(census["valid"] / denom, 3), "rejects_per_group": round(census["rejects"] / denom, 5)}
+        if workload == 5:
+            extra["elections_per_group"] = round(census["elections"] / denom, 5)
+        if inflights:
+            pt = parts[0]
+            tick_us = sorted(a.elapsed_time(b) for a, b, _ in per_launch)[len(per_launch) // 2] * 1e3
+            stage_us = sorted(b.elapsed_time(c) for _, b, c in per_launch)[len(per_launch) // 2] * 1e3
+            items = len(pt.eng.send_items())
+            sb = send_stage_bytes(rg, pt.eng, items)
+            sg = sb / (stage_us * 1e-6) / 1e9
+            extra["send_stage"] = {
+                "max_inflight": inflights, "max_entries_per_msg": 0, "work_items_last_tick": int(items),
+                "us_per_tick_median": tick_us, "us_per_stage_median": stage_us,
+                "roofline": {"bound": "hbm", "regime": regime_of(hot), "achieved": sg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": sg / HBM_PEAK_GBS, "kernel": "k_send_dense", "algorithmic_bytes_per_launch": sb,
+                             "bytes_per_group": sb / n_groups, "avg_launch_us": stage_us, "traffic": None,
+                             "note": "the stage's OWN byte model (DESIGN.md section 3), counted on the last tick; SURVEY 8(d) "
+                                     "counts no bytes for the send path"}}
+    for pt in parts:
+        pt.eng.close()
     gbs = nbytes / (us * 1e-6) / 1e9
-    return {"groups": n_groups, "peer_slots": n_slots, "steps": steps, "warmup": warmup, "us_per_launch": us,
-            "value": n_groups / (us * 1e-6), "unit": "group-evals/s" if what == "tick" else "commit-index recomputes/s",
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "kernel": kernel, "algorithmic_bytes_per_launch": nbytes, "bytes_per_eval": nbytes / n_groups,
-                         "traffic": None}}
+    traffic, traffic_source = traffic_lookup(key)
+    return {"workload": workload_label(workload, n_groups, n_slots, one_engine) if what == "tick" else
+                        f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers",
+            "groups": n_groups, "peer_slots": n_slots, "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
+            "steps": steps, "warmup": warmup, "us_per_step": us, "value": n_groups / (us * 1e-6), "unit": unit, **extra,
+            "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel": kernel + (" + k_send_dense" if inflights else ""),
+                         "algorithmic_bytes_per_launch": nbytes, "bytes_per_eval": nbytes / n_groups, "avg_launch_us": us,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         **({"note": "avg_launch_us is the tick AND its send stage; the algorithmic bytes are the tick's, so frac "
+                                     "understates this mode -- the stage has its own roofline under send_stage"} if inflights else {})}}
 
 
 def main():
@@ -249,6 +447,8 @@ def main():
                     help="skip the recompute_only and out_of_cache sub-measurements (N=1 only; they run after the "
                          "timed region and do not touch `value`)")
     ap.add_argument("--out-of-cache-groups", type=int, default=8_000_000)
+    ap.add_argument("--c5-variant", type=int, default=C5_VARIANT,
+                    help="kernel variant of the config-5 lines under other_configs (5 = compact, 0 = lane)")
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
@@ -455,6 +655,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if os.environ.get("BENCH_MEASURE_DROP"):  # measurement builds (-DRG_CPT_MEASURE) only: results are wrong by design
+        os.environ["RG_MEASURE_DROP"] = os.environ["BENCH_MEASURE_DROP"]
     wall0 = time.perf_counter()
     e0.record(stream)
     run_ticks(W, K, distributed)
@@ -476,7 +678,7 @@ def main():
     # replay determinism: the timed replay must land on the state the recorded pass produced
     for j, pt in enumerate(parts):
         commit, out = pt.eng.results()
-        if not (np.array_equal(commit, pt.ref_commit) and np.array_equal(out, pt.ref_out)):
+        if not (np.array_equal(commit, pt.ref_commit) and np.array_equal(out, pt.ref_out)) and not os.environ.get("BENCH_MEASURE_DROP"):
             raise SystemExit("timed replay diverged from the recorded pass")
         if distributed and os.environ.get("BENCH_SKIP_VERIFY") != "1":  # (skipped only by RG_PUB_DEBUG measurement builds)
             # every rank's replica must hold every rank's shard: compare against the columns themselves
@@ -503,16 +705,12 @@ def main():
 
     # HBM traffic per launch: PMC-measured in separate rocprofv3 passes of this same command
     # (tools/summarize_prof.py -> profiles/traffic.json); null for configurations not profiled.
-    traffic, traffic_source = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            ent = json.load(f).get(f"{args.workload}:{G}:{P}", {}) if (len(parts) == 1 and not args.inflights) else {}
-        traffic = ent.get("bytes")
-        if traffic is not None:
-            traffic_source = ("profiles/traffic.json: " + ent.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                              "this command (tools/summarize_prof.py)") + " -- NOT measured inside this run")
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_source = (None, None)
+    if not args.inflights and args.split == 1 and args.fuse == 1:
+        traffic, traffic_source = traffic_lookup(
+            f"{args.workload}:{G}:{P}" + (":one-engine" if (args.workload == 5 and args.one_engine) else "") +
+            (f":v{args.variant}" if args.variant else ""))
+    hot = sum(hot_state_bytes(pt.n, pt.slots, bool(args.inflights)) for pt in parts)
 
     result = {
         "metric": "raft-group progress+commit evaluations/sec (commit-index recomputes/sec at 1M groups x 5 peers)",
@@ -522,11 +720,9 @@ def main():
         "config": {"workload": (f"{world} M groups x 7 peers sharded over {world} GPUs, commit indices published every "
                                 f"{'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3] at 8 GPUs)"
                                 if (args.workload == 2 and (G, P) == (1_000_000, 7) and distributed) else
-                                {2: "1M groups x 5 peers, majority quorum (BASELINE configs[1])",
-                                 3: "1M groups x 5 slots, joint {0,1,2}&&{1,2,3} + learner (configs[2])",
-                                 5: "1M groups mixed 3/5/7 peers + 10% leader-term rollover (configs[4])"}[args.workload]
-                                if (G, P) in ((1_000_000, 5), (1_000_000, 7)) else
-                                f"{G} groups x {P} slots, workload {args.workload}"),
+                                workload_label(args.workload, G, P, args.one_engine) +
+                                (f", x {world} ranks (weak scaling), commit indices published every "
+                                 f"{'tick' if E == 1 else str(E) + ' ticks'}" if distributed else "")),
                    "groups_per_gpu": G, "peer_slots": P, "workload_id": args.workload, "seed": hex(args.seed),
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
                    **({"elections_per_group": round(EL, 5),
@@ -544,7 +740,11 @@ def main():
                        if distributed else ""),
                    **({"publication": pub_stats} if distributed else {}),
                    "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot,
+                     "regime_note": "infinity-cache: the state columns every launch re-reads fit the 256 MB Infinity Cache, so part "
+                                    "of the traffic never reaches HBM and frac can exceed what a pure HBM stream sustains "
+                                    "(the honest HBM-regime figure is out_of_cache.roofline.frac); hbm: they do not fit",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_lane")) +
                                (" + k_send_appends" if args.inflights else ""),
@@ -564,12 +764,30 @@ def main():
         pt.cols = pt.flags = None
     torch.cuda.empty_cache()
     if world == 1 and not distributed and not args.no_extras:
-        # the literal BASELINE metric ("commit-index recomputes/sec"): Raft::maybe_commit for every group, no messages
-        result["recompute_only"] = side_measurement(rg, torch, G, P, args.workload if args.workload != 5 else 2,
-                                                    5, 50, args.seed, "recompute")
+        wl = args.workload if args.workload != 5 else 2
+        # the literal BASELINE metric ("commit-index recomputes/sec"): Raft::maybe_commit for every group, no messages --
+        # at BASELINE's size (77 MB working set: an Infinity-Cache number) and at 8 M groups (616 MB: an HBM number)
+        result["recompute_only"] = run_config(rg, torch, G, P, wl, 5, 50, args.seed, what="recompute")
+        result["recompute_only_out_of_cache"] = run_config(rg, torch, args.out_of_cache_groups, P, wl, 3, 20, args.seed,
+                                                           what="recompute")
         # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
-        result["out_of_cache"] = side_measurement(rg, torch, args.out_of_cache_groups, P, args.workload if args.workload != 5 else 2,
-                                                  3, 12, args.seed, "tick")
+        result["out_of_cache"] = run_config(rg, torch, args.out_of_cache_groups, P, wl, 3, 12, args.seed)
+        # every other BASELINE configuration that fits one GPU, each with its own roofline object (driver-timed like the
+        # headline): configs[2] joint, one rank's shard of configs[3], configs[4] in both layouts, and configs[1] with the
+        # Inflights on the device and the send stage after every tick
+        oc = {}
+        c5v = args.c5_variant
+        for name, kw in (("configs[2] joint", dict(n_groups=1_000_000, n_slots=5, workload=3)),
+                         ("configs[3] one rank's shard", dict(n_groups=1_000_000, n_slots=7, workload=2)),
+                         ("configs[4] size-class engines", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v)),
+                         ("configs[4] one 7-slot engine", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v, one_engine=True)),
+                         ("configs[1] + send stage", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256))):
+            if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") \
+                    and kw.get("variant", 0) == args.variant and kw.get("one_engine", False) == args.one_engine:
+                continue  # that is the headline itself
+            oc[name] = run_config(rg, torch, warmup=5, steps=30, seed=args.seed, **kw)
+            torch.cuda.empty_cache()
+        result["other_configs"] = oc
         # the other end of the scale: the round trip of a flush that touches 1 / 10 groups (not a throughput number)
         result["small_batch_latency"] = small_batch_latency(rg, torch, G, P, args.seed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1355,15 +1355,25 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     // needed when some group has ProgressTracker.group_commit set
     const u32 variant = (h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
                             ? h->cfg.variant : RG_VARIANT_LANE;
+#ifdef RG_CPT_MEASURE /* measurement builds only: see k_tick_compact */
+    RgState st_m = h->st;
+    if (!st_m.pub) {
+        const char *e = getenv("RG_MEASURE_DROP");
+        st_m.pub_cap = e ? (u32)atoi(e) : 0u;
+    }
+#define RG_TICK_STATE st_m
+#else
+#define RG_TICK_STATE h->st
+#endif
     switch (h->P) {
-    case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    case 3: rg_launch_tick_t<3>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    case 4: rg_launch_tick_t<4>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    case 5: rg_launch_tick_t<5>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    case 6: rg_launch_tick_t<6>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    case 7: rg_launch_tick_t<7>(h->stream, h->st, ms, variant, h->any_group_commit); break;
-    default: rg_launch_tick_t<8>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 1: rg_launch_tick_t<1>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 2: rg_launch_tick_t<2>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 3: rg_launch_tick_t<3>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 4: rg_launch_tick_t<4>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 5: rg_launch_tick_t<5>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 6: rg_launch_tick_t<6>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 7: rg_launch_tick_t<7>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    default: rg_launch_tick_t<8>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));

@@ -122,6 +122,50 @@ extern "C" int rg_host_check_tick(unsigned P, unsigned long G, unsigned long str
     return 0;
 }
 
+// The same tick over contiguous group ranges on n_threads host threads (std::thread inside this library, like the
+// oracle's ro_tick_soa_mt) -- bench.py's "engine arithmetic on the host cores" line. Every thread derives the pending
+// bits of its own range first, then ticks it; groups are independent.
+#include <thread>
+extern "C" int rg_host_check_tick_mt(unsigned P, unsigned long G, unsigned long stride, void *const *state,
+                                     const void *const *msg, int group_commit_kernel, unsigned n_threads) {
+    if (P == 0 || P > 8 || n_threads == 0) return -1;
+    const RgState st = make_state(state, G, stride);
+    const RgMsgs ms = make_msgs(msg);
+    const bool gc = group_commit_kernel != 0;
+    // (the pre-pass of host_tick<> decides per RANGE whether a tick carries log terms; results are the same either way)
+    auto work = [&](u64 g0, u64 g1) {
+        RgState sub = st;
+        for (u64 g = g0; g < g1; g++) {
+            u64 row = st.pflags[g];
+            for (unsigned p = 0; p < P; p++) {
+                const u64 o = (u64)p * st.stride + g;
+                row &= ~((u64)RG_PF_PENDING << (8 * p));
+                row |= (u64)((st.psnap[o] ? RG_PF_PEND_SNAP : 0u) | (st.prs[o] ? RG_PF_PEND_RS : 0u)) << (8 * p);
+            }
+            st.pflags[g] = row;
+        }
+        switch (P) {
+        case 1: host_tick<1>(sub, ms, gc, g0, g1); break;
+        case 2: host_tick<2>(sub, ms, gc, g0, g1); break;
+        case 3: host_tick<3>(sub, ms, gc, g0, g1); break;
+        case 4: host_tick<4>(sub, ms, gc, g0, g1); break;
+        case 5: host_tick<5>(sub, ms, gc, g0, g1); break;
+        case 6: host_tick<6>(sub, ms, gc, g0, g1); break;
+        case 7: host_tick<7>(sub, ms, gc, g0, g1); break;
+        default: host_tick<8>(sub, ms, gc, g0, g1); break;
+        }
+    };
+    if (n_threads == 1) {
+        work(0, G);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    th.reserve(n_threads);
+    for (unsigned i = 0; i < n_threads; i++) th.emplace_back(work, (u64)i * G / n_threads, (u64)(i + 1) * G / n_threads);
+    for (auto &t : th) t.join();
+    return 0;
+}
+
 extern "C" int rg_host_check_fused(unsigned P, unsigned long G, unsigned long stride, void *const *state, unsigned T,
                                    const void *const *const *msgs, u32 *out_t, u64 *commit_t, int group_commit_kernel) {
     const RgState st = make_state(state, G, stride);

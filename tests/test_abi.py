@@ -11,10 +11,12 @@ HEADER = os.path.join(ROOT, "include", "raftgroups.h")
 
 
 def declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|uint64_t|char)\s*\*?\s*(rg_\w+)\s*\(", src, flags=re.M)
-    return sorted(set(names))
+    """Every function prototype of the header (parsed by the binding generator: any return type)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_bindings
+    funcs = gen_rust_bindings.parse(open(HEADER, encoding="utf-8").read())[3]
+    return sorted({name for name, _, _ in funcs})
 
 
 def header_defines():
@@ -84,3 +86,33 @@ def test_oracle_flag_bits_are_the_headers():
     assert {"PF_PEND_SNAP", "PF_PEND_RS", "PF_INS_FULL", "PF_PAUSED"} <= set(common)
     for k in common:
         assert rg[k] == ro[k], (k, hex(rg[k]), hex(ro[k]))
+
+
+def test_rust_binding_is_generated_from_the_header_and_complete(rg):
+    """INTEGRATION.md's `extern "C"` block and bindings/raftgroups.rs are OUTPUT of tools/gen_rust_bindings.py: up to date,
+    one declaration per function the header declares = per symbol libraftgroups.so exports, with the header's arity."""
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "tools", "gen_rust_bindings.py")
+    r = subprocess.run([sys.executable, gen, "--check"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    rs = open(os.path.join(ROOT, "bindings", "raftgroups.rs")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert rs in doc, "INTEGRATION.md does not carry the generated block verbatim"
+    rust = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (rg_\w+)\((.*?)\)(?: -> [^;]+)?;", rs)}
+    declared = declared_functions()
+    assert sorted(rust) == declared, (sorted(set(declared) - set(rust)), sorted(set(rust) - set(declared)))
+    # arity: count the parameters of every prototype in the header and in the Rust block
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name in declared:
+        m = re.search(r"\b" + name + r"\s*\(([^()]*)\)\s*;", src, flags=re.S)
+        assert m, name
+        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        r_args = [a for a in rust[name].split(",") if a.strip()]
+        assert len(c_args) == len(r_args), (name, c_args, r_args)
+    lib = ctypes.CDLL(rg.LIB_PATH)
+    assert all(hasattr(lib, n) for n in rust)
+    # ... and the library exports nothing rg_* beyond them
+    out = subprocess.run(["nm", "-D", "--defined-only", rg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("rg_") and " T " in l})
+    assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))

@@ -28,7 +28,7 @@ def build_lib():
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         # no -march=native: the built .so travels with gpurun snapshots to hosts with other CPUs
         subprocess.check_call([hipcc, "-O3", "-std=c++17", "-shared", "-fPIC", "--offload-arch=gfx950",
-                               "-Wno-pass-failed", SRC, "-o", LIB])
+                               "-Wno-pass-failed", "-pthread", SRC, "-o", LIB])
     return LIB
 
 
@@ -119,6 +119,41 @@ def test_device_arithmetic_on_host_matches_oracle(host_tick, n_slots, gc):
         diffs = fuzz.diff_states(st, eng_st, G, n_slots)
         assert not diffs, (t, diffs[:6])
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+
+
+@pytest.mark.parametrize("n_slots", [3, 5, 7, 8])
+def test_acks_from_paused_peers_against_the_sequential_reference(host_tick, n_slots):
+    """RgTick::paused_acks decides `else if old_paused { send_append }` (raft.rs:1749-1751) from two quorum evaluations
+    per paused ack instead of replaying the sequence: streams where HALF the accepted acks come from paused peers (full
+    windows, paused probes), joint and majority configurations, small values so that ties and commits at every position
+    of the sequence occur, some malformed acks (the replay fallback)."""
+    rng = np.random.default_rng(9100 + n_slots)
+    G = 4000
+    st = O.alloc_state(G, n_slots)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.02)
+    fuzz.random_state(rng, st, small_values=True)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    msgs = O.alloc_msgs(G, n_slots)
+    gout = np.zeros(G, dtype=np.uint32)
+    out = np.zeros(G, dtype=np.uint32)
+    n_paused_changed = 0
+    for t in range(14):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, malformed_p=0.02 if t % 5 == 4 else 0.0)
+        f = msgs["m_flags"]
+        accept = ((f & 3) == 1)  # VALID, not REJECT
+        f[...] = np.where(accept & (rng.random(f.shape) < 0.5), f | fuzz.MF_INS_FULL, f)
+        host_tick(eng_st, msgs, out, False)
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (t, diffs[:6])
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5], [hex(x) for x in out[out != gout][:5]],
+                                     [hex(x) for x in gout[out != gout][:5]])
+        n_paused_changed += int((((gout & 1) != 0) & (((gout >> 8) & 0xff) != 0)).sum())
+    assert n_paused_changed > 500, n_paused_changed  # commits AND owed send_appends in the same tick: the decided case
 
 
 def test_device_arithmetic_near_the_top_of_the_index_range(host_tick):
