@@ -386,7 +386,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         hot = sum(hot_state_bytes(pt.n, pt.slots, bool(inflights)) for pt in parts)
         kernel = {2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(variant, "k_tick_lane")
         unit = "group-evals/s"
-        key = f"{workload}:{n_groups}:{n_slots}" + (":one-engine" if (workload == 5 and one_engine) else "") + (f":v{variant}" if variant else "")
+        key = (f"{workload}:{n_groups}:{n_slots}" + (":one-engine" if (workload == 5 and one_engine) else "") +
+               (f":v{variant}" if variant else "") + (":inflights" if inflights else ""))
         denom = float(n_groups * steps)
         extra = {"acks_per_group": round(census["valid"] / denom, 3), "rejects_per_group": round(census["rejects"] / denom, 5)}
         if workload == 5:
