@@ -487,8 +487,6 @@ def main():
     # other streams of the process, which serialises the publication's side stream with the ticks
     # (tools/probe_publish_host.py: 66 vs 43 us per tick + publication at world size 1).
     torch.cuda.set_stream(torch.cuda.Stream())
-    if args.workload == 5 and args.fuse > 1:
-        raise SystemExit("--fuse cannot replay config 5: fused launches do not apply elections (include/raftgroups.h)")
     stream = torch.cuda.current_stream()
 
     # A rank's shard is one engine per replica-set size class. Configs 2-4 have one size; config 5

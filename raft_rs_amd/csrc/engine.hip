@@ -1412,9 +1412,6 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
     if (h->ins_arena)
         return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: engines with device Inflights (max_inflight > 0) need "
                                      "rg_send_appends after every tick; fused launches are not available");
-    if (h->pub)
-        return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: not available while commit publication is active "
-                                     "(rg_comm_init): the per-tick advance of a fused launch is not recorded");
     RG_ENTER(h);
     RgFused fm;
     memset(&fm, 0, sizeof(fm));

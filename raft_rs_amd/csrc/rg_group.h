@@ -454,11 +454,11 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
 #pragma unroll
         for (int i = 0; i < P; i++) // slots without a Progress ack 0 and are never written back
             if (!((present >> i) & 1u)) r.mt[i] = 0;
-        // An election lands before every message of the tick (they answer the NEW leader). Fused launches do not
-        // apply it (k_tick_fused flags the group-tick instead): with several ticks of state in registers the rare
-        // path would cost that kernel a wave of occupancy.
+        // An election lands before every message of the tick (they answer the NEW leader). In a fused launch the group's
+        // registers simply carry on with the new leader's state; the cold cells (RG_COL_CUR_TERM, the term-run table) are
+        // read and written in memory on the spot, so a second election of the same group later in the launch sees them.
 #ifndef RG_NO_ELECT /* (measurement builds only: python -m raft_rs_amd.build --exp noelect -DRG_NO_ELECT) */
-        if (!FUSED && rg_has_election(r.mf, r.cfg, P)) become_leader();
+        if (rg_has_election(r.mf, r.cfg, P)) become_leader();
 #endif
 #pragma unroll
         for (int i = 0; i < P; i++)

@@ -564,14 +564,10 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_fus
     }
     r.dirty = 0;
     r.evm = 0;
-    r.adv = 0; // (fused launches are refused while commit publication is active)
+    r.adv = rg_pub_load(st, g); // commit publication: the launch's total advance lands in the group's byte (rg_store_group)
     for (u32 t = 0; t < fm.n_ticks; t++) {
         const RgMsgs &ms = fm.m[t];
         r.mf = rg_ld_stream(&rg_at(ms.mflags, g));
-        // RG_MF_BECOME_LEADER is not applied by fused launches (the rare path would cost this kernel, which holds
-        // several ticks of state in registers, a wave of occupancy): such a group-tick is flagged RG_OUT_FAULT and
-        // the event is ignored (include/raftgroups.h: elections go through single-tick launches)
-        const u32 efault = rg_has_election(r.mf, r.cfg, P) ? RG_OUT_FAULT : 0u;
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const IX o = (IX)p * (IX)st.stride + g;
@@ -579,7 +575,6 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_fus
             r.mc[p] = rg_ld_stream(&rg_at(ms.mc, o));
         }
         rg_group_tick<P, GC, RG_NX_LAZY, true, IX>(r, st, ms, g);
-        r.out |= efault;
         fm.out_t[(u64)t * st.G + g64] = r.out;
         if (fm.commit_t) fm.commit_t[(u64)t * st.G + g64] = r.commit;
     }

@@ -82,14 +82,12 @@ template <int P> static void host_fused(const RgState &st, const RgMsgs *ms, u32
         r.dirty = 0; r.evm = 0; r.adv = 0;
         for (u32 t = 0; t < T; t++) {
             r.mf = ms[t].mflags[g];
-            const u32 efault = rg_has_election(r.mf, r.cfg, P) ? RG_OUT_FAULT : 0u; // as in k_tick_fused
             for (int p = 0; p < P; p++) {
                 const u64 o = (u64)p * st.stride + g;
                 r.mi[p] = ms[t].mi[o]; r.mc[p] = ms[t].mc[o];
             }
             if (gc) rg_group_tick<P, true, RG_NX_LAZY, true>(r, st, ms[t], g);
             else rg_group_tick<P, false, RG_NX_LAZY, true>(r, st, ms[t], g);
-            r.out |= efault;
             out_t[(u64)t * st.G + g] = r.out;
             if (commit_t) commit_t[(u64)t * st.G + g] = r.commit;
         }

@@ -239,6 +239,52 @@ def test_fused_ticks_equal_sequential_ticks(host_fused, n_slots, T, gc):
         assert not diffs, (rnd, diffs[:6])
 
 
+@pytest.mark.parametrize("n_slots,T", [(3, 8), (5, 4), (7, 6)])
+def test_fused_ticks_with_elections_equal_sequential_ticks(host_fused, n_slots, T):
+    """RG_MF_BECOME_LEADER inside a fused launch (k_tick_fused keeps the group in registers across the ticks and applies
+    the election to them; RG_COL_CUR_TERM and the term-run table are written in memory): ~15 % of the groups elect per
+    tick, several times per launch, next to ordinary traffic -- every tick's result word and commit index, the final
+    state and the term table against the oracle stepping the ticks one at a time."""
+    rng = np.random.default_rng(7700 + n_slots)
+    G, TERM = 3000, 9
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05, transfer_frac=0.3)
+    fuzz.random_state(rng, st, small_values=True, probe_frac=0.3)
+    fuzz.random_term_table(rng, st, TERM)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    eng_st = copy_state(st)
+    term = TERM
+    elections = 0
+    for rnd in range(2):
+        ticks, want_out, want_commit = [], [], []
+        gout = np.zeros(G, dtype=np.uint32)
+        for t in range(T):
+            term += 1
+            cl.store_soa(st)
+            msgs = O.alloc_msgs(G, n_slots)
+            fuzz.random_msgs(rng, st, msgs, reject_p=0.2, elect_p=0.15, elect_term=term)
+            cl.tick_soa(msgs, gout)
+            cl.store_soa(st)
+            ticks.append(msgs)
+            want_out.append(gout.copy())
+            want_commit.append(st["commit"].copy())
+            elections += int(((gout & 0x10) != 0).sum())
+        out_t = np.zeros((T, G), dtype=np.uint32)
+        commit_t = np.zeros((T, G), dtype=np.uint64)
+        out_last = np.zeros(G, dtype=np.uint32)
+        host_fused(eng_st, ticks, out_last, out_t, commit_t, False)
+        for t in range(T):
+            bad = np.nonzero(out_t[t] != want_out[t])[0]
+            assert bad.size == 0, (rnd, t, bad[:5], [hex(x) for x in out_t[t][bad[:5]]], [hex(x) for x in want_out[t][bad[:5]]])
+            assert (commit_t[t] == want_commit[t]).all(), (rnd, t)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (rnd, diffs[:6])
+        for k in ("run_first", "run_term", "cur_term"):
+            assert (st[k] == eng_st[k]).all(), (rnd, k)
+    assert elections > G, elections
+
+
 @pytest.mark.parametrize("n_slots", [1, 3, 5, 8])
 def test_elections_between_and_inside_ticks(host_tick, n_slots):
     """RG_MF_BECOME_LEADER (Raft::reset + become_leader, raft.rs:942-971,1151-1202) on ~15% of the groups per tick,

@@ -295,8 +295,6 @@ def test_fused_launch_equals_sequential_ticks(rg, workload, n_slots, T):
         for t in range(T):
             cl.store_soa(st)
             E.workload_gen_host(st, host, workload, rnd * T + t)
-            # fused launches do not apply elections (they would fault): the stream without them is still well-formed
-            host.m_flags[:, 0] &= np.uint8(~rg.MF.BECOME_LEADER & 0xff)
             cols = [torch.from_numpy(getattr(host, k).view(np.int64).copy()).cuda()
                     for k in ("m_index", "m_commit", "m_hint", "m_rs")]
             flags = torch.from_numpy(host.m_flags.copy()).cuda()
@@ -480,34 +478,46 @@ def test_allocation_failures_are_reported_not_fatal(rg):
     eng.close()
 
 
-def test_fused_launch_flags_elections_instead_of_applying_them(rg):
-    """RG_MF_BECOME_LEADER rewrites a group's cells in memory; a fused launch holds them in registers, so it reports
-    RG_OUT_FAULT for that group-tick and leaves the election unapplied (include/raftgroups.h)."""
+def test_fused_launch_applies_elections(rg):
+    """RG_MF_BECOME_LEADER inside a fused launch: the group's registers carry on with the new leader's state, the cold
+    cells (RG_COL_CUR_TERM, the term-run table) are written in memory -- same result as a single-tick launch, including
+    two elections of one group within the launch."""
     import torch
     G, P = 1000, 3
-    eng = rg.Engine(G, P)
-    eng.workload_init(2)
-    before = eng.read_state()
-    mb = rg.MsgBuffers(G, P, eng.stride)
-    mb.m_flags[::2, 0] = rg.MF.BECOME_LEADER
-    mb.m_hint[0, :G] = 77
-    cols = [torch.from_numpy(getattr(mb, k).view(np.int64).copy()).cuda() for k in ("m_index", "m_commit", "m_hint", "m_rs")]
-    flags = torch.from_numpy(mb.m_flags.copy()).cuda()
-    out_t = torch.zeros((1, G), dtype=torch.int32, device="cuda")
-    eng.tick_device_fused([[c.data_ptr() for c in cols] + [flags.data_ptr()]], out_t.data_ptr())
-    eng.sync()
-    o = out_t.cpu().numpy().view(np.uint32)[0]
-    assert (o[::2] == rg.OUT.FAULT).all() and (o[1::2] == 0).all()
-    after = eng.read_state()
+    engs = [rg.Engine(G, P) for _ in range(2)]
+    for e in engs:
+        e.workload_init(2)
+    before = engs[0].read_state()
+    ticks = []
+    for t, term in enumerate((77, 78, 90)):
+        mb = rg.MsgBuffers(G, P, engs[0].stride)
+        if t != 1:
+            mb.m_flags[::2, 0] = rg.MF.BECOME_LEADER
+            mb.m_hint[0, :G] = term
+        else:  # in between: the new leader's followers answer its first probe
+            mb.m_flags[::2, 1] = rg.MF.VALID
+            mb.m_index[1, :G] = before["term_hi"]
+        cols = [torch.from_numpy(getattr(mb, k).view(np.int64).copy()).cuda() for k in ("m_index", "m_commit", "m_hint", "m_rs")]
+        ticks.append((cols, torch.from_numpy(mb.m_flags.copy()).cuda()))
+    out_t = torch.zeros((3, G), dtype=torch.int32, device="cuda")
+    engs[0].tick_device_fused([[c.data_ptr() for c in cols] + [flags.data_ptr()] for cols, flags in ticks], out_t.data_ptr())
+    engs[0].sync()
+    o = out_t.cpu().numpy().view(np.uint32)
+    for t, (cols, flags) in enumerate(ticks):
+        engs[1].tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        _, o1 = engs[1].results()
+        assert np.array_equal(o[t], o1), t
+    assert (o[0][::2] == (rg.OUT.BECAME_LEADER | rg.OUT.APPENDED)).all() and (o[0][1::2] == 0).all()
+    assert (o[2][::2] == (rg.OUT.BECAME_LEADER | rg.OUT.APPENDED)).all()
+    a, b = engs[0].read_state(), engs[1].read_state()
     for k in fuzz.STATE_KEYS:
-        assert np.array_equal(before[k], after[k]), k
-    # the same tick through a single-tick launch applies it
-    eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
-    _, o2 = eng.results()
-    assert (o2[::2] == (rg.OUT.BECAME_LEADER | rg.OUT.APPENDED)).all() and (o2[1::2] == 0).all()
-    st = eng.read_state()
-    assert (st["term_lo"][::2] == before["term_hi"][::2] + 1).all() and (st["match"][1:, :G:2] == 0).all()
-    eng.close()
+        assert np.array_equal(a[k], b[k]), k
+    for col in (rg.COL.CUR_TERM, rg.COL.RUN_FIRST, rg.COL.RUN_TERM):
+        assert np.array_equal(engs[0].read_column(col), engs[1].read_column(col)), col
+    assert (engs[0].read_column(rg.COL.CUR_TERM)[::2] == 90).all()
+    assert (a["term_lo"][::2] == before["term_hi"][::2] + 2).all()
+    for e in engs:
+        e.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -86,9 +86,22 @@ def test_ticks_accumulate_between_publications_and_other_commit_paths(rg):
     commit = eng.read_column(rg.COL.COMMIT)
     assert (commit[groups] == st["term_hi"][groups] + 40).all()
     assert np.array_equal(eng.published_commit(0), commit)
-    with pytest.raises(rg.EngineError):  # fused launches do not record their per-tick advance
-        out_t = torch.zeros((1, G), dtype=torch.int32, device="cuda")
-        eng.tick_device_fused([[c.data_ptr() for c in cols] + [flags.data_ptr()]], out_t.data_ptr())
+    # a fused launch (4 ticks of the stream in one launch) between two publications: its total advance is published
+    T = 4
+    tcols = [[torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)] for _ in range(T)]
+    tflags = [torch.zeros((G, 8), dtype=torch.uint8, device="cuda") for _ in range(T)]
+    ref = rg.Engine(G, P)  # the same four ticks one at a time: what the fused launch must equal
+    ref.load_state(eng.read_state())
+    for t in range(T):
+        ref.workload_gen(2, 20 + t, *[c.data_ptr() for c in tcols[t]], tflags[t].data_ptr())
+        ref.tick_device(*[c.data_ptr() for c in tcols[t]], tflags[t].data_ptr())
+    out_t = torch.zeros((T, G), dtype=torch.int32, device="cuda")
+    eng.tick_device_fused([[c.data_ptr() for c in tcols[t]] + [tflags[t].data_ptr()] for t in range(T)], out_t.data_ptr())
+    eng.publish_commit()
+    commit2 = eng.read_column(rg.COL.COMMIT)
+    assert np.array_equal(commit2, ref.read_column(rg.COL.COMMIT)) and (commit2 > commit).sum() > G // 2
+    assert np.array_equal(eng.published_commit(0), commit2)
+    ref.close()
     eng.close()  # (rg_destroy tears the communicator down)
 
 
