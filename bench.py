@@ -436,6 +436,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--publish-every", type=int, default=1,
                     help="N>1: publish the commit advances every E ticks (and after the last tick); default every tick")
+    ap.add_argument("--publish-raw", action="store_true",
+                    help="N>1: publish the full 8 B/group commit column every time (RG_PUBLISH_FULL) instead of the ~1 B/group "
+                         "delta slices -- the naive exchange, for comparison")
+    ap.add_argument("--no-publish-compare", action="store_true",
+                    help="N>1: skip the second run of the K ticks with the other publication form (publication_compare)")
     ap.add_argument("--fuse", type=int, default=1,
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
@@ -607,7 +612,7 @@ def main():
 
     issued = [0.0]  # when the host had issued the last tick / publication of a run_ticks call
 
-    def run_ticks(t0, n, publish):
+    def run_ticks(t0, n, publish, raw=False):
         if multi:
             fork = torch.cuda.Event()
             fork.record(stream)
@@ -631,7 +636,7 @@ def main():
                 if args.inflights:
                     pt.eng.send_appends(0)
                 if pub_now:
-                    pt.eng.publish_commit()
+                    pt.eng.publish_commit(full=raw)  # raw: the 8 B/group column itself (RG_PUBLISH_FULL) instead of the ~1 B/group slice
         issued[0] = time.perf_counter()
         if publish:  # the region ends when every exchange has landed and the replicas are up to date
             for pt in parts:
@@ -647,7 +652,7 @@ def main():
         pt.eng.restore()
         if distributed:
             pt.eng.publish_commit(full=True)  # the replicas restart from the restored columns (outside the region)
-    run_ticks(0, W, distributed)
+    run_ticks(0, W, distributed, args.publish_raw)
     torch.cuda.synchronize()
     launch_mode = "eager"
     if distributed:
@@ -658,7 +663,7 @@ def main():
         os.environ["RG_MEASURE_DROP"] = os.environ["BENCH_MEASURE_DROP"]
     wall0 = time.perf_counter()
     e0.record(stream)
-    run_ticks(W, K, distributed)
+    run_ticks(W, K, distributed, args.publish_raw)
     e1.record(stream)
     host_issue_s = issued[0] - wall0  # the host's share: how long it took to ISSUE the K steps
     torch.cuda.synchronize()
@@ -688,10 +693,40 @@ def main():
                 if not np.array_equal(rep[r], cols_all[r].numpy().view(np.uint64)):
                     raise SystemExit(f"rank {rank}: published commit indices of rank {r} differ from its commit column")
     pub_stats = parts[0].eng.publish_stats() if distributed else None
+    pub_compare = None
     if distributed:
         tmax = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
+        if not args.no_publish_compare:
+            # the same K ticks once more with the OTHER publication form (delta slices <-> the raw 8 B/group column), so
+            # that a multi-GPU run reports both side by side; outside the headline region, same barriers, max over ranks
+            other = not args.publish_raw
+            for pt in parts:
+                pt.eng.restore()
+                pt.eng.publish_commit(full=True)
+            run_ticks(0, W, True, other)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            run_ticks(W, K, True, other)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            w2 = torch.tensor([time.perf_counter() - w0], dtype=torch.float64)
+            dist.all_reduce(w2, op=dist.ReduceOp.MAX)
+            for pt in parts:  # same final state, whatever travelled
+                commit, _ = pt.eng.results()
+                if not np.array_equal(commit, pt.ref_commit):
+                    raise SystemExit("publication comparison run diverged")
+                rep = pt.eng.published_commit(rank)
+                if not np.array_equal(rep, commit):
+                    raise SystemExit("publication comparison run: replica differs from the commit column")
+            st2 = parts[0].eng.publish_stats()
+            pub_compare = {"mode": "raw 8 B/group column every tick (RG_PUBLISH_FULL)" if other else "delta slices (~1 B/group)",
+                           "ms_per_step": float(w2.item()) * 1e3 / K, "value": world * G * K / float(w2.item()),
+                           "bytes_per_rank_per_publication": st2["bytes_per_rank_full"] if other else st2["bytes_per_rank_delta"]}
 
     evals = world * G * K
     value = evals / wall
@@ -716,9 +751,10 @@ def main():
         "value": value, "unit": "group-evals/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": (f"{world} M groups x 7 peers sharded over {world} GPUs, commit indices published every "
-                                f"{'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3] at 8 GPUs)"
-                                if (args.workload == 2 and (G, P) == (1_000_000, 7) and distributed) else
+        "config": {"workload": (f"{world * G} groups x 7 peers sharded over {world} GPUs ({G} per GPU), commit indices published "
+                                f"every {'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3]: 8 M x 7 over 8 GPUs"
+                                f"{'' if (world, G) == (8, 1_000_000) else ' -- here at ' + str(world) + ' x ' + str(G)})"
+                                if (args.workload == 2 and P == 7 and distributed) else
                                 workload_label(args.workload, G, P, args.one_engine) +
                                 (f", x {world} ranks (weak scaling), commit indices published every "
                                  f"{'tick' if E == 1 else str(E) + ' ticks'}" if distributed else "")),
@@ -737,7 +773,9 @@ def main():
                        f"{'gloo transport callback (shared-GPU test hook)' if share_gpu else (transport_note or 'ncclAllGather (RCCL)')} of "
                        f"{pub_stats['bytes_per_rank_delta']} B/rank delta slices (full column: {pub_stats['bytes_per_rank_full']} B)"
                        if distributed else ""),
-                   **({"publication": pub_stats} if distributed else {}),
+                   **({"publication": pub_stats,
+                       "publication_mode": "raw 8 B/group column every tick (RG_PUBLISH_FULL)" if args.publish_raw else "delta slices (~1 B/group)",
+                       "publication_compare": pub_compare} if distributed else {}),
                    "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot,
                      "regime_note": "infinity-cache: the state columns every launch re-reads fit the 256 MB Infinity Cache, so part "

@@ -241,3 +241,107 @@ def test_ranks_sharing_the_gpu_publish_through_the_c_entry_point(rg, tmp_path, w
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     assert f"PUBLISH_OK {world}" in r.stdout, r.stdout[-3000:]
+
+
+WORKER8 = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["RG_ROOT"]); sys.path.insert(0, os.path.join(os.environ["RG_ROOT"], "tests"))
+import raft_rs_amd as rg
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)  # every rank shares the box's one GPU
+# BASELINE configs[3]'s shape: 7-peer groups sharded over 8 ranks, >= 128 k groups per rank, a publication after EVERY tick
+G, P, WL, RING, TICKS, LOSER = 131_072 + 5, 7, rg.WL_MAJORITY, 4, 19, 5
+
+class Dev:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+calls = []
+def allgather(dev_send, dev_recv, nbytes, stream):
+    torch.cuda.synchronize()
+    send = torch.as_tensor(Dev(dev_send, nbytes), device="cuda").cpu()
+    out = torch.empty(world * nbytes, dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, send)
+    torch.as_tensor(Dev(dev_recv, world * nbytes), device="cuda").copy_(out)
+    torch.cuda.synchronize()
+    calls.append(nbytes)
+    return 0
+
+eng = rg.Engine(G, P)
+eng.workload_init(WL, first_group=rank * G)
+eng.comm_init(rank, world, transport=allgather, ring_ticks=RING)
+cols = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+flags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
+exact_at = []
+for t in range(TICKS):
+    if rank == LOSER and t == 3:
+        eng.checkpoint()
+    if rank == LOSER and t == 6:
+        eng.restore()          # a rollback on ONE rank: its published advances no longer describe its column
+    eng.workload_gen(WL, t, *[c.data_ptr() for c in cols], flags.data_ptr(), first_group=rank * G)
+    eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+    eng.publish_commit()
+    # every rank's replica against every rank's column, after every tick (reading folds the ring: any cadence is legal)
+    mine = eng.read_column(rg.COL.COMMIT)
+    allc = [torch.empty(G, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, torch.from_numpy(mine.view(np.int64)))
+    rep = eng.published_commit()
+    ok = all(np.array_equal(rep[r], allc[r].numpy().view(np.uint64)) for r in range(world))
+    exact_at.append(ok)
+    others_ok = all(np.array_equal(rep[r], allc[r].numpy().view(np.uint64)) for r in range(world) if r != LOSER)
+    assert others_ok, (rank, t)  # only the rank that rolled back may be inexact, and only for a while
+st = eng.publish_stats()
+# exact before the rollback, inexact for at most 2 x ring_ticks publications after it, exact again from then on
+assert all(exact_at[:6]), exact_at
+assert not all(exact_at[6:6 + 2 * RING + 1]) and all(exact_at[6 + 2 * RING + 1:]), exact_at
+assert st["full_publications"] == 2, st          # rg_comm_init's and the resynchronisation
+assert calls.count(st["bytes_per_rank_full"]) == 2 and calls.count(st["bytes_per_rank_delta"]) == TICKS - 1, (calls, st)
+assert st["bytes_per_rank_delta"] < 1.1 * G + 4096
+if rank == 0:
+    print("PUBLISH8_OK", world, st["bytes_per_rank_delta"], st["bytes_per_rank_full"], exact_at.count(False))
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+'''
+
+
+def test_eight_ranks_of_the_config4_shape_publish_every_tick_with_one_rollback(rg, tmp_path):
+    """BASELINE configs[3]'s exchange at its real rank count, on the one GPU this box has: 8 ranks x 131 k groups x 7
+    peers through rg_publish_commit (transport callback: gloo moves the slices), a publication after every tick, the
+    ring of 4 wrapping several times, and ONE rank rolling back (rg_restore) in the middle -- its slice is announced lost
+    in the gathered headers, every rank decides at the same check point that the next one carries full 8 B/group
+    snapshots, and all replicas are exact again within 2 x ring_ticks publications."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8)
+    env = dict(os.environ, RG_ROOT=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+           "--master-addr", "127.0.0.1", "--master-port", "29578", str(script)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "PUBLISH8_OK 8" in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_line_of_eight_ranks_sharing_the_gpu(rg):
+    """`bench.py --gpus 8 --slots 7` as the driver launches it (torch.distributed.run, one rank per GPU) -- here with
+    BENCH_SHARE_GPU=1 (all ranks on GPU 0, gloo moving the slices): the N = 8 line's JSON end to end."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--slots", "7", "--groups", "131072",
+           "--steps", "6", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 6 and line["scaling"] == "weak" and line["unit"] == "group-evals/s"
+    assert line["value"] == pytest.approx(8 * 131072 * 6 / (line["ms_per_step"] * 6 / 1e3), rel=1e-6)
+    cfg = line["config"]
+    assert "configs[3]" in cfg["workload"] and "sharded over 8 GPUs" in cfg["workload"] and cfg["peer_slots"] == 7
+    pub = cfg["publication"]
+    assert pub["publications"] >= 6 + 2 and pub["bytes_per_rank_delta"] < 1.1 * 131072 + 4096 <= pub["bytes_per_rank_full"]
+    assert cfg["publication_mode"].startswith("delta") and cfg["publication_compare"]["mode"].startswith("raw")
+    assert cfg["publication_compare"]["bytes_per_rank_per_publication"] == pub["bytes_per_rank_full"]
+    assert line["roofline"]["regime"] in ("infinity-cache", "hbm") and line["cpu_baseline"] is None
