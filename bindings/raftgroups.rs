@@ -30,7 +30,7 @@ pub const RG_OUT_FAULT: u32 = 0x2;
 pub const RG_OUT_TIMEOUT_NOW: u32 = 0x4;
 pub const RG_OUT_APPENDED: u32 = 0x8;
 pub const RG_OUT_BECAME_LEADER: u32 = 0x10;
-pub const RG_TERM_RUNS: u32 = 4;
+pub const RG_TERM_RUNS: u32 = 8;
 pub const RG_VARIANT_DEFAULT: u32 = 0;
 pub const RG_VARIANT_LANE: u32 = 1;
 pub const RG_VARIANT_LDS: u32 = 2;

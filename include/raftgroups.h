@@ -152,7 +152,7 @@ typedef enum {
     RG_COL_CUR_TERM = 16,    /* u64 [G] the leader's term (Raft.term) */
     RG_COL_COUNT = 17
 } rg_column;
-#define RG_TERM_RUNS 4
+#define RG_TERM_RUNS 8
 
 /* ---- a tick's messages, struct-of-arrays, HOST or DEVICE memory (see rg_tick / rg_tick_device) ---- */
 typedef struct {

@@ -800,9 +800,9 @@ int ro_load_soa(ro_cluster *c, const ro_soa_state *s, uint64_t term, size_t max_
          * empty range (term_lo > term_hi) = no entry of the current term yet. */
         uint64_t lo = s->term_lo[g], hi = s->term_hi[g];
         if (s->run_first) { /* explicit table: dummy entry + older runs + the leader's own run [lo, hi] */
-            uint64_t rf[5], rt[5];
+            uint64_t rf[RO_TERM_RUNS + 1], rt[RO_TERM_RUNS + 1];
             size_t nr = 0;
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < RO_TERM_RUNS; k++) {
                 uint64_t f = s->run_first[(size_t)k * s->stride + g];
                 if (f == 0) continue;
                 rf[nr] = f;
@@ -860,7 +860,7 @@ int ro_store_soa(ro_cluster *c, ro_soa_state *s) {
         s->cfg[g] = (s->cfg[g] & ~(0xfu << 20)) | (((uint32_t)gr->lead_transferee & 0xfu) << 20);
         if (s->run_first) {
             size_t older = gr->n_runs - (own ? 1 : 0);
-            for (size_t k = 0; k < 4; k++) {
+            for (size_t k = 0; k < RO_TERM_RUNS; k++) {
                 s->run_first[k * s->stride + g] = k < older ? gr->runs[k].first : 0;
                 s->run_term[k * s->stride + g] = k < older ? gr->runs[k].term : 0;
             }
@@ -888,7 +888,7 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
                 out |= RO_OUT_BECAME_LEADER | RO_OUT_APPENDED; /* bcast_append follows become_leader, raft.rs:2190-2191 */
                 /* engine contract: the term table keeps RG_TERM_RUNS runs of older terms; deeper history loses the
                  * boundary between its two oldest runs */
-                if (gr->n_runs > 4 + 1) {
+                if (gr->n_runs > RO_TERM_RUNS + 1) {
                     memmove(&gr->runs[1], &gr->runs[2], (gr->n_runs - 2) * sizeof(ro_run));
                     gr->n_runs--;
                 }

@@ -322,7 +322,7 @@ template <int P> struct RgGroup {
 };
 // (RgGroup::push_rf: with fewer than 4 slots the dead message registers do not cover the five loads -- P = 3 would lose a
 // wave of occupancy -- so small groups read the table after their stores instead)
-#define RG_PUSH_EARLY(P) ((P) >= 4)
+#define RG_PUSH_EARLY(P) ((P) >= 9)
 #if defined(__HIP_DEVICE_COMPILE__)
 // The value stays what it is, but the compiler may not look through: without this it computes `hint + 1` (and the
 // election's term comparison) inside the very branch that issued the prefetch, i.e. waits for the load on the spot.
@@ -359,10 +359,28 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 // runs is forgotten (include/raftgroups.h: RG_COL_RUN_FIRST).
 template <typename IX> RG_HD void rg_push_run_loaded(const RgState &st, IX g, const u64 (&rf)[RG_TERM_RUNS], u64 first, u64 term);
 template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first, u64 term) {
-    u64 rf[RG_TERM_RUNS];
+    // (loops over the table in memory, four cells per round trip: a rare path that runs behind the group's stores -- no
+    // register array that lives through the tick, so the depth of the table costs the dense kernel nothing)
+    int k = RG_TERM_RUNS;
+#pragma unroll 1
+    for (int b = 0; b < RG_TERM_RUNS && k == RG_TERM_RUNS; b += 4) {
+        u64 rf[4];
 #pragma unroll
-    for (int k = 0; k < RG_TERM_RUNS; k++) rf[k] = rg_at(st.run_first, (IX)k * (IX)st.stride + g);
-    rg_push_run_loaded<IX>(st, g, rf, first, term);
+        for (int i = 0; i < 4; i++) rf[i] = rg_at(st.run_first, (IX)(b + i) * (IX)st.stride + g);
+#pragma unroll
+        for (int i = 3; i >= 0; i--)
+            if (rf[i] == 0) k = b + i; // first unused run
+    }
+    if (k == RG_TERM_RUNS) { // table full: forget the boundary between the two oldest runs
+#pragma unroll 1
+        for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
+            rg_at(st.run_first, (IX)j * (IX)st.stride + g) = rg_at(st.run_first, (IX)(j + 1) * (IX)st.stride + g);
+            rg_at(st.run_term, (IX)j * (IX)st.stride + g) = rg_at(st.run_term, (IX)(j + 1) * (IX)st.stride + g);
+        }
+        k = RG_TERM_RUNS - 1;
+    }
+    rg_at(st.run_first, (IX)k * (IX)st.stride + g) = first;
+    rg_at(st.run_term, (IX)k * (IX)st.stride + g) = term;
 }
 template <typename IX> RG_HD void rg_push_run_loaded(const RgState &st, IX g, const u64 (&rf)[RG_TERM_RUNS], u64 first, u64 term) {
     int k = 0;

@@ -27,7 +27,7 @@ class COL:
              "term_lo", "term_hi", "cfg", "out", "run_first", "run_term", "dummy_index", "dummy_term", "cur_term")
 
 
-TERM_RUNS = 4
+TERM_RUNS = 8
 
 
 class PF:

@@ -4,6 +4,8 @@ Test infrastructure: plain numpy, no dependency on the oracle or the engine.
 """
 import numpy as np
 
+TERM_RUNS = 8  # RG_TERM_RUNS (include/raftgroups.h)
+
 MF_VALID, MF_REJECT, MF_HAS_RS, MF_INS_FULL, MF_SENT, MF_APPEND, MF_HEARTBEAT = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -74,7 +76,7 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
 
 
 def random_term_table(rng, st, term):
-    """Fill st's term-run table (oracle_lib.add_term_table): 0..4 runs of terms OLDER than the leader's `term`
+    """Fill st's term-run table (oracle_lib.add_term_table): 0..TERM_RUNS runs of terms OLDER than the leader's `term`
     right below term_lo (the leader's own entries [term_lo, term_hi] are implicit), the dummy entry below them."""
     G = st["n_groups"]
     st["cur_term"][:] = term
@@ -82,7 +84,7 @@ def random_term_table(rng, st, term):
         lo, hi = int(st["term_lo"][g]), int(st["term_hi"][g])
         top = lo if lo <= hi else hi + 1  # first index that is NOT an older entry
         runs, first, t = [], top, term
-        for _ in range(int(rng.integers(0, 5))):
+        for _ in range(int(rng.integers(0, TERM_RUNS + 1))):
             if first <= 1 or t <= 1:
                 break
             first = max(1, first - int(rng.integers(1, 6)))
@@ -92,7 +94,7 @@ def random_term_table(rng, st, term):
         # the dummy (snapshot) entry is older than the leader's term: a snapshot index is always committed,
         # so "term(dummy) == current term" can never gate a commit in a real log
         d_term = int(rng.integers(0, min(runs[0][1] if runs else term - 1, term - 1) + 1))
-        for k in range(4):
+        for k in range(TERM_RUNS):
             st["run_first"][k, g] = runs[k][0] if k < len(runs) else 0
             st["run_term"][k, g] = runs[k][1] if k < len(runs) else 0
         st["dummy_index"][g] = d_idx

@@ -279,6 +279,7 @@ STATE_COLS = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pfla
               "term_lo", "term_hi", "cfg")
 
 
+TERM_RUNS = 8  # RG_TERM_RUNS / RO_TERM_RUNS (tests/test_abi.py compares the three)
 TERM_TABLE_COLS = ("run_first", "run_term", "dummy_index", "dummy_term", "cur_term")
 
 
@@ -318,9 +319,9 @@ def alloc_msgs(n_groups, n_slots, stride=None):
 
 
 def add_term_table(st):
-    """Attach an (empty) term-run table to a state dict: run_first/run_term [4][stride], dummy [G]."""
-    st["run_first"] = np.zeros((4, st["stride"]), dtype=np.uint64)
-    st["run_term"] = np.zeros((4, st["stride"]), dtype=np.uint64)
+    """Attach an (empty) term-run table to a state dict: run_first/run_term [TERM_RUNS][stride], dummy [G]."""
+    st["run_first"] = np.zeros((TERM_RUNS, st["stride"]), dtype=np.uint64)
+    st["run_term"] = np.zeros((TERM_RUNS, st["stride"]), dtype=np.uint64)
     st["dummy_index"] = np.zeros(st["n_groups"], dtype=np.uint64)
     st["dummy_term"] = np.zeros(st["n_groups"], dtype=np.uint64)
     st["cur_term"] = np.zeros(st["n_groups"], dtype=np.uint64)

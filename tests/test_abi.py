@@ -54,6 +54,17 @@ def test_oracle_adapter_uses_the_header_bit_layouts():
     assert E.cfg_make(0x07, 0x0e, 2, True, 3, 0x1f) == (0x07 | (0x0e << 8) | (2 << 16) | 0x80000 | (3 << 20) | (0x1f << 24))
 
 
+def test_term_run_table_depth_is_the_same_everywhere():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fuzz
+    import oracle_lib as O
+    from raft_rs_amd import engine as E
+    n = header_defines()["RG_TERM_RUNS"]
+    ro = int(re.search(r"#define RO_TERM_RUNS (\d+)", open(os.path.join(ROOT, "oracle", "raft_oracle.h")).read()).group(1))
+    assert n == ro == O.TERM_RUNS == fuzz.TERM_RUNS == E.TERM_RUNS == 8
+
+
 def test_engine_fails_loudly_without_a_gpu(rg):
     lib = rg.load_library()
     if lib.rg_device_count() > 0:

@@ -43,7 +43,7 @@ def state_ptrs(st, out):
     """17 pointers in the order host_tick.hip expects; a zero table when the state has no term-run table."""
     key = (st["n_groups"], st["stride"])
     if key not in _ZERO:
-        _ZERO[key] = (np.zeros((4, st["stride"]), dtype=np.uint64), np.zeros(st["n_groups"], dtype=np.uint64))
+        _ZERO[key] = (np.zeros((O.TERM_RUNS, st["stride"]), dtype=np.uint64), np.zeros(st["n_groups"], dtype=np.uint64))
     z4, zg = _ZERO[key]
     table = [st.get("run_first", z4), st.get("run_term", z4), st.get("dummy_index", zg), st.get("dummy_term", zg),
              st.get("cur_term", zg)]
@@ -346,7 +346,7 @@ def test_find_conflict_by_term_on_the_device_table(host_tick, n_slots):
     for g in range(0, G, 37):
         for idx in range(max(0, int(st["dummy_index"][g]) - 1), int(st["term_hi"][g]) + 2):
             want = L.ro_log_term(cl.h, g, idx)
-            runs = [(int(st["run_first"][k, g]), int(st["run_term"][k, g])) for k in range(4) if st["run_first"][k, g]]
+            runs = [(int(st["run_first"][k, g]), int(st["run_term"][k, g])) for k in range(O.TERM_RUNS) if st["run_first"][k, g]]
             d = int(st["dummy_index"][g])
             if idx < d or idx > int(st["term_hi"][g]):
                 got = 0

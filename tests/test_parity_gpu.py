@@ -494,7 +494,9 @@ def test_fused_launch_applies_elections(rg):
         if t != 1:
             mb.m_flags[::2, 0] = rg.MF.BECOME_LEADER
             mb.m_hint[0, :G] = term
-        else:  # in between: the new leader's followers answer its first probe
+        else:  # in between: the new leader persists its empty entry, a follower answers its first probe
+            mb.m_flags[::2, 0] = rg.MF.VALID
+            mb.m_index[0, :G] = before["term_hi"] + 1
             mb.m_flags[::2, 1] = rg.MF.VALID
             mb.m_index[1, :G] = before["term_hi"]
         cols = [torch.from_numpy(getattr(mb, k).view(np.int64).copy()).cuda() for k in ("m_index", "m_commit", "m_hint", "m_rs")]
