@@ -314,15 +314,10 @@ template <int P> struct RgGroup {
     u64 hint[P];
     u64 el_old;         // an election: the current term (the new one comes in hint[self]) = the term of the previous
                         // leader's entries, which rg_push_run files in the term-run table after the group's stores
-                        // (RG_TICK_PUSH)
-    u64 push_rf[RG_TERM_RUNS], push_lo; // ... what that needs from memory (the table's first column; the previous
-                        // leader's first index, still in the term_lo column), requested once the slots have been walked
-                        // -- Message.index / .commit are dead by then, so this costs no registers at the kernel's peak,
-                        // and the data is there when the stores have been issued
+                        // (RG_TICK_PUSH: from memory, behind everything else -- round 2 requested the table's cells early, into
+                        // the registers the dead message columns leave; with RG_TERM_RUNS = 8 that cost the dense kernel a wave
+                        // of occupancy at P = 5, the late reads cost config 5 nothing measurable, profiles/r03_*)
 };
-// (RgGroup::push_rf: with fewer than 4 slots the dead message registers do not cover the five loads -- P = 3 would lose a
-// wave of occupancy -- so small groups read the table after their stores instead)
-#define RG_PUSH_EARLY(P) ((P) >= 9)
 #if defined(__HIP_DEVICE_COMPILE__)
 // The value stays what it is, but the compiler may not look through: without this it computes `hint + 1` (and the
 // election's term comparison) inside the very branch that issued the prefetch, i.e. waits for the load on the spot.
@@ -357,7 +352,6 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 // The previous leader's entries [first, ...] of term `term` become one more run of the group's term-run table
 // (RgTick::become_leader). Used runs come first; when all RG_TERM_RUNS are in use the boundary between the two oldest
 // runs is forgotten (include/raftgroups.h: RG_COL_RUN_FIRST).
-template <typename IX> RG_HD void rg_push_run_loaded(const RgState &st, IX g, const u64 (&rf)[RG_TERM_RUNS], u64 first, u64 term);
 template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first, u64 term) {
     // (loops over the table in memory, four cells per round trip: a rare path that runs behind the group's stores -- no
     // register array that lives through the tick, so the depth of the table costs the dense kernel nothing)
@@ -382,23 +376,6 @@ template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first
     rg_at(st.run_first, (IX)k * (IX)st.stride + g) = first;
     rg_at(st.run_term, (IX)k * (IX)st.stride + g) = term;
 }
-template <typename IX> RG_HD void rg_push_run_loaded(const RgState &st, IX g, const u64 (&rf)[RG_TERM_RUNS], u64 first, u64 term) {
-    int k = 0;
-#pragma unroll
-    for (int j = RG_TERM_RUNS - 1; j >= 0; j--)
-        if (rf[j] == 0) k = j; // first unused run
-    if (rf[RG_TERM_RUNS - 1] != 0) { // table full
-#pragma unroll
-        for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
-            rg_at(st.run_first, (IX)j * (IX)st.stride + g) = rf[j + 1];
-            rg_at(st.run_term, (IX)j * (IX)st.stride + g) = rg_at(st.run_term, (IX)(j + 1) * (IX)st.stride + g);
-        }
-        k = RG_TERM_RUNS - 1;
-    }
-    rg_at(st.run_first, (IX)k * (IX)st.stride + g) = first;
-    rg_at(st.run_term, (IX)k * (IX)st.stride + g) = term;
-}
-
 // RG_NX_PREFETCH: everything a tick may read beyond the bulk columns, decided from the two flag rows and the cfg
 // word alone and requested in ONE batch right behind the bulk loads -- the old `next` of the slots where it can
 // matter (see RgTick: not where SENT on a Replicate peer overwrites it first), the reject hint of every slot whose
@@ -852,16 +829,6 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
         mc_self = 0;
         (peer_committed<S>(), ...);
         (slot<S>(), ...);
-        if (PREF && RG_PUSH_EARLY(P)) { // (rg_store_group's rg_push_run_loaded: see RgGroup::push_rf)
-#pragma unroll
-            for (int k = 0; k < RG_TERM_RUNS; k++) r.push_rf[k] = 0;
-            r.push_lo = 0;
-            if (r.dirty & RG_TICK_PUSH) {
-#pragma unroll
-                for (int k = 0; k < RG_TERM_RUNS; k++) r.push_rf[k] = rg_at(st.run_first, (IX)k * (IX)st.stride + g);
-                r.push_lo = rg_at(st.lo, g);
-            }
-        }
         commit_phase(seq);
         r.out = out;
     }

@@ -105,18 +105,7 @@ template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, con
     if (d & (RG_DIRTY_LO | RG_DIRTY_CFG | RG_TICK_PUSH)) { // an election (rare)
         // its table update comes last (it reads the table, and nothing else of the wave should wait for that) but before
         // term_lo is overwritten: the previous leader's first index is taken from there
-        if (!RG_PUSH_EARLY(P)) {
-            if (d & RG_TICK_PUSH) rg_push_run<IX>(st, g, rg_at(st.lo, g), r.el_old);
-        } else if (d & RG_TICK_PUSH) {
-            u64 rf[RG_TERM_RUNS], lo = r.push_lo;
-#pragma unroll
-            for (int k = 0; k < RG_TERM_RUNS; k++) {
-                rf[k] = r.push_rf[k];
-                RG_OPAQUE64(rf[k]);
-            }
-            RG_OPAQUE64(lo);
-            rg_push_run_loaded<IX>(st, g, rf, lo, r.el_old);
-        }
+        if (d & RG_TICK_PUSH) rg_push_run<IX>(st, g, rg_at(st.lo, g), r.el_old);
         if (d & RG_DIRTY_LO) rg_at(st.lo, g) = r.lo;
         if (d & RG_DIRTY_CFG) rg_at(st.cfg, g) = r.cfg;
     }
