@@ -396,6 +396,11 @@ int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
  * may send it): cum_bytes = the total size of the group's entries up to and including `index`, counted from wherever
  * the host likes (only differences are used, modulo 2^32: a window's total has to stay below 4 GiB). Entries whose
  * record has left the window (a follower more than window - 1 entries behind) are served by the host: RG_SEND_HOST.
+ * EVERY entry the leader's log gains needs its record before a stage may send it -- including the empty entry an
+ * RG_MF_BECOME_LEADER event appends on the device (index = the group's last_index once RG_OUT_BECAME_LEADER is reported; its
+ * size is what Entry::compute_size() gives for {term, index} alone): the ring is indexed by `index & (window - 1)`, so a
+ * missing record silently yields the size of the entry `window` places earlier. The engine cannot tell a missing record
+ * from a written one; a host that cannot guarantee the order runs such a group's sends itself (rg_update_state).
  * Checkpoints include the table. Asynchronous (engine stream). */
 typedef struct {
     uint64_t group;
