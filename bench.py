@@ -452,6 +452,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the recompute_only and out_of_cache sub-measurements (N=1 only; they run after the "
                          "timed region and do not touch `value`)")
+    ap.add_argument("--side", default=None, choices=["recompute", "tick"],
+                    help="profiling hook: run ONLY one sub-measurement (run_config) of --groups x --slots, workload "
+                         "--workload, and print its object -- what the PMC passes behind profiles/traffic.json wrap")
     ap.add_argument("--out-of-cache-groups", type=int, default=8_000_000)
     ap.add_argument("--c5-variant", type=int, default=C5_VARIANT,
                     help="kernel variant of the config-5 lines under other_configs (5 = compact, 0 = lane)")
@@ -488,6 +491,11 @@ def main():
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
     T = W + K
+    if args.side:
+        torch.cuda.set_stream(torch.cuda.Stream())
+        print(json.dumps(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
+                                    one_engine=args.one_engine, inflights=args.inflights)), flush=True)
+        return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
     # other streams of the process, which serialises the publication's side stream with the ticks
     # (tools/probe_publish_host.py: 66 vs 43 us per tick + publication at world size 1).
