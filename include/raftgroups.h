@@ -269,11 +269,12 @@ int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
  * ticks and is written back once, so per tick only the message columns plus 1/n of the state traffic move.
  * Results are bit-identical to n_ticks calls of rg_tick_device. `dev_out_t` (u32 [n_ticks][G], device,
  * required) receives every tick's RG_OUT_* word, `dev_commit_t` (u64 [n_ticks][G], device, may be NULL) the
- * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. m_logterm must be NULL (hints
- * are not passed through find_conflict_by_term in fused launches -- last_index changes between the fused ticks: resolve
- * them on the host). RG_MF_BECOME_LEADER events ARE applied, as in a single-tick launch. With commit publication active
- * (rg_comm_init) the launch's total advance of every group lands in its publication byte, exactly as n_ticks single
- * launches without a publication in between would leave it.
+ * commit index after every tick; RG_COL_OUT / RG_COL_COMMIT hold the last tick's. RG_MF_BECOME_LEADER events are applied as
+ * in a single-tick launch. A tick whose m_logterm is not NULL needs find_conflict_by_term against the log as it stands
+ * BEFORE that tick, so the library runs it as a single-tick launch (behind its pre-pass) between the fused launches of the
+ * ticks around it -- same results, same arrays. With commit publication active (rg_comm_init) the call's total advance of
+ * every group lands in its publication byte, exactly as n_ticks single launches without a publication in between would
+ * leave it. Not available with device Inflights (rg_send_appends has to follow every tick).
  * Asynchronous. Use it to
  * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
 #define RG_MAX_FUSE 8

@@ -1405,33 +1405,23 @@ extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
     return rg_tick_impl(h, ms);
 }
 
-extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_ticks, uint32_t *dev_out_t,
-                                    uint64_t *dev_commit_t) {
-    if (!h || !m || !dev_out_t || n_ticks == 0 || n_ticks > RG_MAX_FUSE)
-        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: need 1..%d ticks and an out buffer", RG_MAX_FUSE);
-    if (h->ins_arena)
-        return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: engines with device Inflights (max_inflight > 0) need "
-                                     "rg_send_appends after every tick; fused launches are not available");
-    RG_ENTER(h);
+// One fused launch over ticks [t0, t0 + n) of the caller's array (none of them carries Message.log_term).
+static int rg_fused_run(rg_engine *h, const rg_msgs *m, u32 t0, u32 n, uint32_t *dev_out_t, uint64_t *dev_commit_t) {
     RgFused fm;
     memset(&fm, 0, sizeof(fm));
-    for (u32 t = 0; t < n_ticks; t++) {
-        if (!m[t].m_index || !m[t].m_commit || !m[t].m_flags)
-            return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: tick %u lacks m_index/m_commit/m_flags", t);
-        fm.m[t].mi = (const u64 *)m[t].m_index;
-        fm.m[t].mc = (const u64 *)m[t].m_commit;
-        fm.m[t].mh = m[t].m_hint ? (const u64 *)m[t].m_hint : h->zero_col;
-        fm.m[t].mrs = m[t].m_rs ? (const u64 *)m[t].m_rs : h->zero_col;
-        if (m[t].m_logterm)
-            return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: Message.log_term is not resolved in fused launches "
-                                               "(last_index changes between the fused ticks); resolve hints on the host");
-        fm.m[t].mlt = h->zero_col;
-        fm.m[t].mhr = fm.m[t].mh;
-        fm.m[t].mflags = (const u64 *)m[t].m_flags;
+    for (u32 i = 0; i < n; i++) {
+        const rg_msgs &x = m[t0 + i];
+        fm.m[i].mi = (const u64 *)x.m_index;
+        fm.m[i].mc = (const u64 *)x.m_commit;
+        fm.m[i].mh = x.m_hint ? (const u64 *)x.m_hint : h->zero_col;
+        fm.m[i].mrs = x.m_rs ? (const u64 *)x.m_rs : h->zero_col;
+        fm.m[i].mlt = h->zero_col;
+        fm.m[i].mhr = fm.m[i].mh;
+        fm.m[i].mflags = (const u64 *)x.m_flags;
     }
-    fm.out_t = dev_out_t;
-    fm.commit_t = (u64 *)dev_commit_t;
-    fm.n_ticks = n_ticks;
+    fm.out_t = dev_out_t + (size_t)t0 * h->G;
+    fm.commit_t = dev_commit_t ? (u64 *)dev_commit_t + (size_t)t0 * h->G : nullptr;
+    fm.n_ticks = n;
     switch (h->P) {
     case 1: rg_launch_tick_fused_t<1>(h->stream, h->st, fm, h->any_group_commit); break;
     case 2: rg_launch_tick_fused_t<2>(h->stream, h->st, fm, h->any_group_commit); break;
@@ -1444,6 +1434,51 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "fused tick launch failed: %s", hipGetErrorString(e));
+    return RG_OK;
+}
+
+extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_ticks, uint32_t *dev_out_t,
+                                    uint64_t *dev_commit_t) {
+    if (!h || !m || !dev_out_t || n_ticks == 0 || n_ticks > RG_MAX_FUSE)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: need 1..%d ticks and an out buffer", RG_MAX_FUSE);
+    if (h->ins_arena)
+        return rg_fail(RG_ERR_STATE, "rg_tick_device_fused: engines with device Inflights (max_inflight > 0) need "
+                                     "rg_send_appends after every tick; fused launches are not available");
+    for (u32 t = 0; t < n_ticks; t++)
+        if (!m[t].m_index || !m[t].m_commit || !m[t].m_flags)
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: tick %u lacks m_index/m_commit/m_flags", t);
+    RG_ENTER(h);
+    // A tick that carries Message.log_term needs find_conflict_by_term against the log as it stands BEFORE that tick
+    // (last_index, the leader's range and the term table change from tick to tick): such a tick runs as a single-tick
+    // launch behind its pre-pass, between the fused launches of the ticks around it -- same results, in the caller's arrays.
+    u32 t = 0;
+    while (t < n_ticks) {
+        u32 e = t;
+        while (e < n_ticks && !m[e].m_logterm) e++;
+        if (e > t) {
+            int rc = rg_fused_run(h, m, t, e - t, dev_out_t, dev_commit_t);
+            if (rc) return rc;
+        }
+        if (e < n_ticks) {
+            RgMsgs ms;
+            ms.mi = (const u64 *)m[e].m_index;
+            ms.mc = (const u64 *)m[e].m_commit;
+            ms.mh = m[e].m_hint ? (const u64 *)m[e].m_hint : h->zero_col;
+            ms.mrs = m[e].m_rs ? (const u64 *)m[e].m_rs : h->zero_col;
+            ms.mlt = (const u64 *)m[e].m_logterm;
+            ms.mflags = (const u64 *)m[e].m_flags;
+            hipLaunchKernelGGL(k_resolve_hints, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, ms, h->P,
+                               h->rhint);
+            ms.mhr = h->rhint;
+            int rc = rg_tick_impl(h, ms);
+            if (rc) return rc;
+            RG_HIP(hipMemcpyAsync(dev_out_t + (size_t)e * h->G, h->st.out, h->G * 4, hipMemcpyDeviceToDevice, h->stream));
+            if (dev_commit_t)
+                RG_HIP(hipMemcpyAsync(dev_commit_t + (size_t)e * h->G, h->st.commit, h->G * 8, hipMemcpyDeviceToDevice, h->stream));
+            e++;
+        }
+        t = e;
+    }
     h->ticked = true;
     h->host_res_valid = false;
     h->out_is_dense = true;

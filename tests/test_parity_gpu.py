@@ -369,6 +369,51 @@ def test_find_conflict_by_term_on_device(rg, n_slots, variant):
     eng.close()
 
 
+@pytest.mark.parametrize("n_slots", [3, 7])
+def test_fused_call_with_log_term_ticks_and_elections(rg, n_slots):
+    """rg_tick_device_fused over 6 ticks of which two carry Message.log_term (the library runs those behind their
+    find_conflict_by_term pre-pass, between the fused launches of the others) and all carry elections: every tick's
+    result word and commit index and the final state against the oracle."""
+    import torch
+    rng = np.random.default_rng(660 + n_slots)
+    G, TERM, T = 5000, 9, 6
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots)
+    fuzz.random_state(rng, st, small_values=True, probe_frac=0.4)
+    fuzz.random_term_table(rng, st, TERM)
+    eng = rg.Engine(G, n_slots)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM)
+    gout = np.zeros(G, dtype=np.uint32)
+    dev, want_out, want_commit, n_lt = [], [], [], 0
+    for t in range(T):
+        cl.store_soa(st)
+        msgs = O.alloc_msgs(G, n_slots)
+        with_lt = t in (1, 4)
+        fuzz.random_msgs(rng, st, msgs, reject_p=0.3, logterm_max=(TERM + t) if with_lt else 0, elect_p=0.1, elect_term=TERM + 1 + t)
+        n_lt += int(((msgs["m_flags"] & 0x80) != 0).sum())
+        cl.tick_soa(msgs, gout)
+        cl.store_soa(st)
+        want_out.append(gout.copy())
+        want_commit.append(st["commit"].copy())
+        keys = ("m_index", "m_commit", "m_hint", "m_rs", "m_flags") + (("m_logterm",) if with_lt else ())
+        dev.append([torch.from_numpy(np.ascontiguousarray(msgs[k]).view(np.uint8 if k == "m_flags" else np.int64).copy()).cuda()
+                    for k in keys])
+    out_t = torch.zeros((T, G), dtype=torch.int32, device="cuda")
+    commit_t = torch.zeros((T, G), dtype=torch.int64, device="cuda")
+    eng.tick_device_fused([[c.data_ptr() for c in tick] for tick in dev], out_t.data_ptr(), commit_t.data_ptr())
+    eng.sync()
+    ot, ct = out_t.cpu().numpy().view(np.uint32), commit_t.cpu().numpy().view(np.uint64)
+    for t in range(T):
+        bad = np.nonzero(ot[t] != want_out[t])[0]
+        assert bad.size == 0, (t, bad[:5], [hex(x) for x in ot[t][bad[:5]]], [hex(x) for x in want_out[t][bad[:5]]])
+        assert (ct[t] == want_commit[t]).all(), t
+    assert_same(eng, cl, st, gout, f"fused call with log-term ticks P={n_slots}")
+    assert n_lt > 300 and (np.array(want_out) & 0x10).any()
+    eng.close()
+
+
 @pytest.mark.parametrize("n_slots", [3, 8])
 def test_garbage_events_on_gpu(rg, n_slots):
     rng = np.random.default_rng(4321 + n_slots)
