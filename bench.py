@@ -242,7 +242,7 @@ def workload_label(workload, n_groups, n_slots, one_engine=False):
     return f"{n_groups} groups x {n_slots} slots, workload {workload}"
 
 
-def send_stage_bytes(rg, eng, n_items):
+def send_stage_bytes(rg, eng, n_items, with_work=False):
     """The send stage's own algorithmic bytes for the LAST tick: per group out 4 + cfg 4 +
     last_index 8 + first_index 8 + flag row 8 r + 8 w = 40; per peer in the work set (a send request, an Inflights effect,
     or a broadcast) window meta 4 r + 4 w, oldest / newest inflight 16 r + 16 w, next 8 r + 8 w, pending snapshot request
@@ -254,17 +254,19 @@ def send_stage_bytes(rg, eng, n_items):
     work = ((out >> 8) | (out >> 16) | (out >> 24)) & 0xff
     work = np.where(bcast, work | present, work) & present & ~(1 << self_slot)
     n_work = int(sum(((work >> p) & 1).sum() for p in range(8)))
-    return 40 * eng.n_groups + 72 * n_work + 4 * eng.n_slots * eng.n_groups + 16 * n_items
+    b = 40 * eng.n_groups + 72 * n_work + 4 * eng.n_slots * eng.n_groups + 16 * n_items
+    return (b, n_work) if with_work else b
 
 
 def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
-               inflights=0):
+               inflights=0, fused_send=False):
     """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
     headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
     synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
     checkpoint, and the K recorded ticks are replayed back to back between two HIP events on the engines' streams.
       what == "tick":      the hot path; config 5 runs one engine per replica-set size on its own stream unless one_engine;
-                           inflights > 0 adds the send stage (rg_send_appends) after every tick, timed per launch too
+                           inflights > 0 adds the send stage (rg_send_appends) after every tick, timed per launch too;
+                           fused_send: the timed replay runs the tick and its stage as ONE launch (rg_tick_device_send)
       what == "recompute": K launches of rg_recompute -- Raft::maybe_commit for every group with no messages, literally
                            BASELINE's "commit-index recomputes"
     Returns a dict with its own `roofline` object (bound, regime, achieved, peak, frac, traffic...)."""
@@ -357,6 +359,13 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                     if record and inflights:
                         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                         ev[0].record(pt.stream)
+                    if inflights and fused_send:
+                        pt.eng.tick_device_send(*ptrs(pt, t0 + i), max_entries_per_msg=0)
+                        if record:
+                            ev[1].record(pt.stream)
+                            ev[2] = ev[1]
+                            per_launch.append(ev)
+                        continue
                     pt.eng.tick_device(*ptrs(pt, t0 + i))
                     if inflights:
                         if record:
@@ -387,12 +396,31 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         kernel = {2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(variant, "k_tick_lane")
         unit = "group-evals/s"
         key = (f"{workload}:{n_groups}:{n_slots}" + (":one-engine" if (workload == 5 and one_engine) else "") +
-               (f":v{variant}" if variant else "") + (":inflights" if inflights else ""))
+               (f":v{variant}" if variant else "") + (":inflights" if inflights else "") + (":fused-send" if (inflights and fused_send) else ""))
         denom = float(n_groups * steps)
         extra = {"acks_per_group": round(census["valid"] / denom, 3), "rejects_per_group": round(census["rejects"] / denom, 5)}
         if workload == 5:
             extra["elections_per_group"] = round(census["elections"] / denom, 5)
-        if inflights:
+        if inflights and fused_send:
+            pt = parts[0]
+            step_us = sorted(a.elapsed_time(b) for a, b, _ in per_launch)[len(per_launch) // 2] * 1e3
+            items = len(pt.eng.send_items())
+            sb, n_work = send_stage_bytes(rg, pt.eng, items, with_work=True)
+            # what one launch for both removes from the two models' sum: the stage no longer reads the result word, cfg,
+            # last_index and the flag row (24 B per group), the flag row is written once (8), and per peer in the work set
+            # `next` is neither re-read nor written twice and `matched` is not re-read (24)
+            fb = alg[-1] + sb - 32 * n_groups - 24 * n_work
+            fg = fb / (step_us * 1e-6) / 1e9
+            extra["send_stage"] = {
+                "max_inflight": inflights, "max_entries_per_msg": 0, "work_items_last_tick": int(items), "one_launch": True,
+                "us_per_step_median": step_us,
+                "roofline": {"bound": "hbm", "regime": regime_of(hot), "achieved": fg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fg / HBM_PEAK_GBS, "kernel": "k_tick_send", "algorithmic_bytes_per_launch": fb,
+                             "bytes_per_group": fb / n_groups, "avg_launch_us": step_us, "traffic": None,
+                             "note": "tick + send stage in ONE launch: the tick's SURVEY 8(d) bytes plus the stage's own byte model "
+                                     "(DESIGN.md section 3) minus what the shared registers save (32 B per group, 24 B per peer in "
+                                     "the work set), counted on the last tick"}}
+        elif inflights:
             pt = parts[0]
             tick_us = sorted(a.elapsed_time(b) for a, b, _ in per_launch)[len(per_launch) // 2] * 1e3
             stage_us = sorted(b.elapsed_time(c) for _, b, c in per_launch)[len(per_launch) // 2] * 1e3
@@ -416,7 +444,7 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
             "groups": n_groups, "peer_slots": n_slots, "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
             "steps": steps, "warmup": warmup, "us_per_step": us, "value": n_groups / (us * 1e-6), "unit": unit, **extra,
             "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot, "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel": kernel + (" + k_send_dense" if inflights else ""),
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel": ("k_tick_send" if fused_send else kernel + " + k_send_dense") if inflights else kernel,
                          "algorithmic_bytes_per_launch": nbytes, "bytes_per_eval": nbytes / n_groups, "avg_launch_us": us,
                          "traffic": traffic, "traffic_source": traffic_source,
                          **({"note": "avg_launch_us is the tick AND its send stage; the algorithmic bytes are the tick's, so frac "
@@ -449,6 +477,8 @@ def main():
                     help="N > 0: keep the Inflights (cap N) on the device and run the send stage (rg_send_appends: "
                          "maybe_send_append decisions, SURVEY 8f row 3) after every tick, inside the timed region; the "
                          "stream then carries no host SENT events. Not the headline configuration.")
+    ap.add_argument("--fused-send", action="store_true",
+                    help="with --inflights N: the tick and its send stage as ONE launch (rg_tick_device_send, k_tick_send)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the recompute_only and out_of_cache sub-measurements (N=1 only; they run after the "
                          "timed region and do not touch `value`)")
@@ -494,7 +524,8 @@ def main():
     if args.side:
         torch.cuda.set_stream(torch.cuda.Stream())
         print(json.dumps(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
-                                    one_engine=args.one_engine, inflights=args.inflights)), flush=True)
+                                    one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send)),
+              flush=True)
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
     # other streams of the process, which serialises the publication's side stream with the ticks
@@ -640,9 +671,12 @@ def main():
         for i in range(n):
             pub_now = publish and ((i + 1) % E == 0 or i == n - 1)
             for pt in parts:
-                pt.eng.tick_device(*tick_ptrs(pt, t0 + i))
-                if args.inflights:
-                    pt.eng.send_appends(0)
+                if args.inflights and args.fused_send:
+                    pt.eng.tick_device_send(*tick_ptrs(pt, t0 + i), max_entries_per_msg=0)
+                else:
+                    pt.eng.tick_device(*tick_ptrs(pt, t0 + i))
+                    if args.inflights:
+                        pt.eng.send_appends(0)
                 if pub_now:
                     pt.eng.publish_commit(full=raw)  # raw: the 8 B/group column itself (RG_PUBLISH_FULL) instead of the ~1 B/group slice
         issued[0] = time.perf_counter()
@@ -792,7 +826,7 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_lane")) +
-                               (" + k_send_appends" if args.inflights else ""),
+                               (" + k_send_dense" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6,
                      **({"note": "temporal fusion: state stays in registers across the fused ticks, so fewer bytes "
@@ -826,7 +860,9 @@ def main():
                          ("configs[3] one rank's shard", dict(n_groups=1_000_000, n_slots=7, workload=2)),
                          ("configs[4] size-class engines", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v)),
                          ("configs[4] one 7-slot engine", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v, one_engine=True)),
-                         ("configs[1] + send stage", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256))):
+                         ("configs[1] + send stage", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256)),
+                         ("configs[1] + send stage, one launch", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256,
+                                                                      fused_send=True))):
             if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") \
                     and kw.get("variant", 0) == args.variant and kw.get("one_engine", False) == args.one_engine:
                 continue  # that is the headline itself

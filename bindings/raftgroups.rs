@@ -289,6 +289,8 @@ extern "C" {
     pub fn rg_local_become_leader(h: *mut RgEngine, group: u64, term: u64) -> i32;
     pub fn rg_flush(h: *mut RgEngine) -> i32;
     pub fn rg_send_appends(h: *mut RgEngine, max_entries_per_msg: u64, flags: u32) -> i32;
+    pub fn rg_tick_send(h: *mut RgEngine, host_msgs: *const RgMsgs, max_entries_per_msg: u64, flags: u32) -> i32;
+    pub fn rg_tick_device_send(h: *mut RgEngine, dev_msgs: *const RgMsgs, max_entries_per_msg: u64, flags: u32) -> i32;
     pub fn rg_log_sizes_enable(h: *mut RgEngine, window: u32) -> i32;
     pub fn rg_log_sizes_write(h: *mut RgEngine, recs: *const RgLogSize, n: u64) -> i32;
     pub fn rg_workload_sizes(h: *mut RgEngine, seed: u64, min_bytes: u32, spread: u32) -> i32;

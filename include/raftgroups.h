@@ -388,6 +388,15 @@ typedef struct {
                               (src/util.rs:52-76; UINT64_MAX = NO_LIMIT, 0 = one entry per message). Needs the entry sizes
                               on the device: rg_log_sizes_enable / rg_log_sizes_write. */
 int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags);
+/* The dense tick AND its send stage as ONE launch: rg_tick(_device) immediately followed by rg_send_appends, same
+ * results in the same columns (RG_COL_*, the Inflights, rg_send_items / rg_send_columns), but the stage runs on the registers
+ * the tick leaves instead of re-reading what the tick has just stored (the result word, cfg, the flag row, last_index,
+ * `matched`, `next`) one kernel boundary later -- the host's Ready loop (RawNode::ready, src/raw_node.rs:402-441, collects the
+ * messages of a whole batch of steps anyway). With RG_SEND_BYTES the size records of the entries this tick's
+ * local-append events announce must have been written (rg_log_sizes_write) BEFORE the call, since the stage reads them in
+ * the same launch. rg_tick_send synchronises like rg_tick; rg_tick_device_send is asynchronous like rg_tick_device. */
+int rg_tick_send(rg_engine *h, const rg_msgs *host_msgs, uint64_t max_entries_per_msg, uint32_t flags);
+int rg_tick_device_send(rg_engine *h, const rg_msgs *dev_msgs, uint64_t max_entries_per_msg, uint32_t flags);
 
 /* ---- entry sizes for RG_SEND_BYTES (byte-accurate Config::max_size_per_msg) ----
  * The send decision needs Entry::compute_size() of the entries it is about to attach (util::limit_size keeps the first

@@ -534,18 +534,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
     for (int s = 0; s < P; s++) it.n[s] = 0;
     const u32 out = rg_at(st.out, g);
     rg_group_send<P, IX, RG_SEND_SPEC_LOADS != 0>(st, ins, g, out, max_entries, flags, it); // (unconditional: its loads ride with `out`)
-#pragma unroll
-    for (int s = 0; s < P; s++) {
-        const IX o = (IX)s * (IX)st.stride + g;
-        const u32 nk = rg_send_nk<P>(it, s);
-        rg_at(oc.n, o) = nk; // every cell, every stage: 0 = nothing for this peer
-        // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
-        // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
-        if (RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0) != 0 : nk != 0) {
-            rg_at(oc.prev, o) = nk ? it.prev[s] : 0ULL;
-            rg_at(oc.last, o) = nk ? it.last[s] : 0ULL;
-        }
-    }
+    rg_store_send_items<P, IX>(it, oc, st.stride, g);
 }
 template <int P>
 static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
@@ -1348,9 +1337,39 @@ static int rg_settle_send(rg_engine *h) {
     return rc;
 }
 
-static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
+// `send` != NULL: the tick and its send stage as ONE launch (k_tick_send; rg_tick_send / rg_tick_device_send)
+struct RgSendReq {
+    u64 max_entries;
+    u32 flags;
+};
+static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = nullptr) {
     int src = rg_settle_send(h);
     if (src) return src;
+    if (send) {
+        switch (h->P) {
+        case 1: rg_launch_tick_send_t<1>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 2: rg_launch_tick_send_t<2>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 3: rg_launch_tick_send_t<3>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 4: rg_launch_tick_send_t<4>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 5: rg_launch_tick_send_t<5>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 6: rg_launch_tick_send_t<6>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 7: rg_launch_tick_send_t<7>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        default: rg_launch_tick_send_t<8>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick + send stage launch failed: %s", hipGetErrorString(e));
+        h->tick_launches++;
+        h->ticked = true;
+        h->out_is_dense = true;
+        h->host_res_valid = false;
+        // what rg_send_appends leaves behind a dense stage
+        h->send_ready = false;
+        h->send_bound = h->G * h->P;
+        h->send_cols_fresh = true;
+        h->send_last_dense = true;
+        h->host_items_valid = false;
+        return RG_OK;
+    }
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
     const u32 variant = (h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
@@ -1385,9 +1404,14 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms) {
     return RG_OK;
 }
 
-extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
-    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
-        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device: m_index, m_commit and m_flags are required");
+static int rg_send_check(rg_engine *h, uint32_t flags, const char *who) {
+    if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "%s: engine created with max_inflight = 0 (Inflights are the host's)", who);
+    if (flags & ~(RG_SEND_SKIP_BCAST_COMMIT | RG_SEND_BYTES)) return rg_fail(RG_ERR_INVALID_ARG, "%s: unknown flags %#x", who, flags);
+    if ((flags & RG_SEND_BYTES) && !h->esz) return rg_fail(RG_ERR_STATE, "%s: RG_SEND_BYTES needs the entry sizes (rg_log_sizes_enable)", who);
+    return RG_OK;
+}
+
+static int rg_tick_device_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     RG_ENTER(h);
     RgMsgs ms;
     ms.mi = (const u64 *)m->m_index;
@@ -1402,7 +1426,22 @@ extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
                            h->rhint);
         ms.mhr = h->rhint;
     }
-    return rg_tick_impl(h, ms);
+    return rg_tick_impl(h, ms, send);
+}
+
+extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
+    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device: m_index, m_commit and m_flags are required");
+    return rg_tick_device_impl(h, m, nullptr);
+}
+
+extern "C" int rg_tick_device_send(rg_engine *h, const rg_msgs *m, uint64_t max_entries_per_msg, uint32_t flags) {
+    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_send: m_index, m_commit and m_flags are required");
+    int rc = rg_send_check(h, flags, "rg_tick_device_send");
+    if (rc) return rc;
+    const RgSendReq send = {(u64)max_entries_per_msg, (u32)flags};
+    return rg_tick_device_impl(h, m, &send);
 }
 
 // One fused launch over ticks [t0, t0 + n) of the caller's array (none of them carries Message.log_term).
@@ -1499,9 +1538,7 @@ static int rg_ensure_msg_arena(rg_engine *h) {
     return RG_OK;
 }
 
-extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
-    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
-        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick: m_index, m_commit and m_flags are required");
+static int rg_tick_host_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     RG_ENTER(h);
     int rc = rg_ensure_msg_arena(h);
     if (rc) return rc;
@@ -1522,12 +1559,27 @@ extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
                            h->rhint);
         ms.mhr = h->rhint;
     }
-    rc = rg_tick_impl(h, ms);
+    rc = rg_tick_impl(h, ms, send);
     if (rc) return rc;
     // the engine-owned message columns must read "no events" outside a tick (sparse-path invariant)
     RG_HIP(hipMemsetAsync((void *)h->staged.mflags, 0, h->stride * 8, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // caller-owned host buffers may be reused after return
     return RG_OK;
+}
+
+extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
+    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick: m_index, m_commit and m_flags are required");
+    return rg_tick_host_impl(h, m, nullptr);
+}
+
+extern "C" int rg_tick_send(rg_engine *h, const rg_msgs *m, uint64_t max_entries_per_msg, uint32_t flags) {
+    if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_send: m_index, m_commit and m_flags are required");
+    int rc = rg_send_check(h, flags, "rg_tick_send");
+    if (rc) return rc;
+    const RgSendReq send = {(u64)max_entries_per_msg, (u32)flags};
+    return rg_tick_host_impl(h, m, &send);
 }
 
 static RgIngest rg_ingest_args(rg_engine *h, const rg_wire_msg *rec, u64 n, const RgClear &clr) {
@@ -1875,12 +1927,9 @@ static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t 
 
 extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: null engine");
-    if (!h->ins_arena)
-        return rg_fail(RG_ERR_STATE, "rg_send_appends: engine created with max_inflight = 0 (Inflights are the host's)");
+    int src = rg_send_check(h, flags, "rg_send_appends");
+    if (src) return src;
     if (!h->send_ready) return rg_fail(RG_ERR_STATE, "rg_send_appends: no tick since the last send stage");
-    if (flags & ~(RG_SEND_SKIP_BCAST_COMMIT | RG_SEND_BYTES)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: unknown flags %#x", flags);
-    if ((flags & RG_SEND_BYTES) && !h->esz)
-        return rg_fail(RG_ERR_STATE, "rg_send_appends: RG_SEND_BYTES needs the entry sizes (rg_log_sizes_enable)");
     RG_ENTER(h);
     const u64 *list = h->out_is_dense ? nullptr : h->res_list; // sparse tick: only the touched groups have an out word
     const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;

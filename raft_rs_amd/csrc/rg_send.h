@@ -7,7 +7,7 @@
 // Compacted), src/tracker/progress.rs:210-216,231-243 (is_paused, update_state).
 #pragma once
 
-#include "rg_common.h"
+#include "rg_group.h"
 
 // RG_SEND_EXP: measurement-only knobs (never set in the product build): bit0 = no work-item list,
 // bit1 = no ring accesses (results are wrong for windows deeper than one message), bit2 = list positions are
@@ -151,72 +151,128 @@ RG_HD void rg_ins_add(const RgIns &ins, u64 base, u32 start, u32 &count, u64 &he
 // the result word says which peers are in the work set -- one memory round trip like the tick's instead of two, at the
 // price of the cells that turn out not to be needed (the leader's own slot; groups with nothing to do). After a dense
 // tick of a busy shard nearly every follower is in the work set (every commit advance broadcasts).
-template <int P, typename IX = u64, bool SPEC = false>
-RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags,
-                         RgSendRegs<P> &it) {
-    // everything indexed by the group alone is requested at once, before anything is decided: with the result word the
-    // caller loaded that is ONE memory round trip ahead of the per-peer cells (it used to be three: out, cfg, the rest)
-    const u32 cfg = rg_at(st.cfg, g);
-    const u64 row0 = rg_at(st.pflags, g);
-    const u64 hi = rg_at(st.hi, g);                     // last_index
-    const u64 first_index = rg_at(st.dummy_idx, g) + 1; // RaftLog::first_index (dummy entry = first_index - 1)
+// FUSED (k_tick_send: the stage runs in the SAME launch as the tick, on the registers the tick leaves): the result
+// word, cfg, the flag row, last_index, `matched` and every `next` cell the tick holds (bit s of `nxv`) come from the
+// group's registers `r` instead of memory, and what the stage changes of them (`next`, the flag row) goes back there --
+// the caller stores the group once, behind the stage. The stage is split in two so that such a caller can put the
+// tick's own stores between the stage's loads and their first use (rg_send_request / rg_send_serve).
+
+// The operands of one group's stage, as requested from memory (or taken over from the tick)
+template <int P> struct RgSendOps {
+    u32 cfg, work;
+    u64 row0, hi, first_index;
     u32 meta_v[P];
     u64 head_v[P], tail_v[P], next_v[P], prs_v[P], match_v[P];
+    bool bcast, serve, elected;
+};
+
+// Part 0 (k_tick_send with RG_TS_SPEC): the window columns of EVERY slot and first_index requested together with the
+// group's own loads, before the tick has run -- the stage then needs no second memory round trip (after a dense tick nearly
+// every follower is in the work set anyway); rg_send_request<.., PRE = true> skips what is already on its way.
+template <int P, typename IX> RG_HD void rg_send_prefetch(const RgState &st, const RgIns &ins, IX g, RgSendOps<P> &q) {
+    q.first_index = rg_at(st.dummy_idx, g) + 1;
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const IX o = (IX)s * (IX)st.stride + g;
+        q.meta_v[s] = rg_at(ins.meta, o);
+        q.head_v[s] = rg_at(ins.head, o);
+        q.tail_v[s] = rg_at(ins.tail, o);
+    }
+}
+
+// Part 1: decide the work set and request every cell the stage reads (no loaded value is touched here, except -- unless
+// SPEC or FUSED -- the group-level words the work set is decided from, which the caller requested with `out`).
+template <int P, typename IX, bool SPEC, bool FUSED, bool PRE = false>
+RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u32 flags, RgSendOps<P> &q,
+                           RgGroup<P> *r, u32 nxv) {
+    // everything indexed by the group alone is requested at once, before anything is decided: with the result word the
+    // caller loaded that is ONE memory round trip ahead of the per-peer cells (it used to be three: out, cfg, the rest)
+    if (FUSED) {
+        q.cfg = r->cfg;
+        q.row0 = r->pf;
+        q.hi = r->hi;
+    } else {
+        q.cfg = rg_at(st.cfg, g);
+        q.row0 = rg_at(st.pflags, g);
+        q.hi = rg_at(st.hi, g);                     // last_index
+    }
+    if (!PRE) q.first_index = rg_at(st.dummy_idx, g) + 1; // RaftLog::first_index (dummy entry = first_index - 1)
     if (SPEC) {
 #pragma unroll
         for (int s = 0; s < P; s++) {
             const IX o = (IX)s * (IX)st.stride + g;
-            meta_v[s] = rg_at(ins.meta, o);
-            head_v[s] = rg_at(ins.head, o);
-            tail_v[s] = rg_at(ins.tail, o);
-            next_v[s] = rg_at(st.next, o);
-            prs_v[s] = rg_at(st.prs, o); // (the flag row is not known yet)
-            match_v[s] = rg_at(st.match, o);
+            q.meta_v[s] = rg_at(ins.meta, o);
+            q.head_v[s] = rg_at(ins.head, o);
+            q.tail_v[s] = rg_at(ins.tail, o);
+            q.next_v[s] = rg_at(st.next, o);
+            q.prs_v[s] = rg_at(st.prs, o); // (the flag row is not known yet)
+            q.match_v[s] = rg_at(st.match, o);
         }
     }
-    const u32 present = RG_CFG_PRESENT(cfg), self = RG_CFG_SELF(cfg);
+    const u32 present = RG_CFG_PRESENT(q.cfg), self = RG_CFG_SELF(q.cfg);
     // bcast_append: the leader appended entries (a proposal, raft.rs:2049-2053), or the commit index moved and
     // should_bcast_commit() (raft.rs:1745-1748, :2684-2686: !skip_bcast_commit || has_pending_conf())
     // RG_SEND_EFFECTS_ONLY (engine-internal, a skipped stage being settled): only the Inflights effects below
-    const bool serve = !(flags & 0x80000000u);
-    bool bcast = serve && (out & RG_OUT_APPENDED) != 0;
-    if (serve && (out & RG_OUT_CHANGED))
-        bcast = bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((row0 >> (8 * self)) & RG_PF_PENDING_CONF);
+    q.serve = !(flags & 0x80000000u);
+    q.bcast = q.serve && (out & RG_OUT_APPENDED) != 0;
+    if (q.serve && (out & RG_OUT_CHANGED))
+        q.bcast = q.bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((q.row0 >> (8 * self)) & RG_PF_PENDING_CONF);
     const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
+    q.elected = (out & RG_OUT_BECAME_LEADER) != 0; // Raft::reset: every Progress's ins.reset() (progress.rs:82-92)
+    u32 work = sa_bits | sm_bits | fr_bits;
+    if (q.bcast || q.elected) work |= present;
+    work &= present & ~(1u << self);
+    q.work = work;
+    if (work == 0 || SPEC) return;
+    // all column loads of the group are issued before any of the (dependent, scattered) ring accesses
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const bool w = (work >> s) & 1u;
+        const IX o = (IX)s * (IX)st.stride + g;
+        const bool sends = w && (q.bcast || (((sa_bits | sm_bits) >> s) & 1u));
+        // (each destination is written once BEFORE its load is issued and not again: `x = w ? load : 0` made the
+        // compiler wait for slot s's loads -- a pending write to the same registers -- before issuing slot s+1's)
+        if (!PRE) {
+            q.meta_v[s] = 0u;
+            q.head_v[s] = q.tail_v[s] = 0ULL;
+            if (w) {
+                q.meta_v[s] = rg_at(ins.meta, o);
+                q.head_v[s] = rg_at(ins.head, o);
+                q.tail_v[s] = rg_at(ins.tail, o);
+            }
+        }
+        if (FUSED) {
+            // the cells of `next` the tick fetched or wrote are in its registers (bit s of nxv); a broadcast also reaches
+            // peers that had no event in this tick -- only theirs are read here, into the register the tick left unused
+            // (it holds 0, written before the group's bulk loads were issued: no write behind a pending load)
+            if (sends && !((nxv >> s) & 1u)) r->nx[s] = rg_at(st.next, o);
+            // (a pending snapshot request -- RG_PF_PEND_RS, almost never -- is read where it is needed, rg_send_serve)
+            continue;
+        }
+        q.next_v[s] = q.prs_v[s] = q.match_v[s] = 0ULL;
+        if (sends) q.next_v[s] = rg_at(st.next, o);
+        // pending_request_snapshot: zero unless the flag byte says otherwise (RG_PF_PEND_RS) -- a column the stage used
+        // to read for every peer it sends to
+        if (sends && ((q.row0 >> (8 * s)) & RG_PF_PEND_RS)) q.prs_v[s] = rg_at(st.prs, o);
+        if (w && (((fr_bits & sm_bits) >> s) & 1u)) q.match_v[s] = rg_at(st.match, o);
+    }
+}
+
+// Part 2: the Inflights effects of the tick and the send decisions, peer by peer; stores what it changes.
+template <int P, typename IX, bool FUSED>
+RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags, const RgSendOps<P> &q,
+                         RgSendRegs<P> &it, RgGroup<P> *r, u32 nxv) {
     it.snap = 0;
     it.hostm = 0;
     it.count = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
-    const bool elected = (out & RG_OUT_BECAME_LEADER) != 0; // Raft::reset: every Progress's ins.reset() (progress.rs:82-92)
-    u32 work = sa_bits | sm_bits | fr_bits;
-    if (bcast || elected) work |= present;
-    work &= present & ~(1u << self);
+    const u32 work = q.work;
     if (work == 0) return;
-
+    const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
+    const bool bcast = q.bcast, serve = q.serve, elected = q.elected;
+    const u64 hi = q.hi, first_index = q.first_index, row0 = q.row0;
     u64 row = row0;
-    // all column loads of the group are issued before any of the (dependent, scattered) ring accesses
-#pragma unroll
-    for (int s = 0; s < P; s++) {
-        if (SPEC) break;
-        const bool w = (work >> s) & 1u;
-        const IX o = (IX)s * (IX)st.stride + g;
-        const bool sends = w && (bcast || (((sa_bits | sm_bits) >> s) & 1u));
-        // (each destination is written once BEFORE its load is issued and not again: `x = w ? load : 0` made the
-        // compiler wait for slot s's loads -- a pending write to the same registers -- before issuing slot s+1's)
-        meta_v[s] = 0u;
-        head_v[s] = tail_v[s] = next_v[s] = prs_v[s] = match_v[s] = 0ULL;
-        if (w) {
-            meta_v[s] = rg_at(ins.meta, o);
-            head_v[s] = rg_at(ins.head, o);
-            tail_v[s] = rg_at(ins.tail, o);
-        }
-        if (sends) next_v[s] = rg_at(st.next, o);
-        // pending_request_snapshot: zero unless the flag byte says otherwise (RG_PF_PEND_RS) -- a column the stage used
-        // to read for every peer it sends to
-        if (sends && ((row0 >> (8 * s)) & RG_PF_PEND_RS)) prs_v[s] = rg_at(st.prs, o);
-        if (w && (((fr_bits & sm_bits) >> s) & 1u)) match_v[s] = rg_at(st.match, o);
-    }
 #pragma unroll
     for (int s = 0; s < P; s++) {
         if (!((work >> s) & 1u)) continue;
@@ -224,11 +280,11 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
         const u64 base = ((u64)g * (u64)P + (u64)s) * ins.cap;
         u32 pb = (u32)(row >> (8 * s)) & 0xffu;
         const u32 state = pb & RG_PF_STATE_MASK;
-        const u32 meta0 = meta_v[s];
+        const u32 meta0 = q.meta_v[s];
         u32 start = meta0 & 0xffffu, count = meta0 >> 16;
-        const u64 head0 = head_v[s];
+        const u64 head0 = q.head_v[s];
         u64 head = head0;
-        const u64 tail0 = tail_v[s];
+        const u64 tail0 = q.tail_v[s];
         u64 tail = tail0;
 
         // ---- what the tick did to this peer's Inflights ----
@@ -238,18 +294,19 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             start = 0;
             count = 0;
         } else if ((fr_bits >> s) & 1u) {
-            if ((sm_bits >> s) & 1u) rg_ins_free_to(ins, base, start, count, head, tail, match_v[s]); // accepted ack: m.index == matched
-            else if (count) rg_ins_free_to(ins, base, start, count, head, tail, head);                // free_first_one (:114-117)
+            const u64 matched = FUSED ? r->mt[s] : q.match_v[s];
+            if ((sm_bits >> s) & 1u) rg_ins_free_to(ins, base, start, count, head, tail, matched); // accepted ack: m.index == matched
+            else if (count) rg_ins_free_to(ins, base, start, count, head, tail, head);             // free_first_one (:114-117)
         }
 
         // ---- send_append(to) then `while maybe_send_append(to, false)` ----
         const bool sa = bcast || (serve && ((sa_bits >> s) & 1u));
         const bool sm = serve && ((sm_bits >> s) & 1u);
         if (sa || sm) {
-            u64 next = next_v[s];
+            u64 next = FUSED ? r->nx[s] : q.next_v[s];
             const u64 next0 = next;
             (void)next0;
-            const u64 prs = prs_v[s];
+            const u64 prs = !FUSED ? q.prs_v[s] : ((row0 >> (8 * s)) & RG_PF_PEND_RS) ? rg_at(st.prs, o) : 0ULL;
             u32 n = 0;
             bool snap = false, host = false;
             bool first = sa; // the first call is send_append (allow_empty) only if one was requested
@@ -319,7 +376,12 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             }
             it.n[s] = n;
             if (n || snap || host) it.count++;
-            if (RG_SEND_WHOLE_LINES || next != next0) rg_at(st.next, o) = next;
+            if (FUSED) { // the group's `next` cells are stored once, by the caller (whole lines: every cell the stage looked at)
+                r->nx[s] = next;
+                r->dirty |= 1u << (8 + s);
+            } else if (RG_SEND_WHOLE_LINES || next != next0) {
+                rg_at(st.next, o) = next;
+            }
         }
         pb = (pb & ~RG_PF_INS_FULL) | ((state == RG_STATE_REPLICATE && count == ins.cap) ? RG_PF_INS_FULL : 0u);
         row = (row & ~(0xffULL << (8 * s))) | ((u64)pb << (8 * s));
@@ -332,5 +394,21 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
         if (RG_SEND_WHOLE_LINES || (head != head0 && count)) rg_at(ins.head, o) = count ? head : head0;
         if (RG_SEND_WHOLE_LINES || (tail != tail0 && count)) rg_at(ins.tail, o) = count ? tail : tail0;
     }
-    if (row != row0) rg_at(st.pflags, g) = row;
+    if (row != row0) {
+        if (FUSED) {
+            r->pf = row;
+            r->dirty |= RG_DIRTY_PF;
+        } else {
+            rg_at(st.pflags, g) = row;
+        }
+    }
+}
+
+// The stage of one group in its own launch (k_send_dense, k_send_appends, the host twin of the tests).
+template <int P, typename IX = u64, bool SPEC = false>
+RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags,
+                         RgSendRegs<P> &it) {
+    RgSendOps<P> q;
+    rg_send_request<P, IX, SPEC, false>(st, ins, g, out, flags, q, nullptr, 0u);
+    rg_send_serve<P, IX, false>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);
 }

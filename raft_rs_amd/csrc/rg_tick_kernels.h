@@ -4,6 +4,14 @@
 #pragma once
 
 #include "rg_group.h"
+#include "rg_send.h"
+
+#ifndef RG_TS_ORDER /* k_tick_send: 1 = the tick's stores are issued before the stage's loads (experiment) */
+#define RG_TS_ORDER 0
+#endif
+#ifndef RG_TS_SPEC /* k_tick_send: 1 = the window columns of every slot are requested with the group's own loads (rg_send_prefetch) */
+#define RG_TS_SPEC 0
+#endif
 
 // Build-time tuning knobs (python -m raft_rs_amd.build --opt N); the default is what measured best
 // on MI355X (profiles/).  bit0: non-temporal loads of the read-once message columns;
@@ -80,7 +88,9 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
     if (NXM == RG_NX_PREFETCH) rg_prefetch_rare<P, IX>(r, st, ms, g);
 }
 
-template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
+// WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
+// stage, which changes both; every other caller stores the group in one go).
+template <int P, typename IX, int WHICH = 3> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
@@ -91,11 +101,12 @@ template <int P, typename IX> RG_HD void rg_store_group(const RgGroup<P> &r, con
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const IX o = (IX)p * (IX)st.stride + g;
-        if (d & (1u << p)) rg_st(rg_at(st.match, o), r.mt[p], RG_OPT_NT_ALL != 0);
-        if (d & (1u << (8 + p))) rg_st(rg_at(st.next, o), r.nx[p], (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
-        if (d & (1u << (16 + p))) rg_st(rg_at(st.prc, o), r.pc[p], RG_OPT_NT_ALL != 0);
+        if ((WHICH & 1) && (d & (1u << p))) rg_st(rg_at(st.match, o), r.mt[p], RG_OPT_NT_ALL != 0);
+        if ((WHICH & 2) && (d & (1u << (8 + p)))) rg_st(rg_at(st.next, o), r.nx[p], (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
+        if ((WHICH & 1) && (d & (1u << (16 + p)))) rg_st(rg_at(st.prc, o), r.pc[p], RG_OPT_NT_ALL != 0);
     }
-    if (d & RG_DIRTY_PF) rg_at(st.pflags, g) = r.pf;
+    if ((WHICH & 2) && (d & RG_DIRTY_PF)) rg_at(st.pflags, g) = r.pf;
+    if (!(WHICH & 1)) return;
     if (d & RG_DIRTY_COMMIT) {
         if (st.pub) rg_pub_store(st, g, r.adv, r.commit); // commit publication: one byte per advanced group
         rg_at(st.commit, g) = r.commit;
@@ -139,6 +150,80 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lan
 #endif
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
     rg_store_group<P, IX>(r, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick AND its send stage in one launch (rg_tick_device_send; engines with device Inflights)
+// ------------------------------------------------------------------------------------------------
+// rg_tick_device + rg_send_appends as two launches move every word the stage needs twice: the tick stores the result
+// word, the flag row, `next`, `matched`, last_index -- and the stage, one kernel boundary later, reads them back (88 B per
+// group at P = 5) and rewrites `next` and the flag row (46 B). Here the stage runs on the registers the tick leaves:
+// what it still reads from memory is what the tick never touched (the window columns of the peers in the work set,
+// first_index, the `next` cell of a peer a broadcast reaches although it had no event in this tick), and the group is
+// stored once. Order inside a lane: tick -> the stage's loads are REQUESTED -> the tick's own stores (everything but
+// `next` and the flag row) -> the stage -> `next`, the flag row, the window columns, the work items. The stores sit
+// between the request and the first use so that the wave waits for the loads only (vmcnt counts in issue order).
+// One group of that launch, shared with the host twin of the tests (tests/host_check):
+template <int P, bool GC, typename IX>
+RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, const RgIns &ins, IX g, u64 max_entries,
+                              u32 flags, RgSendRegs<P> &it) {
+    RgSendOps<P> q;
+    if (RG_TS_SPEC) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
+    rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    // the `next` cells the tick holds: every slot with an event was fetched (or is overwritten by its SENT event), an
+    // election rewrites all of them (rg_prefetch_rare / RgTick::set_next)
+    const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
+#if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
+    rg_store_group<P, IX, 1>(r, st, g);
+    rg_send_request<P, IX, false, true, RG_TS_SPEC != 0>(st, ins, g, r.out, flags, q, &r, nxv);
+#else
+    rg_send_request<P, IX, false, true, RG_TS_SPEC != 0>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_store_group<P, IX, 1>(r, st, g);
+#endif
+#if defined(RG_TS_DBG) && RG_TS_DBG == 1 /* (register-pressure probes, never built into the product) */
+    it.count = q.meta_v[0] + (u32)q.head_v[1] + (u32)q.tail_v[2]; it.snap = it.hostm = 0;
+    for (int s = 0; s < P; s++) { it.n[s] = q.meta_v[s]; it.prev[s] = q.head_v[s]; it.last[s] = q.tail_v[s]; }
+#else
+    rg_send_serve<P, IX, true>(st, ins, g, r.out, max_entries, flags, q, it, &r, nxv);
+#endif
+    rg_store_group<P, IX, 2>(r, st, g);
+}
+
+// The work items of a dense stage into their peer-major columns (k_send_dense, k_tick_send).
+template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P> &it, const RgSendCols &oc, u64 stride, IX g) {
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const IX o = (IX)s * (IX)stride + g;
+        const u32 nk = rg_send_nk<P>(it, s);
+        rg_at(oc.n, o) = nk; // every cell, every stage: 0 = nothing for this peer
+        // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
+        // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool any = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0) != 0 : nk != 0;
+#else
+        const bool any = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
+#endif
+        if (any) {
+            rg_at(oc.prev, o) = nk ? it.prev[s] : 0ULL;
+            rg_at(oc.last, o) = nk ? it.last[s] : 0ULL;
+        }
+    }
+}
+
+#ifndef RG_TS_WAVES
+#define RG_TS_WAVES 1 /* minimum waves per SIMD k_tick_send is compiled for (experiment knob) */
+#endif
+template <int P, bool GC, typename IX>
+__global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgState st, RgMsgs ms, RgIns ins, u64 max_entries, u32 flags,
+                                                                     RgSendCols oc) {
+    const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g64 >= st.G) return;
+    const IX g = (IX)g64;
+    RgGroup<P> r;
+    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    RgSendRegs<P> it;
+    rg_group_tick_send<P, GC, IX>(r, st, ms, ins, g, max_entries, flags, it);
+    rg_store_send_items<P, IX>(it, oc, st.stride, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,6 +773,9 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo);
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc);
 template <int P>
+void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIns &ins, u64 max_entries,
+                           u32 flags, const RgSendCols &oc);
+template <int P>
 void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
                              u64 *mflags_rw, const RgListOut &lo);
 
@@ -755,45 +843,66 @@ template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &
         else hipLaunchKernelGGL((k_tick_fused<P, false, u64>), grid, block, 0, stream, st, fm);
     }
 }
+template <int P>
+void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIns &ins, u64 max_entries,
+                           u32 flags, const RgSendCols &oc) {
+    const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
+    const bool ix32 = rg_ix32(P, st.stride); // 32-bit cell offsets (rg_launch_tick_t)
+    if (gc) {
+        if (ix32) hipLaunchKernelGGL((k_tick_send<P, true, u32>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
+        else hipLaunchKernelGGL((k_tick_send<P, true, u64>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
+    } else {
+        if (ix32) hipLaunchKernelGGL((k_tick_send<P, false, u32>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
+        else hipLaunchKernelGGL((k_tick_send<P, false, u64>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
+    }
+}
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
+extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_mailbox_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 #endif

@@ -9,6 +9,8 @@ template void rg_launch_tick_t<RG_P>(hipStream_t, const RgState &, const RgMsgs 
 template void rg_launch_tick_list_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64,
                                           u64 *, const RgListOut &);
 template void rg_launch_tick_fused_t<RG_P>(hipStream_t, const RgState &, const RgFused &, bool);
+template void rg_launch_tick_send_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32,
+                                          const RgSendCols &);
 template void rg_launch_flush_small_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *,
                                             const RgListOut &);
 template void rg_launch_mailbox_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *,

@@ -194,6 +194,8 @@ SYMBOLS = {
     "rg_ingest_tick": (_i, [_vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "rg_ingested_results": (_i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_appends": (_i, [_vp, _u64, C.c_uint32]),
+    "rg_tick_send": (_i, [_vp, _vp, _u64, C.c_uint32]),
+    "rg_tick_device_send": (_i, [_vp, _vp, _u64, C.c_uint32]),
     "rg_flush_send": (_i, [_vp, _u64, C.c_uint32]),
     "rg_mailbox_start": (_i, [_vp, C.c_uint32]),
     "rg_mailbox_stop": (_i, [_vp]),
@@ -475,6 +477,24 @@ class Engine:
         if max_bytes is not None:
             max_entries_per_msg, flags = max_bytes, flags | SEND_BYTES
         self._check(self.L.rg_send_appends(self.h, max_entries_per_msg, flags))
+
+    def tick_send(self, msgs, max_entries_per_msg=0, skip_bcast_commit=False, max_bytes=None):
+        """tick(msgs) + send_appends(...) as ONE launch (k_tick_send); host buffers, synchronises like tick()."""
+        flags = SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0
+        if max_bytes is not None:
+            max_entries_per_msg, flags = max_bytes, flags | SEND_BYTES
+        m = _Msgs(_ptr(msgs.m_index), _ptr(msgs.m_commit), _ptr(msgs.m_hint), _ptr(msgs.m_rs), _ptr(msgs.m_flags),
+                  _ptr(getattr(msgs, "m_logterm", None)))
+        self._check(self.L.rg_tick_send(self.h, C.byref(m), max_entries_per_msg, flags))
+
+    def tick_device_send(self, m_index, m_commit, m_hint, m_rs, m_flags, m_logterm=None, max_entries_per_msg=0,
+                         skip_bcast_commit=False, max_bytes=None):
+        """tick_device(...) + send_appends(...) as ONE launch; device pointers, asynchronous."""
+        flags = SEND_SKIP_BCAST_COMMIT if skip_bcast_commit else 0
+        if max_bytes is not None:
+            max_entries_per_msg, flags = max_bytes, flags | SEND_BYTES
+        m = _Msgs(_ptr(m_index), _ptr(m_commit), _ptr(m_hint), _ptr(m_rs), _ptr(m_flags), _ptr(m_logterm))
+        self._check(self.L.rg_tick_device_send(self.h, C.byref(m), max_entries_per_msg, flags))
 
     def flush_send(self, max_entries_per_msg=0, skip_bcast_commit=False, max_bytes=None):
         """flush() + send_appends(); one host<->device round trip for small batches."""

@@ -215,6 +215,66 @@ extern "C" long rg_host_check_send(unsigned P, unsigned long G, unsigned long st
     return n;
 }
 
+// The tick and its send stage in ONE pass over the group's registers (rg_group_tick_send, what k_tick_send runs per lane;
+// rg_tick_send / rg_tick_device_send): the group is loaded once, ticked, the stage runs on what the tick left and the group
+// is stored once. Items are appended in group order, like host_send.
+template <int P, typename IX>
+static void host_tick_send_one(const RgState &st, const RgMsgs &ms, const RgIns &ins, bool gc, IX g, u64 max_entries, u32 flags,
+                               RgSendRegs<P> &it) {
+    RgGroup<P> r;
+    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    if (gc) rg_group_tick_send<P, true, IX>(r, st, ms, ins, g, max_entries, flags, it);
+    else rg_group_tick_send<P, false, IX>(r, st, ms, ins, g, max_entries, flags, it);
+}
+template <int P>
+static long host_tick_send(const RgState &st, const RgMsgs &ms_in, const RgIns &ins, bool gc, u64 max_entries, u32 flags,
+                           rg_send_item *items, u64 cap) {
+    std::vector<u64> rh;
+    RgMsgs ms = ms_in;
+    bool any = false;
+    for (u64 g = 0; g < st.G && !any; g++) any = (ms_in.mflags[g] & 0x8080808080808080ULL) != 0;
+    if (any) {
+        rh.assign((size_t)P * st.stride, 0);
+        for (u64 g = 0; g < st.G; g++) rg_resolve_hints(st, ms_in, g, P, rh.data());
+        ms.mhr = rh.data();
+    }
+    const bool fits32 = rg_fits_u32_offsets(P, st.stride);
+    u64 k = 0;
+    for (u64 g = 0; g < st.G; g++) {
+        RgSendRegs<P> it;
+        if (fits32 && !(g & 1)) host_tick_send_one<P, u32>(st, ms, ins, gc, (u32)g, max_entries, flags, it);
+        else host_tick_send_one<P, u64>(st, ms, ins, gc, g, max_entries, flags, it);
+        for (int s = 0; s < P; s++) {
+            const u32 nk = rg_send_nk<P>(it, s);
+            if (!nk) continue;
+            if (k < cap) {
+                rg_send_item r;
+                r.group = g; r.prev_index = it.prev[s]; r.last_index = it.last[s]; r.slot = (u32)s;
+                r.n_msgs = (uint16_t)(nk & 0xffffu);
+                r.kind = (uint16_t)(nk >> 16);
+                items[k] = r;
+            }
+            k++;
+        }
+    }
+    return (long)k;
+}
+
+extern "C" long rg_host_check_tick_send(unsigned P, unsigned long G, unsigned long stride, void *const *state,
+                                        const void *const *msg, int group_commit_kernel, u32 *meta, u64 *head, u64 *tail,
+                                        u64 *ring, unsigned cap, unsigned long max_entries, unsigned flags, rg_send_item *items,
+                                        unsigned long items_cap, const u32 *esz, unsigned esz_w) {
+    const RgState st = make_state(state, G, stride);
+    derive_pending(st, P);
+    const RgMsgs ms = make_msgs(msg);
+    RgIns ins;
+    ins.meta = meta; ins.head = head; ins.tail = tail; ins.ring = ring; ins.cap = cap;
+    ins.esz = esz; ins.esz_w = esz_w;
+    long n = -1;
+    RG_DISPATCH_P(P, n = host_tick_send<N>(st, ms, ins, group_commit_kernel != 0, max_entries, flags, items, items_cap));
+    return n;
+}
+
 // rg_limit_size (rg_send.h) on a caller-provided window of cumulative entry sizes: how many of the entries
 // [next, next + avail) one MsgAppend of at most `max` bytes carries.
 extern "C" unsigned long rg_host_check_limit_size(const u32 *row, unsigned window, unsigned long next, unsigned long avail,

@@ -460,6 +460,34 @@ def host_send():
     return send
 
 
+@pytest.fixture(scope="module")
+def host_tick_send():
+    """rg_group_tick_send (k_tick_send's per-lane code: the tick and its send stage on one set of registers) on the host."""
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_tick_send
+    fn.restype = C.c_long
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_uint, C.c_ulong, C.c_uint, C.c_void_p, C.c_ulong, C.c_void_p, C.c_uint]
+
+    def tick_send(st, msgs, out, gc, meta, head, ring, cap, max_entries, flags=0, esz=None):
+        head, tail = head
+        items = np.zeros(st["n_groups"] * st["n_slots"], dtype=SEND_ITEM_DTYPE)
+        n = fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), msg_ptrs(msgs), int(gc), meta.ctypes.data,
+               head.ctypes.data, tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items),
+               None if esz is None else esz.ctypes.data, 0 if esz is None else esz.shape[1])
+        assert 0 <= n <= len(items)
+        G, P = st["n_groups"], st["n_slots"]
+        for p in range(P):
+            m = meta[p, :G]
+            live = np.nonzero(m >> 16)[0]
+            start, count = (m[live] & 0xffff).astype(np.int64), (m[live] >> 16).astype(np.int64)
+            ring[live, p, start] = head[p, live]
+            ring[live, p, (start + count - 1) % cap] = tail[p, live]
+        return items[:n]
+    return tick_send
+
+
 def apply_snapshots(rng, items, cl, st, meta):
     """The host's half of a snapshot send: Progress::become_snapshot(snapshot index) on both sides."""
     for (g, p), (kind, prev, last, n) in items.items():
@@ -476,7 +504,9 @@ def apply_snapshots(rng, items, cl, st, meta):
 
 @pytest.mark.parametrize("cap,max_entries", [(1, 0), (3, 2), (4, 1), (256, 0), (2, 7), (5, 1)])
 @pytest.mark.parametrize("n_slots", [1, 3, 5, 8])
-def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, max_entries):
+@pytest.mark.parametrize("fused", [False, True])
+def test_send_stage_on_host_matches_oracle(host_tick, host_send, host_tick_send, fused, n_slots, cap, max_entries):
+    """fused: the tick and its stage as ONE pass over the group's registers (rg_group_tick_send, k_tick_send's lane code)."""
     rng = np.random.default_rng(9100 + 17 * n_slots + cap + max_entries)
     G, ticks = (300, 60) if cap == 5 else (1500, 10)  # cap 5: a long run, the ring positions wrap many times
     st = O.add_term_table(O.alloc_state(G, n_slots))
@@ -502,11 +532,15 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
         else:
             fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
         sendstage.prepare_msgs(msgs)
-        host_tick(eng_st, msgs, out, False)
+        skip = t % 2 == 1  # Config::skip_bcast_commit on every other tick
+        if fused:
+            items = host_tick_send(eng_st, msgs, out, False, meta, head, ring, cap, max_entries, 1 if skip else 0)
+        else:
+            host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
-        skip = t % 2 == 1  # Config::skip_bcast_commit on every other tick
-        items = host_send(eng_st, out, meta, head, ring, cap, max_entries, 1 if skip else 0)
+        if not fused:
+            items = host_send(eng_st, out, meta, head, ring, cap, max_entries, 1 if skip else 0)
         omsgs = cl.send_stage_soa(gout, max_entries, skip_bcast_commit=skip)
         got = sendstage.compare_items(items, omsgs)
         apply_snapshots(rng, got, cl, eng_st, meta)
@@ -529,7 +563,8 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, n_slots, cap, m
 
 @pytest.mark.parametrize("n_slots,cap,window,max_bytes", [(3, 4, 8, 900), (5, 256, 64, 1500), (5, 3, 16, 0), (7, 8, 32, 2**32 + 5),
                                                          (5, 16, 64, O.U64_MAX), (8, 5, 8, 300)])
-def test_send_stage_byte_limit_on_host_matches_oracle(host_tick, host_send, n_slots, cap, window, max_bytes):
+@pytest.mark.parametrize("fused", [False, True])
+def test_send_stage_byte_limit_on_host_matches_oracle(host_tick, host_send, host_tick_send, fused, n_slots, cap, window, max_bytes):
     """Config::max_size_per_msg in BYTES (RG_SEND_BYTES): rg_limit_size over the device's window of cumulative entry sizes
     against util::limit_size restated literally in the oracle, entry sizes random with a tenth of them zero; peers that
     need entries outside the window come back as RG_SEND_HOST and are served the way rg_update_state does."""
@@ -560,12 +595,21 @@ def test_send_stage_byte_limit_on_host_matches_oracle(host_tick, host_send, n_sl
         cl.store_soa(st)
         fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
         sendstage.prepare_msgs(msgs)
-        host_tick(eng_st, msgs, out, False)
+        if fused:
+            # the host writes the size records of what it appends BEFORE the launch that learns of them: the last_index this
+            # tick leaves is taken from a dry run of the tick alone on a copy
+            dry, dry_out = copy_state(eng_st), out.copy()
+            host_tick(dry, msgs, dry_out, False)
+            sendstage.fill_size_window(esz, cum, dry["term_hi"])
+            items = host_tick_send(eng_st, msgs, out, False, meta, head, ring, cap, max_bytes, 2, esz=esz)
+        else:
+            host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
         assert int(eng_st["term_hi"].max()) < n_index
-        sendstage.fill_size_window(esz, cum, eng_st["term_hi"])
-        items = host_send(eng_st, out, meta, head, ring, cap, max_bytes, 2, esz=esz)  # RG_SEND_BYTES
+        if not fused:
+            sendstage.fill_size_window(esz, cum, eng_st["term_hi"])
+            items = host_send(eng_st, out, meta, head, ring, cap, max_bytes, 2, esz=esz)  # RG_SEND_BYTES
         omsgs = cl.send_stage_soa(gout, max_bytes)
         items, omsgs_dev, served = sendstage.split_host_items(items, omsgs)
         got = sendstage.compare_items(items, omsgs_dev)

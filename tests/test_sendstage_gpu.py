@@ -41,8 +41,12 @@ def check(rg, eng, cl, st, cap, what):
     sendstage.compare_rings(cl, meta, ring, st, cap)
 
 
-@pytest.mark.parametrize("n_slots,cap,max_entries", [(3, 2, 1), (5, 3, 2), (5, 256, 0), (7, 4, 0), (8, 1, 3)])
-def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries):
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("n_slots,cap,max_entries", [(3, 2, 1), (5, 3, 2), (5, 256, 0), (7, 4, 0), (8, 1, 3), (1, 2, 0), (2, 3, 1),
+                                                    (4, 2, 2), (6, 5, 0)])
+def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries, fused):
+    """fused: rg_tick_send -- the tick and its stage as ONE launch (k_tick_send) -- must leave exactly what rg_tick followed
+    by rg_send_appends leaves: result words, work items, Progress columns, rings."""
     rng = np.random.default_rng(7700 + 31 * n_slots + cap)
     G = 6000 + 13
     st = O.add_term_table(O.alloc_state(G, n_slots))
@@ -65,18 +69,23 @@ def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries):
         sendstage.prepare_msgs(msgs)
         for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
             getattr(mb, k)[...] = msgs[k]
-        eng.tick(mb)
+        skip = t % 2 == 1  # Config::skip_bcast_commit on every other tick
+        if fused:
+            eng.tick_send(mb, max_entries, skip_bcast_commit=skip)
+        else:
+            eng.tick(mb)
         cl.tick_soa(msgs, gout)
         _, out = eng.results()
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
-        skip = t % 2 == 1  # Config::skip_bcast_commit on every other tick
-        eng.send_appends(max_entries, skip_bcast_commit=skip)
+        if not fused:
+            eng.send_appends(max_entries, skip_bcast_commit=skip)
         items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, max_entries, skip_bcast_commit=skip))
         seen["snap"] += apply_snapshots(rg, eng, cl, st, items)
         check(rg, eng, cl, st, cap, f"P={n_slots} cap={cap} tick {t}")
         seen["items"] += len(items)
         seen["multi"] += sum(1 for v in items.values() if v[3] > 1)
-    assert seen["items"] > 1000 and seen["snap"] > 0, seen
+    if n_slots > 1:  # (a single-voter group has nobody to send to)
+        assert seen["items"] > 1000 and seen["snap"] > 0, seen
     if max_entries and cap > 1:
         assert seen["multi"] > 0, seen
     eng.close()
@@ -128,9 +137,15 @@ def test_send_stage_call_sequence_and_checkpoint(rg):
     with pytest.raises(EngineError) as e:
         host.send_appends()
     assert e.value.code == ERR["STATE"]
+    with pytest.raises(EngineError) as e:
+        host.tick_send(rg.MsgBuffers(G, P, host.stride))  # the one-launch form needs the device Inflights as well
+    assert e.value.code == ERR["STATE"]
     host.close()
     eng = rg.Engine(G, P, max_inflight=cap)
     eng.workload_init(2)
+    with pytest.raises(EngineError) as e:
+        eng.tick_send(rg.MsgBuffers(G, P, eng.stride), max_bytes=100)  # RG_SEND_BYTES without the entry sizes
+    assert e.value.code == ERR["STATE"]
     with pytest.raises(EngineError) as e:
         eng.send_appends()  # no tick yet
     assert e.value.code == ERR["STATE"]
@@ -158,6 +173,12 @@ def test_send_stage_call_sequence_and_checkpoint(rg):
     eng.tick(mb)
     eng.send_appends(1)
     assert len(eng.send_items()) == 0
+    mb.m_commit[0, :G] = hi + 6
+    eng.tick_send(mb, 1)  # a tick and its stage in one launch: the stage has run when the call returns
+    assert len(eng.send_items()) == 0
+    with pytest.raises(EngineError) as e:
+        eng.send_appends(1)
+    assert e.value.code == ERR["STATE"]
     eng.restore()  # back to "second tick done, its stage not run": rings and flags are part of the checkpoint
     meta0, _ = eng.read_inflights()
     assert ((meta0[1:P, :G] >> 16) == 1).all() and (meta0[0, :G] == 0).all()
@@ -350,8 +371,11 @@ def test_dense_stage_work_item_columns_equal_the_compact_list(rg):
     for t in range(4):
         eng.workload_gen(2, t, *[c.data_ptr() for c in cols], flags.data_ptr())
         flags &= 0xEF  # no RG_MF_SENT: the device sends
-        eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
-        eng.send_appends(2 if t % 2 else 0)
+        if t >= 2:  # the same through rg_tick_device_send (one launch)
+            eng.tick_device_send(*[c.data_ptr() for c in cols], flags.data_ptr(), max_entries_per_msg=2 if t % 2 else 0)
+        else:
+            eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+            eng.send_appends(2 if t % 2 else 0)
         pp, pl, pn = eng.send_columns()
         n_cells = P * eng.stride
         eng.sync()
@@ -390,7 +414,8 @@ def size_records(rg, cum, lo, hi):
 
 @pytest.mark.parametrize("n_slots,cap,window,max_bytes", [(3, 4, 8, 900), (5, 256, 64, 1500), (5, 3, 16, 0),
                                                          (7, 8, 32, 2**32 + 5), (5, 16, 64, O.U64_MAX)])
-def test_send_stage_byte_limit_matches_oracle(rg, n_slots, cap, window, max_bytes):
+@pytest.mark.parametrize("fused", [False, True])
+def test_send_stage_byte_limit_matches_oracle(rg, n_slots, cap, window, max_bytes, fused):
     """rg_send_appends(RG_SEND_BYTES): util::limit_size over the entry sizes the host wrote to the device
     (rg_log_sizes_write) against the oracle's literal restatement; RG_SEND_HOST peers served through rg_update_state."""
     rng = np.random.default_rng(7900 + 31 * n_slots + cap + window)
@@ -424,16 +449,21 @@ def test_send_stage_byte_limit_matches_oracle(rg, n_slots, cap, window, max_byte
         sendstage.prepare_msgs(msgs)
         for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
             getattr(mb, k)[...] = msgs[k]
-        eng.tick(mb)
+        if not fused:
+            eng.tick(mb)
         cl.tick_soa(msgs, gout)
-        _, out = eng.results()
-        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
         cl.store_soa(st)  # (last_index after the tick's appends)
         hi = st["term_hi"].astype(np.int64)
         assert int(hi.max()) < n_index
+        # (fused: the size records of what this tick's local-append events announce are written BEFORE the launch)
         eng.log_sizes_write(size_records(rg, cum, written.astype(np.int64), hi))
         written = st["term_hi"].copy()
-        eng.send_appends(max_bytes=max_bytes)
+        if fused:
+            eng.tick_send(mb, max_bytes=max_bytes)
+        _, out = eng.results()
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        if not fused:
+            eng.send_appends(max_bytes=max_bytes)
         items, omsgs, served = sendstage.split_host_items(eng.send_items(), cl.send_stage_soa(gout, max_bytes))
         got = sendstage.compare_items(items, omsgs)
         if served:

@@ -22,7 +22,7 @@ for sub, name in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
     for f in glob.glob(f"{O}/{sub}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].replace("void ", "")
-            if not re.search(r"k_tick|k_send_dense|k_send_appends|k_recompute", k) or row["Counter_Name"] != name:
+            if not re.search(r"k_tick|k_tick_send|k_send_dense|k_send_appends|k_recompute", k) or row["Counter_Name"] != name:
                 continue
             rows[k][int(row["Dispatch_Id"])] = rows[k].get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
     for k, d in rows.items():
