@@ -104,32 +104,39 @@ template <int P> RG_HD u32 rg_send_nk(const RgSendRegs<P> &it, int s) {
     return it.n[s] ? (it.n[s] | (RG_SEND_APPEND << 16)) : 0u;
 }
 
-// Inflights::free_to (inflights.rs:84-110) over (head, middle entries in the ring, tail)
+// Inflights::free_to (inflights.rs:84-110) over (head, middle entries in the ring, tail).
+// Written as arithmetic on predicates (the stage is instruction-bound: every `if` of lane-varying code is a saveexec /
+// branch / restore sequence): only a partial free of a window of MORE than two messages walks the ring.
 RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &head, u64 tail, u64 to) {
-    if (count == 0 || to < head) return; // out of the left side of the window
-    if (to >= tail) {                    // everything in the window is <= tail <= to
-        start += count;
-        if (start >= ins.cap) start -= ins.cap;
-        count = 0;
+    const bool hit = count != 0 && to >= head; // (else: out of the left side of the window)
+    const bool all = hit && to >= tail;        // everything in the window is <= tail <= to
+    if (hit && !all && count > 2) {
+        // head <= to < tail: the new oldest is the first entry > to -- a middle one, or the newest
+        u32 i = 1, idx = start + 1;
+        if (idx >= ins.cap) idx -= ins.cap;
+        u64 nh = tail;
+        while (i + 1 < count) { // middle entries only
+            const u64 v = (RG_SEND_EXP & 2) ? ~0ULL : ins.ring[base + idx];
+            if (to < v) {
+                nh = v;
+                break;
+            }
+            idx++;
+            if (idx >= ins.cap) idx -= ins.cap;
+            i++;
+        }
+        head = nh;
+        count -= i;
+        start = idx;
         return;
     }
-    // head <= to < tail, so count >= 2: the new oldest is the first entry > to -- a middle one, or the newest
-    u32 i = 1, idx = start + 1;
-    if (idx >= ins.cap) idx -= ins.cap;
-    u64 nh = tail;
-    while (i + 1 < count) { // middle entries only
-        const u64 v = (RG_SEND_EXP & 2) ? ~0ULL : ins.ring[base + idx];
-        if (to < v) {
-            nh = v;
-            break;
-        }
-        idx++;
-        if (idx >= ins.cap) idx -= ins.cap;
-        i++;
-    }
-    head = nh;
-    count -= i;
-    start = idx;
+    // nothing freed, everything freed, or the older of exactly two: no ring word is involved
+    const bool one = hit && !all;
+    const u32 adv = all ? count : (one ? 1u : 0u);
+    start += adv;
+    if (start >= ins.cap) start -= ins.cap;
+    count -= adv;
+    head = one ? tail : head;
 }
 
 // Inflights::add (inflights.rs:65-81): the previous newest becomes a middle entry (only then does it need a ring word)
@@ -309,59 +316,93 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             const u64 prs = !FUSED ? q.prs_v[s] : ((row0 >> (8 * s)) & RG_PF_PEND_RS) ? rg_at(st.prs, o) : 0ULL;
             u32 n = 0;
             bool snap = false, host = false;
-            bool first = sa; // the first call is send_append (allow_empty) only if one was requested
-            for (;;) {
-                const bool allow_empty = first;
-                // Progress::is_paused (progress.rs:210-216)
-                const bool paused = state == RG_STATE_PROBE       ? (pb & RG_PF_PAUSED) != 0
-                                    : state == RG_STATE_REPLICATE ? count == ins.cap
-                                                                  : true;
-                bool sent = false;
-                if (!paused) {
-                    if (prs != 0) { // pending_request_snapshot: prepare_send_snapshot
-                        snap = (pb & RG_PF_RECENT_ACTIVE) != 0;
-                    } else {
-                        const u64 avail = next > hi ? 0 : hi - next + 1;
-                        const bool compacted = next <= hi && next < first_index; // entries() = Err(Compacted)
-                        if (compacted) {
-                            if (allow_empty) snap = (pb & RG_PF_RECENT_ACTIVE) != 0; // else: `return false`
-                        } else if (avail != 0 || allow_empty) {
-                            u64 take;
-                            if (flags & RG_SEND_BYTES) {
-                                // Config::max_size_per_msg in bytes: util::limit_size over the group's entry sizes. A peer
-                                // so far behind that the entries it needs have left the window is the host's to serve
-                                // (it owns the log): RG_SEND_HOST, Progress untouched, like a snapshot.
-                                if (avail > 1 && max_entries != ~0ULL && avail >= ins.esz_w) {
-                                    host = true;
-                                    break;
-                                }
-                                take = rg_limit_size(ins.esz + (u64)g * ins.esz_w, ins.esz_w - 1u, next, avail, max_entries);
-                            } else {
-                                take = (max_entries && avail > max_entries) ? max_entries : avail;
-                            }
-                            if (n == 0) it.prev[s] = next - 1;
-                            it.last[s] = next - 1 + take;
-                            n++;
-                            if (take) { // Progress::update_state(last) (progress.rs:231-243)
-                                if (state == RG_STATE_REPLICATE) {
-                                    next += take; // optimistic_update
-                                    rg_ins_add(ins, base, start, count, head, tail, next - 1);
+            // The common peer needs at most ONE message and no decision beyond "is there anything to send": paused (nothing
+            // happens: send_append and every maybe_send_append return at is_paused), or no pending snapshot request, nothing
+            // compacted away and everything that is left fits one message. For it the loop below collapses to
+            //   n = !paused && (entries left || send_append was requested)   [send_append sends an empty message, the
+            //   `while maybe_send_append(to, false)` loop does not]; update_state(last) if entries went out
+            // -- the second pass of the loop finds nothing left (or a Probe peer paused) whatever the first one did. Written
+            // as predicate arithmetic; every other peer takes the literal loop.
+            const bool repl = state == RG_STATE_REPLICATE, probe = state == RG_STATE_PROBE;
+            const bool paused0 = probe ? (pb & RG_PF_PAUSED) != 0 : repl ? count == ins.cap : true; // Progress::is_paused (progress.rs:210-216)
+            const u64 avail0 = next > hi ? 0 : hi - next + 1;
+            const bool limited = (flags & RG_SEND_BYTES) != 0 || (max_entries != 0 && avail0 > max_entries);
+            const bool simple = paused0 || (prs == 0 && !(next <= hi && next < first_index) && !limited);
+            if (simple) {
+                const bool snd = !paused0 && (avail0 != 0 || sa);
+                const bool took = snd && avail0 != 0;
+                const u64 last = next - 1 + avail0;
+                if (snd) {
+                    it.prev[s] = next - 1;
+                    it.last[s] = last;
+                }
+                n = snd ? 1u : 0u;
+                const bool addw = took && repl; // Progress::update_state(last) (progress.rs:231-243): optimistic_update + ins.add(last)
+                if (addw && count >= 2) {       // Inflights::add: the previous newest becomes a middle entry
+                    u32 pos = start + count - 1;
+                    if (pos >= ins.cap) pos -= ins.cap;
+                    if (!(RG_SEND_EXP & 2)) ins.ring[base + pos] = tail;
+                }
+                head = (addw && count == 0) ? last : head;
+                tail = addw ? last : tail;
+                count += addw ? 1u : 0u;
+                next = addw ? last + 1 : next;
+                pb |= (took && probe) ? RG_PF_PAUSED : 0u;
+            } else {
+                bool first = sa; // the first call is send_append (allow_empty) only if one was requested
+                for (;;) {
+                    const bool allow_empty = first;
+                    // Progress::is_paused (progress.rs:210-216)
+                    const bool paused = state == RG_STATE_PROBE       ? (pb & RG_PF_PAUSED) != 0
+                                        : state == RG_STATE_REPLICATE ? count == ins.cap
+                                                                      : true;
+                    bool sent = false;
+                    if (!paused) {
+                        if (prs != 0) { // pending_request_snapshot: prepare_send_snapshot
+                            snap = (pb & RG_PF_RECENT_ACTIVE) != 0;
+                        } else {
+                            const u64 avail = next > hi ? 0 : hi - next + 1;
+                            const bool compacted = next <= hi && next < first_index; // entries() = Err(Compacted)
+                            if (compacted) {
+                                if (allow_empty) snap = (pb & RG_PF_RECENT_ACTIVE) != 0; // else: `return false`
+                            } else if (avail != 0 || allow_empty) {
+                                u64 take;
+                                if (flags & RG_SEND_BYTES) {
+                                    // Config::max_size_per_msg in bytes: util::limit_size over the group's entry sizes. A peer
+                                    // so far behind that the entries it needs have left the window is the host's to serve
+                                    // (it owns the log): RG_SEND_HOST, Progress untouched, like a snapshot.
+                                    if (avail > 1 && max_entries != ~0ULL && avail >= ins.esz_w) {
+                                        host = true;
+                                        break;
+                                    }
+                                    take = rg_limit_size(ins.esz + (u64)g * ins.esz_w, ins.esz_w - 1u, next, avail, max_entries);
                                 } else {
-                                    pb |= RG_PF_PAUSED;
+                                    take = (max_entries && avail > max_entries) ? max_entries : avail;
                                 }
+                                if (n == 0) it.prev[s] = next - 1;
+                                it.last[s] = next - 1 + take;
+                                n++;
+                                if (take) { // Progress::update_state(last) (progress.rs:231-243)
+                                    if (state == RG_STATE_REPLICATE) {
+                                        next += take; // optimistic_update
+                                        rg_ins_add(ins, base, start, count, head, tail, next - 1);
+                                    } else {
+                                        pb |= RG_PF_PAUSED;
+                                    }
+                                }
+                                sent = true;
                             }
-                            sent = true;
                         }
                     }
-                }
-                // send_append runs once; the loop goes on while something was sent. A snapshot pauses the
-                // Progress (become_snapshot, applied by the host), which ends the loop as well.
-                if (snap) break;
-                if (first) {
-                    first = false;
-                    if (!sm) break;
-                } else if (!sent) {
-                    break;
+                    // send_append runs once; the loop goes on while something was sent. A snapshot pauses the
+                    // Progress (become_snapshot, applied by the host), which ends the loop as well.
+                    if (snap) break;
+                    if (first) {
+                        first = false;
+                        if (!sm) break;
+                    } else if (!sent) {
+                        break;
+                    }
                 }
             }
             if (snap) {

@@ -9,7 +9,8 @@
 #ifndef RG_TS_ORDER /* k_tick_send: 1 = the tick's stores are issued before the stage's loads (experiment) */
 #define RG_TS_ORDER 0
 #endif
-#ifndef RG_TS_SPEC /* k_tick_send: 1 = the window columns of every slot are requested with the group's own loads (rg_send_prefetch) */
+#ifndef RG_TS_SPEC /* k_tick_send: 1 = the window columns of every slot are requested with the group's own loads, into registers
+                      (rg_send_prefetch); 2 = the same, straight into LDS (gfx950 LDS-DMA: no register is held across the tick) */
 #define RG_TS_SPEC 0
 #endif
 
@@ -164,28 +165,44 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lan
 // `next` and the flag row) -> the stage -> `next`, the flag row, the window columns, the work items. The stores sit
 // between the request and the first use so that the wave waits for the loads only (vmcnt counts in issue order).
 // One group of that launch, shared with the host twin of the tests (tests/host_check):
+// The window columns of a workgroup's 64 groups as the LDS-DMA of k_tick_send (RG_TS_SPEC == 2) leaves them
+template <int P> struct RgSendWin {
+    u64 ht[P][2][64];             // [slot][0 = oldest inflight (head), 1 = newest (tail)][group of the block]
+    u32 meta[(P + 3) / 4 * 4][64]; // [slot][group]: Inflights.start | count << 16 (rows beyond P: padding of the last DMA)
+};
+
 template <int P, bool GC, typename IX>
 RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, const RgIns &ins, IX g, u64 max_entries,
-                              u32 flags, RgSendRegs<P> &it) {
+                              u32 flags, RgSendRegs<P> &it, const RgSendWin<P> *win = nullptr, u32 lane = 0) {
     RgSendOps<P> q;
-    if (RG_TS_SPEC) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
+    constexpr bool PRE = RG_TS_SPEC != 0;
+    if (RG_TS_SPEC == 1 || (RG_TS_SPEC == 2 && !win)) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
+    if (RG_TS_SPEC == 2 && win) q.first_index = rg_at(st.dummy_idx, g) + 1;
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+#if defined(__HIP_DEVICE_COMPILE__) && RG_TS_SPEC == 2
+    if (win) {
+        // the DMA the kernel issued before the tick is a pending LDS write on the VM counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s = 0; s < P; s++) {
+            q.meta_v[s] = win->meta[s][lane];
+            q.head_v[s] = win->ht[s][0][lane];
+            q.tail_v[s] = win->ht[s][1][lane];
+        }
+    }
+#endif
     // the `next` cells the tick holds: every slot with an event was fetched (or is overwritten by its SENT event), an
     // election rewrites all of them (rg_prefetch_rare / RgTick::set_next)
     const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
 #if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
     rg_store_group<P, IX, 1>(r, st, g);
-    rg_send_request<P, IX, false, true, RG_TS_SPEC != 0>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_send_request<P, IX, false, true, PRE>(st, ins, g, r.out, flags, q, &r, nxv);
 #else
-    rg_send_request<P, IX, false, true, RG_TS_SPEC != 0>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_send_request<P, IX, false, true, PRE>(st, ins, g, r.out, flags, q, &r, nxv);
     rg_store_group<P, IX, 1>(r, st, g);
 #endif
-#if defined(RG_TS_DBG) && RG_TS_DBG == 1 /* (register-pressure probes, never built into the product) */
-    it.count = q.meta_v[0] + (u32)q.head_v[1] + (u32)q.tail_v[2]; it.snap = it.hostm = 0;
-    for (int s = 0; s < P; s++) { it.n[s] = q.meta_v[s]; it.prev[s] = q.head_v[s]; it.last[s] = q.tail_v[s]; }
-#else
     rg_send_serve<P, IX, true>(st, ins, g, r.out, max_entries, flags, q, it, &r, nxv);
-#endif
     rg_store_group<P, IX, 2>(r, st, g);
 }
 
@@ -217,12 +234,45 @@ template <int P, bool GC, typename IX>
 __global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgState st, RgMsgs ms, RgIns ins, u64 max_entries, u32 flags,
                                                                      RgSendCols oc) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+#if RG_TS_SPEC == 2
+    // The stage's window columns (meta 4 B, oldest / newest inflight 8 B each, per slot and group) travel straight from
+    // global memory into LDS while the tick runs: global_load_lds_dwordx4 moves 16 B per lane to `base + lane x 16`, the
+    // lanes' global addresses are free -- lanes 0-31 fetch the wave's 64 `head` cells of a slot, lanes 32-63 its `tail` cells
+    // (one instruction per slot), 16 lanes fetch a slot's 64 `meta` cells (one instruction per four slots). Issued by the
+    // WHOLE wave before the range check (a lane moves other lanes' groups; the columns are padded to the stride, a multiple
+    // of 256, so the last block stays in bounds). No register is held across the tick: one memory round trip instead of
+    // two, at the tick's occupancy.
+    static_assert(RG_BLOCK % 64 == 0, "one window block per wave");
+    __shared__ RgSendWin<P> win_all[RG_BLOCK / 64];
+    RgSendWin<P> &win = win_all[threadIdx.x >> 6];
+    const u32 lane = threadIdx.x & 63u;
+    {
+        const u64 w0 = g64 - lane; // first group of this wave
+#pragma unroll
+        for (int s = 0; s < P; s++) {
+            const u64 *col = lane < 32 ? ins.head : ins.tail;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(col + (u64)s * st.stride + w0 + 2 * (lane & 31u)),
+                                             (__attribute__((address_space(3))) void *)&win.ht[s][0][0], 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < (P + 3) / 4; k++) {
+            const u32 slot = 4 * k + (lane >> 4);
+            const u32 sc = slot < (u32)P ? slot : (u32)P - 1u; // (lanes beyond the last slot refetch it into the padding rows)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ins.meta + (u64)sc * st.stride + w0 + 4 * (lane & 15u)),
+                                             (__attribute__((address_space(3))) void *)&win.meta[4 * k][0], 16, 0, 0);
+        }
+    }
+#endif
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
     RgGroup<P> r;
     rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
     RgSendRegs<P> it;
+#if RG_TS_SPEC == 2
+    rg_group_tick_send<P, GC, IX>(r, st, ms, ins, g, max_entries, flags, it, &win, lane);
+#else
     rg_group_tick_send<P, GC, IX>(r, st, ms, ins, g, max_entries, flags, it);
+#endif
     rg_store_send_items<P, IX>(it, oc, st.stride, g);
 }
 
