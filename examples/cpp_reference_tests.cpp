@@ -1,0 +1,246 @@
+// cpp_reference_tests.cpp -- the reference's own tests for this path, restated against include/raftgroups.hpp (the C++
+// host side above the C ABI) and run on the GPU. Each function names the reference test it follows; the expectations are
+// the reference's rows, verbatim.
+//   g++ -std=c++17 -Iinclude examples/cpp_reference_tests.cpp -o cpp_reference_tests -Lraft_rs_amd -lraftgroups
+//   (plus -Wl,-rpath,$PWD/raft_rs_amd), then ./cpp_reference_tests on an MI355X
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+
+#include "raftgroups.hpp"
+
+using namespace raftgroups;
+
+#define EXPECT(cond, ...)                                   \
+    do {                                                    \
+        if (!(cond)) {                                      \
+            std::fprintf(stderr, "%s:%d: ", __FILE__, __LINE__); \
+            std::fprintf(stderr, __VA_ARGS__);              \
+            std::fprintf(stderr, "\n");                     \
+            std::exit(1);                                   \
+        }                                                   \
+    } while (0)
+
+static Message new_message(u64 from, MessageType t, u64 term) {
+    Message m;
+    m.from = from;
+    m.msg_type = t;
+    m.term = term;
+    return m;
+}
+static std::vector<u64> range(u64 n) {
+    std::vector<u64> v;
+    for (u64 i = 1; i <= n; i++) v.push_back(i);
+    return v;
+}
+static size_t count_messages(const std::vector<LightReady> &rd) {
+    size_t n = 0;
+    for (const LightReady &r : rd)
+        for (const SendItem &m : r.messages) n += m.n_msgs;
+    return n;
+}
+
+// harness/tests/integration_cases/test_raft.rs:2611-2675
+static void test_leader_append_response() {
+    struct Row { u64 index; bool reject; u64 wmatch, wnext; size_t wmsg_num; u64 windex, wcommitted; };
+    const Row tests[] = {
+        {3, true, 0, 3, 0, 0, 0},  // stale resp; no replies
+        {2, true, 0, 2, 1, 1, 0},  // denied resp; decrease next and send probing message
+        {2, false, 2, 4, 2, 2, 2}, // accepted resp; leader commits; broadcast with committed index
+        {0, false, 0, 3, 0, 0, 0},
+    };
+    int i = 0;
+    for (const Row &t : tests) {
+        Config c;
+        c.n_groups = 1;
+        c.max_peers = 3;
+        c.max_inflight_msgs = 256;
+        MultiRaft sm(c);
+        // initial raft logs: entries (term 0, 1) (term 1, 2); become_candidate takes the node to term 1, become_leader
+        // appends its empty entry (term 1, 3); followers: match = 0, next = 3 (Progress::reset ran before the append)
+        GroupSpec s;
+        s.id = 1;
+        s.term = 1;
+        s.voters = {1, 2, 3};
+        s.first_index_of_term = 2;
+        s.last_index = 3;
+        s.committed = 0;
+        s.next_idx = 3;
+        sm.init_group(0, s);
+        sm.bootstrap();
+
+        Message m = new_message(2, MessageType::MsgAppendResponse, 1);
+        m.index = t.index;
+        m.reject = t.reject;
+        m.reject_hint = t.index;
+        sm.step(0, m);
+        const std::vector<LightReady> rd = sm.ready();
+
+        const Progress pr = sm.progress(0, 2);
+        EXPECT(pr.matched == t.wmatch, "#%d: match = %llu, want %llu", i, (unsigned long long)pr.matched, (unsigned long long)t.wmatch);
+        EXPECT(pr.next_idx == t.wnext, "#%d: next = %llu, want %llu", i, (unsigned long long)pr.next_idx, (unsigned long long)t.wnext);
+        EXPECT(count_messages(rd) == t.wmsg_num, "#%d msg_num = %zu, want %zu", i, count_messages(rd), t.wmsg_num);
+        for (const LightReady &r : rd)
+            for (const SendItem &msg : r.messages) {
+                EXPECT(msg.prev_index == t.windex, "#%d index = %llu, want %llu", i, (unsigned long long)msg.prev_index, (unsigned long long)t.windex);
+                EXPECT(r.commit_index == t.wcommitted, "#%d commit = %llu, want %llu", i, (unsigned long long)r.commit_index, (unsigned long long)t.wcommitted);
+            }
+        EXPECT(sm.committed(0) == t.wcommitted, "#%d committed = %llu", i, (unsigned long long)sm.committed(0));
+        i++;
+    }
+}
+
+// harness/tests/integration_cases/test_raft_paper.rs:499-534: an entry is committed once the leader that created it has
+// replicated it on a majority of the servers
+static void test_leader_acknowledge_commit() {
+    struct Row { u64 size; std::set<u64> acceptors; bool wack; };
+    const Row tests[] = {
+        {1, {}, true},      {3, {}, false},       {3, {2}, true},          {3, {2, 3}, true},          {5, {}, false},
+        {5, {2}, false},    {5, {2, 3}, true},    {5, {2, 3, 4}, true},    {5, {2, 3, 4, 5}, true},
+    };
+    int i = 0;
+    for (const Row &t : tests) {
+        Config c;
+        c.n_groups = 1;
+        c.max_peers = (unsigned)t.size;
+        c.max_inflight_msgs = 256;
+        MultiRaft r(c);
+        // become_candidate + become_leader at term 1, commit_noop_entry: everybody holds and has acknowledged entry 1
+        GroupSpec s;
+        s.id = 1;
+        s.term = 1;
+        s.voters = range(t.size);
+        s.first_index_of_term = 1;
+        s.last_index = 1;
+        s.committed = 1;
+        s.next_idx = 2;
+        s.follower_matched = 1;
+        s.follower_state = ProgressState::Replicate;
+        r.init_group(0, s);
+        r.bootstrap();
+        const u64 li = r.last_index(0);
+        r.propose(0, 1); // MsgPropose with one entry
+        r.on_persist_entries(0, li + 1);
+        const std::vector<LightReady> rd = r.ready();
+        // the MsgAppend of the proposal went to every follower: entries (1, 2]
+        std::map<u64, SendItem> sent;
+        for (const LightReady &x : rd)
+            for (const SendItem &m : x.messages) sent[m.to] = m;
+        EXPECT(sent.size() == t.size - 1, "#%d: %zu MsgAppend, want %llu", i, sent.size(), (unsigned long long)(t.size - 1));
+        for (const auto &kv : sent) {
+            if (!t.acceptors.count(kv.first)) continue;
+            Message m = new_message(kv.first, MessageType::MsgAppendResponse, 1); // accept_and_reply
+            m.index = kv.second.last_index;
+            r.step(0, m);
+        }
+        r.ready();
+        const bool g = r.committed(0) > li;
+        EXPECT(g == t.wack, "#%d: ack commit = %d, want %d", i, (int)g, (int)t.wack);
+        i++;
+    }
+}
+
+// harness/tests/integration_cases/test_raft_flow_control.rs:24-58: a full Inflights window stops the leader from sending
+static void test_msg_app_flow_control_full() {
+    Config c;
+    c.n_groups = 1;
+    c.max_peers = 2;
+    c.max_inflight_msgs = 256;
+    MultiRaft r(c);
+    GroupSpec s;
+    s.id = 1;
+    s.term = 1;
+    s.voters = {1, 2};
+    s.first_index_of_term = 1;
+    s.last_index = 1;
+    s.committed = 0;
+    s.next_idx = 1; // force the progress to be in replicate state: become_replicate -> next = matched + 1
+    s.follower_state = ProgressState::Replicate;
+    r.init_group(0, s);
+    r.bootstrap();
+    for (unsigned i = 0; i < c.max_inflight_msgs; i++) { // fill in the inflights window
+        r.propose(0, 1);
+        const size_t ms = count_messages(r.ready());
+        EXPECT(ms == 1, "#%u: ms count = %zu, want 1", i, ms);
+    }
+    EXPECT(r.progress(0, 2).ins_full, "ensure 1: the window must be full");
+    for (unsigned i = 0; i < 10; i++) { // ensure 2
+        r.propose(0, 1);
+        const size_t ms = count_messages(r.ready());
+        EXPECT(ms == 0, "#%u: ms count = %zu, want 0", i, ms);
+    }
+}
+
+// src/raw_node.rs:402-411 (RawNode::step) and the term gate of Raft::step (src/raft.rs:1282-1411)
+static void test_raw_node_step() {
+    Config c;
+    c.n_groups = 2;
+    c.max_peers = 3;
+    MultiRaft rn(c);
+    for (u64 g = 0; g < 2; g++) {
+        GroupSpec s;
+        s.id = 1;
+        s.term = 3;
+        s.voters = {1, 2, 3};
+        s.first_index_of_term = 5;
+        s.last_index = 9;
+        s.committed = 4;
+        s.next_idx = 5;
+        rn.init_group(g, s);
+    }
+    rn.bootstrap();
+    try { // raw_node.rs:404-406: local messages are refused
+        rn.step(0, new_message(1, MessageType::MsgHup, 0));
+        EXPECT(false, "a local message must be refused");
+    } catch (const Error &e) {
+        EXPECT(e.kind == ErrorKind::StepLocalMsg, "want StepLocalMsg, got %d", e.code);
+    }
+    try { // raw_node.rs:407-410: a response from a peer without a Progress
+        rn.step(0, new_message(9, MessageType::MsgAppendResponse, 3));
+        EXPECT(false, "an unknown peer must be refused");
+    } catch (const Error &e) {
+        EXPECT(e.kind == ErrorKind::StepPeerNotFound, "want StepPeerNotFound, got %d", e.code);
+    }
+    try { // raft.rs:1284-1348: a higher term deposes the leader -- the host's business
+        rn.step(0, new_message(2, MessageType::MsgAppendResponse, 4));
+        EXPECT(false, "a higher term must be reported");
+    } catch (const Error &e) {
+        EXPECT(e.kind == ErrorKind::HigherTerm, "want HigherTerm, got %d", e.code);
+    }
+    Message stale = new_message(2, MessageType::MsgAppendResponse, 2); // raft.rs:1349-1411: a lower term is dropped
+    stale.index = 9;
+    rn.step(0, stale);
+    Message ack = new_message(2, MessageType::MsgAppendResponse, 3);
+    ack.index = 9;
+    rn.step(1, ack);
+    const std::vector<LightReady> rd = rn.ready();
+    EXPECT(rn.committed(0) == 4 && rn.progress(0, 2).matched == 0, "the stale response must change nothing");
+    EXPECT(rn.committed(1) == 9 && rn.progress(1, 2).matched == 9, "group 1 commits 9 with {1, 2}");
+    bool seen = false;
+    for (const LightReady &r : rd)
+        if (r.group == 1) {
+            seen = true;
+            EXPECT(r.commit_changed && r.commit_index == 9, "LightReady.commit_index of group 1");
+        }
+    EXPECT(seen, "group 1 must have a Ready");
+}
+
+int main() {
+    try {
+        Config probe;
+        MultiRaft m(probe);
+    } catch (const Error &e) {
+        if (e.kind == ErrorKind::NoDevice) {
+            std::printf("no gfx950 device: %s (there is no CPU fallback)\n", e.what());
+            return 2;
+        }
+        throw;
+    }
+    test_leader_append_response();
+    test_leader_acknowledge_commit();
+    test_msg_app_flow_control_full();
+    test_raw_node_step();
+    std::printf("CPP_REFERENCE_TESTS_OK\n");
+    return 0;
+}

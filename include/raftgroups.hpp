@@ -1,0 +1,397 @@
+// raftgroups.hpp -- the C++17 host side above the C ABI (include/raftgroups.h). Header-only; links against
+// libraftgroups.so like any C caller. It mirrors the reference's own interface for this path -- same names, argument
+// meaning and error behaviour -- so that a driver (or a test) reads like code written against raft-rs:
+//
+//   raftgroups::MultiRaft::step(group, Message)     RawNode::step           src/raw_node.rs:402-411 -> src/raft.rs:1280-1411
+//   raftgroups::Message                             eraftpb::Message        proto/proto/eraftpb.proto:71-92 (the fields the path reads)
+//   raftgroups::Progress / ProgressState            tracker::Progress       src/tracker/progress.rs:8-56, src/tracker/state.rs:22-29
+//   raftgroups::Error (StepLocalMsg, ...)           raft::Error             src/errors.rs:6-50
+//   MultiRaft::ready() -> LightReady per group      RawNode::ready          src/raw_node.rs:469-532, :643-651 (commit_index, messages)
+//   MultiRaft::propose / on_persist_entries /       Raft::append_entry, on_persist_entries, become_leader
+//     become_leader                                 src/raft.rs:976-1016, :1151-1202
+//
+// One MultiRaft holds the leader-side replication state of N raft groups on ONE GPU. Messages are queued by step() and
+// applied -- all groups at once, on the device -- by ready(), which returns what the reference's Ready would carry for
+// this path: the new commit index of every group that saw traffic and the MsgAppend sends the path asked for (as work
+// items: messages are built by the host, which owns the log). There is no CPU path: constructing a MultiRaft without a
+// gfx950 device throws Error{NoDevice}.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "raftgroups.h"
+
+namespace raftgroups {
+
+using u64 = std::uint64_t;
+constexpr u64 INVALID_ID = 0;    // src/raft.rs:78
+constexpr u64 INVALID_INDEX = 0; // src/raft.rs:81
+constexpr u64 NO_LIMIT = ~0ULL;  // src/util.rs:14
+
+// ---- raft::Error (src/errors.rs:6-50), plus what only a device back end can report ----
+enum class ErrorKind {
+    StepLocalMsg,     // Error::StepLocalMsg    (raw_node.rs:404-406)
+    StepPeerNotFound, // Error::StepPeerNotFound (raw_node.rs:407-410)
+    HigherTerm,       // m.term > term: Raft::step would become_follower (raft.rs:1284-1348) -- the host's to handle
+    SlotBusy,         // a second message of one peer before ready(): call ready() first
+    InvalidArgument,
+    State,            // call sequence error
+    NoDevice,         // no gfx950 device / HIP error (no CPU fallback)
+    OutOfMemory,
+};
+class Error : public std::runtime_error {
+  public:
+    Error(ErrorKind k, int code, const std::string &what) : std::runtime_error(what), kind(k), code(code) {}
+    ErrorKind kind;
+    int code; // the rg_status the C ABI returned
+};
+inline void check(int rc) {
+    if (rc == RG_OK) return;
+    ErrorKind k = ErrorKind::InvalidArgument;
+    switch (rc) {
+    case RG_ERR_STEP_LOCAL_MSG: k = ErrorKind::StepLocalMsg; break;
+    case RG_ERR_STEP_PEER_NOT_FOUND: k = ErrorKind::StepPeerNotFound; break;
+    case RG_ERR_HIGHER_TERM: k = ErrorKind::HigherTerm; break;
+    case RG_ERR_SLOT_BUSY: k = ErrorKind::SlotBusy; break;
+    case RG_ERR_STATE: k = ErrorKind::State; break;
+    case RG_ERR_NO_DEVICE: k = ErrorKind::NoDevice; break;
+    case RG_ERR_OUT_OF_MEMORY: k = ErrorKind::OutOfMemory; break;
+    default: break;
+    }
+    throw Error(k, rc, rg_last_error());
+}
+
+// ---- eraftpb::MessageType / Message: the two response types of the path ----
+enum class MessageType { MsgAppendResponse, MsgHeartbeatResponse, MsgHup /* any local type: step() refuses it */ };
+struct Message {
+    MessageType msg_type = MessageType::MsgAppendResponse;
+    u64 from = INVALID_ID, term = 0;
+    u64 index = 0, commit = 0;
+    bool reject = false;
+    u64 reject_hint = 0, log_term = 0; // log_term > 0 on a reject: find_conflict_by_term runs on the device (raft.rs:1657-1660)
+    u64 request_snapshot = INVALID_INDEX;
+};
+
+// ---- tracker::ProgressState / Progress ----
+enum class ProgressState : std::uint8_t { Probe = RG_STATE_PROBE, Replicate = RG_STATE_REPLICATE, Snapshot = RG_STATE_SNAPSHOT };
+struct Progress {
+    u64 matched = 0, next_idx = 0;
+    ProgressState state = ProgressState::Probe;
+    bool paused = false, recent_active = false;
+    u64 pending_snapshot = 0, pending_request_snapshot = 0;
+    u64 committed_index = 0;
+    unsigned inflights = 0; // ins.count() (0 unless the engine holds the Inflights)
+    bool ins_full = false;  // ins.full()
+    bool is_paused() const { // progress.rs:210-216
+        return state == ProgressState::Probe ? paused : state == ProgressState::Replicate ? ins_full : true;
+    }
+};
+
+// What a group looks like right after Raft::become_leader (raft.rs:1151-1202) -- or at any later point a host restores:
+// the configuration (tracker.rs:37-49), the leader's log summary and one Progress per peer.
+struct GroupSpec {
+    u64 id = 1;                 // this node (the leader)
+    u64 term = 1;               // Raft.term
+    std::vector<u64> voters;    // voters.incoming
+    std::vector<u64> voters_outgoing; // joint consensus: voters.outgoing
+    std::vector<u64> learners;
+    u64 first_index_of_term = 1; // first log index whose term == term (the leader's empty entry)
+    u64 last_index = 1;          // RaftLog::last_index(); entries [first_index_of_term, last_index] carry `term`
+    u64 committed = 0;           // RaftLog.committed
+    u64 next_idx = 0;            // followers' Progress.next_idx (0 = last_index + 1, what Progress::reset leaves)
+    u64 follower_matched = 0;    // followers' Progress.matched (0 right after an election)
+    ProgressState follower_state = ProgressState::Probe;
+};
+
+// One MsgAppend / MsgSnapshot the path wants sent: the host builds it (prepare_send_entries, raft.rs:714-731)
+struct SendItem {
+    u64 to = INVALID_ID;
+    u64 prev_index = 0, last_index = 0; // entries (prev_index, last_index]; prev_index == last_index: one empty MsgAppend
+    unsigned n_msgs = 0;                // messages of max_entries_per_msg entries each
+    bool snapshot = false;              // prepare_send_snapshot instead (last_index = the requested index, 0 = any)
+    bool host = false;                  // RG_SEND_HOST: the host runs maybe_send_append for this peer itself
+};
+// What RawNode::ready / LightReady carry for this path, for ONE group that saw traffic
+struct LightReady {
+    u64 group = 0;
+    u64 commit_index = 0;   // raft_log.committed after the batch (LightReady.commit_index, raw_node.rs:643-651)
+    bool commit_changed = false; // some maybe_commit() returned true (raft.rs:1745)
+    bool fault = false;          // where the reference would have panicked (fatal!): the group's input was malformed
+    bool timeout_now = false;    // send_timeout_now(lead_transferee) (raft.rs:1764-1774)
+    bool became_leader = false;
+    std::vector<u64> send_append; // peers the path called send_append for (engines WITHOUT device Inflights: the host sends)
+    std::vector<u64> send_more;   // peers in the `while maybe_send_append` loop (raft.rs:1761)
+    std::vector<u64> free_to;     // peers whose ins.free_to(m.index) / free_first_one the host applies
+    std::vector<SendItem> messages; // engines WITH device Inflights: the send decisions, already applied to the Progress
+};
+
+struct Config { // the subset of raft::Config (src/config.rs) the path depends on + the engine's shape
+    u64 n_groups = 1;
+    unsigned max_peers = 3;          // peer slots per group, 1..8
+    int device = 0;
+    unsigned max_inflight_msgs = 0;  // 0: Inflights stay with the host; else Config::max_inflight_msgs (config.rs:112), on the device
+    u64 max_entries_per_msg = 0;     // stands in for max_size_per_msg with equal-sized entries (0 = NO_LIMIT)
+    bool skip_bcast_commit = false;  // Config::skip_bcast_commit (config.rs:87)
+};
+
+class MultiRaft {
+  public:
+    explicit MultiRaft(const Config &c) : cfg_(c) {
+        rg_config rc;
+        std::memset(&rc, 0, sizeof rc);
+        rc.n_groups = c.n_groups;
+        rc.n_slots = c.max_peers;
+        rc.device = c.device;
+        rc.max_inflight = c.max_inflight_msgs;
+        check(rg_create(&rc, &h_));
+        stride_ = rg_stride(h_);
+        const std::size_t cells = (std::size_t)c.max_peers * stride_;
+        match_.assign(cells, 0);
+        next_.assign(cells, 0);
+        prc_.assign(cells, 0);
+        pflags_.assign((std::size_t)c.n_groups * 8, 0);
+        commit_.assign(c.n_groups, 0);
+        lo_.assign(c.n_groups, 1);
+        hi_.assign(c.n_groups, 0);
+        term_.assign(c.n_groups, 0);
+        cfgw_.assign(c.n_groups, 0);
+        ids_.assign((std::size_t)c.n_groups * 8, 0);
+        self_.assign(c.n_groups, 0);
+    }
+    MultiRaft(const MultiRaft &) = delete;
+    MultiRaft &operator=(const MultiRaft &) = delete;
+    ~MultiRaft() {
+        if (h_) rg_destroy(h_);
+    }
+    rg_engine *handle() const { return h_; }
+    const Config &config() const { return cfg_; }
+
+    // ---- set-up: describe every group, then bootstrap() once (bulk column loads), then step away ----
+    void init_group(u64 group, const GroupSpec &s) {
+        if (group >= cfg_.n_groups) throw Error(ErrorKind::InvalidArgument, RG_ERR_INVALID_ARG, "init_group: no such group");
+        std::vector<u64> ids;
+        auto add = [&](const std::vector<u64> &v) {
+            for (u64 id : v) {
+                if (id == INVALID_ID) throw Error(ErrorKind::InvalidArgument, RG_ERR_INVALID_ARG, "peer id 0 is invalid (raw_node.rs:303)");
+                bool seen = false;
+                for (u64 x : ids) seen = seen || x == id;
+                if (!seen) ids.push_back(id);
+            }
+        };
+        add(s.voters);
+        add(s.voters_outgoing);
+        add(s.learners);
+        if (ids.size() > cfg_.max_peers) throw Error(ErrorKind::InvalidArgument, RG_ERR_INVALID_ARG, "init_group: more peers than max_peers");
+        auto mask = [&](const std::vector<u64> &v) {
+            unsigned m = 0;
+            for (u64 id : v)
+                for (std::size_t i = 0; i < ids.size(); i++)
+                    if (ids[i] == id) m |= 1u << i;
+            return m;
+        };
+        int self = -1;
+        for (std::size_t i = 0; i < ids.size(); i++)
+            if (ids[i] == s.id) self = (int)i;
+        if (self < 0) throw Error(ErrorKind::InvalidArgument, RG_ERR_INVALID_ARG, "init_group: the leader is not a member");
+        for (unsigned i = 0; i < 8; i++) ids_[group * 8 + i] = i < ids.size() ? ids[i] : 0;
+        self_[group] = (unsigned)self;
+        cfgw_[group] = RG_CFG_MAKE(mask(s.voters), mask(s.voters_outgoing), self, 0, 0, (1u << ids.size()) - 1u);
+        commit_[group] = s.committed;
+        lo_[group] = s.first_index_of_term;
+        hi_[group] = s.last_index;
+        term_[group] = s.term;
+        for (std::size_t i = 0; i < ids.size(); i++) {
+            const std::size_t o = i * stride_ + group;
+            const bool me = (int)i == self;
+            // Progress::reset(last_index + 1) for everybody, then the leader's own: matched = persisted = last_index,
+            // Replicate, committed_index = committed (raft.rs:960-970, :1163-1201)
+            match_[o] = me ? s.last_index : s.follower_matched;
+            next_[o] = me ? s.last_index + 1 : (s.next_idx ? s.next_idx : s.last_index + 1);
+            prc_[o] = me ? s.committed : 0;
+            pflags_[group * 8 + i] = (std::uint8_t)((me ? RG_STATE_REPLICATE : (unsigned)s.follower_state) | (me ? RG_PF_RECENT_ACTIVE : 0u));
+        }
+    }
+    void bootstrap() {
+        load(RG_COL_MATCH, match_.data());
+        load(RG_COL_NEXT, next_.data());
+        load(RG_COL_PR_COMMIT, prc_.data());
+        load(RG_COL_PFLAGS, pflags_.data());
+        load(RG_COL_COMMIT, commit_.data());
+        load(RG_COL_TERM_LO, lo_.data());
+        load(RG_COL_TERM_HI, hi_.data());
+        load(RG_COL_CUR_TERM, term_.data());
+        load(RG_COL_CFG, cfgw_.data());
+        for (u64 g = 0; g < cfg_.n_groups; g++) {
+            unsigned n = 0;
+            while (n < 8 && ids_[g * 8 + n]) n++;
+            if (n) check(rg_set_peers(h_, g, &ids_[g * 8], n, term_[g]));
+        }
+        booted_ = true;
+    }
+
+    // ---- RawNode::step (raw_node.rs:402-411): local message types and unknown peers are errors; Raft::step's term
+    // gate drops a stale term silently and reports a higher one (the host steps down) ----
+    void step(u64 group, const Message &m) {
+        need_boot();
+        switch (m.msg_type) {
+        case MessageType::MsgAppendResponse: {
+            rg_append_response r;
+            std::memset(&r, 0, sizeof r);
+            r.from = m.from;
+            r.term = m.term;
+            r.index = m.index;
+            r.commit = m.commit;
+            r.reject = m.reject;
+            r.reject_hint = m.reject_hint;
+            r.log_term = m.log_term;
+            r.request_snapshot = m.request_snapshot;
+            check(rg_step(h_, group, &r));
+            return;
+        }
+        case MessageType::MsgHeartbeatResponse:
+            check(rg_step_heartbeat_response(h_, group, m.from, m.term, m.commit, 0));
+            return;
+        default: // is_local_msg (raw_node.rs:404-406)
+            throw Error(ErrorKind::StepLocalMsg, RG_ERR_STEP_LOCAL_MSG, "raft: cannot step raft local message");
+        }
+    }
+    // ---- the leader's own events of a batch ----
+    void propose(u64 group, u64 n_entries) { // Raft::append_entry (raft.rs:976-991): last_index += n
+        need_boot();
+        hi_[group] += n_entries;
+        check(rg_local_append(h_, group, hi_[group]));
+    }
+    void on_persist_entries(u64 group, u64 index) { check(rg_local_persisted(h_, group, index)); } // raft.rs:994-1016
+    void become_leader(u64 group, u64 term) {                                                       // raft.rs:1151-1202
+        need_boot();
+        check(rg_local_become_leader(h_, group, term));
+        term_[group] = term;
+        hi_[group] += 1; // the new leader's empty entry
+    }
+    void mark_sent(u64 group, u64 to) { check(rg_mark_sent(h_, group, to)); } // host Inflights: a MsgAppend up to last_index went out
+
+    // ---- RawNode::ready for every group with queued traffic: ONE launch for all of them ----
+    std::vector<LightReady> ready() {
+        need_boot();
+        const bool dev_ins = cfg_.max_inflight_msgs != 0;
+        if (dev_ins)
+            check(rg_flush_send(h_, cfg_.max_entries_per_msg, cfg_.skip_bcast_commit ? RG_SEND_SKIP_BCAST_COMMIT : 0u));
+        else
+            check(rg_flush(h_));
+        u64 n = 0;
+        check(rg_ingested_results(h_, nullptr, nullptr, nullptr, 0, &n));
+        std::vector<u64> groups(n), commit(n);
+        std::vector<std::uint32_t> out(n);
+        if (n) check(rg_ingested_results(h_, groups.data(), commit.data(), out.data(), n, &n));
+        std::vector<LightReady> rd(n);
+        for (u64 i = 0; i < n; i++) {
+            LightReady &r = rd[i];
+            const u64 g = groups[i];
+            r.group = g;
+            r.commit_index = commit[i];
+            r.commit_changed = (out[i] & RG_OUT_CHANGED) != 0;
+            r.fault = (out[i] & RG_OUT_FAULT) != 0;
+            r.timeout_now = (out[i] & RG_OUT_TIMEOUT_NOW) != 0;
+            r.became_leader = (out[i] & RG_OUT_BECAME_LEADER) != 0;
+            for (unsigned s = 0; s < cfg_.max_peers; s++) {
+                if ((RG_OUT_SEND_APPEND(out[i]) >> s) & 1u) r.send_append.push_back(ids_[g * 8 + s]);
+                if ((RG_OUT_SEND_MORE(out[i]) >> s) & 1u) r.send_more.push_back(ids_[g * 8 + s]);
+                if ((RG_OUT_FREE_TO(out[i]) >> s) & 1u) r.free_to.push_back(ids_[g * 8 + s]);
+            }
+        }
+        if (dev_ins && n) {
+            u64 k = 0;
+            std::vector<rg_send_item> items(n * cfg_.max_peers); // at most one item per peer of a touched group
+            check(rg_send_items(h_, items.data(), items.size(), &k));
+            items.resize(k < items.size() ? k : items.size());
+            for (const rg_send_item &it : items) {
+                for (LightReady &r : rd) {
+                    if (r.group != it.group) continue;
+                    SendItem s;
+                    s.to = ids_[it.group * 8 + it.slot];
+                    s.prev_index = it.prev_index;
+                    s.last_index = it.last_index;
+                    s.n_msgs = it.n_msgs;
+                    s.snapshot = it.kind == RG_SEND_SNAPSHOT;
+                    s.host = it.kind == RG_SEND_HOST;
+                    r.messages.push_back(s);
+                    break;
+                }
+            }
+        }
+        return rd;
+    }
+
+    // ---- ProgressTracker::get / Status (tracker.rs:261-287, status.rs:25-52) ----
+    Progress progress(u64 group, u64 id) {
+        rg_group_status st;
+        check(rg_read_groups(h_, &group, 1, &st));
+        const int s = slot_of(group, id);
+        Progress p;
+        p.matched = st.match[s];
+        p.next_idx = st.next[s];
+        p.state = (ProgressState)(st.pflags[s] & RG_PF_STATE_MASK);
+        p.paused = (st.pflags[s] & RG_PF_PAUSED) != 0;
+        p.recent_active = (st.pflags[s] & RG_PF_RECENT_ACTIVE) != 0;
+        p.pending_snapshot = st.pend_snap[s];
+        p.pending_request_snapshot = st.pend_rs[s];
+        p.committed_index = st.pr_commit[s];
+        p.inflights = st.inflights[s];
+        p.ins_full = (st.pflags[s] & RG_PF_INS_FULL) != 0;
+        return p;
+    }
+    u64 committed(u64 group) { // raft_log.committed
+        rg_group_status st;
+        check(rg_read_groups(h_, &group, 1, &st));
+        return st.commit;
+    }
+    u64 last_index(u64 group) {
+        rg_group_status st;
+        check(rg_read_groups(h_, &group, 1, &st));
+        return st.last_index;
+    }
+    // Overwrite fields of one Progress (what the send path and the other host-side writers do between batches:
+    // update_state / become_snapshot / become_probe ...)
+    void set_progress(u64 group, u64 id, const Progress &p) {
+        rg_cell_write c;
+        std::memset(&c, 0, sizeof c);
+        c.group = group;
+        c.slot = (std::uint32_t)slot_of(group, id);
+        c.field_mask = (1u << RG_COL_MATCH) | (1u << RG_COL_NEXT) | (1u << RG_COL_PR_COMMIT) | (1u << RG_COL_PEND_SNAP) |
+                       (1u << RG_COL_PEND_RS) | (1u << RG_COL_PFLAGS);
+        c.match = p.matched;
+        c.next = p.next_idx;
+        c.pr_commit = p.committed_index;
+        c.pend_snap = p.pending_snapshot;
+        c.pend_rs = p.pending_request_snapshot;
+        c.pflags = (std::uint8_t)((unsigned)p.state | (p.paused ? RG_PF_PAUSED : 0u) | (p.recent_active ? RG_PF_RECENT_ACTIVE : 0u));
+        check(rg_write_cells(h_, &c, 1));
+    }
+
+  private:
+    void need_boot() const {
+        if (!booted_) throw Error(ErrorKind::State, RG_ERR_STATE, "MultiRaft: bootstrap() has not run");
+    }
+    int slot_of(u64 group, u64 id) const {
+        if (group < cfg_.n_groups && id != INVALID_ID)
+            for (unsigned s = 0; s < cfg_.max_peers; s++)
+                if (ids_[group * 8 + s] == id) return (int)s;
+        throw Error(ErrorKind::StepPeerNotFound, RG_ERR_STEP_PEER_NOT_FOUND, "raft: no such peer in this group");
+    }
+    void load(int col, const void *src) { check(rg_load_column(h_, col, src, rg_column_bytes(h_, col))); }
+
+    Config cfg_;
+    rg_engine *h_ = nullptr;
+    u64 stride_ = 0;
+    bool booted_ = false;
+    std::vector<u64> match_, next_, prc_, commit_, lo_, hi_, term_, ids_;
+    std::vector<std::uint8_t> pflags_;
+    std::vector<std::uint32_t> cfgw_;
+    std::vector<unsigned> self_;
+};
+
+} // namespace raftgroups

@@ -1,0 +1,36 @@
+"""The C++ host side above the C ABI (include/raftgroups.hpp: RawNode::step / ready surface, Progress, Error under the
+reference's names): examples/cpp_reference_tests.cpp restates reference tests against it -- test_leader_append_response
+(test_raft.rs:2611-2675), test_leader_acknowledge_commit (test_raft_paper.rs:499-534), test_msg_app_flow_control_full
+(test_raft_flow_control.rs:24-58), RawNode::step's error behaviour (raw_node.rs:402-411) -- and runs them on the GPU.
+On a CPU-only host the program must build warning-free and fail loudly."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(tmp_path, rg):
+    exe = str(tmp_path / "cpp_reference_tests")
+    libdir = os.path.dirname(rg.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "cpp_reference_tests.cpp"), "-o", exe, "-L", libdir, "-lraftgroups",
+           "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return exe
+
+
+def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path, rg):
+    exe = build(tmp_path, rg)
+    if rg.load_library().rg_device_count() == 0:
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 2 and "no CPU fallback" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_tests_through_the_cpp_host_side(tmp_path, rg):
+    exe = build(tmp_path, rg)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "CPP_REFERENCE_TESTS_OK" in r.stdout, r.stdout
