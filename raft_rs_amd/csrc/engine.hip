@@ -533,7 +533,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
     const u32 out = rg_at(st.out, g);
-    rg_group_send<P, IX, RG_SEND_SPEC_LOADS != 0>(st, ins, g, out, max_entries, flags, it); // (unconditional: its loads ride with `out`)
+    rg_group_send<P, IX, RG_SEND_SPEC_LOADS != 0, RG_SEND_WAVE_LINES != 0>(st, ins, g, out, max_entries, flags, it); // (unconditional: its loads ride with `out`)
     rg_store_send_items<P, IX>(it, oc, st.stride, g);
 }
 template <int P>

@@ -18,6 +18,9 @@
 #ifndef RG_SEND_WHOLE_LINES
 #define RG_SEND_WHOLE_LINES 1
 #endif
+#ifndef RG_SEND_WAVE_LINES /* the dense kernels: a cell one lane of a wave needs is loaded and rewritten by all of them (rg_wave_any) */
+#define RG_SEND_WAVE_LINES 1
+#endif
 
 struct RgIns {
     u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31)
@@ -164,9 +167,21 @@ RG_HD void rg_ins_add(const RgIns &ins, u64 base, u32 start, u32 &count, u64 &he
 // the caller stores the group once, behind the stage. The stage is split in two so that such a caller can put the
 // tick's own stores between the stage's loads and their first use (rg_send_request / rg_send_serve).
 
+// Does ANY lane of the wave want it? (the dense kernels, WAVE: a column cell is loaded and rewritten by every lane of a wave
+// as soon as one lane needs it, so that the wave's store covers whole 128-B lines -- a lane-masked partial line costs the
+// memory side a read-merge-write: tools/microbench/send_shape.hip measures one skipped lane in 20 at -30 % throughput for the
+// stage's access shape. On the host, and where lanes hold unrelated groups (k_send_appends), a lane decides for itself.)
+template <bool WAVE> RG_HD bool rg_wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WAVE) return __builtin_amdgcn_ballot_w64(x) != 0;
+#endif
+    return x;
+}
+
 // The operands of one group's stage, as requested from memory (or taken over from the tick)
 template <int P> struct RgSendOps {
     u32 cfg, work;
+    u32 wv, sv; // WAVE: bit s = some lane of the wave has slot s in its work set / sends to it (whole-line accesses)
     u64 row0, hi, first_index;
     u32 meta_v[P];
     u64 head_v[P], tail_v[P], next_v[P], prs_v[P], match_v[P];
@@ -189,7 +204,7 @@ template <int P, typename IX> RG_HD void rg_send_prefetch(const RgState &st, con
 
 // Part 1: decide the work set and request every cell the stage reads (no loaded value is touched here, except -- unless
 // SPEC or FUSED -- the group-level words the work set is decided from, which the caller requested with `out`).
-template <int P, typename IX, bool SPEC, bool FUSED, bool PRE = false>
+template <int P, typename IX, bool SPEC, bool FUSED, bool PRE = false, bool WAVE = false>
 RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u32 flags, RgSendOps<P> &q,
                            RgGroup<P> *r, u32 nxv) {
     // everything indexed by the group alone is requested at once, before anything is decided: with the result word the
@@ -230,19 +245,23 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
     if (q.bcast || q.elected) work |= present;
     work &= present & ~(1u << self);
     q.work = work;
-    if (work == 0 || SPEC) return;
+    q.wv = q.sv = 0;
+    if ((work == 0 && !WAVE) || SPEC) return; // (WAVE: a lane with nothing to do still helps fill its wave's lines)
     // all column loads of the group are issued before any of the (dependent, scattered) ring accesses
 #pragma unroll
     for (int s = 0; s < P; s++) {
         const bool w = (work >> s) & 1u;
         const IX o = (IX)s * (IX)st.stride + g;
         const bool sends = w && (q.bcast || (((sa_bits | sm_bits) >> s) & 1u));
+        const bool wv = rg_wave_any<WAVE>(w), sv = rg_wave_any<WAVE>(sends);
+        q.wv |= (wv ? 1u : 0u) << s;
+        q.sv |= (sv ? 1u : 0u) << s;
         // (each destination is written once BEFORE its load is issued and not again: `x = w ? load : 0` made the
         // compiler wait for slot s's loads -- a pending write to the same registers -- before issuing slot s+1's)
         if (!PRE) {
             q.meta_v[s] = 0u;
             q.head_v[s] = q.tail_v[s] = 0ULL;
-            if (w) {
+            if (wv) {
                 q.meta_v[s] = rg_at(ins.meta, o);
                 q.head_v[s] = rg_at(ins.head, o);
                 q.tail_v[s] = rg_at(ins.tail, o);
@@ -252,12 +271,13 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
             // the cells of `next` the tick fetched or wrote are in its registers (bit s of nxv); a broadcast also reaches
             // peers that had no event in this tick -- only theirs are read here, into the register the tick left unused
             // (it holds 0, written before the group's bulk loads were issued: no write behind a pending load)
-            if (sends && !((nxv >> s) & 1u)) r->nx[s] = rg_at(st.next, o);
+            if (sv && !((nxv >> s) & 1u)) r->nx[s] = rg_at(st.next, o);
+            if (WAVE && sv) r->dirty |= 1u << (8 + s); // (the caller stores the group's `next` cells: every lane's, for this slot)
             // (a pending snapshot request -- RG_PF_PEND_RS, almost never -- is read where it is needed, rg_send_serve)
             continue;
         }
         q.next_v[s] = q.prs_v[s] = q.match_v[s] = 0ULL;
-        if (sends) q.next_v[s] = rg_at(st.next, o);
+        if (sv) q.next_v[s] = rg_at(st.next, o);
         // pending_request_snapshot: zero unless the flag byte says otherwise (RG_PF_PEND_RS) -- a column the stage used
         // to read for every peer it sends to
         if (sends && ((q.row0 >> (8 * s)) & RG_PF_PEND_RS)) q.prs_v[s] = rg_at(st.prs, o);
@@ -266,7 +286,7 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
 }
 
 // Part 2: the Inflights effects of the tick and the send decisions, peer by peer; stores what it changes.
-template <int P, typename IX, bool FUSED>
+template <int P, typename IX, bool FUSED, bool WAVE = false>
 RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags, const RgSendOps<P> &q,
                          RgSendRegs<P> &it, RgGroup<P> *r, u32 nxv) {
     it.snap = 0;
@@ -275,15 +295,25 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
     const u32 work = q.work;
-    if (work == 0) return;
+    if (work == 0 && !(WAVE && q.wv)) return;
     const u32 sa_bits = RG_OUT_SEND_APPEND(out), sm_bits = RG_OUT_SEND_MORE(out), fr_bits = RG_OUT_FREE_TO(out);
     const bool bcast = q.bcast, serve = q.serve, elected = q.elected;
     const u64 hi = q.hi, first_index = q.first_index, row0 = q.row0;
     u64 row = row0;
 #pragma unroll
     for (int s = 0; s < P; s++) {
-        if (!((work >> s) & 1u)) continue;
         const IX o = (IX)s * (IX)st.stride + g;
+        if (!((work >> s) & 1u)) {
+            // WAVE: another lane of the wave works on this slot -- this one rewrites what it loaded, so that the wave's
+            // stores cover whole lines
+            if (WAVE && ((q.wv >> s) & 1u)) {
+                rg_at(ins.meta, o) = q.meta_v[s];
+                rg_at(ins.head, o) = q.head_v[s];
+                rg_at(ins.tail, o) = q.tail_v[s];
+                if (!FUSED && ((q.sv >> s) & 1u)) rg_at(st.next, o) = q.next_v[s];
+            }
+            continue;
+        }
         const u64 base = ((u64)g * (u64)P + (u64)s) * ins.cap;
         u32 pb = (u32)(row >> (8 * s)) & 0xffu;
         const u32 state = pb & RG_PF_STATE_MASK;
@@ -423,6 +453,8 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             } else if (RG_SEND_WHOLE_LINES || next != next0) {
                 rg_at(st.next, o) = next;
             }
+        } else if (WAVE && !FUSED && ((q.sv >> s) & 1u)) {
+            rg_at(st.next, o) = q.next_v[s]; // (another lane of the wave sends to this slot: whole lines)
         }
         pb = (pb & ~RG_PF_INS_FULL) | ((state == RG_STATE_REPLICATE && count == ins.cap) ? RG_PF_INS_FULL : 0u);
         row = (row & ~(0xffULL << (8 * s))) | ((u64)pb << (8 * s));
@@ -446,10 +478,11 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
 }
 
 // The stage of one group in its own launch (k_send_dense, k_send_appends, the host twin of the tests).
-template <int P, typename IX = u64, bool SPEC = false>
+// WAVE: the lanes of a wave hold consecutive groups (k_send_dense): whole-line accesses, see rg_wave_any.
+template <int P, typename IX = u64, bool SPEC = false, bool WAVE = false>
 RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags,
                          RgSendRegs<P> &it) {
     RgSendOps<P> q;
-    rg_send_request<P, IX, SPEC, false>(st, ins, g, out, flags, q, nullptr, 0u);
-    rg_send_serve<P, IX, false>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);
+    rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u);
+    rg_send_serve<P, IX, false, WAVE && !SPEC>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);
 }

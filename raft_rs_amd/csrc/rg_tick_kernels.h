@@ -30,6 +30,9 @@
 // the next one, so they need not displace the columns that are; bit4: non-temporal stores of every state column
 #define RG_OPT_NT_NEXT (RG_OPT & 8)
 #define RG_OPT_NT_ALL (RG_OPT & 16)
+// bit5: the lane kernels rewrite a slot's `matched` / `committed_index` cell in EVERY lane of a wave as soon as one lane
+// changed it (both are in registers anyway): whole 128-B lines instead of lane-masked ones (tools/microbench/send_shape.hip)
+#define RG_OPT_WAVE_ST (RG_OPT & 32)
 template <typename T> RG_HD void rg_st(T &dst, T v, bool nt) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nt) __builtin_nontemporal_store(v, &dst);
@@ -91,12 +94,23 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
 
 // WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
 // stage, which changes both; every other caller stores the group in one go).
-template <int P, typename IX, int WHICH = 3> RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
+// WAVE_ST (kernels whose lanes hold CONSECUTIVE groups, all lanes of the wave arriving here together): RG_OPT_WAVE_ST
+template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false>
+RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
         const u32 ev = r.evm; // slots with a Progress that had an event (RgTick)
         d |= ev | (ev << 8) | (ev << 16);
+    }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WAVE_ST && RG_OPT_WAVE_ST && (WHICH & 1)) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            if (__builtin_amdgcn_ballot_w64((d >> p) & 1u) != 0) d |= 1u << p;
+            if (__builtin_amdgcn_ballot_w64((d >> (16 + p)) & 1u) != 0) d |= 1u << (16 + p);
+        }
     }
 #endif
 #pragma unroll
@@ -150,7 +164,7 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lan
 #endif
 #endif
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<P, IX>(r, st, g);
+    rg_store_group<P, IX, 3, true>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -176,6 +190,7 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
                               u32 flags, RgSendRegs<P> &it, const RgSendWin<P> *win = nullptr, u32 lane = 0) {
     RgSendOps<P> q;
     constexpr bool PRE = RG_TS_SPEC != 0;
+    constexpr bool TSW = RG_SEND_WAVE_LINES != 0; // (on the host rg_wave_any is the lane's own answer)
     if (RG_TS_SPEC == 1 || (RG_TS_SPEC == 2 && !win)) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
     if (RG_TS_SPEC == 2 && win) q.first_index = rg_at(st.dummy_idx, g) + 1;
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
@@ -196,13 +211,13 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
     // election rewrites all of them (rg_prefetch_rare / RgTick::set_next)
     const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
 #if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
-    rg_store_group<P, IX, 1>(r, st, g);
-    rg_send_request<P, IX, false, true, PRE>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_store_group<P, IX, 1, true>(r, st, g);
+    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, r.out, flags, q, &r, nxv);
 #else
-    rg_send_request<P, IX, false, true, PRE>(st, ins, g, r.out, flags, q, &r, nxv);
-    rg_store_group<P, IX, 1>(r, st, g);
+    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_store_group<P, IX, 1, true>(r, st, g);
 #endif
-    rg_send_serve<P, IX, true>(st, ins, g, r.out, max_entries, flags, q, it, &r, nxv);
+    rg_send_serve<P, IX, true, TSW>(st, ins, g, r.out, max_entries, flags, q, it, &r, nxv);
     rg_store_group<P, IX, 2>(r, st, g);
 }
 
