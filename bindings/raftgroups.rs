@@ -59,6 +59,7 @@ pub const RG_ERR_STEP_PEER_NOT_FOUND: i32 = -5;
 pub const RG_ERR_SLOT_BUSY: i32 = -6;
 pub const RG_ERR_HIGHER_TERM: i32 = -7;
 pub const RG_ERR_STATE: i32 = -8;
+pub const RG_ERR_NOT_ON_PATH: i32 = -9;
 
 // rg_column
 pub const RG_COL_MATCH: i32 = 0;
@@ -157,6 +158,25 @@ pub struct RgAppendResponse {
     pub ins_full: u8,
     pub pad: [u8; 6],
     pub log_term: u64,
+}
+
+#[repr(C)]
+pub struct RgDecodedMessage {
+    pub msg_type: u32,
+    pub reject: u32,
+    pub to: u64,
+    pub from: u64,
+    pub term: u64,
+    pub log_term: u64,
+    pub index: u64,
+    pub commit: u64,
+    pub commit_term: u64,
+    pub reject_hint: u64,
+    pub request_snapshot: u64,
+    pub priority: u64,
+    pub n_entries: u64,
+    pub has_snapshot: u32,
+    pub context_len: u32,
 }
 
 #[repr(C)]
@@ -283,6 +303,8 @@ extern "C" {
     pub fn rg_set_peers(h: *mut RgEngine, group: u64, peer_ids: *const u64, n: u32, term: u64) -> i32;
     pub fn rg_step(h: *mut RgEngine, group: u64, m: *const RgAppendResponse) -> i32;
     pub fn rg_step_heartbeat_response(h: *mut RgEngine, group: u64, from: u64, term: u64, commit: u64, ins_full: u8) -> i32;
+    pub fn rg_decode_message(bytes: *const u8, len: u64, out: *mut RgDecodedMessage) -> i32;
+    pub fn rg_step_bytes(h: *mut RgEngine, group: u64, bytes: *const u8, len: u64) -> i32;
     pub fn rg_local_append(h: *mut RgEngine, group: u64, new_last_index: u64) -> i32;
     pub fn rg_local_persisted(h: *mut RgEngine, group: u64, index: u64) -> i32;
     pub fn rg_mark_sent(h: *mut RgEngine, group: u64, peer_id: u64) -> i32;

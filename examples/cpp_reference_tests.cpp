@@ -208,12 +208,21 @@ static void test_raw_node_step() {
     } catch (const Error &e) {
         EXPECT(e.kind == ErrorKind::HigherTerm, "want HigherTerm, got %d", e.code);
     }
+    { // the same gate on the wire bytes: msg_type = MsgRequestVote (5), from = 2, term = 3 -> not this path's
+        const std::uint8_t vote[] = {0x08, 0x05, 0x18, 0x02, 0x20, 0x03};
+        try {
+            rn.step(0, vote, sizeof vote);
+            EXPECT(false, "a vote request is not on this path");
+        } catch (const Error &e) {
+            EXPECT(e.kind == ErrorKind::NotOnPath, "want NotOnPath, got %d", e.code);
+        }
+    }
     Message stale = new_message(2, MessageType::MsgAppendResponse, 2); // raft.rs:1349-1411: a lower term is dropped
     stale.index = 9;
     rn.step(0, stale);
-    Message ack = new_message(2, MessageType::MsgAppendResponse, 3);
-    ack.index = 9;
-    rn.step(1, ack);
+    // MsgAppendResponse { from: 2, term: 3, index: 9 } as protobuf bytes (field 1 = 4, 3 = 2, 4 = 3, 6 = 9)
+    const std::uint8_t ack[] = {0x08, 0x04, 0x18, 0x02, 0x20, 0x03, 0x30, 0x09};
+    rn.step(1, ack, sizeof ack);
     const std::vector<LightReady> rd = rn.ready();
     EXPECT(rn.committed(0) == 4 && rn.progress(0, 2).matched == 0, "the stale response must change nothing");
     EXPECT(rn.committed(1) == 9 && rn.progress(1, 2).matched == 9, "group 1 commits 9 with {1, 2}");

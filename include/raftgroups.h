@@ -47,7 +47,9 @@ typedef enum {
     RG_ERR_STEP_PEER_NOT_FOUND = -5, /* Error::StepPeerNotFound (src/errors.rs:22, src/raw_node.rs:407-410) */
     RG_ERR_SLOT_BUSY = -6,       /* a second message for the same (group, peer) before rg_tick */
     RG_ERR_HIGHER_TERM = -7,     /* m.term > term: the host must step down (src/raft.rs:1284-1348) */
-    RG_ERR_STATE = -8            /* call sequence error (e.g. results before any tick) */
+    RG_ERR_STATE = -8,           /* call sequence error (e.g. results before any tick) */
+    RG_ERR_NOT_ON_PATH = -9      /* rg_step_bytes: a well-formed message of a type this path does not handle (MsgAppend,
+                                    votes, ...): the host's own Raft::step takes it */
 } rg_status;
 
 /* ---- Progress flag byte (one per slot; src/tracker/progress.rs:8-56, src/tracker/state.rs:22-29) ---- */
@@ -337,6 +339,24 @@ int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m);
 /* Queue one MsgHeartbeatResponse (src/raft.rs:2099-2101 -> handle_heartbeat_response :1777-1803). */
 int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t from, uint64_t term, uint64_t commit,
                                uint8_t ins_full);
+/* RawNode::step on the BYTES a transport delivers: one protobuf-encoded eraftpb::Message (proto3 wire format of
+ * proto/proto/eraftpb.proto:71-92 -- what Message::parse_from_bytes reads before RawNode::step sees the message). The
+ * fields of the path are decoded (msg_type 1, from 3, term 4, log_term 5, index 6, commit 8, reject 10, reject_hint 11,
+ * request_snapshot 13; `to`, entries, snapshot, context, priority, commit_term and unknown fields are skipped) and the
+ * message is stepped: MsgAppendResponse like rg_step, MsgHeartbeatResponse like rg_step_heartbeat_response, a local
+ * message type (is_local_msg, src/raw_node.rs:57-66) is RG_ERR_STEP_LOCAL_MSG, every other type RG_ERR_NOT_ON_PATH (nothing
+ * queued), bytes that are not a protobuf message RG_ERR_INVALID_ARG. rg_decode_message is the decoder alone (pure host
+ * code: no engine, no device). */
+typedef struct {
+    uint32_t msg_type; /* eraftpb::MessageType */
+    uint32_t reject;   /* Message.reject */
+    uint64_t to, from, term, log_term, index, commit, commit_term, reject_hint, request_snapshot, priority;
+    uint64_t n_entries;     /* repeated Entry entries = 7: how many (their bytes are skipped) */
+    uint32_t has_snapshot;  /* Snapshot snapshot = 9 present */
+    uint32_t context_len;   /* bytes context = 12 */
+} rg_decoded_message;
+int rg_decode_message(const uint8_t *bytes, uint64_t len, rg_decoded_message *out);
+int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len);
 /* Leader-local events, queued the same way (src/raft.rs:976-1016). */
 int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index);
 int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index);

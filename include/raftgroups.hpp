@@ -38,6 +38,7 @@ enum class ErrorKind {
     StepPeerNotFound, // Error::StepPeerNotFound (raw_node.rs:407-410)
     HigherTerm,       // m.term > term: Raft::step would become_follower (raft.rs:1284-1348) -- the host's to handle
     SlotBusy,         // a second message of one peer before ready(): call ready() first
+    NotOnPath,        // step(bytes): a well-formed message of a type this path does not handle
     InvalidArgument,
     State,            // call sequence error
     NoDevice,         // no gfx950 device / HIP error (no CPU fallback)
@@ -57,6 +58,7 @@ inline void check(int rc) {
     case RG_ERR_STEP_PEER_NOT_FOUND: k = ErrorKind::StepPeerNotFound; break;
     case RG_ERR_HIGHER_TERM: k = ErrorKind::HigherTerm; break;
     case RG_ERR_SLOT_BUSY: k = ErrorKind::SlotBusy; break;
+    case RG_ERR_NOT_ON_PATH: k = ErrorKind::NotOnPath; break;
     case RG_ERR_STATE: k = ErrorKind::State; break;
     case RG_ERR_NO_DEVICE: k = ErrorKind::NoDevice; break;
     case RG_ERR_OUT_OF_MEMORY: k = ErrorKind::OutOfMemory; break;
@@ -258,6 +260,12 @@ class MultiRaft {
         default: // is_local_msg (raw_node.rs:404-406)
             throw Error(ErrorKind::StepLocalMsg, RG_ERR_STEP_LOCAL_MSG, "raft: cannot step raft local message");
         }
+    }
+    // ... and on the bytes a transport delivers: Message::parse_from_bytes + RawNode::step (rg_step_bytes). A message type
+    // outside the path (MsgAppend, votes, ...) is Error{NotOnPath}: the host's own Raft::step takes it.
+    void step(u64 group, const std::uint8_t *bytes, std::size_t len) {
+        need_boot();
+        check(rg_step_bytes(h_, group, bytes, len));
     }
     // ---- the leader's own events of a batch ----
     void propose(u64 group, u64 n_entries) { // Raft::append_entry (raft.rs:976-991): last_index += n

@@ -2398,6 +2398,96 @@ static int rg_self_slot(rg_engine *h, u64 group, u32 *slot) {
     return RG_OK;
 }
 
+// ---- eraftpb::Message off the wire (proto3; proto/proto/eraftpb.proto:49-92) ----
+// varint: 7 bits per byte, least significant group first, at most 10 bytes for a u64
+static bool rg_pb_varint(const uint8_t *&p, const uint8_t *end, u64 &v) {
+    v = 0;
+    for (int shift = 0; shift < 70 && p < end; shift += 7) {
+        const uint8_t b = *p++;
+        if (shift < 64) v |= (u64)(b & 0x7f) << shift;
+        if (!(b & 0x80)) return true;
+    }
+    return false;
+}
+
+extern "C" int rg_decode_message(const uint8_t *bytes, uint64_t len, rg_decoded_message *out) {
+    if ((!bytes && len) || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: bad argument");
+    memset(out, 0, sizeof(*out));
+    const uint8_t *p = bytes, *end = bytes + len;
+    while (p < end) {
+        u64 key;
+        if (!rg_pb_varint(p, end, key)) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated field key");
+        const u64 field = key >> 3;
+        const u32 wt = (u32)(key & 7);
+        if (field == 0) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: field number 0");
+        if (wt == 0) {
+            u64 v;
+            if (!rg_pb_varint(p, end, v)) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated varint");
+            switch (field) {
+            case 1: out->msg_type = (uint32_t)v; break;
+            case 2: out->to = v; break;
+            case 3: out->from = v; break;
+            case 4: out->term = v; break;
+            case 5: out->log_term = v; break;
+            case 6: out->index = v; break;
+            case 8: out->commit = v; break;
+            case 10: out->reject = v != 0; break;
+            case 11: out->reject_hint = v; break;
+            case 13: out->request_snapshot = v; break;
+            case 14: out->priority = v; break;
+            case 15: out->commit_term = v; break;
+            default: break; // unknown varint field: skipped, like protobuf does
+            }
+        } else if (wt == 2) {
+            u64 n;
+            if (!rg_pb_varint(p, end, n) || n > (u64)(end - p))
+                return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: length-delimited field runs past the end");
+            if (field == 7) out->n_entries++;
+            else if (field == 9) out->has_snapshot = 1;
+            else if (field == 12) out->context_len = (uint32_t)n;
+            p += n;
+        } else if (wt == 1) {
+            if (end - p < 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated fixed64");
+            p += 8;
+        } else if (wt == 5) {
+            if (end - p < 4) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated fixed32");
+            p += 4;
+        } else {
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: wire type %u is not proto3", wt);
+        }
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_bytes: bad argument");
+    rg_decoded_message m;
+    int rc = rg_decode_message(bytes, len, &m);
+    if (rc) return rc;
+    switch (m.msg_type) {
+    case 0: case 1: case 10: case 11: case 12: // MsgHup, MsgBeat, MsgUnreachable, MsgSnapStatus, MsgCheckQuorum: is_local_msg
+        return rg_fail(RG_ERR_STEP_LOCAL_MSG, "rg_step_bytes: raft: cannot step raft local message (raw_node.rs:404-406)");
+    case 4: { // MsgAppendResponse
+        rg_append_response r;
+        memset(&r, 0, sizeof(r));
+        r.from = m.from;
+        r.term = m.term;
+        r.index = m.index;
+        r.commit = m.commit;
+        r.reject = (uint8_t)m.reject;
+        r.reject_hint = m.reject_hint;
+        r.log_term = m.log_term;
+        r.request_snapshot = m.request_snapshot;
+        return rg_step(h, group, &r);
+    }
+    case 9: // MsgHeartbeatResponse
+        return rg_step_heartbeat_response(h, group, m.from, m.term, m.commit, 0);
+    default:
+        return rg_fail(RG_ERR_NOT_ON_PATH, "rg_step_bytes: message type %u is not handled on this path (the host's Raft::step takes it)",
+                       m.msg_type);
+    }
+}
+
 extern "C" int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index) {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_append: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_append: rg_set_peers was never called");

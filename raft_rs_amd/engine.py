@@ -55,7 +55,7 @@ class OUT:
         return (int(o) >> 24) & 0xff
 
 
-ERR = {"INVALID_ARG": -1, "NO_DEVICE": -2, "OUT_OF_MEMORY": -3, "STEP_LOCAL_MSG": -4,
+ERR = {"NOT_ON_PATH": -9, "INVALID_ARG": -1, "NO_DEVICE": -2, "OUT_OF_MEMORY": -3, "STEP_LOCAL_MSG": -4,
        "STEP_PEER_NOT_FOUND": -5, "SLOT_BUSY": -6, "HIGHER_TERM": -7, "STATE": -8}
 
 WL_MAJORITY, WL_JOINT, WL_MIXED = 2, 3, 5
@@ -108,6 +108,16 @@ class AppendResponse(C.Structure):
     _fields_ = [("from_", C.c_uint64), ("term", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
                 ("reject_hint", C.c_uint64), ("request_snapshot", C.c_uint64), ("reject", C.c_uint8),
                 ("ins_full", C.c_uint8), ("pad", C.c_uint8 * 6), ("log_term", C.c_uint64)]
+
+
+class DecodedMessage(C.Structure):
+    """rg_decoded_message: the fields of one protobuf-encoded eraftpb::Message (rg_decode_message)."""
+    _fields_ = [("msg_type", C.c_uint32), ("reject", C.c_uint32), ("to", C.c_uint64), ("from_", C.c_uint64),
+                ("term", C.c_uint64), ("log_term", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
+                ("commit_term", C.c_uint64), ("reject_hint", C.c_uint64), ("request_snapshot", C.c_uint64),
+                ("priority", C.c_uint64), ("n_entries", C.c_uint64), ("has_snapshot", C.c_uint32),
+                ("context_len", C.c_uint32)]
+
 
 
 class WireMsg(C.Structure):
@@ -215,6 +225,8 @@ SYMBOLS = {
     "rg_quorum_recently_active": (_i, [_vp, _vp]),
     "rg_set_peers": (_i, [_vp, _u64, C.POINTER(_u64), C.c_uint32, _u64]),
     "rg_step": (_i, [_vp, _u64, C.POINTER(AppendResponse)]),
+    "rg_step_bytes": (_i, [_vp, _u64, C.c_char_p, _u64]),
+    "rg_decode_message": (_i, [C.c_char_p, _u64, C.POINTER(DecodedMessage)]),
     "rg_local_append": (_i, [_vp, _u64, _u64]),
     "rg_local_persisted": (_i, [_vp, _u64, _u64]),
     "rg_mark_sent": (_i, [_vp, _u64, _u64]),
@@ -637,6 +649,10 @@ class Engine:
                            (C.c_uint8 * 6)(), log_term)
         self._check(self.L.rg_step(self.h, group, C.byref(m)))
 
+    def step_bytes(self, group, data):
+        """RawNode::step on one protobuf-encoded eraftpb::Message (bytes)."""
+        self._check(self.L.rg_step_bytes(self.h, group, bytes(data), len(data)))
+
     def local_append(self, group, new_last_index):
         self._check(self.L.rg_local_append(self.h, group, new_last_index))
 
@@ -767,3 +783,13 @@ def pub_apply_host(n_groups, world, gathered, replica, overflow_slots=0):
     if rc:
         raise EngineError(rc, L.rg_last_error().decode())
     return lost.value
+
+
+def decode_message(data):
+    """rg_decode_message: the decoder behind rg_step_bytes alone (pure host code). Returns a dict of the fields."""
+    m = DecodedMessage()
+    L = load_library()
+    rc = L.rg_decode_message(bytes(data), len(data), C.byref(m))
+    if rc != 0:
+        raise EngineError(rc, L.rg_last_error().decode())
+    return {k.rstrip("_"): int(getattr(m, k)) for k, _ in DecodedMessage._fields_}

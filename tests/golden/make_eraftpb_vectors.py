@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Golden vectors for the wire format of the path's input: protobuf-encoded eraftpb::Message.
+
+Run in the build container (where /root/reference exists):
+
+    python tests/golden/make_eraftpb_vectors.py          # writes tests/golden/eraftpb_messages.json
+
+The message types are NOT typed in here: the script parses /root/reference/proto/proto/eraftpb.proto (proto3; enums,
+messages, scalar / message / repeated fields -- the whole grammar that file uses), builds the descriptors with the
+protobuf runtime (no protoc in the image) and lets THAT runtime serialise seeded random messages. Every vector is
+`{"hex": <serialised bytes>, "fields": {...}}`; consumers (tests/test_wire_format.py) check rg_decode_message -- the
+decoder behind rg_step_bytes -- against them. A few hand-made malformed byte strings (truncated varint, a length that
+runs past the end, a group wire type) carry `"error": true`.
+"""
+import json
+import os
+import random
+import re
+import sys
+
+PROTO = "/root/reference/proto/proto/eraftpb.proto"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "eraftpb_messages.json")
+
+SCALARS = {"uint64": 4, "uint32": 13, "int64": 3, "int32": 5, "bool": 8, "bytes": 12, "string": 9}  # FieldDescriptorProto.Type
+
+
+def parse_proto(text):
+    """-> (package, {enum: [(name, number)]}, {message: [(label, type, name, number)]})"""
+    text = re.sub(r"//[^\n]*", "", text)
+    package = re.search(r"package\s+([\w.]+)\s*;", text).group(1)
+    enums, messages = {}, {}
+    for kind, name, body in re.findall(r"(enum|message)\s+(\w+)\s*\{([^{}]*)\}", text):
+        if kind == "enum":
+            enums[name] = [(n, int(v)) for n, v in re.findall(r"(\w+)\s*=\s*(\d+)\s*;", body)]
+        else:
+            messages[name] = [(lab or "", typ, fname, int(num))
+                              for lab, typ, fname, num in re.findall(r"(repeated\s+)?([\w.]+)\s+(\w+)\s*=\s*(\d+)\s*;", body)]
+    return package, enums, messages
+
+
+def build_classes(package, enums, messages):
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="eraftpb.proto", package=package, syntax="proto3")
+    for name, values in enums.items():
+        e = fd.enum_type.add(name=name)
+        for n, v in values:
+            e.value.add(name=n, number=v)
+    for name, fields in messages.items():
+        m = fd.message_type.add(name=name)
+        for lab, typ, fname, num in fields:
+            f = m.field.add(name=fname, number=num)
+            f.label = 3 if lab.strip() == "repeated" else 1
+            if typ in SCALARS:
+                f.type = SCALARS[typ]
+            elif typ in enums:
+                f.type, f.type_name = 14, f".{package}.{typ}"
+            elif typ in messages:
+                f.type, f.type_name = 11, f".{package}.{typ}"
+            else:
+                raise ValueError(f"unknown type {typ} in {name}.{fname}")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return {name: message_factory.GetMessageClass(pool.FindMessageTypeByName(f"{package}.{name}")) for name in messages}
+
+
+def rand_u64(rng):
+    k = rng.random()
+    if k < 0.15:
+        return 0
+    if k < 0.5:
+        return rng.randrange(1, 200)
+    if k < 0.8:
+        return rng.randrange(1, 1 << 32)
+    if k < 0.95:
+        return rng.randrange(1 << 32, 1 << 64)
+    return (1 << 64) - 1
+
+
+def main():
+    package, enums, messages = parse_proto(open(PROTO, encoding="utf-8").read())
+    cls = build_classes(package, enums, messages)
+    Message, Entry, Snapshot = cls["Message"], cls["Entry"], cls["Snapshot"]
+    types = dict(enums["MessageType"])
+    rng = random.Random(0xE7AF)
+    vectors = []
+    order = ["MsgAppendResponse"] * 6 + ["MsgHeartbeatResponse"] * 3 + sorted(types)
+    for i in range(240):
+        tname = order[i % len(order)]
+        m = Message()
+        m.msg_type = types[tname]
+        for f in ("to", "from", "term", "log_term", "index", "commit", "commit_term", "reject_hint", "request_snapshot",
+                  "priority"):
+            if rng.random() < 0.7:
+                setattr(m, f, rand_u64(rng))
+        m.reject = rng.random() < 0.4
+        if tname in ("MsgAppend", "MsgPropose") or rng.random() < 0.1:
+            for _ in range(rng.randrange(0, 4)):
+                e = m.entries.add()
+                e.term, e.index = rand_u64(rng), rand_u64(rng)
+                e.data = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 40)))
+        if tname == "MsgSnapshot" or rng.random() < 0.05:
+            m.snapshot.data = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 30)))
+            m.snapshot.metadata.index = rand_u64(rng)
+            m.snapshot.metadata.term = rand_u64(rng)
+        if rng.random() < 0.2:
+            m.context = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 20)))
+        data = m.SerializeToString(deterministic=True)
+        vectors.append({"hex": data.hex(), "type": tname, "fields": {
+            "msg_type": int(m.msg_type), "to": int(m.to), "from": int(getattr(m, "from")), "term": int(m.term),
+            "log_term": int(m.log_term), "index": int(m.index), "commit": int(m.commit), "commit_term": int(m.commit_term),
+            "reject": int(m.reject), "reject_hint": int(m.reject_hint), "request_snapshot": int(m.request_snapshot),
+            "priority": int(m.priority), "n_entries": len(m.entries), "has_snapshot": int(m.HasField("snapshot")),
+            "context_len": len(m.context)}})
+    # an unknown field (number 99, varint and length-delimited) in front of a real message: protobuf skips it
+    base = bytes.fromhex(vectors[0]["hex"])
+    vectors.append({"hex": (bytes([0x98, 0x06, 0x2A]) + bytes([0x9A, 0x06, 0x03, 1, 2, 3]) + base).hex(), "type": "unknown-fields",
+                    "fields": vectors[0]["fields"]})
+    for bad, why in ((b"\x08", "truncated varint"), (b"\x3a\x7f\x00", "length past the end"), (b"\x0b\x00", "group wire type"),
+                     (b"\x00\x01", "field number 0"), (b"\x19\x01\x02", "truncated fixed64"),
+                     (b"\x08" + b"\xff" * 11, "varint longer than 10 bytes")):
+        vectors.append({"hex": bad.hex(), "type": why, "error": True})
+    doc = {"source": "proto/proto/eraftpb.proto (enum MessageType :49-69, message Message :71-92), serialised by the protobuf "
+                     "runtime from descriptors parsed out of that file (tests/golden/make_eraftpb_vectors.py)",
+           "message_types": types, "message_fields": {n: num for _, _, n, num in messages["Message"]}, "vectors": vectors}
+    text = json.dumps(doc, indent=0, sort_keys=True) + "\n"
+    if "--check" in sys.argv:
+        sys.exit(0 if open(OUT).read() == text else 1)
+    open(OUT, "w").write(text)
+    print(f"wrote {OUT}: {len(vectors)} vectors")
+
+
+if __name__ == "__main__":
+    main()

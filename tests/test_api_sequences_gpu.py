@@ -183,9 +183,12 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
     mb = rg.MsgBuffers(G, P, eng.stride)
     gout = np.zeros(G, dtype=np.uint32)
     n_items = 0
-    for step in range(50):
+    ops_seen = set()
+    for step in range(60):
         cl.store_soa(st)
-        op = rng.choice(["dense", "sparse3", "sparse1", "mirror_sparse", "mirror_flush_send", "mirror_dense", "recompute"])
+        op = rng.choice(["dense", "dense_send", "sparse3", "sparse1", "mirror_sparse", "mirror_flush_send", "mirror_dense",
+                         "recompute"])
+        ops_seen.add(op)
         max_entries, skip = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
         staged = False
         touched = None
@@ -196,17 +199,21 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
         else:
             fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
             sendstage.prepare_msgs(msgs)
-            if op not in ("dense", "mirror_dense"):
+            if op not in ("dense", "dense_send", "mirror_dense"):
                 touched = np.sort(rng.choice(G, size=int(rng.integers(1, G // 3)), replace=False))
                 keep = np.zeros(G, dtype=bool)
                 keep[touched] = True
                 msgs["m_flags"][~keep] = 0
             if op.startswith("mirror"):
                 clean_for_mirror(msgs, P, self_slot)
-            if op == "dense":
+            if op in ("dense", "dense_send"):
                 for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
                     getattr(mb, k)[...] = msgs[k]
-                eng.tick(mb)
+                if op == "dense_send":  # the tick and its stage as ONE launch (rg_tick_send)
+                    eng.tick_send(mb, max_entries, skip_bcast_commit=skip)
+                    staged = True
+                else:
+                    eng.tick(mb)
             elif op == "sparse3":
                 assert eng.ingest(records(msgs, touched, P, rng)) == 0
                 eng.tick_ingested()
@@ -232,5 +239,5 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
         assert not diffs, (step, op, diffs[:5])
         meta, ring = eng.read_inflights()
         sendstage.compare_rings(cl, meta, ring, st, cap)
-    assert n_items > 2000
+    assert n_items > 2000 and "dense_send" in ops_seen, (n_items, ops_seen)
     eng.close()

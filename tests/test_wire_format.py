@@ -1,0 +1,146 @@
+"""The wire format of the path's input: rg_decode_message / rg_step_bytes (RawNode::step on the protobuf bytes a transport
+delivers) against vectors the protobuf runtime serialised from the reference's own eraftpb.proto
+(tests/golden/make_eraftpb_vectors.py -> tests/golden/eraftpb_messages.json)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "eraftpb_messages.json")
+DOC = json.load(open(GOLD))
+MT = DOC["message_types"]
+
+
+def varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def encode(fields):
+    """A scalar-only eraftpb::Message as proto3 serialises it: fields in number order, defaults omitted (test
+    infrastructure for the GPU test below, where neither the reference nor its .proto exists; pinned against the golden
+    bytes by test_the_test_encoder_reproduces_the_runtime)."""
+    num = DOC["message_fields"]
+    out = bytearray()
+    for name, n in sorted(num.items(), key=lambda kv: kv[1]):
+        v = int(fields.get(name, 0))
+        if v:
+            out += varint(n << 3) + varint(v)
+    return bytes(out)
+
+
+def test_decoder_matches_every_golden_vector(rg):
+    from raft_rs_amd.engine import decode_message, EngineError
+    n_ok = n_err = 0
+    for v in DOC["vectors"]:
+        data = bytes.fromhex(v["hex"])
+        if v.get("error"):
+            with pytest.raises(EngineError) as e:
+                decode_message(data)
+            assert e.value.code == -1, (v["type"], e.value)
+            n_err += 1
+            continue
+        got = decode_message(data)
+        assert got == v["fields"], (v["type"], got, v["fields"])
+        n_ok += 1
+    assert n_ok >= 240 and n_err >= 6
+    assert decode_message(b"") == {k: 0 for k in DOC["vectors"][0]["fields"]}  # the empty message: every field default
+
+
+def test_the_test_encoder_reproduces_the_runtime():
+    n = 0
+    for v in DOC["vectors"]:
+        f = v.get("fields")
+        if not f or f["n_entries"] or f["has_snapshot"] or f["context_len"] or v["type"] == "unknown-fields":
+            continue
+        assert encode(f).hex() == v["hex"], v
+        n += 1
+    assert n > 100
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/proto/proto/eraftpb.proto"), reason="reference tree not present")
+def test_committed_vectors_are_what_the_generator_produces():
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_eraftpb_vectors.py"), "--check"])
+    assert r.returncode == 0, "tests/golden/eraftpb_messages.json is out of date: rerun make_eraftpb_vectors.py"
+
+
+@pytest.mark.gpu
+def test_step_bytes_equals_step(rg):
+    """Two engines, the same stream: one stepped through rg_step / rg_step_heartbeat_response, the other through
+    rg_step_bytes on the protobuf encoding of the same messages; identical state and results. Plus RawNode::step's
+    error behaviour on bytes: local types, unknown peers, other types, garbage."""
+    import fuzz
+    import oracle_lib as O
+    from raft_rs_amd.engine import EngineError, ERR
+    rng = np.random.default_rng(5150)
+    G, P, TERM = 600, 5, 7
+    st = O.add_term_table(O.alloc_state(G, P))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, TERM)
+    self_slot = ((st["cfg"] >> 16) & 7).astype(np.int64)
+    a, b = rg.Engine(G, P), rg.Engine(G, P)
+    for eng in (a, b):
+        eng.load_state(st)
+        for g in range(G):
+            eng.set_peers(g, [11 * (s + 1) for s in range(P)], TERM)
+    n_app = n_hb = 0
+    for rnd in range(6):
+        for g in range(G):
+            for s in range(P):
+                if s == self_slot[g] or rng.random() < 0.4:
+                    continue
+                frm = 11 * (s + 1)
+                if rng.random() < 0.2:
+                    commit = int(rng.integers(0, 50))
+                    a.step_heartbeat_response(g, frm, TERM, commit)
+                    b.step_bytes(g, encode({"msg_type": MT["MsgHeartbeatResponse"], "from": frm, "to": 1, "term": TERM, "commit": commit}))
+                    n_hb += 1
+                else:
+                    reject = rng.random() < 0.2
+                    idx = int(rng.integers(0, 60))
+                    f = {"msg_type": MT["MsgAppendResponse"], "from": frm, "to": 1, "term": TERM, "index": idx,
+                         "commit": int(rng.integers(0, 40)), "reject": int(reject), "reject_hint": int(rng.integers(0, 60)) if reject else 0,
+                         "log_term": int(rng.integers(1, TERM)) if reject and rng.random() < 0.5 else 0,
+                         "request_snapshot": int(rng.integers(1, 30)) if reject and rng.random() < 0.1 else 0}
+                    a.step(g, frm, TERM, idx, commit=f["commit"], reject=reject, reject_hint=f["reject_hint"],
+                           request_snapshot=f["request_snapshot"], log_term=f["log_term"])
+                    b.step_bytes(g, encode(f))
+                    n_app += 1
+        a.flush()
+        b.flush()
+        ra, rb = a.ingested_results(), b.ingested_results()
+        oa, ob = np.argsort(ra[0]), np.argsort(rb[0])
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x[oa], y[ob]), rnd
+        sa, sb = a.read_state(), b.read_state()
+        assert not fuzz.diff_states(sa, sb, G, P), rnd
+    assert n_app > 3000 and n_hb > 500
+    for typ in ("MsgHup", "MsgBeat", "MsgUnreachable", "MsgSnapStatus", "MsgCheckQuorum"):  # is_local_msg (raw_node.rs:57-66)
+        with pytest.raises(EngineError) as e:
+            b.step_bytes(0, encode({"msg_type": MT[typ], "from": 22, "term": TERM}))
+        assert e.value.code == ERR["STEP_LOCAL_MSG"], typ
+    with pytest.raises(EngineError) as e:
+        b.step_bytes(0, encode({"msg_type": MT["MsgAppendResponse"], "from": 999, "term": TERM, "index": 3}))
+    assert e.value.code == ERR["STEP_PEER_NOT_FOUND"]
+    with pytest.raises(EngineError) as e:
+        b.step_bytes(0, encode({"msg_type": MT["MsgAppendResponse"], "from": 22, "term": TERM + 1, "index": 3}))
+    assert e.value.code == ERR["HIGHER_TERM"]
+    for typ in ("MsgAppend", "MsgRequestVote", "MsgRequestVoteResponse", "MsgSnapshot", "MsgHeartbeat", "MsgTimeoutNow"):
+        with pytest.raises(EngineError) as e:
+            b.step_bytes(0, encode({"msg_type": MT[typ], "from": 22, "term": TERM}))
+        assert e.value.code == ERR["NOT_ON_PATH"], typ
+    with pytest.raises(EngineError) as e:
+        b.step_bytes(0, b"\x08")
+    assert e.value.code == ERR["INVALID_ARG"]
+    a.close()
+    b.close()
