@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long differential soak of the send stage on a GPU box: engine (tick + rg_send_appends through the C ABI) vs the
-oracle (message-at-a-time ticks + maybe_send_append) on the synthetic stream with the host's SENT events removed.
+oracle (message-at-a-time ticks + maybe_send_append) on the synthetic stream with the host's SENT events removed; every
+other tick runs as ONE launch (rg_tick_send).
 Ad hoc: python tools/soak_send_gpu.py [ticks] [groups]."""
 import os
 import sys
@@ -37,10 +38,13 @@ for wl, P, cap, max_entries in ((2, 5, 4, 3), (5, 7, 256, 0), (3, 5, 2, 1)):
     for t in range(ticks):
         E.workload_gen_host(st, mb, wl, t)
         mb.m_flags &= np.uint8(0xE7)  # no SENT, no host INS_FULL: the device owns the send path
-        eng.tick(mb)
-        cl.tick_soa_mt(mb.as_dict(), gout, 32)
         skip = t % 3 == 2
-        eng.send_appends(max_entries, skip_bcast_commit=skip)
+        if t % 2:  # every other tick as ONE launch (rg_tick_send: k_tick_send)
+            eng.tick_send(mb, max_entries, skip_bcast_commit=skip)
+        else:
+            eng.tick(mb)
+            eng.send_appends(max_entries, skip_bcast_commit=skip)
+        cl.tick_soa_mt(mb.as_dict(), gout, 32)
         items = eng.send_items()
         omsgs = cl.send_stage_soa(gout, max_entries, capacity=G * P * max(4, min(cap, 64)), skip_bcast_commit=skip)
         cl.store_soa(st)
