@@ -2960,7 +2960,13 @@ static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
         m.m_rs = h->q_mrs.data();
         m.m_logterm = h->q_any_logterm ? h->q_mlt.data() : nullptr;
         m.m_flags = h->q_mf.data();
-        rc = rg_tick(h, &m);
+        // (with a send request: the tick and its stage as ONE launch, k_tick_send)
+        if (send) {
+            const RgSendReq sr = {(u64)send->max_entries, (u32)send->flags};
+            rc = rg_tick_host_impl(h, &m, &sr);
+        } else {
+            rc = rg_tick(h, &m);
+        }
         // rg_ingested_results must work after ANY flush: gather the dirty groups' results compactly
         if (rc == RG_OK) rc = rg_ensure_sparse(h);
         if (rc == RG_OK) {
@@ -2977,7 +2983,6 @@ static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
             if (e != hipSuccess) rc = rg_fail(RG_ERR_NO_DEVICE, "rg_flush: %s", hipGetErrorString(e));
             else h->last_sparse_n = n;
         }
-        if (rc == RG_OK && send) rc = rg_send_appends(h, send->max_entries, send->flags); // dense stage, items on request
     } else {
         // few groups have events: ship only their records and tick only them -- ONE host<->device round trip
         // (pinned record staging, five back-to-back launches, one packed D2H copy, one synchronisation)
