@@ -83,6 +83,13 @@ int main() {
     CHECK(hipMemset(g8, 1, NMAX * 40 * 8));
     CHECK(hipMemset(g4, 1, NMAX * 12 * 4));
     CHECK(hipDeviceSynchronize());
+    // (column c starts c x N x 8 B behind column 0: 2^23 groups put every stream at a multiple of 64 MiB -- does the chip's
+    // address interleaving mind? 8 000 000 is what the engine's 8 M-group runs use, 8 388 608 + 4 352 a near-by odd multiple of 256)
+    for (u64 N : {(u64)8000000, NMAX - 65536 + 4352}) {
+        run<27, 0, 17, 0>("k_tick_lane shape", N);
+        run<15, 6, 21, 9>("k_send_dense shape", N);
+        run<36, 4, 33, 9>("k_tick_send shape", N);
+    }
     for (u64 N : {NMAX, (u64)1 << 20}) {
         run<27, 0, 17, 0>("k_tick_lane shape", N);
         run<15, 6, 21, 9>("k_send_dense shape", N);
