@@ -1687,7 +1687,7 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
 // Everything of a sparse tick that needs no host round trip: clear the previous results, resolve hints, tick the
 // listed groups, gather their results (also into `packed` when given). `upper` bounds the list length.
 static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_logterm, bool out_cleared = false,
-                             const RgIngest *one_launch = nullptr) {
+                             const RgIngest *one_launch = nullptr, const RgSmallSend *small_send = nullptr) {
     int src = rg_settle_send(h); // (walks the PREVIOUS tick's result list, before it is cleared below)
     if (src) return src;
     // RG_COL_OUT must hold zeros for every group this tick does not touch
@@ -1711,6 +1711,23 @@ static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_log
     lo.rc = h->res_commit;
     lo.ro = h->res_out;
     lo.packed = packed;
+    if (one_launch && small_send) { // ... and the touched groups' send stage as well (rg_flush_send)
+        if (any_logterm) ms.mhr = h->rhint;
+        switch (h->P) {
+        case 1: rg_launch_flush_small_send_t<1>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        case 2: rg_launch_flush_small_send_t<2>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        case 3: rg_launch_flush_small_send_t<3>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        case 4: rg_launch_flush_small_send_t<4>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        case 5: rg_launch_flush_small_send_t<5>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        case 6: rg_launch_flush_small_send_t<6>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        case 7: rg_launch_flush_small_send_t<7>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        default: rg_launch_flush_small_send_t<8>(h->stream, h->st, ms, h->any_group_commit, *one_launch, h->rhint, mf, lo, *small_send); break;
+        }
+        hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "sparse tick + send stage: launch failed: %s", hipGetErrorString(e1));
+        h->tick_launches++;
+        return RG_OK;
+    }
     if (one_launch) { // <= 256 records: ingest, hint resolution, tick and results in ONE single-workgroup launch
         if (any_logterm) ms.mhr = h->rhint;
         switch (h->P) {
@@ -2706,13 +2723,31 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
                            rg_ingest_args(h, src, n, clr));
     }
     // (records ingested on the device in this window may carry log terms the host has not seen)
+    // One launch AND a send request: the stage of every touched group runs behind its tick inside k_flush_small_send, on the
+    // tick's registers; its work items land in the device list and, through the mapped pinned buffer, in host memory.
+    const bool stage_inside = one_launch && send;
+    RgSmallSend small_send;
+    if (stage_inside) {
+        if (!h->pin_send)
+            RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_send), 16 + RG_SEND_SPEC * sizeof(rg_send_item),
+                                 hipHostMallocDefault));
+        small_send.ins = h->ins;
+        small_send.max_entries = send->max_entries;
+        small_send.flags = send->flags;
+        small_send.items = h->send_items;
+        small_send.counter = h->send_counter;
+        small_send.pin = h->pin_send;
+        h->send_cols_fresh = false; // (what rg_send_enqueue records for a stage over a list)
+        h->send_last_dense = false;
+        h->host_items_valid = false;
+    }
     rc = rg_sparse_enqueue(h, upper, zero_copy ? h->pin_packed : h->d_packed, any_logterm || h->ingested_upper != 0, out_cleared,
-                           one_launch ? &fused_args : nullptr);
+                           one_launch ? &fused_args : nullptr, stage_inside ? &small_send : nullptr);
     if (rc) return rc;
     // the send stage rides along: it walks the gathered list, whose length is still only on the device
     const u64 item_bound = upper * h->P;
-    fetch_items = send && upper && item_bound <= RG_SEND_SPEC;
-    if (send && upper) {
+    fetch_items = send && upper && (stage_inside || item_bound <= RG_SEND_SPEC);
+    if (send && upper && !stage_inside) {
         rc = rg_send_enqueue(h, send->max_entries, send->flags, h->res_list, upper, h->counters);
         if (rc) return rc;
         if (fetch_items) {

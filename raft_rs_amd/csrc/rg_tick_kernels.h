@@ -185,12 +185,14 @@ template <int P> struct RgSendWin {
     u32 meta[(P + 3) / 4 * 4][64]; // [slot][group]: Inflights.start | count << 16 (rows beyond P: padding of the last DMA)
 };
 
-template <int P, bool GC, typename IX>
+// WAVE: the lanes of the calling wave hold consecutive groups and arrive together (k_tick_send): whole-line accesses
+// (rg_wave_any); the small-batch flush, whose lanes hold unrelated groups, passes false.
+template <int P, bool GC, typename IX, bool WAVE = (RG_SEND_WAVE_LINES != 0)>
 RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, const RgIns &ins, IX g, u64 max_entries,
                               u32 flags, RgSendRegs<P> &it, const RgSendWin<P> *win = nullptr, u32 lane = 0) {
     RgSendOps<P> q;
     constexpr bool PRE = RG_TS_SPEC != 0;
-    constexpr bool TSW = RG_SEND_WAVE_LINES != 0; // (on the host rg_wave_any is the lane's own answer)
+    constexpr bool TSW = WAVE; // (on the host rg_wave_any is the lane's own answer)
     if (RG_TS_SPEC == 1 || (RG_TS_SPEC == 2 && !win)) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
     if (RG_TS_SPEC == 2 && win) q.first_index = rg_at(st.dummy_idx, g) + 1;
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
@@ -211,11 +213,11 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
     // election rewrites all of them (rg_prefetch_rare / RgTick::set_next)
     const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
 #if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
-    rg_store_group<P, IX, 1, true>(r, st, g);
+    rg_store_group<P, IX, 1, WAVE>(r, st, g);
     rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, r.out, flags, q, &r, nxv);
 #else
     rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, r.out, flags, q, &r, nxv);
-    rg_store_group<P, IX, 1, true>(r, st, g);
+    rg_store_group<P, IX, 1, WAVE>(r, st, g);
 #endif
     rg_send_serve<P, IX, true, TSW>(st, ins, g, r.out, max_entries, flags, q, it, &r, nxv);
     rg_store_group<P, IX, 2>(r, st, g);
@@ -464,6 +466,53 @@ RG_D void rg_tick_listed(const RgState &st, const RgMsgs &ms, u64 g64, u64 i, u6
     }
 }
 
+// The send stage inside the one-launch small flush (rg_flush_send on engines with device Inflights): where its work items go
+struct RgSmallSend {
+    RgIns ins;
+    u64 max_entries;
+    u32 flags;
+    rg_send_item *items; // the device-side list (rg_send_items_ptr) ...
+    u32 *counter;        // ... and its length
+    char *pin;           // the same in pinned host memory for the caller: u32 count at byte 0, the items from byte 16
+};
+
+// entry i of the tick list with the send stage of its group behind the tick, on the tick's registers (rg_group_tick_send);
+// the group's work items are appended through `lds_cnt`, a counter in the workgroup's LDS
+template <int P, bool GC, typename IX = u64>
+RG_D void rg_tick_send_listed(const RgState &st, const RgMsgs &ms, u64 g64, u64 i, u64 *mflags_rw, const RgListOut &lo,
+                              const RgSmallSend &ss, u32 *lds_cnt) {
+    const IX g = (IX)g64;
+    RgGroup<P> r;
+    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    RgSendRegs<P> it;
+    rg_group_tick_send<P, GC, IX, false>(r, st, ms, ss.ins, g, ss.max_entries, ss.flags, it);
+    rg_at(mflags_rw, g) = 0;
+    lo.rl[i] = g;
+    lo.rc[i] = r.commit;
+    lo.ro[i] = r.out;
+    if (lo.packed) {
+        u64 *rec = reinterpret_cast<u64 *>(lo.packed + 16 + i * 24);
+        rec[0] = g;
+        rec[1] = r.commit;
+        rec[2] = (u64)r.out;
+    }
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        const u32 nk = rg_send_nk<P>(it, s);
+        if (!nk) continue;
+        rg_send_item rec;
+        rec.group = g64;
+        rec.prev_index = it.prev[s];
+        rec.last_index = it.last[s];
+        rec.slot = (u32)s;
+        rec.n_msgs = (uint16_t)(nk & 0xffffu);
+        rec.kind = (uint16_t)(nk >> 16);
+        const u32 k = atomicAdd(lds_cnt, 1u);
+        ss.items[k] = rec;
+        reinterpret_cast<rg_send_item *>(ss.pin + 16)[k] = rec;
+    }
+}
+
 template <int P, bool GC, typename IX>
 __global__ RG_TICK_BOUNDS void k_tick_list(RgState st, RgMsgs ms, const u64 *list, const u32 *n_ptr, u64 *mflags_rw,
                                            RgListOut lo) {
@@ -551,9 +600,11 @@ RG_D void rg_ingest_block(const RgIngest &a, uint4 *stage) {
 // The whole small-batch flush in ONE launch (<= 256 records, one workgroup): housekeeping, ingest, hint resolution,
 // the tick of the touched groups and the packed results -- what k_ingest, k_resolve_hints_list and k_tick_list do
 // in three. A host that waits for one RawNode::step's worth of results pays one launch latency instead of two or three.
-template <int P, bool GC>
+// SEND: every touched group's send stage runs behind its tick (ss, lds_cnt: rg_tick_send_listed)
+template <int P, bool GC, bool SEND = false>
 RG_D void rg_flush_small_body(const RgState &st, const RgMsgs &ms, const RgIngest &a, u64 *rh, u64 *mflags_rw,
-                              const RgListOut &lo, uint4 *stage) {
+                              const RgListOut &lo, uint4 *stage, const RgSmallSend *ss = nullptr, u32 *lds_cnt = nullptr) {
+    if (SEND && threadIdx.x == 0) *lds_cnt = 0; // (published by the barrier behind the ingest)
     rg_ingest_housekeeping(a.clr);
     rg_ingest_block(a, stage);
     // the message cells, the tick list and the counters were written by this workgroup: make them visible to all of it
@@ -569,7 +620,18 @@ RG_D void rg_flush_small_body(const RgState &st, const RgMsgs &ms, const RgInges
         reinterpret_cast<u32 *>(lo.packed)[0] = n_groups;
         reinterpret_cast<u32 *>(lo.packed)[1] = n_dropped;
     }
-    for (u32 i = threadIdx.x; i < n_groups; i += RG_INGEST_BLOCK) rg_tick_listed<P, GC>(st, ms, a.list[i], i, mflags_rw, lo);
+    for (u32 i = threadIdx.x; i < n_groups; i += RG_INGEST_BLOCK) {
+        if (SEND) rg_tick_send_listed<P, GC>(st, ms, a.list[i], i, mflags_rw, lo, *ss, lds_cnt);
+        else rg_tick_listed<P, GC>(st, ms, a.list[i], i, mflags_rw, lo);
+    }
+    if (SEND) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const u32 cnt = *lds_cnt;
+            *ss->counter = cnt;
+            *reinterpret_cast<u32 *>(ss->pin) = cnt;
+        }
+    }
 }
 
 template <int P, bool GC>
@@ -577,6 +639,15 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small(RgState st, RgM
                                                                  RgListOut lo) {
     __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
     rg_flush_small_body<P, GC>(st, ms, a, rh, mflags_rw, lo, stage);
+}
+
+// ... and with the send stage of the touched groups in the same launch (rg_flush_send, engines with device Inflights)
+template <int P, bool GC>
+__global__ __launch_bounds__(RG_INGEST_BLOCK) void k_flush_small_send(RgState st, RgMsgs ms, RgIngest a, u64 *rh, u64 *mflags_rw,
+                                                                      RgListOut lo, RgSmallSend ss) {
+    __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
+    __shared__ u32 lds_cnt;
+    rg_flush_small_body<P, GC, true>(st, ms, a, rh, mflags_rw, lo, stage, &ss, &lds_cnt);
 }
 
 // The resident small-batch path ("mailbox", rg_mailbox_start): ONE workgroup stays on the device and serves small flushes
@@ -847,8 +918,17 @@ void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs
 template <int P>
 void rg_launch_mailbox_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a0, u32 *ctr_base,
                          u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks);
+template <int P>
+void rg_launch_flush_small_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
+                                  u64 *mflags_rw, const RgListOut &lo, const RgSmallSend &ss);
 
 #ifdef RG_TICK_INSTANTIATE
+template <int P>
+void rg_launch_flush_small_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
+                                  u64 *mflags_rw, const RgListOut &lo, const RgSmallSend &ss) {
+    if (gc) hipLaunchKernelGGL((k_flush_small_send<P, true>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a, rh, mflags_rw, lo, ss);
+    else hipLaunchKernelGGL((k_flush_small_send<P, false>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a, rh, mflags_rw, lo, ss);
+}
 template <int P>
 void rg_launch_mailbox_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a0, u32 *ctr_base,
                          u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks) {
@@ -927,47 +1007,55 @@ extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, cons
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
+extern template void rg_launch_flush_small_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
 #endif

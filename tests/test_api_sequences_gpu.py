@@ -184,10 +184,10 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
     gout = np.zeros(G, dtype=np.uint32)
     n_items = 0
     ops_seen = set()
-    for step in range(60):
+    for step in range(70):
         cl.store_soa(st)
         op = rng.choice(["dense", "dense_send", "sparse3", "sparse1", "mirror_sparse", "mirror_flush_send", "mirror_dense",
-                         "recompute"])
+                         "mirror_small_flush_send", "recompute"])
         ops_seen.add(op)
         max_entries, skip = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
         staged = False
@@ -200,7 +200,9 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
             fuzz.random_msgs(rng, st, msgs, sent_p=0.0, heartbeat_p=0.2)
             sendstage.prepare_msgs(msgs)
             if op not in ("dense", "dense_send", "mirror_dense"):
-                touched = np.sort(rng.choice(G, size=int(rng.integers(1, G // 3)), replace=False))
+                # (mirror_small_flush_send: few enough records for the ONE-launch flush with the stage inside, k_flush_small_send)
+                hi = 40 if op == "mirror_small_flush_send" else G // 3
+                touched = np.sort(rng.choice(G, size=int(rng.integers(1, hi)), replace=False))
                 keep = np.zeros(G, dtype=bool)
                 keep[touched] = True
                 msgs["m_flags"][~keep] = 0
@@ -221,7 +223,7 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
                 assert eng.ingest_tick(records(msgs, touched, P, rng))[1] == 0
             else:
                 mirror_steps(rg, eng, msgs, touched if touched is not None else range(G), P, self_slot)
-                if op == "mirror_flush_send" or (op == "mirror_dense" and rng.random() < 0.5):
+                if op in ("mirror_flush_send", "mirror_small_flush_send") or (op == "mirror_dense" and rng.random() < 0.5):
                     eng.flush_send(max_entries, skip_bcast_commit=skip)
                     staged = True
                 else:
@@ -239,5 +241,5 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
         assert not diffs, (step, op, diffs[:5])
         meta, ring = eng.read_inflights()
         sendstage.compare_rings(cl, meta, ring, st, cap)
-    assert n_items > 2000 and "dense_send" in ops_seen, (n_items, ops_seen)
+    assert n_items > 2000 and {"dense_send", "mirror_small_flush_send"} <= ops_seen, (n_items, ops_seen)
     eng.close()
