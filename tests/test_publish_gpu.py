@@ -50,6 +50,36 @@ def test_rccl_world1_replica_follows_every_tick(rg, workload, n_slots):
     eng.close()
 
 
+def test_the_one_launch_tick_and_send_stage_publishes_like_the_tick(rg):
+    """rg_tick_device_send (k_tick_send) carries the tick's publication byte in its store path as well: with the Inflights on
+    the device the replica follows every tick, whichever form the tick takes."""
+    import torch
+    from raft_rs_amd import engine as E
+    G, P = 30_000 + 11, 5
+    eng = rg.Engine(G, P, max_inflight=8)
+    eng.workload_init(2)
+    eng.comm_init(0, 1, unique_id=E.comm_unique_id(), ring_ticks=4)
+    cols, flags = _device_msgs(torch, eng, P)
+    moved = 0
+    for t in range(9):
+        eng.workload_gen(2, t, *[c.data_ptr() for c in cols], flags.data_ptr())
+        flags &= 0xE7  # the device owns the send path: no SENT / INS_FULL events from the host
+        before = eng.read_column(rg.COL.COMMIT).copy()
+        if t % 2:
+            eng.tick_device_send(*[c.data_ptr() for c in cols], flags.data_ptr())
+        else:
+            eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+            eng.send_appends()
+        eng.publish_commit()
+        now = eng.read_column(rg.COL.COMMIT)
+        assert np.array_equal(eng.published_commit(0), now), t
+        moved += int((now != before).sum())
+    assert moved > G
+    assert eng.publish_stats()["full_publications"] == 1
+    eng.comm_destroy()
+    eng.close()
+
+
 def test_ticks_accumulate_between_publications_and_other_commit_paths(rg):
     """Any cadence: several dense ticks, a sparse tick (rg_ingest_tick) and rg_recompute between two publications."""
     import torch
