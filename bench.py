@@ -194,6 +194,29 @@ def small_batch_latency(rg, torch, n_groups, n_slots, seed):
     served, launches = eng.mailbox_stats()
     out["mailbox_flushes_served"], out["mailbox_launches"] = served, launches
     eng.close()
+    # the same with the Inflights on the device: rg_flush_send = tick + the send stage of the touched groups + results +
+    # work items in one round trip (one launch, k_flush_small_send) -- and through the resident workgroup
+    eng = rg.Engine(min(n_groups, 200_000), n_slots, device=torch.cuda.current_device(), max_inflight=8)
+    eng.workload_init(2, seed=seed)
+    for g in range(n_mirror):
+        eng.set_peers(g, list(range(1, n_slots + 1)), 4)
+    hi = eng.read_column(rg.COL.TERM_HI)
+    match = eng.read_column(rg.COL.MATCH)
+    for mode in ("launch", "mailbox"):
+        if mode == "mailbox":
+            eng.mailbox_start()
+        lat = []
+        for rep in range(70):
+            g = int(rng.integers(0, n_mirror))
+            eng.step(g, 2, 4, int(min(hi[g], match[1, g] + (rep if mode == "launch" else 70 + rep) + 1)))
+            t0 = time.perf_counter()
+            eng.flush_send()
+            lat.append(time.perf_counter() - t0)
+            eng.send_items()
+            assert len(eng.ingested_results()[0]) == 1
+        out[f"{mode}_flush_send_1_groups"] = round(float(np.median(lat[10:])) * 1e6, 2)
+    out["mailbox_flush_send_served"] = eng.mailbox_stats()[0]
+    eng.close()
     return out
 
 

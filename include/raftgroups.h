@@ -482,8 +482,8 @@ int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *h
  * out of pinned host memory: the host writes the records and a request word and spins on the answer word -- no launch, no
  * stream synchronisation. Same results as the launch path (it runs the same code). The workgroup leaves when any other
  * entry point needs the engine's stream (automatically), when it has been idle for idle_timeout_us (0 = 2000), or after
- * 200 ms, and is relaunched by the next small flush. Not with device Inflights or commit publication (those flushes take
- * the launch path). The caller's thread spins while it waits: meant for a latency-bound host loop. */
+ * 200 ms, and is relaunched by the next small flush. With device Inflights it serves rg_flush_send -- the send stage of the
+ * touched groups runs inside the same request -- and leaves plain rg_flush to the launch path; not with commit publication. The caller's thread spins while it waits: meant for a latency-bound host loop. */
 int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us);
 int rg_mailbox_stop(rg_engine *h);
 /* Flushes the resident workgroup has answered so far / how often it was (re)launched (either may be NULL). */

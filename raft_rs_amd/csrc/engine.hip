@@ -2052,16 +2052,16 @@ static int rg_send_materialize(rg_engine *h) {
 extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n) {
     if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
+    if (h->host_items_valid) { // rg_flush_send already brought them over with the tick's results: no device access (and a
+        *n = h->host_items.size(); // resident mailbox workgroup stays where it is)
+        const u64 k = *n < cap ? *n : cap;
+        if (k) memcpy(host_items, h->host_items.data(), k * sizeof(rg_send_item));
+        return RG_OK;
+    }
     RG_ENTER(h);
     {
         int mrc = rg_send_materialize(h);
         if (mrc) return mrc;
-    }
-    if (h->host_items_valid) { // rg_flush_send already brought them over with the tick's results
-        *n = h->host_items.size();
-        const u64 k = *n < cap ? *n : cap;
-        if (k) memcpy(host_items, h->host_items.data(), k * sizeof(rg_send_item));
-        return RG_OK;
     }
     // small stages (the sparse path): counter and items come back together through pinned memory -- one round trip
     const u64 spec = h->send_bound < cap ? h->send_bound : cap;
@@ -2589,7 +2589,7 @@ static int rg_sparse_threecall(rg_engine *h, const rg_wire_msg *recs, u64 n, u32
     return rc;
 }
 
-static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served);
+static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served, const rg_send_req *send);
 static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out,
                                const rg_send_req *send = nullptr) {
     RG_HIP(hipSetDevice(h->cfg.device)); // (not RG_ENTER: this is the one path the resident mailbox kernel serves)
@@ -2601,9 +2601,9 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         for (u64 g : h->q_dirty)
             for (u32 p = 0; p < h->P; p++) n += h->q_mf[g * 8 + p] != 0;
     }
-    if (n > RG_INGEST_BLOCK || send) { // not a flush the resident mailbox workgroup can serve: it leaves now, before
-        rc = rg_mailbox_quiesce(h);    // anything below waits for the stream or replaces a buffer it reads
-        if (rc) return rc;
+    if (n > RG_INGEST_BLOCK || (send && !h->ins_arena)) { // not a flush the resident mailbox workgroup can serve: it leaves
+        rc = rg_mailbox_quiesce(h);                         // now, before anything below waits for the stream or replaces
+        if (rc) return rc;                                  // a buffer it reads
     }
     if (n > h->pin_records_cap) {
         if (h->pin_records) {
@@ -2641,8 +2641,8 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
     }
     // the resident mailbox kernel, when it is on: no launch, no synchronisation (rg_mailbox_flush says whether it took it)
     bool served = false;
-    if (h->mbox_on && !send) {
-        rc = rg_mailbox_flush(h, n, any_logterm, &served);
+    if (h->mbox_on) {
+        rc = rg_mailbox_flush(h, n, any_logterm, &served, send);
         if (rc) return rc;
     }
     if (!served) {
@@ -2658,6 +2658,13 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         rg_ctr_flip(h);
         n_groups = reinterpret_cast<const u32 *>(h->pin_packed)[0];
         dup = reinterpret_cast<const u32 *>(h->pin_packed)[1];
+        if (send) { // the request ran the stage of every touched group: its items are in pin_send (rg_tick_send_listed)
+            upper = n; // (only "something was walked", below)
+            fetch_items = true;
+            h->send_cols_fresh = false;
+            h->send_last_dense = false;
+            h->host_items_valid = false;
+        }
     } else {
     if (n > h->d_records_cap) {
         if (h->d_records) {
@@ -2825,15 +2832,23 @@ static int rg_mailbox_launch(rg_engine *h) {
     const RgIngest a0 = rg_ingest_args(h, h->pin_records, 0, clr);
     u64 *mf = (u64 *)h->staged.mflags;
     const u64 max_ticks = RG_MBOX_MAX_US * RG_MBOX_TICKS_PER_US;
+    RgSmallSend ss0; // where a request's send stage (rg_flush_send) puts its work items; limit and flags come with the request
+    memset(&ss0, 0, sizeof(ss0));
+    if (h->ins_arena) {
+        ss0.ins = h->ins;
+        ss0.items = h->send_items;
+        ss0.counter = h->send_counter;
+        ss0.pin = h->pin_send;
+    }
     switch (h->P) {
-    case 1: rg_launch_mailbox_t<1>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    case 2: rg_launch_mailbox_t<2>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    case 3: rg_launch_mailbox_t<3>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    case 4: rg_launch_mailbox_t<4>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    case 5: rg_launch_mailbox_t<5>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    case 6: rg_launch_mailbox_t<6>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    case 7: rg_launch_mailbox_t<7>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
-    default: rg_launch_mailbox_t<8>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks); break;
+    case 1: rg_launch_mailbox_t<1>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    case 2: rg_launch_mailbox_t<2>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    case 3: rg_launch_mailbox_t<3>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    case 4: rg_launch_mailbox_t<4>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    case 5: rg_launch_mailbox_t<5>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    case 6: rg_launch_mailbox_t<6>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    case 7: rg_launch_mailbox_t<7>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
+    default: rg_launch_mailbox_t<8>(h->stream, h->st, ms, h->any_group_commit, a0, h->counters_base, h->rhint, mf, lo, h->mbox, h->mbox_idle_ticks, max_ticks, ss0); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "mailbox: launch failed: %s", hipGetErrorString(e));
@@ -2844,12 +2859,23 @@ static int rg_mailbox_launch(rg_engine *h) {
 
 // One small flush through the mailbox: the records are in h->pin_records already. Returns RG_OK with *served = false
 // when the request cannot go this way (the caller takes the launch path).
-static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served) {
+static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served, const rg_send_req *send) {
     *served = false;
     // the body clears the PREVIOUS sparse tick's result words itself; a dense predecessor needs a memset on the stream
-    if (!h->mbox_on || h->ins_arena || h->pub || h->out_is_dense || h->ingested_upper || n == 0 || n > RG_INGEST_BLOCK ||
+    if (!h->mbox_on || h->pub || h->out_is_dense || h->ingested_upper || n == 0 || n > RG_INGEST_BLOCK ||
         h->last_sparse_n > RG_ZEROCOPY_MAX || h->epoch == 0xffffffffu)
         return RG_OK;
+    // device Inflights: only a flush that runs its send stage in the same request (rg_flush_send), with no stage of an
+    // earlier tick left to settle (that one needs a launch), and a limit the request word can carry
+    u32 lim = 0;
+    if (h->ins_arena) {
+        if (!send || h->send_ready) return RG_OK;
+        if (send->max_entries == ~0ULL) lim = 0xffffffffu;
+        else if (send->max_entries >= 0xffffffffULL) return RG_OK;
+        else lim = (u32)send->max_entries;
+    } else if (send) {
+        return RG_OK;
+    }
     RgMbox *mb = h->mbox;
     if (h->mbox_running && !__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) &&
         __atomic_load_n(&mb->seq_done, __ATOMIC_ACQUIRE) == h->mbox_seq) {
@@ -2859,10 +2885,12 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served)
     }
     const u32 s = ++h->mbox_seq;
     // (RgMbox: three self-validating words, one 8-byte store each; the records in pin_records are older stores)
-    const u32 w0 = (u32)n | ((h->counters == h->counters_base ? 0u : 1u) << 16) | ((any_logterm ? 1u : 0u) << 17);
+    const u32 w0 = (u32)n | ((h->counters == h->counters_base ? 0u : 1u) << 16) | ((any_logterm ? 1u : 0u) << 17) |
+                   ((send ? 1u : 0u) << 18) | ((send ? (send->flags & 3u) : 0u) << 19);
     __atomic_store_n(&mb->w[0], rg_mbox_word(s, w0), __ATOMIC_RELEASE);
     __atomic_store_n(&mb->w[1], rg_mbox_word(s, h->epoch), __ATOMIC_RELEASE);
     __atomic_store_n(&mb->w[2], rg_mbox_word(s, (u32)h->last_sparse_n), __ATOMIC_RELEASE);
+    __atomic_store_n(&mb->w[3], rg_mbox_word(s, lim), __ATOMIC_RELEASE);
     if (!h->mbox_running) {
         int rc = rg_mailbox_launch(h);
         if (rc) return rc;
@@ -2891,7 +2919,6 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served)
 
 extern "C" int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_start: null engine");
-    if (h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_mailbox_start: not with device Inflights (the send stage is a stream of launches)");
     RG_ENTER(h);
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
@@ -2909,6 +2936,8 @@ extern "C" int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us) {
         RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_packed), RG_PACKED_HDR + 4096 * sizeof(rg_res_rec), hipHostMallocDefault));
         h->packed_cap = 4096;
     }
+    if (h->ins_arena && !h->pin_send) // device Inflights: rg_flush_send's work items come back through this buffer
+        RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_send), 16 + RG_SEND_SPEC * sizeof(rg_send_item), hipHostMallocDefault));
     h->mbox_idle_ticks = (u64)(idle_timeout_us ? idle_timeout_us : 2000u) * RG_MBOX_TICKS_PER_US;
     h->mbox_on = true;
     return RG_OK;

@@ -660,14 +660,15 @@ struct RgMbox {
     // host -> device: 32 bytes the resident workgroup fetches with four independent 8-byte reads over PCIe per poll (in
     // flight together: one round trip). Every request word is SELF-VALIDATING: its upper half carries the request number,
     // its lower half a payload, and the host writes each word with ONE 8-byte store -- a word can never be torn, and a
-    // request is accepted only when all three words carry the same new number, whatever order the four reads were
+    // request is accepted only when all four words carry the same new number, whatever order the four reads were
     // sampled in. (Round 2 bracketed plain fields with a head and a tail sequence word; the head is written first and
     // read first, the tail written last and read last, so a poll could see head = tail = s around fields of request
     // s - 1.)
-    u64 w[3];  // w[0] = n (16 bits) | ctr_sel << 16 | any_logterm << 17, w[1] = epoch, w[2] = clr_n; each | seq << 32
+    u64 w[4];  // w[0] = n (16 bits) | ctr_sel << 16 | any_logterm << 17 | send << 18 | send flags << 19, w[1] = epoch,
+               // w[2] = clr_n, w[3] = the send stage's max_entries_per_msg (0xffffffff = NO_LIMIT); each | seq << 32
     u32 stop;  // written on its own by rg_mailbox_quiesce: not part of a request
     u32 pad_stop;
-    u32 pad0[8];
+    u32 pad0[6];
     // device -> host
     u32 seq_done;
     u32 alive;
@@ -678,9 +679,10 @@ RG_HD u64 rg_mbox_word(u32 seq, u32 payload) { return ((u64)seq << 32) | payload
 template <int P, bool GC>
 __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs ms, RgIngest a0, u32 *ctr_base, u64 *rh,
                                                              u64 *mflags_rw, RgListOut lo, RgMbox *mb, u64 idle_ticks,
-                                                             u64 max_ticks) {
+                                                             u64 max_ticks, RgSmallSend ss0) {
     __shared__ uint4 stage[RG_INGEST_BLOCK * 4];
-    __shared__ u32 req[8];
+    __shared__ u32 req[12];
+    __shared__ u32 lds_cnt;
     const u64 t_start = wall_clock64(); // constant 100 MHz
     u64 t_last = t_start;
     u32 seq = 0;
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs 
     for (;;) {
         if (threadIdx.x == 0) {
             u32 leave = 0;
-            u64 w0, w1, w2, w3;
+            u64 w0, w1, w2, w3, w4;
             u64 *q = reinterpret_cast<u64 *>(mb);
             for (;;) {
                 // four relaxed system-scope loads: independent, so they are in flight together (one PCIe round trip);
@@ -700,10 +702,11 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs 
                 w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w4 = __hip_atomic_load(q + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const u32 s0 = (u32)(w0 >> 32);
-                if (s0 != seq && (u32)(w1 >> 32) == s0 && (u32)(w2 >> 32) == s0) break; // all three words of ONE new request
+                if (s0 != seq && (u32)(w1 >> 32) == s0 && (u32)(w2 >> 32) == s0 && (u32)(w3 >> 32) == s0) break; // all four words of ONE new request
                 const u64 now = wall_clock64();
-                if ((u32)w3 /* stop */ || now - t_last > idle_ticks || now - t_start > max_ticks) {
+                if ((u32)w4 /* stop */ || now - t_last > idle_ticks || now - t_start > max_ticks) {
                     leave = 1;
                     break;
                 }
@@ -717,6 +720,9 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs 
             req[4] = (u32)w2;                  // clr_n
             req[5] = ((u32)w0 >> 16) & 1u;     // ctr_sel
             req[6] = ((u32)w0 >> 17) & 1u;     // any_logterm
+            req[7] = ((u32)w0 >> 18) & 1u;     // the send stage rides along (rg_flush_send)
+            req[8] = ((u32)w0 >> 19) & 3u;     // its RG_SEND_* flags
+            req[9] = (u32)w3;                  // its max_entries_per_msg
         }
         __syncthreads();
         if (req[1]) break;
@@ -729,7 +735,14 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs 
         RgMsgs m = ms;
         m.mhr = req[6] ? rh : ms.mh;
         const u32 s = req[0];
-        rg_flush_small_body<P, GC>(st, m, a, rh, mflags_rw, lo, stage);
+        if (req[7]) {
+            RgSmallSend ss = ss0;
+            ss.flags = req[8];
+            ss.max_entries = req[9] == 0xffffffffu ? ~0ULL : (u64)req[9];
+            rg_flush_small_body<P, GC, true>(st, m, a, rh, mflags_rw, lo, stage, &ss, &lds_cnt);
+        } else {
+            rg_flush_small_body<P, GC>(st, m, a, rh, mflags_rw, lo, stage);
+        }
         __threadfence_system(); // the packed results (pinned host memory) before the sequence word
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -917,7 +930,8 @@ void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs
 
 template <int P>
 void rg_launch_mailbox_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a0, u32 *ctr_base,
-                         u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks);
+                         u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks,
+                         const RgSmallSend &ss0);
 template <int P>
 void rg_launch_flush_small_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
                                   u64 *mflags_rw, const RgListOut &lo, const RgSmallSend &ss);
@@ -931,9 +945,10 @@ void rg_launch_flush_small_send_t(hipStream_t stream, const RgState &st, const R
 }
 template <int P>
 void rg_launch_mailbox_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a0, u32 *ctr_base,
-                         u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks) {
-    if (gc) hipLaunchKernelGGL((k_mailbox<P, true>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a0, ctr_base, rh, mflags_rw, lo, mb, idle_ticks, max_ticks);
-    else hipLaunchKernelGGL((k_mailbox<P, false>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a0, ctr_base, rh, mflags_rw, lo, mb, idle_ticks, max_ticks);
+                         u64 *rh, u64 *mflags_rw, const RgListOut &lo, RgMbox *mb, u64 idle_ticks, u64 max_ticks,
+                         const RgSmallSend &ss0) {
+    if (gc) hipLaunchKernelGGL((k_mailbox<P, true>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a0, ctr_base, rh, mflags_rw, lo, mb, idle_ticks, max_ticks, ss0);
+    else hipLaunchKernelGGL((k_mailbox<P, false>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a0, ctr_base, rh, mflags_rw, lo, mb, idle_ticks, max_ticks, ss0);
 }
 template <int P>
 void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
@@ -1008,54 +1023,54 @@ extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, con
 extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
 extern template void rg_launch_flush_small_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
-extern template void rg_launch_mailbox_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64);
+extern template void rg_launch_mailbox_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 #endif

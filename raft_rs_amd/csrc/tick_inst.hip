@@ -16,4 +16,4 @@ template void rg_launch_flush_small_t<RG_P>(hipStream_t, const RgState &, const 
 template void rg_launch_flush_small_send_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *,
                                                  const RgListOut &, const RgSmallSend &);
 template void rg_launch_mailbox_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *,
-                                        const RgListOut &, RgMbox *, u64, u64);
+                                        const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);

@@ -157,8 +157,8 @@ def test_random_api_sequences_match_the_oracle(rg, seed, P):
     eng.close()
 
 
-@pytest.mark.parametrize("seed,P,cap", [(11, 3, 2), (12, 5, 4)])
-def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
+@pytest.mark.parametrize("seed,P,cap,mailbox", [(11, 3, 2, False), (12, 5, 4, False), (13, 5, 3, True)])
+def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap, mailbox):
     """The same idea with the Inflights on the device: after every kind of tick the send stage (separately or inside
     rg_flush_send) must produce the oracle's send decisions, Progress columns and window contents."""
     import sendstage
@@ -175,6 +175,8 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
     eng.load_state(st)
     for g in range(G):
         eng.set_peers(g, list(range(1, P + 1)), TERM)
+    if mailbox:  # small rg_flush_send batches go through the resident workgroup; everything else makes it step aside
+        eng.mailbox_start()
     cl = O.Cluster(G)
     cl.load_soa(st, term=TERM, max_inflight=cap)
     cl.set_own_inflights(True)
@@ -242,4 +244,6 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap):
         meta, ring = eng.read_inflights()
         sendstage.compare_rings(cl, meta, ring, st, cap)
     assert n_items > 2000 and {"dense_send", "mirror_small_flush_send"} <= ops_seen, (n_items, ops_seen)
+    if mailbox:
+        assert eng.mailbox_stats()[0] > 0, "no flush was served by the resident workgroup"
     eng.close()

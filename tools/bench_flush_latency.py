@@ -102,4 +102,21 @@ for k in (1, 100, 1000):
         lat1.append(time.perf_counter() - t1)
     print(f"  k={k:6d}: {float(np.median(lat[5:]))*1e6:8.1f} us | {float(np.median(lat1[5:]))*1e6:8.1f} us "
           f"({len(items)} work items in the last round)")
+print("... and rg_flush_send with rg_mailbox_start (the resident workgroup runs the tick AND the send stage of a request):")
+eng.mailbox_start()
+for k in (1, 10, 50):
+    lat1 = []
+    for rep in range(40):
+        groups = rng.choice(G, size=k, replace=False)
+        idx = np.minimum(st["term_hi"][groups], st["match"][3, groups] + rep + 1)
+        for g, i in zip(groups.tolist(), idx.tolist()):
+            eng.step(g, 4, 4, i)
+        t1 = time.perf_counter()
+        eng.flush_send()
+        items = eng.send_items()
+        gr, commit, out = eng.ingested_results()
+        lat1.append(time.perf_counter() - t1)
+    print(f"  k={k:6d}: {float(np.median(lat1[5:]))*1e6:8.1f} us ({len(items)} work items in the last round; "
+          f"{eng.mailbox_stats()[0]} flushes served so far)")
+eng.mailbox_stop()
 eng.close()
