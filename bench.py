@@ -462,8 +462,12 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt.eng.close()
     gbs = nbytes / (us * 1e-6) / 1e9
     traffic, traffic_source = traffic_lookup(key)
-    return {"workload": workload_label(workload, n_groups, n_slots, one_engine) if what == "tick" else
-                        f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers",
+    label = (workload_label(workload, n_groups, n_slots, one_engine) if what == "tick" else
+             f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers")
+    if inflights:
+        label += (f" + Inflights (cap {inflights}) on the device and the send stage after every tick, " +
+                  ("tick and stage as ONE launch (rg_tick_device_send)" if fused_send else "as a launch of its own (rg_send_appends)"))
+    return {"workload": label,
             "groups": n_groups, "peer_slots": n_slots, "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
             "steps": steps, "warmup": warmup, "us_per_step": us, "value": n_groups / (us * 1e-6), "unit": unit, **extra,
             "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot, "achieved": gbs, "peak": HBM_PEAK_GBS,
