@@ -266,6 +266,59 @@ def test_mirror_steps_with_device_inflights(rg, one_call):
     eng.close()
 
 
+@pytest.mark.parametrize("mailbox", [False, True])
+def test_small_flush_send_with_the_byte_limit(rg, mailbox):
+    """rg_flush_send(RG_SEND_BYTES) for a handful of groups: the one-launch flush (k_flush_small_send) and the resident
+    mailbox workgroup carry the byte limit and the flags with the request. 100-byte entries, max_size_per_msg = 250:
+    util::limit_size keeps two entries per MsgAppend; a proposal's bcast_append is ONE send_append per peer (raft.rs:850-857),
+    so two of the five new entries go out now and the rest waits for the acks."""
+    G, P, cap = 64, 3, 8
+    eng = rg.Engine(G, P, max_inflight=cap)
+    st = O.alloc_state(G, P, stride=eng.stride)
+    st["match"][:, :G], st["next"][:, :G] = 10, 11
+    st["pr_commit"][:, :G] = 10
+    st["pflags"][:, :P] = rg.PF.REPLICATE | rg.PF.RECENT_ACTIVE
+    st["commit"][:], st["term_lo"][:], st["term_hi"][:] = 10, 1, 10
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    eng.load_state(st)
+    eng.log_sizes_enable(16)
+    for g in range(G):
+        eng.set_peers(g, [1, 2, 3], term=5)
+    if mailbox:
+        eng.mailbox_start()
+    touched = [3, 17, 40]
+    recs = np.zeros(len(touched) * 6, dtype=rg.engine.LOG_SIZE_DTYPE)
+    k = 0
+    for g in touched:  # cumulative sizes of entries 10 (the base of the sums) .. 15
+        for i in range(10, 16):
+            recs[k] = (g, i, 100 * (i - 9))
+            k += 1
+    eng.log_sizes_write(recs)
+    for g in touched:
+        eng.local_append(g, 15)
+    served0 = eng.mailbox_stats()[0]
+    eng.flush_send(max_bytes=250)  # (the first sparse flush of an engine takes the launch path: k_flush_small_send)
+    items = eng.send_items()
+    assert len(items) == 2 * len(touched) and sorted(set(items["group"].tolist())) == touched
+    assert (items["prev_index"] == 10).all() and (items["last_index"] == 12).all() and (items["n_msgs"] == 1).all()
+    assert eng.inflights(17, 1) == [12] and int(eng.read_column(rg.COL.NEXT)[2, 40]) == 13
+    # NO_LIMIT in bytes (UINT64_MAX) fits the request word as well: one message for the next proposal
+    recs = np.zeros(len(touched) * 2, dtype=rg.engine.LOG_SIZE_DTYPE)
+    for j, g in enumerate(touched):
+        recs[2 * j], recs[2 * j + 1] = (g, 16, 700), (g, 17, 800)
+    eng.log_sizes_write(recs)
+    for g in touched:
+        eng.local_append(g, 17)
+    eng.flush_send(max_bytes=O.U64_MAX)
+    items = eng.send_items()
+    assert len(items) == 2 * len(touched) and (items["n_msgs"] == 1).all()
+    assert (items["prev_index"] == 12).all() and (items["last_index"] == 17).all()
+    if mailbox:  # ... and the second one was answered by the resident workgroup
+        assert eng.mailbox_stats()[0] == served0 + 1
+        eng.mailbox_stop()
+    eng.close()
+
+
 def test_send_stage_serves_the_broadcast_after_recompute(rg):
     """post_conf_change (raft.rs:2618-2634): maybe_commit() on the new quorum, then bcast_append."""
     G, P, cap = 512, 3, 8
