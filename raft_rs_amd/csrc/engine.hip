@@ -2427,52 +2427,95 @@ static bool rg_pb_varint(const uint8_t *&p, const uint8_t *end, u64 &v) {
     return false;
 }
 
+// The message-typed and packed fields of eraftpb (proto/proto/eraftpb.proto:23-44, :71-92, :118-132): a real parser
+// descends into them, so bytes that are malformed INSIDE an entry or a snapshot fail the whole Message::parse_from_bytes.
+enum RgPbSchema { RG_PB_MESSAGE, RG_PB_ENTRY, RG_PB_SNAPSHOT, RG_PB_SNAPSHOT_META, RG_PB_CONF_STATE, RG_PB_OPAQUE };
+static int rg_pb_child(int schema, u64 field) { // >= 0: length-delimited `field` is a message of that schema; -1: bytes;
+    switch (schema) {                           // -2: a packed run of varints (repeated uint64)
+    case RG_PB_MESSAGE: return field == 7 ? RG_PB_ENTRY : field == 9 ? RG_PB_SNAPSHOT : -1;
+    case RG_PB_SNAPSHOT: return field == 2 ? RG_PB_SNAPSHOT_META : -1;
+    case RG_PB_SNAPSHOT_META: return field == 1 ? RG_PB_CONF_STATE : -1;
+    case RG_PB_CONF_STATE: return field >= 1 && field <= 4 ? -2 : -1;
+    default: return -1;
+    }
+}
+// Walk one message of `schema` in [p, end): structure only, except for the top-level Message, whose fields land in `out`.
+// `group` != 0: we are inside an unknown GROUP of that field number and stop at its END_GROUP tag.
+static bool rg_pb_walk(const uint8_t *&p, const uint8_t *end, int schema, rg_decoded_message *out, u64 group, int depth) {
+    if (depth > 64) return false;
+    while (p < end) {
+        u64 key, v;
+        if (!rg_pb_varint(p, end, key)) return false;
+        if (key > 0xffffffffULL) return false; // a tag is 32 bits: field numbers end at 2^29 - 1
+        const u64 field = key >> 3;
+        const u32 wt = (u32)(key & 7);
+        if (field == 0) return false;
+        switch (wt) {
+        case 0:
+            if (!rg_pb_varint(p, end, v)) return false;
+            if (out && schema == RG_PB_MESSAGE && !group) {
+                switch (field) {
+                case 1: out->msg_type = (uint32_t)v; break;
+                case 2: out->to = v; break;
+                case 3: out->from = v; break;
+                case 4: out->term = v; break;
+                case 5: out->log_term = v; break;
+                case 6: out->index = v; break;
+                case 8: out->commit = v; break;
+                case 10: out->reject = v != 0; break;
+                case 11: out->reject_hint = v; break;
+                case 13: out->request_snapshot = v; break;
+                case 14: out->priority = v; break;
+                case 15: out->commit_term = v; break;
+                default: break; // unknown varint field (or a known one of another wire type): skipped, like protobuf does
+                }
+            }
+            break;
+        case 1:
+            if (end - p < 8) return false;
+            p += 8;
+            break;
+        case 2: {
+            if (!rg_pb_varint(p, end, v) || v > (u64)(end - p)) return false;
+            const uint8_t *q = p, *qe = p + v;
+            const int child = group ? -1 : rg_pb_child(schema, field);
+            if (child >= 0) {
+                if (!rg_pb_walk(q, qe, child, nullptr, 0, depth + 1)) return false;
+            } else if (child == -2) {
+                while (q < qe) {
+                    u64 x;
+                    if (!rg_pb_varint(q, qe, x)) return false;
+                }
+            }
+            if (out && schema == RG_PB_MESSAGE && !group) {
+                if (field == 7) out->n_entries++;
+                else if (field == 9) out->has_snapshot = 1;
+                else if (field == 12) out->context_len = (uint32_t)v;
+            }
+            p = qe;
+            break;
+        }
+        case 3: // an unknown GROUP (deprecated; a conforming parser skips a well-formed one, nested groups included)
+            if (!rg_pb_walk(p, end, RG_PB_OPAQUE, nullptr, field, depth + 1)) return false;
+            break;
+        case 4: return group != 0 && field == group; // END_GROUP: it has to close THE group we are in
+        case 5:
+            if (end - p < 4) return false;
+            p += 4;
+            break;
+        default: return false;
+        }
+    }
+    return group == 0; // (inside a group: ran off the end)
+}
+
 extern "C" int rg_decode_message(const uint8_t *bytes, uint64_t len, rg_decoded_message *out) {
     if ((!bytes && len) || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: bad argument");
     memset(out, 0, sizeof(*out));
-    const uint8_t *p = bytes, *end = bytes + len;
-    while (p < end) {
-        u64 key;
-        if (!rg_pb_varint(p, end, key)) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated field key");
-        const u64 field = key >> 3;
-        const u32 wt = (u32)(key & 7);
-        if (field == 0) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: field number 0");
-        if (wt == 0) {
-            u64 v;
-            if (!rg_pb_varint(p, end, v)) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated varint");
-            switch (field) {
-            case 1: out->msg_type = (uint32_t)v; break;
-            case 2: out->to = v; break;
-            case 3: out->from = v; break;
-            case 4: out->term = v; break;
-            case 5: out->log_term = v; break;
-            case 6: out->index = v; break;
-            case 8: out->commit = v; break;
-            case 10: out->reject = v != 0; break;
-            case 11: out->reject_hint = v; break;
-            case 13: out->request_snapshot = v; break;
-            case 14: out->priority = v; break;
-            case 15: out->commit_term = v; break;
-            default: break; // unknown varint field: skipped, like protobuf does
-            }
-        } else if (wt == 2) {
-            u64 n;
-            if (!rg_pb_varint(p, end, n) || n > (u64)(end - p))
-                return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: length-delimited field runs past the end");
-            if (field == 7) out->n_entries++;
-            else if (field == 9) out->has_snapshot = 1;
-            else if (field == 12) out->context_len = (uint32_t)n;
-            p += n;
-        } else if (wt == 1) {
-            if (end - p < 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated fixed64");
-            p += 8;
-        } else if (wt == 5) {
-            if (end - p < 4) return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: truncated fixed32");
-            p += 4;
-        } else {
-            return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: wire type %u is not proto3", wt);
-        }
-    }
+    const uint8_t *p = bytes;
+    if (!rg_pb_walk(p, bytes + len, RG_PB_MESSAGE, out, 0, 0))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_decode_message: not a protobuf-encoded eraftpb::Message (malformed at byte %llu)",
+                       (unsigned long long)(p - bytes));
     return RG_OK;
 }
 

@@ -115,10 +115,27 @@ def main():
     base = bytes.fromhex(vectors[0]["hex"])
     vectors.append({"hex": (bytes([0x98, 0x06, 0x2A]) + bytes([0x9A, 0x06, 0x03, 1, 2, 3]) + base).hex(), "type": "unknown-fields",
                     "fields": vectors[0]["fields"]})
-    for bad, why in ((b"\x08", "truncated varint"), (b"\x3a\x7f\x00", "length past the end"), (b"\x0b\x00", "group wire type"),
-                     (b"\x00\x01", "field number 0"), (b"\x19\x01\x02", "truncated fixed64"),
-                     (b"\x08" + b"\xff" * 11, "varint longer than 10 bytes")):
+    # a well-formed unknown GROUP (field 20: START 0xa3 0x01, a varint field inside, END 0xa4 0x01) is skipped as well
+    vectors.append({"hex": (bytes([0xA3, 0x01, 0x08, 0x05, 0xA4, 0x01]) + base).hex(), "type": "unknown-group", "fields": vectors[0]["fields"]})
+    bad_cases = [(b"\x08", "truncated varint"), (b"\x3a\x7f\x00", "length past the end"), (b"\x0b\x00", "group that never ends"),
+                 (b"\x00\x01", "field number 0"), (b"\x19\x01\x02", "truncated fixed64"),
+                 (b"\x08" + b"\xff" * 11, "varint longer than 10 bytes"),
+                 (b"\x3a\x02\x10\x80", "an entry whose own bytes are malformed (truncated varint inside field 7)"),
+                 (b"\x4a\x04\x12\x02\x10\x80", "a snapshot whose metadata is malformed"),
+                 (b"\x80\x80\x80\x80\x10\x01", "a tag that does not fit 32 bits"),
+                 (b"\xa3\x01\x08\x05\xac\x01", "a group closed by another field's END_GROUP"), (b"\x0e\x00", "wire type 6")]
+    for bad, why in bad_cases:
+        try:  # the runtime is the judge of what is malformed
+            Message.FromString(bad)
+            raise SystemExit(f"the protobuf runtime ACCEPTS {why!r}: not an error vector")
+        except SystemExit:
+            raise
+        except Exception:
+            pass
         vectors.append({"hex": bad.hex(), "type": why, "error": True})
+    for v in vectors:
+        if not v.get("error"):
+            Message.FromString(bytes.fromhex(v["hex"]))  # (raises if the runtime disagrees)
     doc = {"source": "proto/proto/eraftpb.proto (enum MessageType :49-69, message Message :71-92), serialised by the protobuf "
                      "runtime from descriptors parsed out of that file (tests/golden/make_eraftpb_vectors.py)",
            "message_types": types, "message_fields": {n: num for _, _, n, num in messages["Message"]}, "vectors": vectors}
