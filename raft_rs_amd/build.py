@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libraftgroups.so")
-DEPS = ["engine.hip", "tick_inst.hip", "rg_common.h", "rg_group.h", "rg_send.h", "rg_workload.h", "rg_tick_kernels.h", "rg_publish.h",
+DEPS = ["engine.hip", "tick_inst.hip", "rg_common.h", "rg_group.h", "rg_send.h", "rg_wire.h", "rg_workload.h", "rg_tick_kernels.h", "rg_publish.h",
         os.path.join("..", "..", "include", "raftgroups.h")]
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
