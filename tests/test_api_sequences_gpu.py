@@ -2,6 +2,8 @@
 the RawNode::step mirror with dense and sparse flushes, rg_recompute, checkpoint/restore -- checking the state
 columns, RG_COL_OUT and the compact results after every step. Catches host-side bookkeeping slips (which result
 words are stale, which caches are valid) that single-path tests cannot see."""
+import os
+
 import numpy as np
 import pytest
 
@@ -157,7 +159,12 @@ def test_random_api_sequences_match_the_oracle(rg, seed, P):
     eng.close()
 
 
-@pytest.mark.parametrize("seed,P,cap,mailbox", [(11, 3, 2, False), (12, 5, 4, False), (13, 5, 3, True)])
+# RG_SOAK_SEEDS=n adds n more seeded cases (P, window depth and mailbox use derived from the seed): an ad hoc soak
+_SEND_CASES = [(11, 3, 2, False), (12, 5, 4, False), (13, 5, 3, True)] + [
+    (100 + i, 2 + i % 7, 1 + (i * 5) % 9, i % 2 == 0) for i in range(int(os.environ.get("RG_SOAK_SEEDS", "0")))]
+
+
+@pytest.mark.parametrize("seed,P,cap,mailbox", _SEND_CASES)
 def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap, mailbox):
     """The same idea with the Inflights on the device: after every kind of tick the send stage (separately or inside
     rg_flush_send) must produce the oracle's send decisions, Progress columns and window contents."""
