@@ -139,7 +139,10 @@ def main():
     doc = {"source": "proto/proto/eraftpb.proto (enum MessageType :49-69, message Message :71-92), serialised by the protobuf "
                      "runtime from descriptors parsed out of that file (tests/golden/make_eraftpb_vectors.py)",
            "message_types": types, "message_fields": {n: num for _, _, n, num in messages["Message"]}, "vectors": vectors}
-    text = json.dumps(doc, indent=0, sort_keys=True) + "\n"
+    # one vector per line: a 250-line fixture instead of a 5 000-line one
+    head = {k: v for k, v in doc.items() if k != "vectors"}
+    text = (json.dumps(head, sort_keys=True)[:-1] + ', "vectors": [\n' +
+            ",\n".join(json.dumps(v, sort_keys=True) for v in vectors) + "\n]}\n")
     if "--check" in sys.argv:
         sys.exit(0 if open(OUT).read() == text else 1)
     open(OUT, "w").write(text)
