@@ -478,6 +478,20 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                                      "understates this mode -- the stage has its own roofline under send_stage"} if inflights else {})}}
 
 
+def guarded(fn, *a, **kw):
+    """A side measurement must never cost the headline its JSON line: whatever goes wrong in it (a device out of memory on
+    a shared box, a fault the stream check raises) is reported in its place."""
+    try:
+        return fn(*a, **kw)
+    except (Exception, SystemExit) as e:  # noqa: BLE001
+        try:
+            import torch
+            torch.cuda.empty_cache()
+        except Exception:  # noqa: BLE001
+            pass
+        return {"error": f"{type(e).__name__}: {e}"[:500]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -873,11 +887,11 @@ def main():
         wl = args.workload if args.workload != 5 else 2
         # the literal BASELINE metric ("commit-index recomputes/sec"): Raft::maybe_commit for every group, no messages --
         # at BASELINE's size (77 MB working set: an Infinity-Cache number) and at 8 M groups (616 MB: an HBM number)
-        result["recompute_only"] = run_config(rg, torch, G, P, wl, 5, 50, args.seed, what="recompute")
-        result["recompute_only_out_of_cache"] = run_config(rg, torch, args.out_of_cache_groups, P, wl, 3, 20, args.seed,
+        result["recompute_only"] = guarded(run_config, rg, torch, G, P, wl, 5, 50, args.seed, what="recompute")
+        result["recompute_only_out_of_cache"] = guarded(run_config, rg, torch, args.out_of_cache_groups, P, wl, 3, 20, args.seed,
                                                            what="recompute")
         # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
-        result["out_of_cache"] = run_config(rg, torch, args.out_of_cache_groups, P, wl, 3, 12, args.seed)
+        result["out_of_cache"] = guarded(run_config, rg, torch, args.out_of_cache_groups, P, wl, 3, 12, args.seed)
         # every other BASELINE configuration that fits one GPU, each with its own roofline object (driver-timed like the
         # headline): configs[2] joint, one rank's shard of configs[3], configs[4] in both layouts, and configs[1] with the
         # Inflights on the device and the send stage after every tick
@@ -893,13 +907,13 @@ def main():
             if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") \
                     and kw.get("variant", 0) == args.variant and kw.get("one_engine", False) == args.one_engine:
                 continue  # that is the headline itself
-            oc[name] = run_config(rg, torch, warmup=5, steps=30, seed=args.seed, **kw)
+            oc[name] = guarded(run_config, rg, torch, warmup=5, steps=30, seed=args.seed, **kw)
             torch.cuda.empty_cache()
         result["other_configs"] = oc
         # the other end of the scale: the round trip of a flush that touches 1 / 10 groups (not a throughput number)
-        result["small_batch_latency"] = small_batch_latency(rg, torch, G, P, args.seed)
+        result["small_batch_latency"] = guarded(small_batch_latency, rg, torch, G, P, args.seed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_groups, G), P, args.workload,
+        result["cpu_baseline"] = guarded(cpu_baseline, min(args.cpu_sample_groups, G), P, args.workload,
                                               args.cpu_sample_ticks, args.seed, os.cpu_count() or 1)
     elif rank == 0:
         result["cpu_baseline"] = None
