@@ -6,6 +6,10 @@
 #include "rg_group.h"
 #include "rg_send.h"
 
+#ifndef RG_SEND_NT_ITEMS /* 1: the work-item columns (written once per stage, read by the message builder) as non-temporal stores:
+                            they stop evicting the tick's state from the Infinity Cache (profiles/r03_tick_send.txt, call r) */
+#define RG_SEND_NT_ITEMS 1
+#endif
 #ifndef RG_TS_ORDER /* k_tick_send: 1 = the tick's stores are issued before the stage's loads (experiment) */
 #define RG_TS_ORDER 0
 #endif
@@ -229,7 +233,7 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
     for (int s = 0; s < P; s++) {
         const IX o = (IX)s * (IX)stride + g;
         const u32 nk = rg_send_nk<P>(it, s);
-        rg_at(oc.n, o) = nk; // every cell, every stage: 0 = nothing for this peer
+        rg_st(rg_at(oc.n, o), nk, RG_SEND_NT_ITEMS != 0); // every cell, every stage: 0 = nothing for this peer
         // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
         // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -238,8 +242,8 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
         const bool any = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
 #endif
         if (any) {
-            rg_at(oc.prev, o) = nk ? it.prev[s] : 0ULL;
-            rg_at(oc.last, o) = nk ? it.last[s] : 0ULL;
+            rg_st(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0, RG_SEND_NT_ITEMS != 0);
+            rg_st(rg_at(oc.last, o), nk ? it.last[s] : (u64)0, RG_SEND_NT_ITEMS != 0);
         }
     }
 }
