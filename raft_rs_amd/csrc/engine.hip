@@ -827,6 +827,7 @@ struct rg_engine {
     std::vector<rg_send_item> host_items; // items of the last stage when rg_flush_send fetched them
     bool host_items_valid;
     char *pin_send;    // pinned host: u32 count | pad | rg_send_item[RG_SEND_SPEC] (small stages: one round trip)
+    bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool send_ready;   // a tick ran since the last rg_send_appends
     bool ckpt_send_ready;
     bool ckpt_any_group_commit;
@@ -1020,6 +1021,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     h->send_ready = false;
+    // Infinity Cache (256 MB on MI355X): when the state a dense tick re-reads (24 P + 40 B per group) and the message columns of
+    // ONE tick (16 P + 8 B per group, read once) do not fit together, the messages are streamed past it
+    // (with the Inflights on the device a step also touches the window and work-item columns: 40 P B per group more)
+    h->nt_msgs = (double)h->G * (double)(40u * h->P + 48u + (cfg->max_inflight ? 40u * h->P : 0u)) > 256.0 * 1024.0 * 1024.0;
+    if (const char *e = getenv("RG_NT_MSGS")) h->nt_msgs = atoi(e) != 0; // (measurement hook)
     h->send_bound = 0;
     h->pin_send = nullptr;
     h->host_items_valid = false;
@@ -1373,8 +1379,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
     }
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
-    const u32 variant = (h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
-                            ? h->cfg.variant : RG_VARIANT_LANE;
+    const u32 variant = ((h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
+                             ? h->cfg.variant : RG_VARIANT_LANE) | (h->nt_msgs ? RG_VARIANT_NT_MSGS : 0u);
 #ifdef RG_CPT_MEASURE /* measurement builds only: see k_tick_compact */
     RgState st_m = h->st;
     if (!st_m.pub) {

@@ -64,20 +64,20 @@ static inline unsigned rg_grid_for(u64 n, unsigned per_block) { return (unsigned
 // ------------------------------------------------------------------------------------------------
 // kernels: the tick (RG_VARIANT_LANE)
 // ------------------------------------------------------------------------------------------------
-template <typename T> RG_HD T rg_ld_stream(const T *p) { // read-once data: keep it out of L2/MALL
-#if RG_OPT_NT_MSG
-    return __builtin_nontemporal_load(p);
-#else
+// NTM: non-temporal. Chosen per launch (rg_launch_tick_t): where an engine's state and one tick of messages together
+// straddle the 256 MB Infinity Cache, streaming the messages keeps the state resident (1.5 M x 5: 86 -> 82 us, config 5 in one
+// 7-slot engine: 117 -> 109); where everything fits anyway (1 M x 5) it costs 0.8 % (profiles/r03_nt_messages.txt).
+template <bool NTM = (RG_OPT_NT_MSG != 0), typename T> RG_HD T rg_ld_stream(const T *p) { // read-once data: keep it out of L2/MALL
+    if (NTM) return __builtin_nontemporal_load(p);
     return *p;
-#endif
 }
 
 // The flag rows and the cfg word go first: rg_prefetch_rare decides from them alone, so its loads can be issued
 // while the bulk loads below are still in flight (memory returns a wave's loads in order).
-template <int P, int NXM, typename IX>
+template <int P, int NXM, typename IX, bool NTM = (RG_OPT_NT_MSG != 0)>
 RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
     constexpr bool LOAD_NX = NXM == RG_NX_LOADED;
-    r.mf = rg_ld_stream(&rg_at(ms.mflags, g));
+    r.mf = rg_ld_stream<NTM>(&rg_at(ms.mflags, g));
     r.pf = rg_at(st.pflags, g);
     r.cfg = rg_at(st.cfg, g);
     r.commit = rg_at(st.commit, g);
@@ -90,8 +90,8 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
         r.mt[p] = rg_at(st.match, o);
         if (LOAD_NX) r.nx[p] = rg_at(st.next, o);
         r.pc[p] = rg_at(st.prc, o);
-        r.mi[p] = rg_ld_stream(&rg_at(ms.mi, o));
-        r.mc[p] = rg_ld_stream(&rg_at(ms.mc, o));
+        r.mi[p] = rg_ld_stream<NTM>(&rg_at(ms.mi, o));
+        r.mc[p] = rg_ld_stream<NTM>(&rg_at(ms.mc, o));
     }
     if (NXM == RG_NX_PREFETCH) rg_prefetch_rare<P, IX>(r, st, ms, g);
 }
@@ -143,7 +143,8 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
 
 template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u64 &cfg_adv, F &&f);
 // IX = u32 when every cell of the engine's columns lies within 4 GiB of its column's start (rg_launch_tick_t decides).
-template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
+// NTM: the read-once message columns as non-temporal loads (rg_ld_stream; decided per launch from the engine's footprint)
+template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
@@ -152,7 +153,7 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_lan
     asm volatile("" ::"v"((u32)(uintptr_t)&occ_pad[threadIdx.x]));
 #endif
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    rg_load_group<P, RG_LANE_NX, IX, NTM || (RG_OPT_NT_MSG != 0)>(r, st, ms, g);
 #if defined(RG_LANE_FENCE) && defined(__HIP_DEVICE_COMPILE__) /* experiment: keep the compiler from interleaving the tick with the loads */
 #if RG_LANE_FENCE == 1
     asm volatile("" ::: "memory");
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgState st,
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
+    rg_load_group<P, RG_LANE_NX, IX, true>(r, st, ms, g); // (message columns streamed: an engine with device Inflights is past the cache at any size that matters)
     RgSendRegs<P> it;
 #if RG_TS_SPEC == 2
     rg_group_tick_send<P, GC, IX>(r, st, ms, ins, g, max_entries, flags, it, &win, lane);
@@ -920,6 +921,7 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
+#define RG_VARIANT_NT_MSGS 0x100u /* engine-internal flag on the variant word: stream the message columns (k_tick_lane<.., NTM>) */
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
@@ -960,7 +962,17 @@ void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs
     if (gc) hipLaunchKernelGGL((k_flush_small<P, true>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a, rh, mflags_rw, lo);
     else hipLaunchKernelGGL((k_flush_small<P, false>), dim3(1), dim3(RG_INGEST_BLOCK), 0, stream, st, ms, a, rh, mflags_rw, lo);
 }
+// (the group-commit instantiation has no streaming twin: it is the rare kernel and twice the code)
+#define RG_LAUNCH_LANE(IXT)                                                                                                       \
+    do {                                                                                                                          \
+        if (ntm && !GC)                                                                                                           \
+            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, !GC>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, false>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+    } while (0)
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
+    const bool ntm = (variant & RG_VARIANT_NT_MSGS) != 0;
+    variant &= ~RG_VARIANT_NT_MSGS;
     if (variant == RG_VARIANT_LDS) {
         hipLaunchKernelGGL((k_tick_lds<P, GC, false>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
@@ -974,9 +986,9 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
     } else {
         // 32-bit cell offsets when every cell a lane addresses is below 4 GiB from its column's start
         if (rg_ix32(P, st.stride))
-            hipLaunchKernelGGL((k_tick_lane<P, GC, u32>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
+            RG_LAUNCH_LANE(u32);
         else
-            hipLaunchKernelGGL((k_tick_lane<P, GC, u64>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms);
+            RG_LAUNCH_LANE(u64);
     }
 }
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc) {

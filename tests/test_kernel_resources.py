@@ -36,8 +36,8 @@ def resource_usage(p):
 
 def test_tick_kernels_keep_their_register_budget():
     rows = resource_usage(5)
-    lane = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjE" in k)    # 32-bit cell offsets: what the bench runs
-    lane64 = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EmE" in k)  # engines beyond 4 GiB per column
+    lane = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLb0EE" in k)    # 32-bit cell offsets: what the bench runs
+    lane64 = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EmLb0EE" in k)  # engines beyond 4 GiB per column
     lst = next(v for k, v in rows.items() if "k_tick_listILi5ELb0E" in k)
     fused = next(v for k, v in rows.items() if "k_tick_fusedILi5ELb0E" in k)
     # the dense sweep is the bandwidth-bound kernel: 4 waves/SIMD. (Round 2 added the election event, the publication
@@ -45,6 +45,8 @@ def test_tick_kernels_keep_their_register_budget():
     # the `SGPR base + 32-bit offset` addressing of rg_at paid for their registers: profiles/r02_*.)
     assert int(lane["VGPRs"]) <= 128 and int(lane["Occupancy [waves/SIMD]"]) >= 4, lane
     assert int(lane64["Occupancy [waves/SIMD]"]) >= 3, lane64
+    lane_nt = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLb1EE" in k)  # message columns streamed (large engines)
+    assert int(lane_nt["VGPRs"]) <= 128 and int(lane_nt["ScratchSize [bytes/lane]"]) == 0, lane_nt
     # the sparse-path kernel carries the list / result pointers on top; round 3 (the term-run table read from memory
     # behind the stores instead of prefetched into registers) brought it to 4 waves as well
     assert int(lst["VGPRs"]) <= 128 and int(lst["Occupancy [waves/SIMD]"]) >= 4, lst
@@ -60,5 +62,5 @@ def test_occupancy_of_the_other_slot_counts():
     # P = 3 runs at 5 waves/SIMD, P = 7 (config 4's shard) at 3
     for p, waves in ((3, 5), (7, 3)):
         rows = resource_usage(p)
-        lane = next(v for k, v in rows.items() if f"k_tick_laneILi{p}ELb0EjE" in k)
+        lane = next(v for k, v in rows.items() if f"k_tick_laneILi{p}ELb0EjLb0EE" in k)
         assert int(lane["Occupancy [waves/SIMD]"]) >= waves and int(lane["ScratchSize [bytes/lane]"]) == 0, (p, lane)
