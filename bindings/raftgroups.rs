@@ -180,6 +180,40 @@ pub struct RgDecodedMessage {
 }
 
 #[repr(C)]
+pub struct RgEntry {
+    pub entry_type: u32,
+    pub sync_log: u32,
+    pub term: u64,
+    pub index: u64,
+    pub data: *const u8,
+    pub data_len: u64,
+    pub context: *const u8,
+    pub context_len: u64,
+}
+
+#[repr(C)]
+pub struct RgMessage {
+    pub msg_type: u32,
+    pub reject: u32,
+    pub to: u64,
+    pub from: u64,
+    pub term: u64,
+    pub log_term: u64,
+    pub index: u64,
+    pub commit: u64,
+    pub commit_term: u64,
+    pub reject_hint: u64,
+    pub request_snapshot: u64,
+    pub priority: u64,
+    pub entries: *const RgEntry,
+    pub n_entries: u64,
+    pub snapshot: *const u8,
+    pub snapshot_len: u64,
+    pub context: *const u8,
+    pub context_len: u64,
+}
+
+#[repr(C)]
 pub struct RgSendItem {
     pub group: u64,
     pub prev_index: u64,
@@ -305,6 +339,10 @@ extern "C" {
     pub fn rg_step_heartbeat_response(h: *mut RgEngine, group: u64, from: u64, term: u64, commit: u64, ins_full: u8) -> i32;
     pub fn rg_decode_message(bytes: *const u8, len: u64, out: *mut RgDecodedMessage) -> i32;
     pub fn rg_step_bytes(h: *mut RgEngine, group: u64, bytes: *const u8, len: u64) -> i32;
+    pub fn rg_entry_size(e: *const RgEntry) -> u64;
+    pub fn rg_limit_size(entries: *const RgEntry, n: u64, max_size: u64) -> u64;
+    pub fn rg_message_size(m: *const RgMessage, len: *mut u64) -> i32;
+    pub fn rg_encode_message(m: *const RgMessage, buf: *mut u8, cap: u64, len: *mut u64) -> i32;
     pub fn rg_local_append(h: *mut RgEngine, group: u64, new_last_index: u64) -> i32;
     pub fn rg_local_persisted(h: *mut RgEngine, group: u64, index: u64) -> i32;
     pub fn rg_mark_sent(h: *mut RgEngine, group: u64, peer_id: u64) -> i32;

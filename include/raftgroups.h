@@ -357,6 +357,49 @@ typedef struct {
 } rg_decoded_message;
 int rg_decode_message(const uint8_t *bytes, uint64_t len, rg_decoded_message *out);
 int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len);
+
+/* ---- the other side of the path: the messages a leader SENDS, as the bytes a transport takes ----
+ * The send stage (below) decides WHAT goes to each peer -- `prev_index`, `last_index`, how many messages -- and leaves
+ * the building to the host, which owns the log: Raft::maybe_send_append -> prepare_send_entries (src/raft.rs:714-731:
+ * msg_type = MsgAppend, index = next_idx - 1, log_term = term(index), entries, commit = raft_log.committed) -> Raft::send
+ * (:602-662: from = self.id, term = self.term) -> Message::write_to_bytes. These three calls are that last step and the
+ * arithmetic both sides have to agree on; pure host code (no engine, no device), like rg_decode_message.
+ * Serialisation is canonical proto3 (fields in field-number order, defaults omitted): byte for byte what the protobuf
+ * runtime writes for eraftpb.proto:23-31, :71-92, and what any protobuf parser -- rust-protobuf and prost included -- reads
+ * back into the same Message. */
+typedef struct {
+    uint32_t entry_type; /* eraftpb::EntryType: 0 EntryNormal, 1 EntryConfChange, 2 EntryConfChangeV2 */
+    uint32_t sync_log;   /* Entry.sync_log (bool) */
+    uint64_t term, index;
+    const uint8_t *data;    /* Entry.data (may be NULL when data_len == 0) */
+    uint64_t data_len;
+    const uint8_t *context; /* Entry.context */
+    uint64_t context_len;
+} rg_entry;
+/* Entry::compute_size(): the number util::limit_size adds up (src/util.rs:52-76) -- what rg_log_sizes_write wants
+ * accumulated per group for RG_SEND_BYTES. Entry::default() is 0 bytes. */
+uint64_t rg_entry_size(const rg_entry *e);
+/* util::limit_size(entries, Some(max_size)) (src/util.rs:52-76; RaftLog::entries / Storage::entries apply it): how many of
+ * the n entries ONE message keeps. n <= 1 and UINT64_MAX (NO_LIMIT) keep all; the first entry always stays, and so does
+ * whatever follows while the running total is still 0. The device's RG_SEND_BYTES stage counts messages with the same rule. */
+uint64_t rg_limit_size(const rg_entry *entries, uint64_t n, uint64_t max_size);
+typedef struct {
+    uint32_t msg_type; /* eraftpb::MessageType (MsgAppend 3, MsgSnapshot 7, MsgHeartbeat 8, MsgTimeoutNow 14, ...) */
+    uint32_t reject;
+    uint64_t to, from, term, log_term, index, commit, commit_term, reject_hint, request_snapshot, priority;
+    const rg_entry *entries; /* repeated Entry entries = 7 */
+    uint64_t n_entries;
+    const uint8_t *snapshot; /* Snapshot snapshot = 9: an already serialised eraftpb::Snapshot (the storage's), NULL = none */
+    uint64_t snapshot_len;
+    const uint8_t *context;  /* bytes context = 12 */
+    uint64_t context_len;
+} rg_message;
+/* Message::compute_size() -> *len. RG_ERR_INVALID_ARG: a length without its pointer, or more than a protobuf message may
+ * hold (2 GiB - 1). */
+int rg_message_size(const rg_message *m, uint64_t *len);
+/* Message::write_to_bytes into buf[cap]. *len (required) always receives the size; nothing is written and
+ * RG_ERR_INVALID_ARG is returned when cap is smaller (call with cap = 0 to size a buffer). */
+int rg_encode_message(const rg_message *m, uint8_t *buf, uint64_t cap, uint64_t *len);
 /* Leader-local events, queued the same way (src/raft.rs:976-1016). */
 int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index);
 int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index);

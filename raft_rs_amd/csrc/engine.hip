@@ -2432,6 +2432,31 @@ extern "C" int rg_decode_message(const uint8_t *bytes, uint64_t len, rg_decoded_
     return RG_OK;
 }
 
+// ---- ... and onto the wire: the encoder is rg_wire.h as well (host code; nothing here touches an engine) ----
+extern "C" uint64_t rg_entry_size(const rg_entry *e) { return e ? rg_wire_entry_size(e) : 0; }
+
+extern "C" uint64_t rg_limit_size(const rg_entry *entries, uint64_t n, uint64_t max_size) {
+    return entries ? rg_wire_limit_size(entries, n, max_size) : 0;
+}
+
+extern "C" int rg_message_size(const rg_message *m, uint64_t *len) {
+    if (!m || !len) return rg_fail(RG_ERR_INVALID_ARG, "rg_message_size: bad argument");
+    if (!rg_wire_message_size(m, len))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_message_size: a length without its pointer, or more than 2 GiB - 1 bytes");
+    return RG_OK;
+}
+
+extern "C" int rg_encode_message(const rg_message *m, uint8_t *buf, uint64_t cap, uint64_t *len) {
+    if (!m || !len || (!buf && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_encode_message: bad argument");
+    if (!rg_wire_message_size(m, len))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_encode_message: a length without its pointer, or more than 2 GiB - 1 bytes");
+    if (cap < *len)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_encode_message: %llu bytes needed, the buffer holds %llu",
+                       (unsigned long long)*len, (unsigned long long)cap);
+    rg_wire_encode(m, buf);
+    return RG_OK;
+}
+
 extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len) {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_bytes: bad argument");
     rg_decoded_message m;

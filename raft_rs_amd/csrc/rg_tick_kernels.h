@@ -430,7 +430,7 @@ __global__ RG_CPT_BOUNDS void k_tick_compact(RgState st, RgMsgs ms) {
         }
     }
 #else
-    (void)x_rare; (void)x_disp; (void)cnt; (void)wave; (void)lane; (void)wd;
+    (void)x_rare; (void)x_disp; (void)cnt; (void)wave; (void)lane; (void)wd; (void)cand;
 #endif
     if (!valid) return;
     const IX g = (IX)g64;

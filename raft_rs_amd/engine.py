@@ -119,6 +119,20 @@ class DecodedMessage(C.Structure):
                 ("context_len", C.c_uint32)]
 
 
+class EntryC(C.Structure):
+    """rg_entry: one eraftpb::Entry handed to the encoder (rg_entry_size / rg_limit_size / rg_encode_message)."""
+    _fields_ = [("entry_type", C.c_uint32), ("sync_log", C.c_uint32), ("term", C.c_uint64), ("index", C.c_uint64),
+                ("data", C.c_char_p), ("data_len", C.c_uint64), ("context", C.c_char_p), ("context_len", C.c_uint64)]
+
+
+class MessageC(C.Structure):
+    """rg_message: an outgoing eraftpb::Message (rg_message_size / rg_encode_message)."""
+    _fields_ = [("msg_type", C.c_uint32), ("reject", C.c_uint32), ("to", C.c_uint64), ("from_", C.c_uint64),
+                ("term", C.c_uint64), ("log_term", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64),
+                ("commit_term", C.c_uint64), ("reject_hint", C.c_uint64), ("request_snapshot", C.c_uint64),
+                ("priority", C.c_uint64), ("entries", C.POINTER(EntryC)), ("n_entries", C.c_uint64),
+                ("snapshot", C.c_char_p), ("snapshot_len", C.c_uint64), ("context", C.c_char_p), ("context_len", C.c_uint64)]
+
 
 class WireMsg(C.Structure):
     _fields_ = [("group", C.c_uint64), ("index", C.c_uint64), ("commit", C.c_uint64), ("hint", C.c_uint64),
@@ -227,6 +241,10 @@ SYMBOLS = {
     "rg_step": (_i, [_vp, _u64, C.POINTER(AppendResponse)]),
     "rg_step_bytes": (_i, [_vp, _u64, C.c_char_p, _u64]),
     "rg_decode_message": (_i, [C.c_char_p, _u64, C.POINTER(DecodedMessage)]),
+    "rg_entry_size": (_u64, [C.POINTER(EntryC)]),
+    "rg_limit_size": (_u64, [C.POINTER(EntryC), _u64, _u64]),
+    "rg_message_size": (_i, [C.POINTER(MessageC), C.POINTER(C.c_uint64)]),
+    "rg_encode_message": (_i, [C.POINTER(MessageC), C.c_char_p, _u64, C.POINTER(C.c_uint64)]),
     "rg_local_append": (_i, [_vp, _u64, _u64]),
     "rg_local_persisted": (_i, [_vp, _u64, _u64]),
     "rg_mark_sent": (_i, [_vp, _u64, _u64]),
@@ -793,3 +811,55 @@ def decode_message(data):
     if rc != 0:
         raise EngineError(rc, L.rg_last_error().decode())
     return {k.rstrip("_"): int(getattr(m, k)) for k, _ in DecodedMessage._fields_}
+
+
+def _entries_c(entries):
+    """[{entry_type, term, index, data, context, sync_log}] -> (EntryC array, keep-alive list)."""
+    arr = (EntryC * max(1, len(entries)))()
+    keep = []
+    for a, e in zip(arr, entries):
+        d, c = bytes(e.get("data", b"")), bytes(e.get("context", b""))
+        keep += [d, c]
+        a.entry_type, a.sync_log = int(e.get("entry_type", 0)), int(bool(e.get("sync_log", False)))
+        a.term, a.index = int(e.get("term", 0)), int(e.get("index", 0))
+        a.data, a.data_len, a.context, a.context_len = (d or None), len(d), (c or None), len(c)
+    return arr, keep
+
+
+def entry_size(entry):
+    """rg_entry_size: Entry::compute_size()."""
+    arr, _keep = _entries_c([entry])
+    return int(load_library().rg_entry_size(arr))
+
+
+def limit_size(entries, max_size):
+    """rg_limit_size: how many of `entries` one message keeps under util::limit_size(max_size) (None = NO_LIMIT)."""
+    arr, _keep = _entries_c(entries)
+    return int(load_library().rg_limit_size(arr, len(entries), (1 << 64) - 1 if max_size is None else int(max_size)))
+
+
+def encode_message(fields, entries=(), snapshot=None, context=b"", cap=None):
+    """rg_encode_message: an outgoing eraftpb::Message -> bytes. `fields`: the scalar fields by their .proto names;
+    `snapshot`: an already serialised eraftpb::Snapshot or None; `cap`: buffer size to offer (default: exactly enough)."""
+    L = load_library()
+    arr, _keep = _entries_c(list(entries))
+    m = MessageC()
+    for k, v in fields.items():
+        setattr(m, "from_" if k == "from" else k, int(v))
+    m.entries, m.n_entries = arr, len(entries)
+    ctx = bytes(context)
+    m.context, m.context_len = (ctx or None), len(ctx)
+    if snapshot is not None:
+        snap = bytes(snapshot)
+        # (c_char_p(b"") is a valid non-NULL pointer: a present, empty Snapshot)
+        m.snapshot, m.snapshot_len = snap, len(snap)
+    n = C.c_uint64(0)
+    rc = L.rg_message_size(C.byref(m), C.byref(n))
+    if rc != 0:
+        raise EngineError(rc, L.rg_last_error().decode())
+    size = n.value if cap is None else int(cap)
+    buf = C.create_string_buffer(max(1, size))
+    rc = L.rg_encode_message(C.byref(m), buf, size, C.byref(n))
+    if rc != 0:
+        raise EngineError(rc, L.rg_last_error().decode())
+    return buf.raw[:n.value]

@@ -144,9 +144,11 @@ def test_decoder_agrees_with_the_protobuf_runtime_on_mutated_bytes(rg):
     assert n_ok > 3000
 
 
-def test_decoder_is_clean_under_the_sanitisers(tmp_path):
-    """raft_rs_amd/csrc/rg_wire.h -- the very code rg_decode_message runs -- built with -fsanitize=address,undefined and fed
-    every golden vector plus 300 seeded mutations of each, every input in a heap buffer of exactly its length."""
+def test_wire_code_is_clean_under_the_sanitisers(tmp_path):
+    """raft_rs_amd/csrc/rg_wire.h -- the very code rg_decode_message and rg_encode_message run -- built with
+    -fsanitize=address,undefined: the decoder over every golden vector (incoming and outgoing) plus 300 seeded mutations of
+    each, every input in a heap buffer of exactly its length; the encoder over 20 000 seeded messages into output buffers of
+    exactly the computed size, read back by the decoder."""
     import shutil
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
@@ -157,9 +159,138 @@ def test_decoder_is_clean_under_the_sanitisers(tmp_path):
     if r.returncode != 0 and "asan" in r.stdout.lower():
         pytest.skip("no sanitiser runtime on this host: " + r.stdout[-200:])
     assert r.returncode == 0, r.stdout
-    feed = "\n".join(v["hex"] for v in DOC["vectors"]) + "\n"
-    r = subprocess.run([exe, "300"], input=feed, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0 and "WIRE_ASAN_OK" in r.stdout, r.stdout[-2000:]
+    feed = "\n".join(v["hex"] for v in DOC["vectors"] + OUT_DOC["vectors"]) + "\n"
+    r = subprocess.run([exe, "300", "20000"], input=feed, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "WIRE_ASAN_OK" in r.stdout and "encoded 20000" in r.stdout, r.stdout[-2000:]
+
+
+# ---- the other direction: rg_encode_message / rg_entry_size / rg_limit_size (what the path SENDS) ----
+OUT_DOC = json.load(open(os.path.join(HERE, "golden", "eraftpb_outgoing.json")))
+
+
+def _entries_of(v):
+    return [dict(e, data=bytes.fromhex(e.get("data", "")), context=bytes.fromhex(e.get("context", ""))) for e in v["entries"]]
+
+
+def _encode_vector(v, **kw):
+    from raft_rs_amd.engine import encode_message
+    return encode_message(v["message"], _entries_of(v), snapshot=None if v["snapshot"] is None else bytes.fromhex(v["snapshot"]),
+                          context=bytes.fromhex(v["context"]), **kw)
+
+
+def test_encoder_reproduces_every_outgoing_vector(rg):
+    """rg_encode_message writes, byte for byte, what the protobuf runtime serialised for the same message (entries with their
+    payloads, a present-but-empty snapshot, every message type); rg_entry_size is the runtime's Entry.ByteSize() =
+    Entry::compute_size(); and the decoder of the input side reads the scalar fields back."""
+    from raft_rs_amd.engine import decode_message, entry_size
+    n_ent = n_snap = 0
+    for v in OUT_DOC["vectors"]:
+        assert _encode_vector(v).hex() == v["hex"], v["type"]
+        assert [entry_size(e) for e in _entries_of(v)] == v["entry_sizes"]
+        back = decode_message(bytes.fromhex(v["hex"]))
+        for k, want in v["message"].items():
+            assert back[k] == want, (k, v["type"])
+        assert back["n_entries"] == len(v["entries"]) and back["has_snapshot"] == int(v["snapshot"] is not None)
+        n_ent += len(v["entries"])
+        n_snap += v["snapshot"] is not None
+    assert len(OUT_DOC["vectors"]) >= 200 and n_ent > 200 and n_snap > 20
+    assert entry_size({}) == 0  # Entry::default()
+
+
+def test_limit_size_is_the_references(rg):
+    """rg_limit_size against util::limit_size (src/util.rs:52-76) restated literally by the vector generator: around every
+    boundary of every vector's entry sizes (incl. Entry::default() runs, where the running total is still 0), NO_LIMIT,
+    and the function's own doc example (five 100-byte entries: Some(220) keeps 2, Some(0) keeps 1)."""
+    from raft_rs_amd.engine import limit_size
+    for c in OUT_DOC["limit_size"]:
+        ents = _entries_of(OUT_DOC["vectors"][c["vector"]])
+        assert limit_size(ents, c["max"]) == c["keep"], c
+    assert len(OUT_DOC["limit_size"]) > 400
+    ex = OUT_DOC["limit_size_doc_example"]
+    ents = [{"data": bytes.fromhex(ex["entry"]["data"])}] * ex["n"]
+    assert (ex["cases"][0]["max"], ex["cases"][0]["keep"], ex["cases"][1]["keep"]) == (220, 2, 1)
+    for c in ex["cases"]:
+        assert limit_size(ents, c["max"]) == c["keep"]
+    assert limit_size([], 10) == 0 and limit_size(ents[:1], 0) == 1 and limit_size(ents, None) == ex["n"]
+
+
+def test_encoder_refuses_what_it_cannot_write(rg):
+    from raft_rs_amd.engine import encode_message, EngineError, MessageC, EntryC, load_library
+    import ctypes as C
+    v = next(x for x in OUT_DOC["vectors"] if len(x["entries"]) >= 2)
+    size = len(bytes.fromhex(v["hex"]))
+    for cap in (0, 1, size - 1):  # too small a buffer: INVALID_ARG, nothing written past it (the ASan harness checks that part)
+        with pytest.raises(EngineError) as e:
+            _encode_vector(v, cap=cap)
+        assert e.value.code == -1 and str(size) in str(e.value)
+    assert _encode_vector(v, cap=size + 7).hex() == v["hex"]
+    L = load_library()
+    m, n = MessageC(), C.c_uint64(0)
+    m.n_entries = 2  # a length without its pointer
+    assert L.rg_message_size(C.byref(m), C.byref(n)) == -1
+    m.n_entries, m.context_len = 0, 5
+    assert L.rg_message_size(C.byref(m), C.byref(n)) == -1
+    m.context_len = 0
+    e = (EntryC * 1)()
+    e[0].data_len = 1 << 31  # beyond what a protobuf message may hold
+    e[0].data = b"x"
+    m.entries, m.n_entries = e, 1
+    assert L.rg_message_size(C.byref(m), C.byref(n)) == -1
+    assert L.rg_message_size(None, C.byref(n)) == -1 and L.rg_entry_size(None) == 0
+    assert encode_message({}) == b""  # Message::default(): zero bytes
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/proto/proto/eraftpb.proto"), reason="reference tree not present")
+def test_committed_outgoing_vectors_are_what_the_generator_produces():
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_eraftpb_outgoing.py"), "--check"])
+    assert r.returncode == 0, "tests/golden/eraftpb_outgoing.json is out of date: rerun make_eraftpb_outgoing.py"
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/proto/proto/eraftpb.proto"), reason="reference tree not present")
+def test_encoder_agrees_with_the_protobuf_runtime_on_random_messages(rg):
+    """Differential, 5 000 seeded messages the committed vectors do not hold: the runtime (descriptors parsed out of the
+    reference's eraftpb.proto) parses what rg_encode_message wrote into a message EQUAL to the one it built from the same
+    content, serialises that to the same bytes, and its ByteSize() is rg_message_size."""
+    import random
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_eraftpb_vectors as M
+    import make_eraftpb_outgoing as MO
+    from raft_rs_amd.engine import encode_message
+    package, enums, messages = M.parse_proto(open(M.PROTO, encoding="utf-8").read())
+    cls = M.build_classes(package, enums, messages)
+    Message, Entry, Snapshot = cls["Message"], cls["Entry"], cls["Snapshot"]
+    rng = random.Random(777)
+    n_ent = 0
+    for i in range(5000):
+        m = Message()
+        m.msg_type = rng.randrange(0, 19)
+        fields = {"msg_type": int(m.msg_type)}
+        for f in MO.SCALARS:
+            if rng.random() < 0.6:
+                setattr(m, f, M.rand_u64(rng))
+            fields[f] = int(getattr(m, f))
+        m.reject = rng.random() < 0.3
+        fields["reject"] = int(m.reject)
+        entries = []
+        for k in range(rng.randrange(0, 5) if rng.random() < 0.6 else 0):
+            e, d = MO.rand_entry(rng, Entry, rng.randrange(1 << 40) + k, M.rand_u64(rng))
+            m.entries.add().CopyFrom(e)
+            entries.append(dict(d, data=bytes.fromhex(d.get("data", "")), context=bytes.fromhex(d.get("context", ""))))
+        snap = None
+        if rng.random() < 0.15:
+            s = Snapshot()
+            if rng.random() < 0.7:
+                s.data = MO.rand_bytes(rng, 50)
+                s.metadata.index = M.rand_u64(rng)
+            m.snapshot.CopyFrom(s)
+            snap = s.SerializeToString(deterministic=True)
+        ctx = MO.rand_bytes(rng, 16) if rng.random() < 0.3 else b""
+        m.context = ctx
+        got = encode_message(fields, entries, snapshot=snap, context=ctx)
+        assert got == m.SerializeToString(deterministic=True), i
+        assert Message.FromString(got) == m and len(got) == m.ByteSize()
+        n_ent += len(entries)
+    assert n_ent > 3000
 
 
 @pytest.mark.gpu
