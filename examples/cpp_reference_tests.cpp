@@ -8,7 +8,7 @@
 #include <map>
 #include <set>
 
-#include "raftgroups.hpp"
+#include "log_fixture.hpp"
 
 using namespace raftgroups;
 
@@ -235,6 +235,128 @@ static void test_raw_node_step() {
     EXPECT(seen, "group 1 must have a Ready");
 }
 
+// harness/tests/integration_cases/test_raft_paper.rs:425-457: upon receiving a proposal the leader appends it and issues
+// AppendEntries to every follower -- checked on the MESSAGES (MultiRaft::messages builds them from the send stage's work
+// items and the host's Storage) and on their bytes
+static void test_leader_start_replication() {
+    Config c;
+    c.n_groups = 1;
+    c.max_peers = 3;
+    c.max_inflight_msgs = 256;
+    MultiRaft r(c);
+    LogFixture st;
+    st.append(0, 1); // become_leader's empty entry (term 1, index 1), committed by commit_noop_entry
+    GroupSpec s;
+    s.id = 1;
+    s.term = 1;
+    s.voters = {1, 2, 3};
+    s.first_index_of_term = 1;
+    s.last_index = 1;
+    s.committed = 1;
+    s.next_idx = 2;
+    s.follower_matched = 1;
+    s.follower_state = ProgressState::Replicate;
+    r.init_group(0, s);
+    r.bootstrap();
+    const u64 li = r.last_index(0);
+    st.append(0, 1, "somedata"); // MsgPropose: the host's log takes the entry ...
+    r.propose(0, 1);             // ... and the path hears about it
+    const std::vector<LightReady> rd = r.ready();
+    EXPECT(r.last_index(0) == li + 1, "last_index = %llu, want %llu", (unsigned long long)r.last_index(0), (unsigned long long)(li + 1));
+    EXPECT(r.committed(0) == li, "committed = %llu, want %llu", (unsigned long long)r.committed(0), (unsigned long long)li);
+    EXPECT(rd.size() == 1, "one group saw traffic");
+    std::map<u64, Message> msgs;
+    for (const Message &m : r.messages(rd[0], st)) msgs[m.to] = m;
+    EXPECT(msgs.size() == 2 && msgs.count(2) && msgs.count(3), "a MsgAppend for each follower");
+    for (const auto &kv : msgs) {
+        const Message &m = kv.second;
+        EXPECT(m.msg_type == MessageType::MsgAppend && m.from == 1 && m.term == 1 && m.index == li && m.log_term == 1 && m.commit == li,
+               "MsgAppend to %llu: index %llu log_term %llu commit %llu", (unsigned long long)kv.first, (unsigned long long)m.index,
+               (unsigned long long)m.log_term, (unsigned long long)m.commit);
+        EXPECT(m.entries.size() == 1 && m.entries[0].term == 1 && m.entries[0].index == li + 1 && m.entries[0].data == "somedata",
+               "wents = [(1, li + 1, SOME_DATA)]");
+        const std::string bytes = m.write_to_bytes();
+        rg_decoded_message d;
+        check(rg_decode_message(reinterpret_cast<const std::uint8_t *>(bytes.data()), bytes.size(), &d));
+        EXPECT(d.msg_type == 3 && d.to == kv.first && d.from == 1 && d.index == li && d.commit == li && d.n_entries == 1, "the bytes read back");
+    }
+}
+
+// harness/tests/integration_cases/test_raft.rs:369-435 with its literal configuration: max_inflight_msgs = 3,
+// max_size_per_msg = 2048 BYTES, ten 1000-byte proposals. The device counts the messages from the entry sizes
+// (RG_SEND_BYTES); the host cuts the same entries out of its Storage -- the two must agree message by message.
+static void test_progress_flow_control() {
+    Config c;
+    c.n_groups = 1;
+    c.max_peers = 2;
+    c.max_inflight_msgs = 3;
+    c.max_size_per_msg = 2048;
+    c.log_size_window = 64;
+    MultiRaft r(c);
+    LogFixture st;
+    st.append(0, 1); // the empty entry that confirms the election
+    GroupSpec s;
+    s.id = 1;
+    s.term = 1;
+    s.voters = {1, 2};
+    s.first_index_of_term = 1;
+    s.last_index = 1;
+    s.committed = 0;
+    s.next_idx = 1; // Progress::reset(last_index + 1) ran before the empty entry was appended
+    s.follower_state = ProgressState::Probe;
+    r.init_group(0, s);
+    r.bootstrap();
+    r.load_log_sizes(0, st);
+    { // nothing is persisted in this test (no r.persist()): the leader's own matched stays 0, the commit index cannot move
+        Progress me = r.progress(0, 1);
+        me.matched = 0;
+        r.set_progress(0, 1, me);
+    }
+    // While node 2 is in probe state, propose a bunch of entries.
+    const std::string data(1000, 'a');
+    std::vector<Message> ms;
+    for (int i = 0; i < 10; i++) {
+        st.append(0, 1, data);
+        Entry e;
+        e.data = data;
+        r.propose(0, std::vector<Entry>{e});
+        for (const LightReady &x : r.ready())
+            for (const Message &m : r.messages(x, st)) ms.push_back(m);
+    }
+    // First append has two entries: the empty entry to confirm the election, and the first proposal (only one proposal
+    // gets sent because we're in probe state).
+    EXPECT(ms.size() == 1, "%zu messages in Probe, want 1", ms.size());
+    EXPECT(ms[0].msg_type == MessageType::MsgAppend && ms[0].entries.size() == 2 && ms[0].entries[0].data.empty() &&
+               ms[0].entries[1].data.size() == 1000,
+           "the first append: the empty entry and the first proposal");
+    EXPECT(ms[0].entries[0].compute_size() == 4 && ms[0].entries[1].compute_size() == 1007, "entry sizes 4 and 1007");
+    // When this append is acked, we change to replicate state and can send multiple messages at once.
+    Message ack = new_message(2, MessageType::MsgAppendResponse, 1);
+    ack.index = ms[0].entries[1].index;
+    r.step(0, ack);
+    ms.clear();
+    for (const LightReady &x : r.ready())
+        for (const Message &m : r.messages(x, st)) ms.push_back(m);
+    EXPECT(ms.size() == 3, "%zu messages after the ack, want 3", ms.size());
+    for (std::size_t i = 0; i < ms.size(); i++)
+        EXPECT(ms[i].msg_type == MessageType::MsgAppend && ms[i].entries.size() == 2, "%zu: expected 2 entries, got %zu", i, ms[i].entries.size());
+    EXPECT(r.progress(0, 2).ins_full, "three messages in flight: the window is full");
+    // Ack all three of those messages together and get the last two messages (containing three entries).
+    ack.index = ms[2].entries[1].index;
+    r.step(0, ack);
+    ms.clear();
+    for (const LightReady &x : r.ready())
+        for (const Message &m : r.messages(x, st)) ms.push_back(m);
+    EXPECT(ms.size() == 2, "%zu messages after the second ack, want 2", ms.size());
+    EXPECT(ms[0].entries.size() == 2 && ms[1].entries.size() == 1, "2 + 1 entries");
+    EXPECT(ms[1].entries[0].index == 11 && r.progress(0, 2).next_idx == 12, "everything up to entry 11 is on its way");
+    for (const Message &m : ms) { // every message obeys the byte limit the way util::limit_size defines it
+        u64 total = 0;
+        for (const Entry &e : m.entries) total += e.compute_size();
+        EXPECT(total <= 2048 && m.write_to_bytes().size() == m.compute_size(), "a message of %llu entry bytes", (unsigned long long)total);
+    }
+}
+
 int main() {
     try {
         Config probe;
@@ -250,6 +372,8 @@ int main() {
     test_leader_acknowledge_commit();
     test_msg_app_flow_control_full();
     test_raw_node_step();
+    test_leader_start_replication();
+    test_progress_flow_control();
     std::printf("CPP_REFERENCE_TESTS_OK\n");
     return 0;
 }

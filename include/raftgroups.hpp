@@ -9,12 +9,19 @@
 //   MultiRaft::ready() -> LightReady per group      RawNode::ready          src/raw_node.rs:469-532, :643-651 (commit_index, messages)
 //   MultiRaft::propose / on_persist_entries /       Raft::append_entry, on_persist_entries, become_leader
 //     become_leader                                 src/raft.rs:976-1016, :1151-1202
+//   raftgroups::Storage                             raft::Storage           src/storage.rs:65-106 (one more argument: the group)
+//   raftgroups::Entry / limit_size                  eraftpb::Entry, util::limit_size   eraftpb.proto:23-31, src/util.rs:52-76
+//   build_messages / MultiRaft::messages            maybe_send_append -> prepare_send_entries / prepare_send_snapshot -> send
+//                                                   src/raft.rs:773-819, :714-731, :664-712, :602-662
+//   Message::write_to_bytes                         protobuf::Message::write_to_bytes (rg_encode_message)
 //
 // One MultiRaft holds the leader-side replication state of N raft groups on ONE GPU. Messages are queued by step() and
 // applied -- all groups at once, on the device -- by ready(), which returns what the reference's Ready would carry for
 // this path: the new commit index of every group that saw traffic and the MsgAppend sends the path asked for (as work
-// items: messages are built by the host, which owns the log). There is no CPU path: constructing a MultiRaft without a
-// gfx950 device throws Error{NoDevice}.
+// items; MultiRaft::messages turns them into the reference's Messages -- entries, log_term, commit -- out of the host's
+// Storage, and Message::write_to_bytes into the bytes a transport takes). There is no CPU path: constructing a MultiRaft
+// without a gfx950 device throws Error{NoDevice}; only the message building (build_messages, Message::write_to_bytes,
+// limit_size) is host code, because the log it reads is the host's.
 #pragma once
 
 #include <cstdint>
@@ -67,15 +74,135 @@ inline void check(int rc) {
     throw Error(k, rc, rg_last_error());
 }
 
-// ---- eraftpb::MessageType / Message: the two response types of the path ----
-enum class MessageType { MsgAppendResponse, MsgHeartbeatResponse, MsgHup /* any local type: step() refuses it */ };
+// ---- eraftpb::EntryType / Entry (proto/proto/eraftpb.proto:17-31) ----
+enum class EntryType : std::uint32_t { EntryNormal = 0, EntryConfChange = 1, EntryConfChangeV2 = 2 };
+struct Entry {
+    EntryType entry_type = EntryType::EntryNormal;
+    u64 term = 0, index = 0;
+    std::string data, context;
+    bool sync_log = false;
+    rg_entry c_entry() const { // (points into this Entry)
+        rg_entry e;
+        std::memset(&e, 0, sizeof e);
+        e.entry_type = (std::uint32_t)entry_type;
+        e.sync_log = sync_log;
+        e.term = term;
+        e.index = index;
+        e.data = reinterpret_cast<const std::uint8_t *>(data.data());
+        e.data_len = data.size();
+        e.context = reinterpret_cast<const std::uint8_t *>(context.data());
+        e.context_len = context.size();
+        return e;
+    }
+    u64 compute_size() const { // Entry::compute_size(): what util::limit_size adds up
+        const rg_entry e = c_entry();
+        return rg_entry_size(&e);
+    }
+};
+// util::limit_size (src/util.rs:52-76): truncate to what ONE message keeps under max_size_per_msg (NO_LIMIT: everything;
+// the first entry always stays)
+inline void limit_size(std::vector<Entry> &entries, u64 max) {
+    std::vector<rg_entry> c;
+    c.reserve(entries.size());
+    for (const Entry &e : entries) c.push_back(e.c_entry());
+    entries.resize((std::size_t)rg_limit_size(c.data(), c.size(), max));
+}
+
+// ---- eraftpb::MessageType / Message (proto/proto/eraftpb.proto:49-92): step() takes the two response types of the path,
+//      messages() hands out what the path sends ----
+enum class MessageType : std::uint32_t {
+    MsgHup = 0, MsgBeat = 1, MsgPropose = 2, MsgAppend = 3, MsgAppendResponse = 4, MsgRequestVote = 5, MsgRequestVoteResponse = 6,
+    MsgSnapshot = 7, MsgHeartbeat = 8, MsgHeartbeatResponse = 9, MsgUnreachable = 10, MsgSnapStatus = 11, MsgCheckQuorum = 12,
+    MsgTransferLeader = 13, MsgTimeoutNow = 14, MsgReadIndex = 15, MsgReadIndexResp = 16, MsgRequestPreVote = 17,
+    MsgRequestPreVoteResponse = 18
+};
+inline bool is_local_msg(MessageType t) { // raw_node.rs:57-66
+    return t == MessageType::MsgHup || t == MessageType::MsgBeat || t == MessageType::MsgUnreachable ||
+           t == MessageType::MsgSnapStatus || t == MessageType::MsgCheckQuorum;
+}
 struct Message {
     MessageType msg_type = MessageType::MsgAppendResponse;
-    u64 from = INVALID_ID, term = 0;
-    u64 index = 0, commit = 0;
+    u64 to = INVALID_ID, from = INVALID_ID, term = 0;
+    u64 log_term = 0; // MsgAppend: term(index). A rejecting response: > 0 makes find_conflict_by_term run on the device (raft.rs:1657-1660)
+    u64 index = 0, commit = 0, commit_term = 0;
     bool reject = false;
-    u64 reject_hint = 0, log_term = 0; // log_term > 0 on a reject: find_conflict_by_term runs on the device (raft.rs:1657-1660)
+    u64 reject_hint = 0;
     u64 request_snapshot = INVALID_INDEX;
+    u64 priority = 0;
+    std::vector<Entry> entries;
+    bool has_snapshot = false;
+    std::string snapshot; // a serialised eraftpb::Snapshot (the Storage's), when has_snapshot
+    std::string context;
+
+    // protobuf::Message::compute_size / write_to_bytes: canonical proto3 bytes (rg_encode_message)
+    u64 compute_size() const {
+        u64 n = 0;
+        with_c([&](const rg_message &m) { check_(rg_message_size(&m, &n)); });
+        return n;
+    }
+    std::string write_to_bytes() const {
+        std::string out;
+        with_c([&](const rg_message &m) {
+            u64 n = 0;
+            check_(rg_message_size(&m, &n));
+            out.resize((std::size_t)n);
+            check_(rg_encode_message(&m, reinterpret_cast<std::uint8_t *>(&out[0]), n, &n));
+        });
+        return out;
+    }
+
+  private:
+    static void check_(int rc) {
+        if (rc != RG_OK) throw Error(ErrorKind::InvalidArgument, rc, rg_last_error());
+    }
+    template <typename F> void with_c(F f) const {
+        std::vector<rg_entry> c;
+        c.reserve(entries.size());
+        for (const Entry &e : entries) c.push_back(e.c_entry());
+        rg_message m;
+        std::memset(&m, 0, sizeof m);
+        m.msg_type = (std::uint32_t)msg_type;
+        m.reject = reject;
+        m.to = to, m.from = from, m.term = term, m.log_term = log_term, m.index = index, m.commit = commit;
+        m.commit_term = commit_term, m.reject_hint = reject_hint, m.request_snapshot = request_snapshot, m.priority = priority;
+        m.entries = c.data();
+        m.n_entries = c.size();
+        static const std::uint8_t present_but_empty = 0;
+        if (has_snapshot) {
+            m.snapshot = snapshot.empty() ? &present_but_empty : reinterpret_cast<const std::uint8_t *>(snapshot.data());
+            m.snapshot_len = snapshot.size();
+        }
+        m.context = reinterpret_cast<const std::uint8_t *>(context.data());
+        m.context_len = context.size();
+        f(m);
+    }
+};
+
+// ---- raft::Storage (src/storage.rs:65-106) for many groups, and StorageError (src/errors.rs:54-70): what building a
+//      message reads. The application implements it over whatever holds its logs; nothing here stores anything. ----
+enum class StorageErrorKind { Compacted, Unavailable, SnapshotOutOfDate, SnapshotTemporarilyUnavailable, Other };
+class StorageError : public std::runtime_error {
+  public:
+    StorageError(StorageErrorKind k, const std::string &what) : std::runtime_error(what), kind(k) {}
+    StorageErrorKind kind;
+};
+struct Snapshot {
+    std::string bytes;       // the serialised eraftpb::Snapshot
+    u64 index = 0, term = 0; // its metadata (eraftpb.proto:33-37)
+};
+class Storage {
+  public:
+    virtual ~Storage() = default;
+    // entries [low, high) of the group's log, cut by util::limit_size(max_size) -- at least one if any is in range
+    // (storage.rs:72-80); StorageError{Compacted} below first_index
+    virtual std::vector<Entry> entries(u64 group, u64 low, u64 high, u64 max_size) = 0;
+    // term of entry idx in [first_index - 1, last_index] (storage.rs:82-86)
+    virtual u64 term(u64 group, u64 idx) = 0;
+    virtual u64 first_index(u64 group) = 0;
+    virtual u64 last_index(u64 group) = 0;
+    // the most recent snapshot, at or above request_index; StorageError{SnapshotTemporarilyUnavailable} while it is
+    // being prepared (storage.rs:98-105)
+    virtual Snapshot snapshot(u64 group, u64 request_index) = 0;
 };
 
 // ---- tracker::ProgressState / Progress ----
@@ -131,12 +258,84 @@ struct LightReady {
     std::vector<SendItem> messages; // engines WITH device Inflights: the send decisions, already applied to the Progress
 };
 
+// ---- from a send decision to the reference's Messages (host code: the log is the host's) ----
+// Who sends, and the limits its Config carries. `committed` is raft_log.committed after the batch (LightReady.commit_index).
+struct SendContext {
+    u64 group = 0;
+    u64 id = INVALID_ID; // Raft.id: Message.from
+    u64 term = 0;        // Raft.term: Message.term (Raft::send, raft.rs:649-651)
+    u64 committed = 0;
+    u64 max_size_per_msg = NO_LIMIT; // Config::max_size_per_msg in bytes (config.rs:58-63): engines run with RG_SEND_BYTES
+    u64 max_entries_per_msg = 0;     // the equal-sized-entries stand-in (0 = no limit): engines run without RG_SEND_BYTES
+};
+// One SendItem -> the Messages Raft::maybe_send_append would have pushed for that peer, in order:
+//  * an append item: n_msgs MsgAppend (prepare_send_entries, raft.rs:714-731: index = next_idx - 1, log_term =
+//    term(index), entries = RaftLog::entries(next_idx, max_size) -- the storage's entries under util::limit_size --,
+//    commit = raft_log.committed; Raft::send: from, term), each starting where the previous one ended (update_state,
+//    already applied on the device); prev_index == last_index is the single empty MsgAppend of send_append (allow_empty);
+//  * a snapshot item: one MsgSnapshot carrying Storage::snapshot(requested index) (prepare_send_snapshot, raft.rs:664-712),
+//    or nothing while the storage answers SnapshotTemporarilyUnavailable (:677-686). The caller applies
+//    Progress::become_snapshot(snapshot index) when a message came back (MultiRaft::messages does);
+//  * a host item (RG_SEND_HOST): nothing -- the host's own maybe_send_append serves that peer.
+// The device counted the messages from the sizes it was given (rg_log_sizes_write); a storage that cuts differently is a
+// host bug and raises Error{State} rather than sending something the Progress does not reflect.
+// *snapshot_index (optional) receives metadata.index of the snapshot a MsgSnapshot carries, 0 otherwise.
+inline std::vector<Message> build_messages(const SendContext &c, const SendItem &s, Storage &st, u64 *snapshot_index = nullptr) {
+    std::vector<Message> out;
+    if (snapshot_index) *snapshot_index = 0;
+    if (s.host) return out;
+    Message m;
+    m.to = s.to;
+    m.from = c.id;
+    m.term = c.term;
+    if (s.snapshot) {
+        Snapshot snap;
+        try {
+            snap = st.snapshot(c.group, s.last_index);
+        } catch (const StorageError &e) {
+            if (e.kind == StorageErrorKind::SnapshotTemporarilyUnavailable) return out;
+            throw;
+        }
+        if (snap.index == 0) throw Error(ErrorKind::State, RG_ERR_STATE, "need non-empty snapshot (raft.rs:696-698)");
+        m.msg_type = MessageType::MsgSnapshot;
+        m.has_snapshot = true;
+        m.snapshot = snap.bytes;
+        if (snapshot_index) *snapshot_index = snap.index;
+        out.push_back(m);
+        return out;
+    }
+    m.msg_type = MessageType::MsgAppend;
+    m.commit = c.committed;
+    u64 next = s.prev_index + 1;
+    for (unsigned k = 0; k < s.n_msgs; k++) {
+        m.index = next - 1;
+        m.log_term = st.term(c.group, next - 1);
+        m.entries.clear();
+        if (next <= s.last_index) {
+            m.entries = st.entries(c.group, next, s.last_index + 1, c.max_entries_per_msg ? NO_LIMIT : c.max_size_per_msg);
+            if (c.max_entries_per_msg && m.entries.size() > c.max_entries_per_msg) m.entries.resize((std::size_t)c.max_entries_per_msg);
+            if (m.entries.empty() || m.entries.front().index != next)
+                throw Error(ErrorKind::State, RG_ERR_STATE, "build_messages: the storage has no entries where the Progress points");
+            next = m.entries.back().index + 1;
+        } else if (s.n_msgs != 1) {
+            throw Error(ErrorKind::State, RG_ERR_STATE, "build_messages: the storage cut the entries into fewer messages than the device counted");
+        }
+        out.push_back(m);
+    }
+    if (next != s.last_index + 1)
+        throw Error(ErrorKind::State, RG_ERR_STATE, "build_messages: the storage cut the entries into more messages than the device counted");
+    return out;
+}
+
 struct Config { // the subset of raft::Config (src/config.rs) the path depends on + the engine's shape
     u64 n_groups = 1;
     unsigned max_peers = 3;          // peer slots per group, 1..8
     int device = 0;
     unsigned max_inflight_msgs = 0;  // 0: Inflights stay with the host; else Config::max_inflight_msgs (config.rs:112), on the device
     u64 max_entries_per_msg = 0;     // stands in for max_size_per_msg with equal-sized entries (0 = NO_LIMIT)
+    u64 max_size_per_msg = NO_LIMIT; // Config::max_size_per_msg in BYTES (config.rs:58-63): takes effect with log_size_window
+    unsigned log_size_window = 0;    // > 0: the device keeps the sizes of each group's last N entries (power of two, 8..4096)
+                                     //      and the send stage applies max_size_per_msg byte for byte (RG_SEND_BYTES)
     bool skip_bcast_commit = false;  // Config::skip_bcast_commit (config.rs:87)
 };
 
@@ -227,6 +426,12 @@ class MultiRaft {
         load(RG_COL_TERM_HI, hi_.data());
         load(RG_COL_CUR_TERM, term_.data());
         load(RG_COL_CFG, cfgw_.data());
+        if (cfg_.log_size_window) {
+            if (!cfg_.max_inflight_msgs)
+                throw Error(ErrorKind::InvalidArgument, RG_ERR_INVALID_ARG, "log_size_window needs the Inflights on the device (max_inflight_msgs > 0)");
+            check(rg_log_sizes_enable(h_, cfg_.log_size_window));
+            cum_.assign(cfg_.n_groups, 0);
+        }
         for (u64 g = 0; g < cfg_.n_groups; g++) {
             unsigned n = 0;
             while (n < 8 && ids_[g * 8 + n]) n++;
@@ -257,8 +462,10 @@ class MultiRaft {
         case MessageType::MsgHeartbeatResponse:
             check(rg_step_heartbeat_response(h_, group, m.from, m.term, m.commit, 0));
             return;
-        default: // is_local_msg (raw_node.rs:404-406)
-            throw Error(ErrorKind::StepLocalMsg, RG_ERR_STEP_LOCAL_MSG, "raft: cannot step raft local message");
+        default:
+            if (is_local_msg(m.msg_type)) // raw_node.rs:404-406
+                throw Error(ErrorKind::StepLocalMsg, RG_ERR_STEP_LOCAL_MSG, "raft: cannot step raft local message");
+            throw Error(ErrorKind::NotOnPath, RG_ERR_NOT_ON_PATH, "a message type this path does not handle: the host's own Raft::step takes it");
         }
     }
     // ... and on the bytes a transport delivers: Message::parse_from_bytes + RawNode::step (rg_step_bytes). A message type
@@ -273,12 +480,55 @@ class MultiRaft {
         hi_[group] += n_entries;
         check(rg_local_append(h_, group, hi_[group]));
     }
+    // ... with the entries themselves (byte-accurate max_size_per_msg, Config::log_size_window > 0): their sizes go to the
+    // device before the stage that may send them. The host appends them to its own log (term = the leader's, indices
+    // last_index + 1 ..) -- this class keeps no entries.
+    void propose(u64 group, const std::vector<Entry> &entries) {
+        need_boot();
+        if (cfg_.log_size_window) {
+            std::vector<rg_log_size> recs(entries.size());
+            for (std::size_t i = 0; i < entries.size(); i++) {
+                Entry e = entries[i]; // what Raft::append_entry stamps (raft.rs:980-984)
+                e.term = term_[group];
+                e.index = hi_[group] + 1 + i;
+                cum_[group] += e.compute_size();
+                recs[i].group = group, recs[i].index = e.index, recs[i].cum_bytes = cum_[group];
+            }
+            if (!recs.empty()) check(rg_log_sizes_write(h_, recs.data(), recs.size()));
+        }
+        propose(group, (u64)entries.size());
+    }
+    // The sizes of the entries a group's log already holds (after bootstrap(), before the first ready(); every index the
+    // send stage may reach without RG_SEND_HOST: the last log_size_window - 1 entries)
+    void load_log_sizes(u64 group, Storage &st) {
+        need_boot();
+        if (!cfg_.log_size_window) return;
+        const u64 last = st.last_index(group), first = st.first_index(group);
+        u64 lo = last + 1 > cfg_.log_size_window ? last + 1 - cfg_.log_size_window + 1 : 1;
+        if (lo < first) lo = first;
+        if (lo > last) return;
+        const std::vector<Entry> ents = st.entries(group, lo, last + 1, NO_LIMIT);
+        std::vector<rg_log_size> recs(ents.size() + 1);
+        recs[0].group = group, recs[0].index = lo - 1, recs[0].cum_bytes = cum_[group]; // the base the first size is a difference to
+        for (std::size_t i = 0; i < ents.size(); i++) {
+            cum_[group] += ents[i].compute_size();
+            recs[i + 1].group = group, recs[i + 1].index = ents[i].index, recs[i + 1].cum_bytes = cum_[group];
+        }
+        check(rg_log_sizes_write(h_, recs.data(), recs.size()));
+    }
     void on_persist_entries(u64 group, u64 index) { check(rg_local_persisted(h_, group, index)); } // raft.rs:994-1016
     void become_leader(u64 group, u64 term) {                                                       // raft.rs:1151-1202
         need_boot();
         check(rg_local_become_leader(h_, group, term));
         term_[group] = term;
         hi_[group] += 1; // the new leader's empty entry
+        if (cfg_.log_size_window) { // ... whose size record is the host's to write (raftgroups.h, "entry sizes")
+            Entry e;
+            e.term = term, e.index = hi_[group];
+            cum_[group] += e.compute_size();
+            const rg_log_size rec = {group, e.index, cum_[group]};
+            check(rg_log_sizes_write(h_, &rec, 1));
+        }
     }
     void mark_sent(u64 group, u64 to) { check(rg_mark_sent(h_, group, to)); } // host Inflights: a MsgAppend up to last_index went out
 
@@ -287,7 +537,8 @@ class MultiRaft {
         need_boot();
         const bool dev_ins = cfg_.max_inflight_msgs != 0;
         if (dev_ins)
-            check(rg_flush_send(h_, cfg_.max_entries_per_msg, cfg_.skip_bcast_commit ? RG_SEND_SKIP_BCAST_COMMIT : 0u));
+            check(rg_flush_send(h_, cfg_.log_size_window ? cfg_.max_size_per_msg : cfg_.max_entries_per_msg,
+                                (cfg_.skip_bcast_commit ? RG_SEND_SKIP_BCAST_COMMIT : 0u) | (cfg_.log_size_window ? RG_SEND_BYTES : 0u)));
         else
             check(rg_flush(h_));
         u64 n = 0;
@@ -332,6 +583,42 @@ class MultiRaft {
             }
         }
         return rd;
+    }
+
+    // ---- Ready.messages for one group of ready(): the send decisions as the reference's Messages, built out of the host's
+    // Storage (build_messages); a snapshot that was actually fetched is followed by Progress::become_snapshot on the
+    // device (progress.rs:117-121), as prepare_send_snapshot does (raft.rs:699-711) ----
+    std::vector<Message> messages(const LightReady &rd, Storage &st) {
+        need_boot();
+        SendContext c;
+        c.group = rd.group;
+        c.id = ids_[rd.group * 8 + self_[rd.group]];
+        c.term = term_[rd.group];
+        c.committed = rd.commit_index;
+        if (cfg_.log_size_window) c.max_size_per_msg = cfg_.max_size_per_msg;
+        else c.max_entries_per_msg = cfg_.max_entries_per_msg;
+        std::vector<Message> out;
+        for (const SendItem &s : rd.messages) {
+            u64 sindex = 0; // metadata.index of the snapshot that goes out
+            const std::vector<Message> ms = build_messages(c, s, st, &sindex);
+            if (s.snapshot && !ms.empty()) become_snapshot(rd.group, s.to, sindex);
+            out.insert(out.end(), ms.begin(), ms.end());
+        }
+        return out;
+    }
+    // Progress::become_snapshot(snapshot_idx) (progress.rs:117-121): reset_state(Snapshot) + pending_snapshot
+    void become_snapshot(u64 group, u64 id, u64 snapshot_idx) {
+        rg_group_status st;
+        check(rg_read_groups(h_, &group, 1, &st));
+        const int s = slot_of(group, id);
+        rg_cell_write c;
+        std::memset(&c, 0, sizeof c);
+        c.group = group;
+        c.slot = (std::uint32_t)s;
+        c.field_mask = (1u << RG_COL_PEND_SNAP) | (1u << RG_COL_PFLAGS);
+        c.pend_snap = snapshot_idx;
+        c.pflags = (std::uint8_t)((st.pflags[s] & ~(RG_PF_STATE_MASK | RG_PF_PAUSED)) | RG_STATE_SNAPSHOT);
+        check(rg_write_cells(h_, &c, 1));
     }
 
     // ---- ProgressTracker::get / Status (tracker.rs:261-287, status.rs:25-52) ----
@@ -396,7 +683,7 @@ class MultiRaft {
     rg_engine *h_ = nullptr;
     u64 stride_ = 0;
     bool booted_ = false;
-    std::vector<u64> match_, next_, prc_, commit_, lo_, hi_, term_, ids_;
+    std::vector<u64> match_, next_, prc_, commit_, lo_, hi_, term_, ids_, cum_;
     std::vector<std::uint8_t> pflags_;
     std::vector<std::uint32_t> cfgw_;
     std::vector<unsigned> self_;
