@@ -37,6 +37,9 @@ pub const RG_VARIANT_LDS: u32 = 2;
 pub const RG_VARIANT_LDS_DMA: u32 = 4;
 pub const RG_VARIANT_COMPACT: u32 = 5;
 pub const RG_VARIANT_COOP: u32 = 3;
+pub const RG_EV_UNREACHABLE: u32 = 1;
+pub const RG_EV_SNAPSHOT_FINISH: u32 = 2;
+pub const RG_EV_SNAPSHOT_FAILURE: u32 = 3;
 pub const RG_MAX_FUSE: u32 = 8;
 pub const RG_SEND_APPEND: u32 = 1;
 pub const RG_SEND_SNAPSHOT: u32 = 2;
@@ -144,6 +147,13 @@ pub struct RgCellWrite {
     pub gid: u64,
     pub pflags: u8,
     pub pad: [u8; 7],
+}
+
+#[repr(C)]
+pub struct RgProgressEvent {
+    pub group: u64,
+    pub slot: u32,
+    pub kind: u32,
 }
 
 #[repr(C)]
@@ -322,6 +332,7 @@ extern "C" {
     pub fn rg_read_groups(h: *mut RgEngine, groups: *const u64, n: u64, host_out: *mut RgGroupStatus) -> i32;
     pub fn rg_write_cells(h: *mut RgEngine, cells: *const RgCellWrite, n: u64) -> i32;
     pub fn rg_set_config(h: *mut RgEngine, group: u64, cfg_word: u32) -> i32;
+    pub fn rg_progress_events(h: *mut RgEngine, events: *const RgProgressEvent, n: u64) -> i32;
     pub fn rg_tick(h: *mut RgEngine, host_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device(h: *mut RgEngine, dev_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device_fused(h: *mut RgEngine, dev_msgs: *const RgMsgs, n_ticks: u32, dev_out_t: *mut u32, dev_commit_t: *mut u64) -> i32;
@@ -347,6 +358,8 @@ extern "C" {
     pub fn rg_local_persisted(h: *mut RgEngine, group: u64, index: u64) -> i32;
     pub fn rg_mark_sent(h: *mut RgEngine, group: u64, peer_id: u64) -> i32;
     pub fn rg_local_become_leader(h: *mut RgEngine, group: u64, term: u64) -> i32;
+    pub fn rg_report_unreachable(h: *mut RgEngine, group: u64, peer_id: u64) -> i32;
+    pub fn rg_report_snapshot(h: *mut RgEngine, group: u64, peer_id: u64, failure: i32) -> i32;
     pub fn rg_flush(h: *mut RgEngine) -> i32;
     pub fn rg_send_appends(h: *mut RgEngine, max_entries_per_msg: u64, flags: u32) -> i32;
     pub fn rg_tick_send(h: *mut RgEngine, host_msgs: *const RgMsgs, max_entries_per_msg: u64, flags: u32) -> i32;

@@ -357,6 +357,65 @@ static void test_progress_flow_control() {
     }
 }
 
+// harness/tests/integration_cases/test_raft.rs:2913-2933: MsgUnreachable puts a Replicate peer back to Probe
+static void test_recv_msg_unreachable() {
+    Config c;
+    c.n_groups = 1;
+    c.max_peers = 2;
+    MultiRaft r(c);
+    GroupSpec s; // three previous entries (term 1), become_leader's empty entry at 4
+    s.id = 1;
+    s.term = 1;
+    s.voters = {1, 2};
+    s.first_index_of_term = 1;
+    s.last_index = 4;
+    s.committed = 0;
+    r.init_group(0, s);
+    r.bootstrap();
+    Progress p2 = r.progress(0, 2); // set node 2 to state replicate
+    p2.matched = 3;
+    p2.state = ProgressState::Replicate;
+    p2.next_idx = 6; // become_replicate (next = 4), optimistic_update(5)
+    r.set_progress(0, 2, p2);
+    r.report_unreachable(0, 2);
+    const Progress peer_2 = r.progress(0, 2);
+    EXPECT(peer_2.state == ProgressState::Probe, "state = %d, want Probe", (int)peer_2.state);
+    EXPECT(peer_2.matched + 1 == peer_2.next_idx, "matched %llu next_idx %llu", (unsigned long long)peer_2.matched,
+           (unsigned long long)peer_2.next_idx);
+    r.report_unreachable(0, 7); // no progress available: ignored
+}
+
+// harness/tests/integration_cases/test_raft_snap.rs:68-87 (test_snapshot_failure) and :89-109 (test_snapshot_succeed)
+static void test_snapshot_failure_and_succeed() {
+    struct Row { SnapshotStatus status; u64 wnext; };
+    const Row tests[] = {{SnapshotStatus::Failure, 1}, {SnapshotStatus::Finish, 12}};
+    for (const Row &t : tests) {
+        Config c;
+        c.n_groups = 1;
+        c.max_peers = 2;
+        MultiRaft sm(c);
+        GroupSpec s; // sm.restore(testing_snap()): snapshot (index 11, term 11); become_leader's empty entry at 12
+        s.id = 1;
+        s.term = 1;
+        s.voters = {1, 2};
+        s.first_index_of_term = 12;
+        s.last_index = 12;
+        s.committed = 11;
+        sm.init_group(0, s);
+        sm.bootstrap();
+        Progress p2 = sm.progress(0, 2);
+        p2.next_idx = 1;
+        p2.state = ProgressState::Snapshot; // become_snapshot(11)
+        p2.pending_snapshot = 11;
+        sm.set_progress(0, 2, p2);
+        sm.report_snapshot(0, 2, t.status);
+        const Progress voter_2 = sm.progress(0, 2);
+        EXPECT(voter_2.pending_snapshot == 0, "pending_snapshot = %llu", (unsigned long long)voter_2.pending_snapshot);
+        EXPECT(voter_2.next_idx == t.wnext, "next_idx = %llu, want %llu", (unsigned long long)voter_2.next_idx, (unsigned long long)t.wnext);
+        EXPECT(voter_2.paused && voter_2.state == ProgressState::Probe, "paused Probe");
+    }
+}
+
 int main() {
     try {
         Config probe;
@@ -374,6 +433,8 @@ int main() {
     test_raw_node_step();
     test_leader_start_replication();
     test_progress_flow_control();
+    test_recv_msg_unreachable();
+    test_snapshot_failure_and_succeed();
     std::printf("CPP_REFERENCE_TESTS_OK\n");
     return 0;
 }

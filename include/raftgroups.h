@@ -259,6 +259,25 @@ int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n);
  * are written with rg_write_cells; follow with rg_recompute for post_conf_change's maybe_commit (raft.rs:2630). */
 int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word);
 
+/* RawNode::report_unreachable / report_snapshot (src/raw_node.rs:692-709): the two LOCAL messages that write a Progress,
+ * applied to the device cell in place (no read-back), in array order -- the records of one (group, slot) must be adjacent:
+ *   RG_EV_UNREACHABLE      handle_unreachable (src/raft.rs:1931-1954): a Replicate peer becomes Probe (become_probe:
+ *                          next = matched + 1, paused = false, pending_snapshot = 0, ins.reset()); any other state: nothing
+ *   RG_EV_SNAPSHOT_FINISH  handle_snapshot_status (src/raft.rs:1891-1929), reject = false: a Snapshot peer becomes Probe
+ *                          with next = max(matched + 1, pending_snapshot + 1), then pause() and pending_request_snapshot = 0
+ *   RG_EV_SNAPSHOT_FAILURE ... reject = true: snapshot_failure() first, so next = matched + 1
+ * A peer that is not in Snapshot ignores both snapshot events; slots beyond the engine's are ignored. With device
+ * Inflights the window is reset whenever the state changes. Synchronises (a control-path call, like rg_write_cells). */
+typedef struct {
+    uint64_t group;
+    uint32_t slot;
+    uint32_t kind; /* RG_EV_* */
+} rg_progress_event;
+#define RG_EV_UNREACHABLE 1u
+#define RG_EV_SNAPSHOT_FINISH 2u
+#define RG_EV_SNAPSHOT_FAILURE 3u
+int rg_progress_events(rg_engine *h, const rg_progress_event *events, uint64_t n);
+
 /* ---- the hot path ---- */
 /* One tick: for every group, apply its <=1 message per slot in slot order exactly as
  * handle_append_response would (commit re-evaluated after every accepted ack), update state in
@@ -408,6 +427,12 @@ int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id);
  * RG_MF_BECOME_LEADER for the group -- applied before every other event of the flush -- and moves the group's
  * term gate (rg_step) to `term`. Errors: RG_ERR_INVALID_ARG when `term` is not above the registered term. */
 int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t term);
+/* RawNode::report_unreachable(id) / report_snapshot(id, status) (src/raw_node.rs:692-709) through the mirror's peer ids:
+ * rg_progress_events on the peer's slot, applied at once. Like the reference (which drops the step's result) an id without
+ * a Progress is ignored. RG_ERR_SLOT_BUSY while the group has traffic queued for the next flush: the reference applies
+ * local messages in call order, so flush first. `failure`: SnapshotStatus::Failure (non-zero) / Finish (0). */
+int rg_report_unreachable(rg_engine *h, uint64_t group, uint64_t peer_id);
+int rg_report_snapshot(rg_engine *h, uint64_t group, uint64_t peer_id, int failure);
 /* Run one tick over everything queued since the last flush and clear the queue. */
 int rg_flush(rg_engine *h);
 

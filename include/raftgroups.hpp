@@ -9,6 +9,7 @@
 //   MultiRaft::ready() -> LightReady per group      RawNode::ready          src/raw_node.rs:469-532, :643-651 (commit_index, messages)
 //   MultiRaft::propose / on_persist_entries /       Raft::append_entry, on_persist_entries, become_leader
 //     become_leader                                 src/raft.rs:976-1016, :1151-1202
+//   MultiRaft::report_unreachable / report_snapshot RawNode::report_unreachable / report_snapshot   src/raw_node.rs:692-709
 //   raftgroups::Storage                             raft::Storage           src/storage.rs:65-106 (one more argument: the group)
 //   raftgroups::Entry / limit_size                  eraftpb::Entry, util::limit_size   eraftpb.proto:23-31, src/util.rs:52-76
 //   build_messages / MultiRaft::messages            maybe_send_append -> prepare_send_entries / prepare_send_snapshot -> send
@@ -204,6 +205,8 @@ class Storage {
     // being prepared (storage.rs:98-105)
     virtual Snapshot snapshot(u64 group, u64 request_index) = 0;
 };
+
+enum class SnapshotStatus { Finish, Failure }; // src/raw_node.rs:47-54
 
 // ---- tracker::ProgressState / Progress ----
 enum class ProgressState : std::uint8_t { Probe = RG_STATE_PROBE, Replicate = RG_STATE_REPLICATE, Snapshot = RG_STATE_SNAPSHOT };
@@ -531,6 +534,18 @@ class MultiRaft {
         }
     }
     void mark_sent(u64 group, u64 to) { check(rg_mark_sent(h_, group, to)); } // host Inflights: a MsgAppend up to last_index went out
+    // ---- RawNode::report_unreachable / report_snapshot (raw_node.rs:692-709): the two local messages that write a
+    // Progress -- handle_unreachable (raft.rs:1931-1954: Replicate -> Probe), handle_snapshot_status (:1891-1929:
+    // Snapshot -> Probe, paused). Applied on the device at once; call ready() first if the group has stepped messages
+    // pending (Error{SlotBusy}: the reference applies local messages in call order). An unknown id is ignored. ----
+    void report_unreachable(u64 group, u64 id) {
+        need_boot();
+        check(rg_report_unreachable(h_, group, id));
+    }
+    void report_snapshot(u64 group, u64 id, SnapshotStatus status) {
+        need_boot();
+        check(rg_report_snapshot(h_, group, id, status == SnapshotStatus::Failure));
+    }
 
     // ---- RawNode::ready for every group with queued traffic: ONE launch for all of them ----
     std::vector<LightReady> ready() {

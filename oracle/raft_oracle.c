@@ -654,6 +654,34 @@ void ro_handle_heartbeat_response(ro_cluster *c, size_t g, uint64_t from, uint64
         out->send_append = true;
 }
 
+/* MsgSnapStatus (RawNode::report_snapshot, raw_node.rs:701-709): raft.rs:1891-1929. Returns whether a Progress was
+ * touched. */
+bool ro_handle_snapshot_status(ro_cluster *c, size_t g, uint64_t from, bool reject) {
+    ro_progress *pr = pmap_get(&c->g[g].progress, from);
+    if (!pr) return false;                      /* "no progress available" */
+    if (pr->state != RO_SNAPSHOT) return false; /* :1903-1905 */
+    if (reject) {
+        pr->pending_snapshot = 0; /* snapshot_failure(), progress.rs:124-127 */
+        ro_progress_become_probe(pr);
+    } else {
+        ro_progress_become_probe(pr);
+    }
+    /* If snapshot finish, wait for the msgAppResp from the remote node before sending out the next msgAppend.
+     * If snapshot failure, wait for a heartbeat interval before next try */
+    pr->paused = true;                                 /* pause() */
+    pr->pending_request_snapshot = RO_INVALID_INDEX;   /* :1928 */
+    return true;
+}
+
+/* MsgUnreachable (RawNode::report_unreachable, raw_node.rs:692-698): raft.rs:1931-1954 */
+bool ro_handle_unreachable(ro_cluster *c, size_t g, uint64_t from) {
+    ro_progress *pr = pmap_get(&c->g[g].progress, from);
+    if (!pr) return false;
+    /* During optimistic replication, if the remote becomes unreachable, there is huge probability that a MsgAppend is lost. */
+    if (pr->state == RO_REPLICATE) ro_progress_become_probe(pr);
+    return true;
+}
+
 uint64_t ro_heartbeat_commit(ro_cluster *c, size_t g, uint64_t to) { /* raft.rs:830-838 */
     ro_group *gr = &c->g[g];
     ro_progress *pr = pmap_get(&gr->progress, to);

@@ -651,6 +651,13 @@ __global__ void k_write_cells(RgState st, const rg_cell_write *cells, u64 n, u32
     *pfb = nf;
 }
 
+// RawNode::report_unreachable / report_snapshot applied to the cells in place (rg_progress_events). Lane i applies the whole
+// run of records of its (group, slot), in order, if it holds the run's first record.
+__global__ __launch_bounds__(256) void k_progress_events(RgState st, u32 *ins_meta, const rg_progress_event *ev, u64 n, u32 P) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rg_progress_events_at(st, ins_meta, ev, n, P, i);
+}
+
 // RG_PF_PEND_SNAP / RG_PF_PEND_RS (pending_snapshot / pending_request_snapshot != 0) re-derived for every cell: after the
 // flag column or one of the two columns was loaded wholesale.
 __global__ __launch_bounds__(RG_BLOCK) void k_fix_pending(RgState st, u32 P) {
@@ -2044,6 +2051,23 @@ extern "C" int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n
     return RG_OK;
 }
 
+extern "C" int rg_progress_events(rg_engine *h, const rg_progress_event *events, uint64_t n) {
+    if (!h || (!events && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_events: bad argument");
+    for (u64 i = 0; i < n; i++)
+        if (events[i].kind < RG_EV_UNREACHABLE || events[i].kind > RG_EV_SNAPSHOT_FAILURE)
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_events: record %llu has kind %u", (unsigned long long)i, events[i].kind);
+    if (n == 0) return RG_OK;
+    RG_ENTER(h);
+    int rc = rg_stage_records(h, events, (size_t)n * sizeof(rg_progress_event));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_progress_events, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->ins_arena ? h->ins.meta : nullptr,
+                       (const rg_progress_event *)h->d_recs, (u64)n, h->P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_progress_events: launch failed: %s", hipGetErrorString(e));
+    RG_HIP(hipStreamSynchronize(h->stream)); // control path, like rg_write_cells: the caller's array may be reused after return
+    return RG_OK;
+}
+
 // After a dense stage the work items live in the columns; the compact list exists once somebody asks for it.
 static int rg_send_materialize(rg_engine *h) {
     if (!h->send_cols_fresh) return RG_OK;
@@ -2534,6 +2558,26 @@ extern "C" int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t ter
     h->q_elections.push_back({group, h->terms[group]});
     h->terms[group] = term;
     return RG_OK;
+}
+
+// RawNode::report_unreachable / report_snapshot (src/raw_node.rs:692-709): MsgUnreachable / MsgSnapStatus stepped at a leader
+static int rg_report(rg_engine *h, uint64_t group, uint64_t peer_id, u32 kind, const char *who) {
+    if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "%s: bad argument", who);
+    if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "%s: rg_set_peers was never called", who);
+    const int slot = rg_find_slot(h, group, peer_id);
+    if (slot < 0) return RG_OK; // "no progress available for {}": ignored (the reference drops the step's result as well)
+    u64 row = 0;
+    memcpy(&row, &h->q_mf[group * 8], 8);
+    if (row) return rg_fail(RG_ERR_SLOT_BUSY, "%s: group %llu has traffic queued; rg_flush first (local messages apply in call order)",
+                            who, (unsigned long long)group);
+    const rg_progress_event ev = {group, (u32)slot, kind};
+    return rg_progress_events(h, &ev, 1);
+}
+extern "C" int rg_report_unreachable(rg_engine *h, uint64_t group, uint64_t peer_id) {
+    return rg_report(h, group, peer_id, RG_EV_UNREACHABLE, "rg_report_unreachable");
+}
+extern "C" int rg_report_snapshot(rg_engine *h, uint64_t group, uint64_t peer_id, int failure) {
+    return rg_report(h, group, peer_id, failure ? RG_EV_SNAPSHOT_FAILURE : RG_EV_SNAPSHOT_FINISH, "rg_report_snapshot");
 }
 
 extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {

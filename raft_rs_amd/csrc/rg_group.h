@@ -338,6 +338,59 @@ template <int P> struct RgGroup {
 #define RG_TICK_ELECTED (1u << 29)  /* not a store bit: RG_MF_BECOME_LEADER was applied in THIS tick */
 #define RG_TICK_PUSH (1u << 30)     /* RG_NX_PREFETCH: ... and the previous leader's run still has to enter the term-run table */
 
+// RawNode::report_unreachable / report_snapshot (src/raw_node.rs:692-709) on ONE Progress cell: handle_unreachable
+// (src/raft.rs:1931-1954) and handle_snapshot_status (:1891-1929). `pf` is the cell's flag byte. Returns whether
+// Progress::reset_state ran (progress.rs:75-80: the caller resets a device-side window and re-derives the engine-owned bits).
+RG_HD bool rg_apply_progress_event(u32 kind, u64 match, u64 &next, u64 &psnap, u64 &prs, u32 &pf) {
+    const u32 state = pf & RG_PF_STATE_MASK;
+    if (kind == RG_EV_UNREACHABLE) {
+        // "During optimistic replication, if the remote becomes unreachable, there is huge probability that a MsgAppend is lost"
+        if (state != RG_STATE_REPLICATE) return false;
+        pf = (pf & ~(RG_PF_STATE_MASK | RG_PF_PAUSED)) | RG_STATE_PROBE; // become_probe(): reset_state(Probe) ...
+        psnap = 0;
+        next = match + 1; // ... next_idx = matched + 1
+        return true;
+    }
+    if (kind == RG_EV_SNAPSHOT_FINISH || kind == RG_EV_SNAPSHOT_FAILURE) {
+        if (state != RG_STATE_SNAPSHOT) return false;
+        const u64 pending = kind == RG_EV_SNAPSHOT_FAILURE ? 0 : psnap; // snapshot_failure() (progress.rs:124-127)
+        next = rg_max(match + 1, pending + 1);                           // become_probe() from Snapshot (progress.rs:99-102)
+        psnap = 0;
+        pf = (pf & ~RG_PF_STATE_MASK) | RG_STATE_PROBE | RG_PF_PAUSED; // wait for the msgAppResp / a heartbeat interval: pause()
+        prs = 0;                                                       // pending_request_snapshot = INVALID_INDEX
+        return true;
+    }
+    return false;
+}
+
+
+// Record i of an rg_progress_events batch against the columns: the whole run of records of its (group, slot) is applied, in
+// order, by the run's first record (k_progress_events: one lane per record; tests/host_check: a loop).
+RG_HD void rg_progress_events_at(const RgState &st, u32 *ins_meta, const rg_progress_event *ev, u64 n, u32 P, u64 i) {
+    const u64 g = ev[i].group;
+    const u32 s = ev[i].slot;
+    if (g >= st.G || s >= P) return;
+    if (i > 0 && ev[i - 1].group == g && ev[i - 1].slot == s) return;
+    const u64 o = (u64)s * st.stride + g;
+    u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + g * 8 + s;
+    u32 pf = *pfb;
+    const u64 match = st.match[o];
+    u64 next = st.next[o], psnap = st.psnap[o], prs = st.prs[o];
+    bool reset = false;
+    for (u64 j = i; j < n && ev[j].group == g && ev[j].slot == s; j++)
+        reset = rg_apply_progress_event(ev[j].kind, match, next, psnap, prs, pf) || reset;
+    if (!reset) return; // (an event that does not apply changes nothing)
+    st.next[o] = next;
+    st.psnap[o] = psnap;
+    st.prs[o] = prs;
+    if (ins_meta) { // Progress::reset_state: ins.reset() (progress.rs:75-80); an empty window is not full
+        ins_meta[o] = 0;
+        pf &= ~RG_PF_INS_FULL;
+    }
+    pf = (pf & ~RG_PF_PENDING) | (psnap ? RG_PF_PEND_SNAP : 0u) | (prs ? RG_PF_PEND_RS : 0u);
+    *pfb = (u8)pf;
+}
+
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
 // (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
 // ends at last_index); commit_to (:286-300) can then never exceed last_index.

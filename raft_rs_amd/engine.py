@@ -176,6 +176,8 @@ SEND_BYTES = 2
 NO_LIMIT = (1 << 64) - 1
 LOG_SIZE_DTYPE = np.dtype([("group", "<u8"), ("index", "<u8"), ("cum_bytes", "<u8")])
 SENT_MSG_DTYPE = np.dtype([("group", "<u8"), ("last", "<u8"), ("slot", "<u4"), ("reserved", "<u4")])
+PROGRESS_EVENT_DTYPE = np.dtype([("group", "<u8"), ("slot", "<u4"), ("kind", "<u4")])  # rg_progress_event
+EV_UNREACHABLE, EV_SNAPSHOT_FINISH, EV_SNAPSHOT_FAILURE = 1, 2, 3
 SEND_ITEM_DTYPE = np.dtype([("group", "<u8"), ("prev_index", "<u8"), ("last_index", "<u8"), ("slot", "<u4"),
                             ("n_msgs", "<u2"), ("kind", "<u2")])
 assert SEND_ITEM_DTYPE.itemsize == 32
@@ -241,6 +243,9 @@ SYMBOLS = {
     "rg_step": (_i, [_vp, _u64, C.POINTER(AppendResponse)]),
     "rg_step_bytes": (_i, [_vp, _u64, C.c_char_p, _u64]),
     "rg_decode_message": (_i, [C.c_char_p, _u64, C.POINTER(DecodedMessage)]),
+    "rg_progress_events": (_i, [_vp, C.c_void_p, _u64]),
+    "rg_report_unreachable": (_i, [_vp, _u64, _u64]),
+    "rg_report_snapshot": (_i, [_vp, _u64, _u64, _i]),
     "rg_entry_size": (_u64, [C.POINTER(EntryC)]),
     "rg_limit_size": (_u64, [C.POINTER(EntryC), _u64, _u64]),
     "rg_message_size": (_i, [C.POINTER(MessageC), C.POINTER(C.c_uint64)]),
@@ -562,6 +567,17 @@ class Engine:
         """msgs: SENT_MSG_DTYPE array of MsgAppends the HOST sent (RG_SEND_HOST items): Progress::update_state(last)."""
         msgs = np.ascontiguousarray(msgs, dtype=SENT_MSG_DTYPE)
         self._check(self.L.rg_update_state(self.h, msgs.ctypes.data, len(msgs)))
+
+    def progress_events(self, events):
+        """events: PROGRESS_EVENT_DTYPE array (or [(group, slot, kind)]): report_unreachable / report_snapshot in place."""
+        events = np.ascontiguousarray(np.array(events, dtype=PROGRESS_EVENT_DTYPE))
+        self._check(self.L.rg_progress_events(self.h, events.ctypes.data, len(events)))
+
+    def report_unreachable(self, group, peer_id):
+        self._check(self.L.rg_report_unreachable(self.h, group, peer_id))
+
+    def report_snapshot(self, group, peer_id, failure):
+        self._check(self.L.rg_report_snapshot(self.h, group, peer_id, int(bool(failure))))
 
     def send_items(self):
         """Work items of the last send stage as a SEND_ITEM_DTYPE array (order unspecified)."""

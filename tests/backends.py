@@ -144,6 +144,14 @@ class OracleLeader:
     def heartbeat_commit(self, to):
         return O.lib().ro_heartbeat_commit(self.cl.h, 0, to)
 
+    def report_unreachable(self, pid):
+        """RawNode::report_unreachable (raw_node.rs:692-698): step(MsgUnreachable) -> handle_unreachable."""
+        return O.lib().ro_handle_unreachable(self.cl.h, 0, pid)
+
+    def report_snapshot(self, pid, failure):
+        """RawNode::report_snapshot (raw_node.rs:701-709): step(MsgSnapStatus { reject: failure })."""
+        return O.lib().ro_handle_snapshot_status(self.cl.h, 0, pid, failure)
+
     def step_heartbeat_response(self, from_, commit=0, ins_full=False):
         o = O.Out()
         O.lib().ro_handle_heartbeat_response(self.cl.h, 0, from_, commit, 1 if ins_full else 0, o)
@@ -414,6 +422,13 @@ class EngineLeader:
     def sent(self, pid):
         self.msgs.m_flags[0, pid - 1] = self.rg.MF.SENT
         return -1 if (self._tick() & 2) else 0
+
+    def report_unreachable(self, pid):
+        self.eng.progress_events([(0, pid - 1, self.rg.engine.EV_UNREACHABLE)])
+
+    def report_snapshot(self, pid, failure):
+        E = self.rg.engine
+        self.eng.progress_events([(0, pid - 1, E.EV_SNAPSHOT_FAILURE if failure else E.EV_SNAPSHOT_FINISH)])
 
     def heartbeat_commit(self, to):
         return int(self.eng.heartbeat_commits()[to - 1, 0])

@@ -203,3 +203,22 @@ def garbage_msgs(rng, st, msgs):
     if "m_logterm" in msgs:
         msgs["m_logterm"][:, :G] = rng.integers(0, 12, size=(P, G), dtype=np.uint64)
     return msgs
+
+
+def random_progress_events(rng, n_groups, n_slots, n, dup_frac=0.2):
+    """[(group, slot, kind)] for rg_progress_events: RawNode::report_unreachable / report_snapshot on random cells (kinds 1..3),
+    sorted so that the records of one (group, slot) are adjacent -- the entry point's contract -- with runs of several
+    events on one cell, and a few slots / groups that do not exist (ignored)."""
+    ev = []
+    for _ in range(n):
+        g, s = int(rng.integers(0, n_groups)), int(rng.integers(0, n_slots))
+        ev.append((g, s, int(rng.integers(1, 4))))
+        while rng.random() < dup_frac:
+            ev.append((g, s, int(rng.integers(1, 4))))
+    keyed = {}
+    for g, s, k in ev:  # group the runs, keep the order inside a run
+        keyed.setdefault((g, s), []).append(k)
+    out = [(g, s, k) for (g, s), ks in keyed.items() for k in ks]
+    out.insert(len(out) // 2, (n_groups + 5, 0, 1))  # no such group
+    out.insert(len(out) // 3, (0, 8, 2))             # no such slot
+    return out

@@ -324,3 +324,15 @@ extern "C" int rg_host_check_mci(unsigned P, const u64 *match, const u64 *gid, u
     RG_DISPATCH_P(P, *mci = host_mci<N>(match, gid, incoming, outgoing, use_group_commit, raise_slot, old_value, used));
     return 0;
 }
+
+
+// rg_progress_events (RawNode::report_unreachable / report_snapshot in place) for the host: the record loop the kernel
+// runs one lane per record. ins_meta may be NULL (Inflights with the host).
+extern "C" int rg_host_check_progress_events(unsigned P, unsigned long G, unsigned long stride, void *const *state, u32 *ins_meta,
+                                             const rg_progress_event *ev, unsigned long n) {
+    if (P < 1 || P > 8) return -1;
+    const RgState st = make_state(state, G, stride);
+    derive_pending(st, P);
+    for (u64 i = 0; i < n; i++) rg_progress_events_at(st, ins_meta, ev, n, P, i);
+    return 0;
+}

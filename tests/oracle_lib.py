@@ -129,6 +129,8 @@ def lib():
         "ro_on_persist_entries": (C.c_bool, [vp, sz, u64]),
         "ro_handle_heartbeat_response": (None, [vp, sz, u64, u64, C.c_int8, C.POINTER(Out)]),
         "ro_heartbeat_commit": (u64, [vp, sz, u64]),
+        "ro_handle_snapshot_status": (C.c_bool, [vp, sz, u64, C.c_bool]),
+        "ro_handle_unreachable": (C.c_bool, [vp, sz, u64]),
         "ro_group_vote_result": (C.c_int, [vp, sz, C.POINTER(u64), C.POINTER(C.c_uint8), sz]),
         "ro_quorum_recently_active": (C.c_bool, [vp, sz, u64]),
         "ro_group_tally_votes": (C.c_int, [vp, sz, C.POINTER(u64), C.POINTER(C.c_uint8), sz, C.POINTER(sz), C.POINTER(sz)]),

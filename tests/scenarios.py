@@ -634,7 +634,62 @@ def scenario_leader_start_replication(B):
     assert ld.committed() == li
 
 
-FLOW = [scenario_leader_start_replication, scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_progress_flow_control_bytes, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
+def scenario_recv_msg_unreachable(B):
+    """test_raft.rs:2913-2933 test_recv_msg_unreachable: three previous entries at term 1, become_leader's empty entry at 4;
+    node 2 matched 3, Replicate, optimistic_update(5); MsgUnreachable puts it back to Probe with next = matched + 1.
+    A second report finds a Probe peer and changes nothing; a peer in Snapshot is left alone (raft.rs:1947-1949)."""
+    ld = B(1, 1, [1, 2, 3], log=[(1, 1), (1, 2), (1, 3), (1, 4)], committed=0, next_idx=4)
+    ld.set_progress(1, match=4, next=5, state=REPLICATE)
+    ld.set_progress(2, match=3, next=6, state=REPLICATE)
+    ld.set_progress(3, match=0, next=1, state=SNAPSHOT, pending_snapshot=4)
+    ld.report_unreachable(2)
+    pr = ld.progress(2)
+    assert pr["state"] == PROBE and pr["match"] + 1 == pr["next"] == 4 and not pr["paused"]
+    ld.set_progress(2, paused=True)  # a Probe peer that was sent to
+    ld.report_unreachable(2)
+    assert ld.progress(2) == dict(pr, paused=True), "only a Replicate peer reacts"
+    before = ld.progress(3)
+    ld.report_unreachable(3)
+    assert ld.progress(3) == before and before["state"] == SNAPSHOT
+    ld.report_unreachable(9)  # "no progress available": ignored
+
+
+def scenario_snapshot_failure_and_succeed(B):
+    """test_raft_snap.rs:68-87 test_snapshot_failure and :89-109 test_snapshot_succeed: snapshot (index 11, term 11)
+    restored, peer 2 at next 1 in Snapshot(pending 11). MsgSnapStatus{reject} -> pending_snapshot 0, next 1, paused;
+    MsgSnapStatus{ok} -> pending_snapshot 0, next 12, paused. Both clear pending_request_snapshot (raft.rs:1928); a peer
+    that is not in Snapshot ignores the message (:1903-1905)."""
+    for failure, wnext in ((True, 1), (False, 12)):
+        ld = B(1, 1, [1, 2], log=[(1, 12)], committed=11, dummy=(11, 11), next_idx=12)
+        ld.set_progress(1, match=11, next=12, state=REPLICATE)
+        ld.set_progress(2, next=1, state=SNAPSHOT, pending_snapshot=11, pending_request_snapshot=11)
+        ld.report_snapshot(2, failure)
+        pr = ld.progress(2)
+        assert pr["pending_snapshot"] == 0 and pr["next"] == wnext and pr["paused"], (failure, pr)
+        assert pr["state"] == PROBE and pr["pending_request_snapshot"] == 0, (failure, pr)
+        ld.report_snapshot(2, not failure)  # no longer in Snapshot
+        assert ld.progress(2) == pr
+        me = ld.progress(1)
+        ld.report_snapshot(1, failure)  # the leader's own Progress is Replicate
+        assert ld.progress(1) == me
+
+
+def scenario_unreachable_resets_the_window(B, cap=4):
+    """handle_unreachable's become_probe is Progress::reset_state: ins.reset() (progress.rs:75-80). A Replicate peer with
+    messages in flight loses them; the next proposal is sent from matched + 1 again, once (Probe pauses)."""
+    ld = _flow_leader(B, cap)
+    for _ in range(3):
+        assert len(ld.propose()) == 1
+    assert ld.inflights(2) == [2, 3, 4] and ld.progress(2)["next"] == 5
+    ld.report_unreachable(2)
+    pr = ld.progress(2)
+    assert pr["state"] == PROBE and pr["next"] == 1 and ld.inflights(2) == [] and not ld.ins_full(2)
+    ms = ld.propose()
+    assert ms == [(2, 1, 0, 5)], ms  # one MsgAppend with everything from index 1 (no limit), then paused
+    assert ld.propose() == []
+
+
+FLOW = [scenario_unreachable_resets_the_window, scenario_leader_start_replication, scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_progress_flow_control_bytes, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
         scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
@@ -644,4 +699,4 @@ ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_com
        scenario_learners_never_count, scenario_joint_needs_both_majorities, scenario_handle_heartbeat_resp,
        scenario_commit_after_remove_node, scenario_fast_log_rejection, scenario_progress_committed_index,
        scenario_send_path_update_state, scenario_leader_commit_preceding_entries, scenario_progress_leader,
-       scenario_become_leader_resets_every_progress]
+       scenario_become_leader_resets_every_progress, scenario_recv_msg_unreachable, scenario_snapshot_failure_and_succeed]

@@ -748,3 +748,53 @@ def test_group_commit_routine_equals_reference(case):
               C.byref(used)) == 0
     want, want_used = _oracle_joint(match, gid, incoming, outgoing, True)
     assert out.value == want and bool(used.value) == want_used, (case, out.value, used.value, want, want_used)
+
+
+def _apply_events_to_oracle(cl, events, G, P):
+    """The oracle's side of an rg_progress_events batch: MsgUnreachable / MsgSnapStatus stepped one by one (ids = slot + 1)."""
+    L = O.lib()
+    for g, s, kind in events:
+        if g >= G or s >= P:
+            continue
+        if kind == 1:
+            L.ro_handle_unreachable(cl.h, g, s + 1)
+        else:
+            L.ro_handle_snapshot_status(cl.h, g, s + 1, kind == 3)
+
+
+@pytest.mark.parametrize("n_slots", [1, 3, 5, 8])
+def test_progress_events_on_host_match_the_oracle(n_slots):
+    """rg_progress_events (RawNode::report_unreachable / report_snapshot applied to the cells in place): the engine's
+    per-cell arithmetic and record loop, compiled for the host, against handle_unreachable / handle_snapshot_status
+    restated in the oracle -- random states with a quarter of the peers in Snapshot, runs of several events on one cell."""
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_progress_events
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong]
+    rng = np.random.default_rng(7100 + n_slots)
+    G = 2000
+    st = O.alloc_state(G, n_slots)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True, snapshot_frac=0.25)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6)
+    eng_st = copy_state(st)
+    out = np.zeros(G, dtype=np.uint32)
+    n_changed = 0
+    for rnd in range(4):
+        cl.store_soa(st)
+        before = copy_state(st)
+        events = fuzz.random_progress_events(rng, G, n_slots, 1500)
+        ev = np.array(events, dtype=[("group", "<u8"), ("slot", "<u4"), ("kind", "<u4")])
+        assert fn(n_slots, G, st["stride"], state_ptrs(eng_st, out), None, ev.ctypes.data, len(ev)) == 0
+        _apply_events_to_oracle(cl, events, G, n_slots)
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, eng_st, G, n_slots)
+        assert not diffs, (rnd, diffs[:6])
+        n_changed += int((before["next"] != st["next"]).sum() + (before["pflags"] != st["pflags"]).sum())
+        if rnd == 1:  # put a fresh crop of peers into Snapshot / Replicate for the later rounds
+            fuzz.random_state(rng, st, small_values=True, snapshot_frac=0.3)
+            cl.load_soa(st, term=6)
+            eng_st = copy_state(st)
+    assert n_changed > 500, n_changed

@@ -667,3 +667,116 @@ def test_new_entry_points_refuse_what_they_cannot_do(rg):
     plain.mailbox_stop()                        # idempotent
     plain.close()
     dev.close()
+
+
+# ---- RawNode::report_unreachable / report_snapshot applied on the device (rg_progress_events) --------------------------
+def _events_to_oracle(cl, events, G, P):
+    for g, s, kind in events:
+        if g >= G or s >= P:
+            continue
+        if kind == 1:
+            cl.L.ro_handle_unreachable(cl.h, g, s + 1)
+        else:
+            cl.L.ro_handle_snapshot_status(cl.h, g, s + 1, kind == 3)
+
+
+@pytest.mark.parametrize("n_slots,cap", [(3, 0), (5, 3), (7, 256), (8, 1)])
+def test_progress_events_match_oracle(rg, n_slots, cap):
+    """MsgUnreachable / MsgSnapStatus between ticks: handle_unreachable (raft.rs:1931-1954) and handle_snapshot_status
+    (:1891-1929) applied to the cells in place, runs of several events on one cell, against the oracle stepping the same
+    local messages one by one -- Progress columns, the engine-owned flag bits and (cap > 0) the Inflights windows, which a
+    state change resets; the ticks and send stages in between run on what the events left."""
+    rng = np.random.default_rng(9100 + 17 * n_slots + cap)
+    G = 5000 + 7
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True, snapshot_frac=0.2)
+    fuzz.random_term_table(rng, st, term=6)
+    eng = rg.Engine(G, n_slots, max_inflight=cap)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    if cap:
+        cl.set_own_inflights(True)
+    msgs = O.alloc_msgs(G, n_slots)
+    mb = rg.MsgBuffers(G, n_slots, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    n_changed = n_items = 0
+    for t in range(5):
+        cl.store_soa(st)
+        before = {k: st[k].copy() for k in ("next", "pflags")}
+        events = fuzz.random_progress_events(rng, G, n_slots, 2500)
+        eng.progress_events(events)
+        _events_to_oracle(cl, events, G, n_slots)
+        cl.store_soa(st)
+        n_changed += int((before["next"] != st["next"]).sum() + (before["pflags"] != st["pflags"]).sum())
+        got = eng.read_state()
+        diffs = fuzz.diff_states(st, got, G, n_slots)
+        assert not diffs, f"events {t}: " + "\n".join(diffs[:10])
+        if cap:
+            meta, ring = eng.read_inflights()
+            sendstage.compare_rings(cl, meta, ring, st, cap)
+        # a tick (and its send stage) on top of what the events left
+        fuzz.random_msgs(rng, st, msgs, sent_p=0.0 if cap else 0.2, heartbeat_p=0.2)
+        if cap:
+            sendstage.prepare_msgs(msgs)
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+            getattr(mb, k)[...] = msgs[k]
+        eng.tick(mb)
+        cl.tick_soa(msgs, gout)
+        _, out = eng.results()
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        if cap:
+            eng.send_appends(2)
+            items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, 2))
+            apply_snapshots(rg, eng, cl, st, items)
+            check(rg, eng, cl, st, cap, f"P={n_slots} cap={cap} tick {t}")
+            n_items += len(items)
+        else:
+            cl.store_soa(st)
+            diffs = fuzz.diff_states(st, eng.read_state(), G, n_slots)
+            assert not diffs, f"tick {t}: " + "\n".join(diffs[:10])
+    assert n_changed > 1000, n_changed
+    assert not cap or n_slots == 1 or n_items > 500
+    with pytest.raises(rg.EngineError) as e:
+        eng.progress_events([(0, 0, 4)])
+    assert e.value.code == -1
+    eng.close()
+
+
+def test_report_unreachable_and_snapshot_through_the_mirror(rg):
+    """rg_report_unreachable / rg_report_snapshot: RawNode::report_unreachable(id) / report_snapshot(id, status)
+    (raw_node.rs:692-709) by peer id. An id without a Progress is ignored; while the group has queued traffic the call is
+    refused (local messages apply in call order: flush first)."""
+    G, P, cap = 8, 3, 4
+    eng = rg.Engine(G, P, max_inflight=cap)
+    st = O.alloc_state(G, P, stride=eng.stride)
+    st["match"][:, :G], st["next"][:, :G] = 10, 14
+    st["pflags"][:, :P] = rg.PF.REPLICATE | rg.PF.RECENT_ACTIVE
+    st["commit"][:], st["term_lo"][:], st["term_hi"][:] = 10, 1, 13
+    st["cfg"][:] = rg.cfg_make(0b111, self_slot=0)
+    st["pflags"][5, 2] = O.SNAPSHOT  # group 5, peer 33: a snapshot (index 20) is on its way
+    st["pend_snap"][2, 5], st["next"][2, 5], st["pend_rs"][2, 5] = 20, 11, 20
+    eng.load_state(st)
+    for g in range(G):
+        eng.set_peers(g, [11, 22, 33], term=5)
+    eng.report_unreachable(2, 22)
+    eng.report_unreachable(2, 99)  # "no progress available": ignored
+    eng.report_snapshot(5, 33, failure=False)
+    eng.report_snapshot(5, 22, failure=True)  # not in Snapshot: ignored
+    got = eng.read_state()
+    assert int(got["pflags"][2, 1]) & 7 == O.PROBE and int(got["next"][1, 2]) == 11
+    f = int(got["pflags"][5, 2])
+    assert f & 3 == O.PROBE and f & 4 and not f & 0xC0, hex(f)  # Probe, paused, both pending bits gone
+    assert int(got["next"][2, 5]) == 21 and int(got["pend_snap"][2, 5]) == 0 and int(got["pend_rs"][2, 5]) == 0
+    assert int(got["pflags"][5, 1]) & 3 == O.REPLICATE and int(got["next"][1, 5]) == 14
+    untouched = [g for g in range(G) if g not in (2, 5)]
+    assert (got["next"][:, untouched] == 14).all()
+    eng.step(3, 22, 5, 12)  # queued, not flushed
+    with pytest.raises(rg.EngineError) as e:
+        eng.report_unreachable(3, 33)
+    assert e.value.code == rg.engine.ERR["SLOT_BUSY"]
+    eng.flush()
+    eng.report_unreachable(3, 33)
+    assert int(eng.read_column(rg.COL.PFLAGS)[3, 2]) & 3 == O.PROBE
+    eng.close()
