@@ -416,6 +416,52 @@ static void test_snapshot_failure_and_succeed() {
     }
 }
 
+// harness/tests/integration_cases/test_raft.rs:2680-2752: MsgBeat makes the leader send a MsgHeartbeat to every follower,
+// with commit = min(matched, committed), no entries, index 0, log_term 0
+static void test_bcast_beat() {
+    const u64 offset = 1000;
+    struct Row { u64 committed, want2, want3; };
+    // the reference's row (nothing is acknowledged: committed = the snapshot's index), and one where a follower's matched
+    // index is what bounds its heartbeat's commit
+    const Row tests[] = {{offset, offset, offset}, {offset + 8, offset + 5, offset + 8}};
+    for (const Row &t : tests) {
+        Config c;
+        c.n_groups = 1;
+        c.max_peers = 3;
+        MultiRaft sm(c);
+        GroupSpec s; // log.offset = 1000, term 2 after become_candidate, the empty entry at 1001 and ten more entries
+        s.id = 1;
+        s.term = 2;
+        s.voters = {1, 2, 3};
+        s.first_index_of_term = offset + 1;
+        s.last_index = offset + 11;
+        s.committed = t.committed;
+        sm.init_group(0, s);
+        sm.bootstrap();
+        const u64 last_index = sm.last_index(0);
+        Progress p = sm.progress(0, 2); // slow follower
+        p.matched = offset + 5, p.next_idx = offset + 6;
+        sm.set_progress(0, 2, p);
+        p = sm.progress(0, 3); // normal follower
+        p.matched = last_index, p.next_idx = last_index + 1;
+        sm.set_progress(0, 3, p);
+        const std::vector<Message> msgs = sm.bcast_heartbeat(0);
+        EXPECT(msgs.size() == 2, "%zu heartbeats, want 2", msgs.size());
+        std::map<u64, u64> want_commit_map = {{2, t.want2}, {3, t.want3}};
+        for (const Message &m : msgs) {
+            EXPECT(m.msg_type == MessageType::MsgHeartbeat && m.from == 1 && m.term == 2, "type = %u", (unsigned)m.msg_type);
+            EXPECT(m.index == 0 && m.log_term == 0 && m.entries.empty(), "prev_index / prev_term / entries");
+            EXPECT(want_commit_map.count(m.to) && m.commit == want_commit_map[m.to], "to %llu: commit = %llu", (unsigned long long)m.to,
+                   (unsigned long long)m.commit);
+            want_commit_map.erase(m.to);
+            const std::string bytes = m.write_to_bytes();
+            rg_decoded_message d;
+            check(rg_decode_message(reinterpret_cast<const std::uint8_t *>(bytes.data()), bytes.size(), &d));
+            EXPECT(d.msg_type == 8 && d.to == m.to && d.commit == m.commit && d.term == 2, "the heartbeat's bytes");
+        }
+    }
+}
+
 int main() {
     try {
         Config probe;
@@ -435,6 +481,7 @@ int main() {
     test_progress_flow_control();
     test_recv_msg_unreachable();
     test_snapshot_failure_and_succeed();
+    test_bcast_beat();
     std::printf("CPP_REFERENCE_TESTS_OK\n");
     return 0;
 }

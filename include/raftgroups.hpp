@@ -621,6 +621,27 @@ class MultiRaft {
         }
         return out;
     }
+    // ---- Raft::bcast_heartbeat (raft.rs:885-891 -> send_heartbeat :822-844) for one group: a MsgHeartbeat per peer with a
+    // Progress, the leader excepted, carrying commit = min(pr.matched, raft_log.committed) -- "the leader MUST NOT forward
+    // the follower's commit to an unmatched index" -- and the read-index context, if any ----
+    std::vector<Message> bcast_heartbeat(u64 group, const std::string &ctx = std::string()) {
+        need_boot();
+        rg_group_status st;
+        check(rg_read_groups(h_, &group, 1, &st));
+        std::vector<Message> out;
+        for (unsigned s = 0; s < cfg_.max_peers; s++) {
+            if (!((RG_CFG_PRESENT(st.cfg) >> s) & 1u) || s == RG_CFG_SELF(st.cfg)) continue;
+            Message m;
+            m.msg_type = MessageType::MsgHeartbeat;
+            m.to = ids_[group * 8 + s];
+            m.from = ids_[group * 8 + RG_CFG_SELF(st.cfg)];
+            m.term = term_[group];
+            m.commit = st.match[s] < st.commit ? st.match[s] : st.commit;
+            m.context = ctx;
+            out.push_back(m);
+        }
+        return out;
+    }
     // Progress::become_snapshot(snapshot_idx) (progress.rs:117-121): reset_state(Snapshot) + pending_snapshot
     void become_snapshot(u64 group, u64 id, u64 snapshot_idx) {
         rg_group_status st;

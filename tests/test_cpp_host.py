@@ -6,7 +6,9 @@ On a CPU-only host the program must build warning-free and fail loudly. Round 3 
 (test_raft_paper.rs:425-457) and test_progress_flow_control (test_raft.rs:369-435, max_size_per_msg in bytes) checked on the
 MESSAGES MultiRaft::messages builds out of a Storage, and examples/cpp_message_builder.cpp -- the host half alone (Storage,
 limit_size, build_messages, Message::write_to_bytes against test_storage_entries, test_slice and a restated send loop), which
-needs no device and runs in the CPU suite."""
+needs no device and runs in the CPU suite. Also restated for the GPU run: test_recv_msg_unreachable (test_raft.rs:2913-2933),
+test_snapshot_failure / test_snapshot_succeed (test_raft_snap.rs:68-109) through MultiRaft::report_unreachable / report_snapshot,
+test_bcast_beat (test_raft.rs:2680-2752) through MultiRaft::bcast_heartbeat."""
 import os
 import subprocess
 
