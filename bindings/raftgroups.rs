@@ -333,6 +333,7 @@ extern "C" {
     pub fn rg_write_cells(h: *mut RgEngine, cells: *const RgCellWrite, n: u64) -> i32;
     pub fn rg_set_config(h: *mut RgEngine, group: u64, cfg_word: u32) -> i32;
     pub fn rg_progress_events(h: *mut RgEngine, events: *const RgProgressEvent, n: u64) -> i32;
+    pub fn rg_progress_event_dense(h: *mut RgEngine, kind: u32, host_slot_plus1: *const u8) -> i32;
     pub fn rg_tick(h: *mut RgEngine, host_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device(h: *mut RgEngine, dev_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device_fused(h: *mut RgEngine, dev_msgs: *const RgMsgs, n_ticks: u32, dev_out_t: *mut u32, dev_commit_t: *mut u64) -> i32;

@@ -266,7 +266,8 @@ int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word);
  *   RG_EV_SNAPSHOT_FINISH  handle_snapshot_status (src/raft.rs:1891-1929), reject = false: a Snapshot peer becomes Probe
  *                          with next = max(matched + 1, pending_snapshot + 1), then pause() and pending_request_snapshot = 0
  *   RG_EV_SNAPSHOT_FAILURE ... reject = true: snapshot_failure() first, so next = matched + 1
- * A peer that is not in Snapshot ignores both snapshot events; slots beyond the engine's are ignored. With device
+ * A peer that is not in Snapshot ignores both snapshot events; a slot without a Progress (RG_CFG_PRESENT) or beyond the
+ * engine's, and a group beyond the shard, are ignored ("no progress available"). With device
  * Inflights the window is reset whenever the state changes. Synchronises (a control-path call, like rg_write_cells). */
 typedef struct {
     uint64_t group;
@@ -277,6 +278,11 @@ typedef struct {
 #define RG_EV_SNAPSHOT_FINISH 2u
 #define RG_EV_SNAPSHOT_FAILURE 3u
 int rg_progress_events(rg_engine *h, const rg_progress_event *events, uint64_t n);
+/* One kind of event for a whole shard at once -- what a lost connection to one store is: MsgUnreachable for that store's
+ * peer in every group that has one. `host_slot_plus1`: u8 [G], 0 = nothing for the group, s + 1 = the event goes to its
+ * slot s (values beyond the engine's slots are ignored). 1 B per group over PCIe instead of a 16 B record: 1 M groups in
+ * 77 us instead of 5.5 ms (profiles/r03_progress_events.txt). Same arithmetic as rg_progress_events. Synchronises. */
+int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slot_plus1);
 
 /* ---- the hot path ---- */
 /* One tick: for every group, apply its <=1 message per slot in slot order exactly as

@@ -658,6 +658,16 @@ __global__ __launch_bounds__(256) void k_progress_events(RgState st, u32 *ins_me
     if (i < n) rg_progress_events_at(st, ins_meta, ev, n, P, i);
 }
 
+// ... and one kind of event for every group that names a slot (rg_progress_event_dense): lane = group
+__global__ __launch_bounds__(256) void k_progress_event_dense(RgState st, u32 *ins_meta, const u8 *slot_plus1, u32 kind, u32 P) {
+    const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (g >= st.G) return;
+    const u32 s1 = slot_plus1[g];
+    if (!s1) return;
+    const rg_progress_event ev = {g, s1 - 1u, kind};
+    rg_progress_events_at(st, ins_meta, &ev, 1, P, 0);
+}
+
 // RG_PF_PEND_SNAP / RG_PF_PEND_RS (pending_snapshot / pending_request_snapshot != 0) re-derived for every cell: after the
 // flag column or one of the two columns was loaded wholesale.
 __global__ __launch_bounds__(RG_BLOCK) void k_fix_pending(RgState st, u32 P) {
@@ -2065,6 +2075,21 @@ extern "C" int rg_progress_events(rg_engine *h, const rg_progress_event *events,
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_progress_events: launch failed: %s", hipGetErrorString(e));
     RG_HIP(hipStreamSynchronize(h->stream)); // control path, like rg_write_cells: the caller's array may be reused after return
+    return RG_OK;
+}
+
+extern "C" int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slot_plus1) {
+    if (!h || !host_slot_plus1) return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_event_dense: bad argument");
+    if (kind < RG_EV_UNREACHABLE || kind > RG_EV_SNAPSHOT_FAILURE)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_event_dense: kind %u", kind);
+    RG_ENTER(h);
+    int rc = rg_stage_records(h, host_slot_plus1, (size_t)h->G);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_progress_event_dense, dim3(rg_grid(h->G, 256)), dim3(256), 0, h->stream, h->st,
+                       h->ins_arena ? h->ins.meta : nullptr, (const u8 *)h->d_recs, (u32)kind, h->P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_progress_event_dense: launch failed: %s", hipGetErrorString(e));
+    RG_HIP(hipStreamSynchronize(h->stream)); // control path: the caller's array may be reused after return
     return RG_OK;
 }
 

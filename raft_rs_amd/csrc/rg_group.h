@@ -371,6 +371,7 @@ RG_HD void rg_progress_events_at(const RgState &st, u32 *ins_meta, const rg_prog
     const u32 s = ev[i].slot;
     if (g >= st.G || s >= P) return;
     if (i > 0 && ev[i - 1].group == g && ev[i - 1].slot == s) return;
+    if (!((RG_CFG_PRESENT(st.cfg[g]) >> s) & 1u)) return; // "no progress available for {}": ignored (raft.rs:1893-1901, :1933-1942)
     const u64 o = (u64)s * st.stride + g;
     u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + g * 8 + s;
     u32 pf = *pfb;

@@ -244,6 +244,7 @@ SYMBOLS = {
     "rg_step_bytes": (_i, [_vp, _u64, C.c_char_p, _u64]),
     "rg_decode_message": (_i, [C.c_char_p, _u64, C.POINTER(DecodedMessage)]),
     "rg_progress_events": (_i, [_vp, C.c_void_p, _u64]),
+    "rg_progress_event_dense": (_i, [_vp, C.c_uint32, C.c_void_p]),
     "rg_report_unreachable": (_i, [_vp, _u64, _u64]),
     "rg_report_snapshot": (_i, [_vp, _u64, _u64, _i]),
     "rg_entry_size": (_u64, [C.POINTER(EntryC)]),
@@ -572,6 +573,12 @@ class Engine:
         """events: PROGRESS_EVENT_DTYPE array (or [(group, slot, kind)]): report_unreachable / report_snapshot in place."""
         events = np.ascontiguousarray(np.array(events, dtype=PROGRESS_EVENT_DTYPE))
         self._check(self.L.rg_progress_events(self.h, events.ctypes.data, len(events)))
+
+    def progress_event_dense(self, kind, slot_plus1):
+        """slot_plus1: u8 [G], 0 = nothing for the group, s + 1 = event `kind` goes to its slot s (rg_progress_event_dense)."""
+        a = np.ascontiguousarray(slot_plus1, dtype=np.uint8)
+        assert a.shape == (self.n_groups,)
+        self._check(self.L.rg_progress_event_dense(self.h, kind, a.ctypes.data))
 
     def report_unreachable(self, group, peer_id):
         self._check(self.L.rg_report_unreachable(self.h, group, peer_id))

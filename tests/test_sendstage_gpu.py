@@ -780,3 +780,47 @@ def test_report_unreachable_and_snapshot_through_the_mirror(rg):
     eng.report_unreachable(3, 33)
     assert int(eng.read_column(rg.COL.PFLAGS)[3, 2]) & 3 == O.PROBE
     eng.close()
+
+
+@pytest.mark.parametrize("cap", [0, 4])
+def test_dense_progress_event_equals_the_record_form(rg, cap):
+    """rg_progress_event_dense (one kind of event for every group that names a slot: 1 B per group instead of a 16 B
+    record) leaves exactly what rg_progress_events leaves for the same events -- and what the oracle leaves."""
+    rng = np.random.default_rng(9300 + cap)
+    G, P = 30000 + 11, 5
+    st = O.add_term_table(O.alloc_state(G, P))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True, snapshot_frac=0.3)
+    fuzz.random_term_table(rng, st, term=6)
+    a, b = rg.Engine(G, P, max_inflight=cap), rg.Engine(G, P, max_inflight=cap)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=6, max_inflight=cap)
+    for eng in (a, b):
+        eng.load_state(st)
+    orig = a.read_state()
+    present = ((st["cfg"] >> 24) & 0xff).astype(np.int64)
+    absent = np.array([[not (present[g] >> p) & 1 for g in range(G)] for p in range(P)])  # [P][G]
+    assert absent.sum() > 1000
+    for kind in (1, 2, 3):
+        slot1 = rng.integers(0, P + 3, size=G).astype(np.uint8)  # 0 = none, 1..P = a slot, P+1..P+2 = no such slot
+        slot1[rng.random(G) < 0.3] = 0
+        a.progress_event_dense(kind, slot1)
+        g = np.nonzero(slot1)[0]
+        b.progress_events([(int(x), int(slot1[x]) - 1, kind) for x in g])
+        _events_to_oracle(cl, [(int(x), int(slot1[x]) - 1, kind) for x in g], G, P)
+        sa, sb = a.read_state(), b.read_state()
+        assert not fuzz.diff_states(sa, sb, G, P), kind
+        # a slot without a Progress is left alone ("no progress available")
+        assert (sa["next"][:, :G][absent] == orig["next"][:, :G][absent]).all()
+        assert (sa["pflags"][:, :P].T[absent] == orig["pflags"][:, :P].T[absent]).all()
+        cl.store_soa(st)
+        diffs = fuzz.diff_states(st, sa, G, P)
+        assert not diffs, (kind, diffs[:6])
+        if cap:
+            ma, ra = a.read_inflights()
+            mb, rb = b.read_inflights()
+            assert (ma == mb).all()
+    with pytest.raises(rg.EngineError):
+        a.progress_event_dense(0, np.zeros(G, dtype=np.uint8))
+    a.close()
+    b.close()
