@@ -74,6 +74,38 @@ def clean_for_mirror(msgs, P, self_slot):
         f[has & zero, p] &= np.uint8(~0x04 & 0xff)
 
 
+def local_messages(rg, eng, cl, rng, G, P, mirror_ok=True):
+    """RawNode::report_unreachable / report_snapshot between two steps of a sequence, through one of the three forms
+    (records, one byte per group, the mirror by peer id), to the engine and to the oracle alike."""
+    E = rg.engine
+    form = rng.choice(["records", "dense", "mirror"] if mirror_ok else ["records", "dense"])
+    if form == "records":
+        events = fuzz.random_progress_events(rng, G, P, int(rng.integers(1, 60)))
+        eng.progress_events(events)
+    elif form == "dense":
+        kind = int(rng.integers(1, 4))
+        slot1 = np.where(rng.random(G) < 0.1, rng.integers(1, P + 1, size=G), 0).astype(np.uint8)
+        eng.progress_event_dense(kind, slot1)
+        events = [(int(g), int(slot1[g]) - 1, kind) for g in np.nonzero(slot1)[0]]
+    else:
+        events = []
+        for _ in range(int(rng.integers(1, 12))):
+            g, s, kind = int(rng.integers(0, G)), int(rng.integers(0, P)), int(rng.integers(1, 4))
+            if kind == E.EV_UNREACHABLE:
+                eng.report_unreachable(g, s + 1)
+            else:
+                eng.report_snapshot(g, s + 1, kind == E.EV_SNAPSHOT_FAILURE)
+            events.append((g, s, kind))
+    for g, s, kind in events:
+        if g >= G or s >= P:
+            continue
+        if kind == 1:
+            cl.L.ro_handle_unreachable(cl.h, g, s + 1)
+        else:
+            cl.L.ro_handle_snapshot_status(cl.h, g, s + 1, kind == 3)
+    return form
+
+
 @pytest.mark.parametrize("seed,P", [(1, 3), (2, 5), (3, 7)])
 def test_random_api_sequences_match_the_oracle(rg, seed, P):
     rng = np.random.default_rng(4200 + seed)
@@ -114,6 +146,9 @@ def test_random_api_sequences_match_the_oracle(rg, seed, P):
             got = eng.read_state()
             assert not fuzz.diff_states(st, got, G, P), (step, op)
             continue
+        if rng.random() < 0.3:  # local messages between the steps: MsgUnreachable / MsgSnapStatus
+            ops_seen.add("local:" + local_messages(rg, eng, cl, rng, G, P))
+            cl.store_soa(st)  # (the tick's messages are generated for the state the events left)
         if op == "recompute":
             eng.recompute()
             for g in range(G):
@@ -155,7 +190,7 @@ def test_random_api_sequences_match_the_oracle(rg, seed, P):
             order = np.argsort(groups)
             assert (groups[order] == with_events).all(), (step, op)
             assert (c2[order] == st["commit"][with_events]).all() and (o2[order] == gout[with_events]).all(), (step, op)
-    assert len(ops_seen) >= 7, ops_seen
+    assert len(ops_seen) >= 9 and any(o.startswith("local:") for o in ops_seen), ops_seen
     eng.close()
 
 
@@ -201,6 +236,9 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap, mailbox):
         max_entries, skip = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
         staged = False
         touched = None
+        if rng.random() < 0.3:  # local messages between the steps (a state change resets the device window)
+            ops_seen.add("local:" + local_messages(rg, eng, cl, rng, G, P))
+            cl.store_soa(st)
         if op == "recompute":
             eng.recompute()
             for g in range(G):
@@ -251,6 +289,7 @@ def test_random_api_sequences_with_the_send_stage(rg, seed, P, cap, mailbox):
         meta, ring = eng.read_inflights()
         sendstage.compare_rings(cl, meta, ring, st, cap)
     assert n_items > 2000 and {"dense_send", "mirror_small_flush_send"} <= ops_seen, (n_items, ops_seen)
+    assert any(o.startswith("local:") for o in ops_seen), ops_seen
     if mailbox:
         assert eng.mailbox_stats()[0] > 0, "no flush was served by the resident workgroup"
     eng.close()
