@@ -293,6 +293,43 @@ def test_encoder_agrees_with_the_protobuf_runtime_on_random_messages(rg):
     assert n_ent > 3000
 
 
+def test_encode_then_decode_is_the_identity_on_the_scalar_fields(rg):
+    """Property (hypothesis): for ANY field values -- the whole u64 range, every message type number, entries and payloads
+    of any size class -- rg_decode_message reads back what rg_encode_message wrote, rg_message_size is the length, and
+    rg_entry_size adds up to the bytes the entries occupy on the wire (minus their tags and length prefixes)."""
+    from hypothesis import given, settings, strategies as S
+    from raft_rs_amd.engine import decode_message, encode_message, entry_size
+    u64 = S.one_of(S.just(0), S.integers(0, 300), S.integers(0, (1 << 64) - 1), S.just((1 << 64) - 1))
+    blob = S.binary(max_size=70)
+    entry = S.fixed_dictionaries({"entry_type": S.integers(0, 2), "term": u64, "index": u64, "data": blob, "context": S.one_of(S.just(b""), blob),
+                                  "sync_log": S.booleans()})
+    fields = S.fixed_dictionaries({"msg_type": S.integers(0, 18), "to": u64, "from": u64, "term": u64, "log_term": u64, "index": u64,
+                                   "commit": u64, "commit_term": u64, "reject": S.integers(0, 1), "reject_hint": u64,
+                                   "request_snapshot": u64, "priority": u64})
+
+    def vlen(v):
+        n = 1
+        while v >= 0x80:
+            v >>= 7
+            n += 1
+        return n
+
+    @settings(max_examples=400, deadline=None)
+    @given(fields, S.lists(entry, max_size=5), S.one_of(S.none(), S.just(b"")), S.one_of(S.just(b""), blob))
+    def check(f, ents, snap, ctx):
+        data = encode_message(f, ents, snapshot=snap, context=ctx)
+        back = decode_message(data)
+        for k, v in f.items():
+            assert back[k] == v, k
+        assert back["n_entries"] == len(ents) and back["has_snapshot"] == int(snap is not None) and back["context_len"] == len(ctx)
+        sizes = [entry_size(e) for e in ents]
+        scalars = sum(1 + vlen(v) for k, v in f.items() if v)
+        want = scalars + sum(1 + vlen(z) + z for z in sizes) + (2 if snap is not None else 0) + ((1 + vlen(len(ctx)) + len(ctx)) if ctx else 0)
+        assert len(data) == want
+
+    check()
+
+
 @pytest.mark.gpu
 def test_step_bytes_equals_step(rg):
     """Two engines, the same stream: one stepped through rg_step / rg_step_heartbeat_response, the other through
