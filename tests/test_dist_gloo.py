@@ -1,4 +1,4 @@
-"""CPU multi-process test of the N>1 path: 2 ranks over gloo. The per-shard ticks run on the CPU
+"""CPU multi-process test of the N>1 path: 2 and 3 ranks over gloo. The per-shard ticks run on the CPU
 oracle here (the HIP engine needs a GPU); what is under test is the product's sharding arithmetic
 (raft_rs_amd/sharding.py), the shard-local stream generation and the commit-index publication ENCODING of the C ABI
 (host twins rg_pub_accumulate_host / rg_pub_apply_host; tests/test_publish_gpu.py drives rg_publish_commit itself)."""
@@ -75,15 +75,19 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_shard_and_publish_commit(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])  # (3: shards of a group count that does not divide, an odd gather)
+def test_ranks_shard_and_publish_commit(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RG_ROOT=ROOT, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29531 + world), str(script)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "DIST_OK 2" in r.stdout, r.stdout[-3000:]
+    assert f"DIST_OK {world}" in r.stdout, r.stdout[-3000:]
 
 
 def test_publication_encoding_saturation_list_and_loss():
