@@ -30,6 +30,7 @@ pub const RG_OUT_FAULT: u32 = 0x2;
 pub const RG_OUT_TIMEOUT_NOW: u32 = 0x4;
 pub const RG_OUT_APPENDED: u32 = 0x8;
 pub const RG_OUT_BECAME_LEADER: u32 = 0x10;
+pub const RG_OUT_HOST_HINT: u32 = 0x20;
 pub const RG_TERM_RUNS: u32 = 8;
 pub const RG_VARIANT_DEFAULT: u32 = 0;
 pub const RG_VARIANT_LANE: u32 = 1;
@@ -82,7 +83,8 @@ pub const RG_COL_RUN_TERM: i32 = 13;
 pub const RG_COL_DUMMY_INDEX: i32 = 14;
 pub const RG_COL_DUMMY_TERM: i32 = 15;
 pub const RG_COL_CUR_TERM: i32 = 16;
-pub const RG_COL_COUNT: i32 = 17;
+pub const RG_COL_HOST_HINT: i32 = 17;
+pub const RG_COL_COUNT: i32 = 18;
 
 pub enum RgEngine {} // opaque
 pub type RgAllgatherFn = Option<unsafe extern "C" fn(*mut c_void, *const c_void, *mut c_void, u64, *mut c_void) -> i32>;
@@ -154,6 +156,22 @@ pub struct RgProgressEvent {
     pub group: u64,
     pub slot: u32,
     pub kind: u32,
+}
+
+#[repr(C)]
+pub struct RgHostHint {
+    pub group: u64,
+    pub slot_mask: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+pub struct RgResolvedHint {
+    pub group: u64,
+    pub index: u64,
+    pub hint: u64,
+    pub slot: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -342,6 +360,8 @@ extern "C" {
     pub fn rg_heartbeat_commits(h: *mut RgEngine, dev_hb_commit: *mut u64, host_hb_commit: *mut u64) -> i32;
     pub fn rg_results(h: *mut RgEngine, host_commit: *mut u64, host_out: *mut u32) -> i32;
     pub fn rg_result_counts(h: *mut RgEngine, n_changed: *mut u64, n_fault: *mut u64) -> i32;
+    pub fn rg_host_hints(h: *mut RgEngine, host_items: *mut RgHostHint, cap: u64, n: *mut u64) -> i32;
+    pub fn rg_resolve_host_hints(h: *mut RgEngine, items: *const RgResolvedHint, n: u64, host_applied: *mut u8) -> i32;
     pub fn rg_msg_stats(h: *mut RgEngine, dev_m_flags: *const u8, counts: *mut u64) -> i32;
     pub fn rg_vote_result(h: *mut RgEngine, host_yes: *const u8, host_no: *const u8, host_result: *mut u8) -> i32;
     pub fn rg_tally_votes(h: *mut RgEngine, host_yes: *const u8, host_no: *const u8, host_granted: *mut u8, host_rejected: *mut u8, host_result: *mut u8) -> i32;

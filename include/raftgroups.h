@@ -121,6 +121,15 @@ typedef enum {
 #define RG_OUT_TIMEOUT_NOW 0x4u /* send_timeout_now(transferee) (src/raft.rs:1764-1774) */
 #define RG_OUT_APPENDED 0x8u    /* the leader's log grew in this tick (RG_MF_APPEND): the bcast_append that follows a proposal is due (src/raft.rs:2049-2053) */
 #define RG_OUT_BECAME_LEADER 0x10u /* an RG_MF_BECOME_LEADER event was applied in this tick (Raft::become_leader): every Progress was reset, so the send stage empties the group's Inflights before anything else */
+#define RG_OUT_HOST_HINT 0x20u /* a reject with RG_MF_HAS_LOGTERM was NOT applied: RaftLog::find_conflict_by_term (src/raft_log.rs:209-235)
+                                 needed terms of log entries the device's bounded term-run table no longer holds (RG_COL_RUN_*:
+                                 more than RG_TERM_RUNS older terms since the last snapshot, and the walk reaches below them). The
+                                 peer's recent_active and committed_index are updated (src/raft.rs:1674-1677: they do not depend on
+                                 the hint), maybe_decr_to and everything behind it is left to the host: it resolves the hint
+                                 against its own log and steps the same reject again with RG_MF_HAS_LOGTERM clear (log_term = 0)
+                                 and WITHOUT RG_MF_SENT (a SENT event of the slot was applied). Which slots: RG_COL_HOST_HINT /
+                                 rg_host_hints. A reject touches only its own peer's Progress and never `matched`, so taking it
+                                 after the other messages of the tick changes no other result. */
 #define RG_OUT_SEND_APPEND(o) (((uint32_t)(o) >> 8) & 0xffu) /* per slot: send_append(from) (raft.rs:1719, :1750) */
 #define RG_OUT_SEND_MORE(o) (((uint32_t)(o) >> 16) & 0xffu)  /* per slot: the maybe_send_append loop (raft.rs:1761) */
 #define RG_OUT_FREE_TO(o) (((uint32_t)(o) >> 24) & 0xffu)    /* per slot: ins.free_to(m.index) (raft.rs:1742) */
@@ -144,15 +153,22 @@ typedef enum {
      * OLDER terms (run k covers [run_first[k], run_first[k+1]), the last one up to term_lo - 1; unused runs have
      * run_first = 0, used runs come first in ascending order), then the entries [term_lo, term_hi] of the leader's
      * own term RG_COL_CUR_TERM (this last run grows with every RG_MF_APPEND without touching the table; an
-     * RG_MF_BECOME_LEADER event pushes it into the table -- when all RG_TERM_RUNS runs are in use the boundary between
-     * the two OLDEST runs is forgotten, i.e. history deeper than the table is approximated by the oldest kept term).
+     * RG_MF_BECOME_LEADER event pushes it into the table). The table is BOUNDED, the reference's log is not: when all
+     * RG_TERM_RUNS runs are in use a push drops the OLDEST run, and the table then starts above the dummy entry. The
+     * terms of the entries in between -- (dummy_index, run_first[0]), or (dummy_index, term_lo) with an empty table --
+     * are not on the device; a find_conflict_by_term walk whose answer depends on one of them is not answered but handed
+     * back (RG_OUT_HOST_HINT), so every hint the engine DOES apply is the reference's. A host that loads a table
+     * therefore loads a contiguous one (run_first[0] = dummy_index + 1) or accepts host hints for the gap.
      * Only read for rejects with RG_MF_HAS_LOGTERM and by RG_MF_BECOME_LEADER. */
     RG_COL_RUN_FIRST = 12,   /* u64 [RG_TERM_RUNS][stride] */
     RG_COL_RUN_TERM = 13,    /* u64 [RG_TERM_RUNS][stride] */
     RG_COL_DUMMY_INDEX = 14, /* u64 [G] */
     RG_COL_DUMMY_TERM = 15,  /* u64 [G] */
     RG_COL_CUR_TERM = 16,    /* u64 [G] the leader's term (Raft.term) */
-    RG_COL_COUNT = 17
+    RG_COL_HOST_HINT = 17,   /* u8 [G] engine-owned, read-only for the host: bit s = slot s's reject of the last tick was left to
+                                the host (RG_OUT_HOST_HINT). Meaningful only for groups whose RG_COL_OUT word of that tick has the
+                                bit; other bytes are stale. rg_host_hints gathers the flagged groups. */
+    RG_COL_COUNT = 18
 } rg_column;
 #define RG_TERM_RUNS 8
 
@@ -322,6 +338,35 @@ int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb_commit, uint64_t *host_h
 int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out);
 /* Sum of RG_OUT_CHANGED / RG_OUT_FAULT bits over all groups for the last tick (device reduction). */
 int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault);
+
+/* Groups whose last tick raised RG_OUT_HOST_HINT, with the slots concerned (bit s of slot_mask) -> host array of capacity
+ * `cap`; *n = number of such groups (only cap are written if it is larger). One device scan of RG_COL_OUT; synchronises.
+ * For each (group, slot) the host runs its own RaftLog::find_conflict_by_term(reject_hint, log_term) and steps the reject
+ * again with log_term = 0 (rg_step / RG_MF_VALID | RG_MF_REJECT without RG_MF_HAS_LOGTERM and without RG_MF_SENT). */
+typedef struct {
+    uint64_t group;
+    uint32_t slot_mask;
+    uint32_t reserved;
+} rg_host_hint;
+int rg_host_hints(rg_engine *h, rg_host_hint *host_items, uint64_t cap, uint64_t *n);
+/* The host's answer: for each record, the rest of handle_append_response's reject branch (src/raft.rs:1679-1721) on the
+ * device cell -- Progress::maybe_decr_to(index, hint, 0) (src/tracker/progress.rs:168-206) with `hint` =
+ * find_conflict_by_term(reject_hint, log_term).0 from the host's log (src/raft.rs:1657-1660), become_probe when that leaves
+ * Replicate -- and the group's RG_COL_OUT word completed: RG_OUT_SEND_APPEND(slot) where maybe_decr_to returned true
+ * (host_applied[i] = 1, may be NULL), RG_OUT_HOST_HINT cleared. Pass all rejects of a group in one call, before anything
+ * else touches the group. With device Inflights the order of the reference is kept by making the GROUP's sends wait for
+ * this call: after rg_tick(_device) call it BEFORE rg_send_appends; the one-launch forms (rg_tick_send, rg_tick_device_send,
+ * rg_flush_send) do not run the stage of a group that raised the bit -- this call runs it, with the limit and flags of that
+ * launch, and appends the work items to the compact list (rg_send_items; rg_send_columns then no longer holds everything).
+ * The compact results rg_ingested_results hands out are not rewritten. Synchronises (control path). */
+typedef struct {
+    uint64_t group;
+    uint64_t index; /* Message.index of the reject */
+    uint64_t hint;  /* the resolved hint */
+    uint32_t slot;
+    uint32_t reserved;
+} rg_resolved_hint;
+int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items, uint64_t n, uint8_t *host_applied);
 
 /* Census of a tick's message flags in DEVICE memory: counts[0] = VALID messages, [1] = rejects,
  * [2] = slots with a Progress, [3] = groups with at least one event, [4] = RG_MF_BECOME_LEADER events

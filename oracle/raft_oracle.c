@@ -497,6 +497,19 @@ ro_progress *ro_group_progress(ro_cluster *c, size_t g, uint64_t id) {
 uint64_t ro_group_committed(const ro_cluster *c, size_t g) { return c->g[g].committed; }
 uint64_t ro_group_last_index(const ro_cluster *c, size_t g) { return c->g[g].last_index; }
 uint64_t ro_group_term(const ro_cluster *c, size_t g) { return c->g[g].term; }
+/* the whole log as runs of equal-term entries (dummy entry excluded): first index / term of run k -> first[k], term[k];
+ * returns the number of runs (only `cap` are written) */
+size_t ro_group_log_runs(const ro_cluster *c, size_t g, uint64_t *first, uint64_t *term, size_t cap,
+                         uint64_t *dummy_index, uint64_t *dummy_term) {
+    const ro_group *gr = &c->g[g];
+    for (size_t k = 0; k < gr->n_runs && k < cap; k++) {
+        first[k] = gr->runs[k].first;
+        term[k] = gr->runs[k].term;
+    }
+    if (dummy_index) *dummy_index = gr->dummy_index;
+    if (dummy_term) *dummy_term = gr->dummy_term;
+    return gr->n_runs;
+}
 
 /* ------------------------------------------------------------------ */
 /* RaftLog::{term, commit_to, maybe_commit, find_conflict_by_term}      */
@@ -887,10 +900,13 @@ int ro_store_soa(ro_cluster *c, ro_soa_state *s) {
         /* cfg: only the transferee field is state (abort_leader_transfer); the rest is an input */
         s->cfg[g] = (s->cfg[g] & ~(0xfu << 20)) | (((uint32_t)gr->lead_transferee & 0xfu) << 20);
         if (s->run_first) {
+            /* the SoA table is a bounded VIEW of the log: the newest RO_TERM_RUNS runs of older terms (what the engine's
+             * table holds by contract, include/raftgroups.h: RG_COL_RUN_FIRST). The log itself is not shortened. */
             size_t older = gr->n_runs - (own ? 1 : 0);
+            size_t skip = older > RO_TERM_RUNS ? older - RO_TERM_RUNS : 0;
             for (size_t k = 0; k < RO_TERM_RUNS; k++) {
-                s->run_first[k * s->stride + g] = k < older ? gr->runs[k].first : 0;
-                s->run_term[k * s->stride + g] = k < older ? gr->runs[k].term : 0;
+                s->run_first[k * s->stride + g] = skip + k < older ? gr->runs[skip + k].first : 0;
+                s->run_term[k * s->stride + g] = skip + k < older ? gr->runs[skip + k].term : 0;
             }
             s->cur_term[g] = gr->term;
         }
@@ -914,12 +930,7 @@ uint64_t ro_tick_soa(ro_cluster *c, const ro_soa_msgs *m, uint32_t *gout, size_t
             if (new_term > gr->term) {
                 if (ro_group_become_leader(c, g, new_term) != 0) out |= RO_OUT_FAULT;
                 out |= RO_OUT_BECAME_LEADER | RO_OUT_APPENDED; /* bcast_append follows become_leader, raft.rs:2190-2191 */
-                /* engine contract: the term table keeps RG_TERM_RUNS runs of older terms; deeper history loses the
-                 * boundary between its two oldest runs */
-                if (gr->n_runs > RO_TERM_RUNS + 1) {
-                    memmove(&gr->runs[1], &gr->runs[2], (gr->n_runs - 2) * sizeof(ro_run));
-                    gr->n_runs--;
-                }
+                /* (the log keeps EVERY run, like RaftLog: nothing here knows how deep the engine's table is) */
             } else {
                 out |= RO_OUT_FAULT;
             }

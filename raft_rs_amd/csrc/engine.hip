@@ -22,6 +22,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <algorithm>
 #include <vector>
 
 #include "rg_group.h"
@@ -659,6 +660,17 @@ __global__ __launch_bounds__(256) void k_progress_events(RgState st, u32 *ins_me
 }
 
 // ... and one kind of event for every group that names a slot (rg_progress_event_dense): lane = group
+// rg_resolve_host_hints: one lane per record
+__global__ __launch_bounds__(256) void k_resolve_apply(RgState st, u32 *ins_meta, const rg_resolved_hint *it, u64 n, u32 P, u8 *applied) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool dec = rg_resolve_hint_at(st, ins_meta, it, P, i, [&](u64 g, u32 bits, u32 clear) {
+        if (bits) atomicOr(&st.out[g], bits);
+        atomicAnd(&st.out[g], ~clear);
+    });
+    applied[i] = dec ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_progress_event_dense(RgState st, u32 *ins_meta, const u8 *slot_plus1, u32 kind, u32 P) {
     const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
     if (g >= st.G) return;
@@ -714,6 +726,15 @@ __global__ __launch_bounds__(RG_BLOCK) void k_count_out(const u32 *out, u64 G, u
     if ((threadIdx.x & 63) == 0) {
         atomicAdd((unsigned long long *)&counts[0], (unsigned long long)ch);
         atomicAdd((unsigned long long *)&counts[1], (unsigned long long)fl);
+    }
+}
+
+// rg_host_hints: the groups whose result word carries RG_OUT_HOST_HINT, packed group | slot mask << 56
+__global__ __launch_bounds__(RG_BLOCK) void k_host_hints(const u32 *out, const u8 *hhint, u64 G, u64 *items, u64 *counter) {
+    for (u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * RG_BLOCK) {
+        if (!(out[g] & RG_OUT_HOST_HINT)) continue; // (rare: one atomic per flagged group)
+        const u64 k = atomicAdd((unsigned long long *)counter, 1ULL);
+        items[k] = g | ((u64)hhint[g] << 56);
     }
 }
 
@@ -846,6 +867,8 @@ struct rg_engine {
     char *pin_send;    // pinned host: u32 count | pad | rg_send_item[RG_SEND_SPEC] (small stages: one round trip)
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool send_ready;   // a tick ran since the last rg_send_appends
+    u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
+    u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
     bool ckpt_send_ready;
     bool ckpt_any_group_commit;
     bool any_group_commit; // some group's cfg word has RG_CFG_GROUP_COMMIT (tracked on cfg loads)
@@ -932,6 +955,7 @@ static size_t rg_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t rg_col_elem(int c) {
     if (c == RG_COL_PFLAGS) return 8; // one u64 row per group
     if (c == RG_COL_CFG || c == RG_COL_OUT) return 4;
+    if (c == RG_COL_HOST_HINT) return 1;
     return 8;
 }
 static bool rg_col_per_slot(int c) { return c <= RG_COL_GID; }
@@ -1038,6 +1062,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     h->send_ready = false;
+    h->stage_max_entries = 0;
+    h->stage_flags = 0;
     // Infinity Cache (256 MB on MI355X): when the state a dense tick re-reads (24 P + 40 B per group) and the message columns of
     // ONE tick (16 P + 8 B per group, read once) do not fit together, the messages are streamed past it
     // (with the Inflights on the device a step also touches the window and work-item columns: 40 P B per group more)
@@ -1101,6 +1127,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.dummy_idx = (u64 *)rg_col(h, RG_COL_DUMMY_INDEX);
     s.dummy_term = (u64 *)rg_col(h, RG_COL_DUMMY_TERM);
     s.cur_term = (u64 *)rg_col(h, RG_COL_CUR_TERM);
+    s.hhint = (u8 *)rg_col(h, RG_COL_HOST_HINT);
     s.G = h->G;
     s.stride = h->stride;
     s.pub = nullptr;
@@ -1193,6 +1220,7 @@ extern "C" int rg_sync(rg_engine *h) {
 
 extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t bytes) {
     if (!h || !src || c < 0 || c >= RG_COL_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: bad argument");
+    if (c == RG_COL_HOST_HINT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: RG_COL_HOST_HINT is written by the ticks only");
     if (bytes != rg_column_bytes(h, c))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column(%d): %llu bytes given, %llu expected", c,
                        (unsigned long long)bytes, (unsigned long long)rg_column_bytes(h, c));
@@ -1347,6 +1375,7 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
 static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, const u64 *list, u64 n,
                            const u32 *n_ptr);
 #define RG_SEND_EFFECTS_ONLY 0x80000000u /* internal: apply the tick's Inflights effects, serve no send request */
+#define RG_SEND_APPEND_LIST 0x40000000u  /* internal: the stage's work items are appended to the compact list (the counter is not reset) */
 
 // Device Inflights: a tick's result word carries free_to / free_first_one / left-Replicate effects for the rings. If
 // the host skipped rg_send_appends, apply those effects (and nothing else: the send requests are dropped, which
@@ -1387,6 +1416,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
         h->out_is_dense = true;
         h->host_res_valid = false;
         // what rg_send_appends leaves behind a dense stage
+        h->stage_max_entries = send->max_entries;
+        h->stage_flags = send->flags;
         h->send_ready = false;
         h->send_bound = h->G * h->P;
         h->send_cols_fresh = true;
@@ -1925,6 +1956,10 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
 // `n` only sizes the grid.
 static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, const u64 *list, u64 n,
                            const u32 *n_ptr) {
+    const bool append = (flags & RG_SEND_APPEND_LIST) != 0; // (rg_resolve_host_hints: the list keeps what it holds)
+    flags &= ~RG_SEND_APPEND_LIST;
+    h->stage_max_entries = max_entries_per_msg;
+    h->stage_flags = flags;
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     if (!list && !n_ptr && n == h->G) { // every group: work items into the peer-major columns, no list
@@ -1946,7 +1981,7 @@ static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t 
         h->host_items_valid = false;
         return RG_OK;
     }
-    RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
+    if (!append) RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
     if (n) {
         const dim3 grid(rg_grid(n, RG_SEND_BLOCK)), block(RG_SEND_BLOCK);
         switch (h->P) {
@@ -2283,6 +2318,80 @@ extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_f
     RG_HIP(hipStreamSynchronize(h->stream));
     if (n_changed) *n_changed = c[0];
     if (n_fault) *n_fault = c[1];
+    return RG_OK;
+}
+
+extern "C" int rg_host_hints(rg_engine *h, rg_host_hint *host_items, uint64_t cap, uint64_t *n) {
+    if (!h || !n || (cap && !host_items)) return rg_fail(RG_ERR_INVALID_ARG, "rg_host_hints: bad argument");
+    *n = 0;
+    if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_host_hints: no tick has run yet");
+    RG_ENTER(h);
+    RG_HIP(hipMemsetAsync(h->d_counts, 0, 8, h->stream));
+    const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
+    u64 *items = reinterpret_cast<u64 *>(h->d_scratch); // G x 8 B: one packed word per flagged group
+    hipLaunchKernelGGL(k_host_hints, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u32 *)h->st.out, (const u8 *)h->st.hhint,
+                       h->G, items, h->d_counts);
+    u64 cnt = 0;
+    RG_HIP(hipMemcpyAsync(&cnt, h->d_counts, 8, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    *n = cnt;
+    const u64 k = cnt < cap ? cnt : cap;
+    if (k) {
+        std::vector<u64> packed(k);
+        RG_HIP(hipMemcpy(packed.data(), items, k * 8, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < k; i++) {
+            host_items[i].group = packed[i] & ((1ULL << 56) - 1);
+            host_items[i].slot_mask = (uint32_t)(packed[i] >> 56);
+            host_items[i].reserved = 0;
+        }
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items, uint64_t n, uint8_t *host_applied) {
+    if (!h || (!items && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_resolve_host_hints: bad argument");
+    if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_resolve_host_hints: no tick has run yet");
+    if (n == 0) return RG_OK;
+    for (u64 i = 0; i < n; i++)
+        if (items[i].group >= h->G || items[i].slot >= h->P)
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_resolve_host_hints: record %llu names group %llu slot %u", (unsigned long long)i,
+                           (unsigned long long)items[i].group, items[i].slot);
+    RG_ENTER(h);
+    // records, then one result byte per record, in the staging buffer
+    const size_t rec_b = (size_t)n * sizeof(rg_resolved_hint);
+    std::vector<char> stage(rec_b + (size_t)n, 0);
+    memcpy(stage.data(), items, rec_b);
+    int rc = rg_stage_records(h, stage.data(), stage.size());
+    if (rc) return rc;
+    u8 *d_applied = reinterpret_cast<u8 *>(h->d_recs) + rec_b;
+    hipLaunchKernelGGL(k_resolve_apply, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->ins_arena ? h->ins.meta : nullptr,
+                       (const rg_resolved_hint *)h->d_recs, (u64)n, h->P, d_applied);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_resolve_host_hints: launch failed: %s", hipGetErrorString(e));
+    std::vector<u8> applied(n);
+    RG_HIP(hipMemcpyAsync(applied.data(), d_applied, n, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    if (host_applied) memcpy(host_applied, applied.data(), n);
+    h->host_res_valid = false; // (the host copy of a sparse tick's result words no longer matches RG_COL_OUT)
+    if (h->ins_arena && !h->send_ready) {
+        // the send stage of this tick has run already and skipped these groups (rg_group_send / rg_group_tick_send): run it
+        // now, over exactly them, with that stage's limit and flags, and append its work items to the compact list
+        // (send_ready still set: the stage is yet to come, rg_send_appends will find the completed result words)
+        std::vector<u64> groups(n);
+        for (u64 i = 0; i < n; i++) groups[i] = items[i].group;
+        std::sort(groups.begin(), groups.end());
+        groups.erase(std::unique(groups.begin(), groups.end()), groups.end());
+        rc = rg_send_materialize(h); // (a dense stage's items: columns -> list, so that the list holds everything)
+        if (rc) return rc;
+        h->send_last_dense = false;
+        rc = rg_stage_records(h, groups.data(), groups.size() * 8);
+        if (rc) return rc;
+        rc = rg_send_enqueue(h, h->stage_max_entries, h->stage_flags | RG_SEND_APPEND_LIST, (const u64 *)h->d_recs,
+                             groups.size(), nullptr);
+        if (rc) return rc;
+        h->send_bound += groups.size() * h->P;
+        RG_HIP(hipStreamSynchronize(h->stream));
+    }
     return RG_OK;
 }
 
@@ -2791,6 +2900,8 @@ static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, boo
         small_send.ins = h->ins;
         small_send.max_entries = send->max_entries;
         small_send.flags = send->flags;
+        h->stage_max_entries = send->max_entries;
+        h->stage_flags = send->flags;
         small_send.items = h->send_items;
         small_send.counter = h->send_counter;
         small_send.pin = h->pin_send;
@@ -2932,6 +3043,10 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served,
         // the instance has left (idle / lifetime): let the stream see it end before the next one goes on
         int rc = rg_mailbox_quiesce(h);
         if (rc) return rc;
+    }
+    if (send) {
+        h->stage_max_entries = send->max_entries;
+        h->stage_flags = send->flags;
     }
     const u32 s = ++h->mbox_seq;
     // (RgMbox: three self-validating words, one 8-byte store each; the records in pin_records are older stores)

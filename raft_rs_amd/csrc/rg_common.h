@@ -25,6 +25,7 @@ struct RgState {
     u32 *cfg, *out;                              // [G]
     u64 *run_first, *run_term;                   // [RG_TERM_RUNS][stride] term-run table (cold)
     u64 *dummy_idx, *dummy_term, *cur_term;      // [G] (cold)
+    u8 *hhint;                                   // [G] (cold) RG_COL_HOST_HINT: rejects of the last log-term tick left to the host
     u64 G, stride;
     // commit publication (rg_publish.h): this rank's slice under construction, nullptr = not publishing
     char *pub;          // [RgPubHdr | RgPubOvf list[pub_cap] | u8 delta[Gpad]]

@@ -168,18 +168,50 @@ __host__ __device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (
 // run at cur_term and everything below comes from the table; when the tick carries RG_MF_BECOME_LEADER the previous
 // leader run [xlo, lo) has just become an older run of term xterm and is not in the table yet (the tick kernel
 // pushes it), so the pre-pass sees it through these two fields. xlo == lo: no such run.
+//
+// The table is BOUNDED (RG_TERM_RUNS runs of older terms, the newest ones: rg_push_run drops the oldest when it is full),
+// the reference's log is not (RaftLog::term reads the whole log, raft_log.rs:122-140). What the device knows is the dummy
+// entry and every index from `known` on; the terms of (dummy, known) are NOT on the device. A walk that would need one of
+// them reports `unknown` instead of guessing -- the tick then leaves that one reject to the host (RG_OUT_HOST_HINT), which
+// owns the log. With a table that still reaches down to the dummy entry (known == dummy + 1: every log that has seen at
+// most RG_TERM_RUNS older terms since its last snapshot) nothing is ever unknown.
 struct RgLogView {
     u64 lo, last, cur_term;
     u64 xlo, xterm;
-    int skip; // table run whose boundary that election's push forgets (table full: run 1), -1 = none
+    int skip;       // table run this tick's election is about to drop (table full: run 0, the oldest), -1 = none
+    u64 dummy, dummy_term;
+    u64 known, known_term; // first index above the dummy entry whose term the device knows, and that term
 };
 
-RG_HD u64 rg_log_term(const RgState &st, u64 g, const RgLogView &v, u64 idx) {
-    const u64 dummy = st.dummy_idx[g];
-    if (idx < dummy || idx > v.last) return 0; // outside [dummy, last_index]
-    if (idx >= v.lo) return v.cur_term;        // the leader's own entries (lo <= idx <= last_index)
-    if (idx >= v.xlo) return v.xterm;          // the previous leader's run (election in this tick)
-    if (idx == dummy) return st.dummy_term[g];
+// (dummy, known): first used run of the table that survives this tick's push, else the previous leader's run, else the
+// leader's own. Used runs come first, in ascending order.
+RG_HD void rg_log_view_known(const RgState &st, u64 g, RgLogView &v) {
+    v.dummy = st.dummy_idx[g];
+    v.dummy_term = st.dummy_term[g];
+    const int k0 = v.skip == 0 ? 1 : 0;
+    const u64 f0 = k0 < RG_TERM_RUNS ? st.run_first[(u64)k0 * st.stride + g] : 0;
+    if (f0 != 0) {
+        v.known = f0;
+        v.known_term = st.run_term[(u64)k0 * st.stride + g];
+    } else if (v.xlo < v.lo) {
+        v.known = v.xlo;
+        v.known_term = v.xterm;
+    } else {
+        v.known = v.lo;
+        v.known_term = v.cur_term;
+    }
+}
+
+// RaftLog::term(idx) (raft_log.rs:122-140); `unk` is raised when idx lies in (dummy, known)
+RG_HD u64 rg_log_term(const RgState &st, u64 g, const RgLogView &v, u64 idx, bool &unk) {
+    if (idx < v.dummy || idx > v.last) return 0; // outside [dummy, last_index]
+    if (idx >= v.lo) return v.cur_term;          // the leader's own entries (lo <= idx <= last_index)
+    if (idx >= v.xlo) return v.xterm;            // the previous leader's run (election in this tick)
+    if (idx == v.dummy) return v.dummy_term;
+    if (idx < v.known) {
+        unk = true;
+        return 0;
+    }
     u64 t = 0;
     for (int k = 0; k < RG_TERM_RUNS; k++) {
         const u64 first = st.run_first[(u64)k * st.stride + g];
@@ -188,11 +220,26 @@ RG_HD u64 rg_log_term(const RgState &st, u64 g, const RgLogView &v, u64 idx) {
     return t;
 }
 
-RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, const RgLogView &v, u64 index, u64 term) {
+// RaftLog::find_conflict_by_term (raft_log.rs:209-235). `unk`: the answer depends on terms the device no longer has.
+// Log terms never decrease with the index, so every entry of (dummy, known) has a term in [dummy_term, known_term]: a
+// walk that arrives there with term >= known_term stops on the spot (the entry's term is <= term whatever it is), one
+// with term < dummy_term passes through the whole gap and the dummy entry; only dummy_term <= term < known_term needs
+// the real terms.
+RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, const RgLogView &v, u64 index, u64 term, bool &unk) {
     if (index > v.last) return index; // "out of range": returned as is (raft_log.rs:214-223)
     u64 ci = index;
-    for (;;) { // every iteration leaves a whole run (or the dummy entry) behind: <= RG_TERM_RUNS + 4 rounds
-        const u64 t = rg_log_term(st, g, v, ci);
+    for (;;) { // every iteration leaves a whole run (or the dummy entry) behind: <= RG_TERM_RUNS + 5 rounds
+        bool u = false;
+        const u64 t = rg_log_term(st, g, v, ci, u);
+        if (u) {
+            if (term >= v.known_term) return ci;
+            if (term >= v.dummy_term) {
+                unk = true;
+                return index;
+            }
+            ci = v.dummy; // every term of the gap is above `term`: the reference steps down to the dummy entry
+            continue;
+        }
         if (t <= term) return ci;
         // t > term: the reference steps ci -= 1 until the term changes; skip to just below this run
         u64 run_start;
@@ -201,7 +248,7 @@ RG_HD u64 rg_find_conflict_by_term(const RgState &st, u64 g, const RgLogView &v,
         } else if (ci >= v.xlo) {
             run_start = v.xlo;
         } else {
-            run_start = st.dummy_idx[g]; // ci == dummy: step below it
+            run_start = v.dummy; // ci == dummy: step below it
             for (int k = 0; k < RG_TERM_RUNS; k++) {
                 const u64 first = st.run_first[(u64)k * st.stride + g];
                 if (k != v.skip && first != 0 && first <= ci) run_start = first;
@@ -223,6 +270,12 @@ RG_HD bool rg_election_valid(const RgState &st, const RgMsgs &ms, u64 g, u32 sel
 // find_conflict_by_term(reject_hint, log_term) (or the hint itself when log_term == 0) into `rh`.
 // last_index "at message time" is reproduced exactly: an election lands before every message of the tick, the
 // leader's APPEND at its own slot, so slots after it see the grown log (RgTick::slot).
+// A walk that needs log terms the bounded table no longer has (RgLogView) cannot be answered here. The group's byte of
+// RG_COL_HOST_HINT receives the slots where that happens AND the tick is going to read the hint -- a reject reads it only in
+// maybe_decr_to's Probe / Snapshot branch, when it is not stale and carries no snapshot request (progress.rs:188-203),
+// which this pre-pass decides from the state the tick will see (an election of the same tick puts every peer in Probe
+// with next = last_index + 1 first; nothing else before a slot's message changes its state or, outside Replicate, its
+// next_idx). The tick leaves exactly those rejects alone and raises RG_OUT_HOST_HINT (RgTick::slot).
 RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u64 *rh) {
     const u64 mf = ms.mflags[g];
     const u32 cfg = st.cfg[g];
@@ -241,6 +294,8 @@ RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_sl
     v.xterm = 0;
     v.skip = -1;
     u64 hi_after = v.last; // last_index once the leader's own slot has been processed
+    bool elected = false;
+    u64 next_elected = 0;
     if (self < n_slots && ((present >> self) & 1u)) {
         const u32 fs = (u32)(mf >> (8 * self)) & 0xffu;
         u64 new_term;
@@ -250,17 +305,22 @@ RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_sl
             v.lo = v.last;
             v.xlo = old_lo <= old_hi ? old_lo : v.lo; // the previous leader's entries keep their term
             v.xterm = v.cur_term;
-            // pushing that run into a FULL table forgets the boundary between the two oldest runs (rg_elect_in_memory)
-            if (old_lo <= old_hi && st.run_first[(u64)(RG_TERM_RUNS - 1) * st.stride + g] != 0) v.skip = 1;
+            // pushing that run into a FULL table drops the oldest run (rg_push_run)
+            if (old_lo <= old_hi && st.run_first[(u64)(RG_TERM_RUNS - 1) * st.stride + g] != 0) v.skip = 0;
             v.cur_term = new_term;
             hi_after = v.last;
+            elected = true;
+            next_elected = old_hi + 1; // Progress::reset(last_index + 1) of every follower (progress.rs:82-92)
         }
         if (fs & RG_MF_APPEND) {
             const u64 nl = ms.mc[(u64)self * st.stride + g];
             if (nl > hi_after) hi_after = nl;
         }
     }
+    rg_log_view_known(st, g, v);
     const u64 hi_before = v.last;
+    const u64 pf = st.pflags[g];
+    u32 defer = 0;
     for (u32 p = 0; p < n_slots; p++) {
         const u32 f = (u32)(mf >> (8 * p)) & 0xffu;
         if (p == self) continue;
@@ -269,9 +329,18 @@ RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_sl
         const u64 lt = ms.mlt[o];
         u64 hint = ms.mh[o];
         v.last = p > self ? hi_after : hi_before;
-        if (lt > 0) hint = rg_find_conflict_by_term(st, g, v, hint, lt);
+        bool unk = false;
+        if (lt > 0) hint = rg_find_conflict_by_term(st, g, v, hint, lt, unk);
         rh[o] = hint;
+        if (unk && ((present >> p) & 1u) && !(f & RG_MF_HEARTBEAT)) {
+            // will the tick read this hint? (RgTick::slot, the reject branch)
+            const u32 state = elected ? RG_STATE_PROBE : (u32)(pf >> (8 * p)) & RG_PF_STATE_MASK;
+            const u64 nx = elected ? next_elected : st.next[o];
+            const u64 rs = (f & RG_MF_HAS_RS) ? ms.mrs[o] : 0ULL;
+            if (state != RG_STATE_REPLICATE && rs == 0 && nx != 0 && nx - 1 == ms.mi[o]) defer |= 1u << p;
+        }
     }
+    st.hhint[g] = (u8)defer;
 }
 
 // Does this tick carry RG_MF_BECOME_LEADER for the group (the REJECT bit of the leader's OWN slot)?
@@ -392,6 +461,61 @@ RG_HD void rg_progress_events_at(const RgState &st, u32 *ins_meta, const rg_prog
     *pfb = (u8)pf;
 }
 
+// rg_resolve_host_hints: a reject the tick left to the host (RG_OUT_HOST_HINT) comes back with its hint resolved -- the
+// rest of handle_append_response's reject branch (raft.rs:1679-1721) for ONE cell: Progress::maybe_decr_to(index, hint, 0)
+// (progress.rs:168-206), become_probe when that leaves Replicate (:95-107). recent_active and update_committed were applied by
+// the tick. Returns maybe_decr_to's result: send_append(from) is due (raft.rs:1719).
+RG_HD bool rg_apply_resolved_reject(u64 match, u64 &next, u64 &psnap, u32 &pf, u64 index, u64 hint, bool &left_replicate) {
+    const u32 state = pf & RG_PF_STATE_MASK;
+    left_replicate = false;
+    if (state == RG_STATE_REPLICATE) {
+        // (a deferred reject never meets this state -- the tick reads a hint only outside Replicate; literal all the same)
+        if (index < match || index == match) return false; // stale (request_snapshot == 0)
+        pf = (pf & ~(RG_PF_STATE_MASK | RG_PF_PAUSED)) | RG_STATE_PROBE; // become_probe(): reset_state(Probe) ...
+        psnap = 0;
+        next = match + 1; // ... next_idx = matched + 1 (what maybe_decr_to had set as well)
+        left_replicate = true;
+        return true;
+    }
+    if (next == 0 || next - 1 != index) return false; // stale
+    const u64 h = hint + 1;
+    u64 n = index < h ? index : h;
+    if (n < 1) n = 1;
+    next = n;
+    pf &= ~RG_PF_PAUSED; // resume()
+    return true;
+}
+
+// Record i of an rg_resolve_host_hints batch against the columns (k_resolve_apply: one lane per record; tests/host_check: a loop).
+// `orw(g, bits, clear)`: out[g] = (out[g] | bits) & ~clear, atomically on the device (records of one group may sit in different lanes).
+template <typename ORW>
+RG_HD bool rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolved_hint *it, u32 P, u64 i, ORW &&orw) {
+    const u64 g = it[i].group;
+    const u32 s = it[i].slot;
+    if (g >= st.G || s >= P) return false;
+    if (!((RG_CFG_PRESENT(st.cfg[g]) >> s) & 1u)) return false;
+    const u64 o = (u64)s * st.stride + g;
+    u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + g * 8 + s;
+    u32 pf = *pfb;
+    u64 next = st.next[o], psnap = st.psnap[o];
+    bool left = false;
+    const bool dec = rg_apply_resolved_reject(st.match[o], next, psnap, pf, it[i].index, it[i].hint, left);
+    if (dec) {
+        st.next[o] = next;
+        if (left) {
+            st.psnap[o] = 0;
+            pf &= ~RG_PF_PEND_SNAP;
+            if (ins_meta) { // Progress::reset_state: ins.reset() (progress.rs:75-80)
+                ins_meta[o] = 0;
+                pf &= ~RG_PF_INS_FULL;
+            }
+        }
+        *pfb = (u8)pf;
+    }
+    orw(g, dec ? 1u << (8 + s) : 0u, (u32)RG_OUT_HOST_HINT);
+    return dec;
+}
+
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi
 // (log terms are non-decreasing, so the entries of the leader's term are one contiguous range that
 // ends at last_index); commit_to (:286-300) can then never exceed last_index.
@@ -404,8 +528,9 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 }
 
 // The previous leader's entries [first, ...] of term `term` become one more run of the group's term-run table
-// (RgTick::become_leader). Used runs come first; when all RG_TERM_RUNS are in use the boundary between the two oldest
-// runs is forgotten (include/raftgroups.h: RG_COL_RUN_FIRST).
+// (RgTick::become_leader). Used runs come first; when all RG_TERM_RUNS are in use the OLDEST run is dropped: the table
+// then starts above the dummy entry, and a find_conflict_by_term walk that would need the dropped terms is handed to
+// the host instead of being answered (RgLogView, RG_OUT_HOST_HINT; include/raftgroups.h: RG_COL_RUN_FIRST).
 template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first, u64 term) {
     // (loops over the table in memory, four cells per round trip: a rare path that runs behind the group's stores -- no
     // register array that lives through the tick, so the depth of the table costs the dense kernel nothing)
@@ -419,9 +544,9 @@ template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first
         for (int i = 3; i >= 0; i--)
             if (rf[i] == 0) k = b + i; // first unused run
     }
-    if (k == RG_TERM_RUNS) { // table full: forget the boundary between the two oldest runs
+    if (k == RG_TERM_RUNS) { // table full: the oldest run goes
 #pragma unroll 1
-        for (int j = 1; j + 1 < RG_TERM_RUNS; j++) {
+        for (int j = 0; j + 1 < RG_TERM_RUNS; j++) {
             rg_at(st.run_first, (IX)j * (IX)st.stride + g) = rg_at(st.run_first, (IX)(j + 1) * (IX)st.stride + g);
             rg_at(st.run_term, (IX)j * (IX)st.stride + g) = rg_at(st.run_term, (IX)(j + 1) * (IX)st.stride + g);
         }
@@ -738,7 +863,14 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                         }
                     } else {
                         const bool stale = (r.nx[S] == 0 || r.nx[S] - 1 != idx) && rs == 0;
-                        if (!stale) {
+                        // find_conflict_by_term needed log terms the bounded term-run table no longer holds (the
+                        // pre-pass, rg_resolve_hints, marks exactly the rejects that get here): nothing that depends on
+                        // the hint is applied -- recent_active and update_committed already are, like for any message
+                        // of the peer --, the host resolves the hint against its own log and steps the reject again
+                        const bool host_hint = !stale && rs == 0 && (f & RG_MF_HAS_LOGTERM) && ms.mhr != ms.mh /* the pre-pass ran */ &&
+                                               ((rg_at(st.hhint, g) >> S) & 1u);
+                        if (host_hint) out |= RG_OUT_HOST_HINT;
+                        if (!stale && !host_hint) {
                             if (rs == 0) {
                                 // rejects that carry log_term > 0 read their hint AFTER find_conflict_by_term
                                 // (raft.rs:1562,1657-1660): resolved by rg_resolve_hints in a pre-pass so that

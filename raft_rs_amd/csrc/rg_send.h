@@ -100,6 +100,17 @@ template <int P> struct RgSendRegs {
     u32 hostm;  // bit s: slot s is the host's to serve (RG_SEND_HOST: entry sizes outside the device's window)
     u32 count;  // items of this group
 };
+template <int P> RG_HD void rg_send_regs_clear(RgSendRegs<P> &it) {
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+        it.prev[s] = 0;
+        it.last[s] = 0;
+        it.n[s] = 0;
+    }
+    it.snap = 0;
+    it.hostm = 0;
+    it.count = 0;
+}
 // The work item of slot s as the `n_msgs | kind << 16` word of the item columns (0 = nothing for this peer)
 template <int P> RG_HD u32 rg_send_nk(const RgSendRegs<P> &it, int s) {
     if ((it.snap >> s) & 1u) return 1u | (RG_SEND_SNAPSHOT << 16);
@@ -482,6 +493,9 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
 template <int P, typename IX = u64, bool SPEC = false, bool WAVE = false>
 RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags,
                          RgSendRegs<P> &it) {
+    // a group that waits for the host's answer to RG_OUT_HOST_HINT keeps ALL its requests for the stage that
+    // rg_resolve_host_hints runs (the deferred reject's send_append comes before the group's other sends of the tick)
+    if (out & RG_OUT_HOST_HINT) out = 0;
     RgSendOps<P> q;
     rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u);
     rg_send_serve<P, IX, false, WAVE && !SPEC>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);

@@ -201,6 +201,10 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
     if (RG_TS_SPEC == 1 || (RG_TS_SPEC == 2 && !win)) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
     if (RG_TS_SPEC == 2 && win) q.first_index = rg_at(st.dummy_idx, g) + 1;
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    // A reject of this group waits for the host's log (RG_OUT_HOST_HINT, rg_resolve_host_hints): its send_append belongs BEFORE
+    // the group's other sends of the tick, so the whole group's stage waits with it -- that call runs it. The stage below sees an
+    // empty result word: no Inflights effect, no work item; the real word goes to RG_COL_OUT as always.
+    const u32 sout = (r.out & RG_OUT_HOST_HINT) ? 0u : r.out;
 #if defined(__HIP_DEVICE_COMPILE__) && RG_TS_SPEC == 2
     if (win) {
         // the DMA the kernel issued before the tick is a pending LDS write on the VM counter
@@ -219,12 +223,12 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
     const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
 #if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
     rg_store_group<P, IX, 1, WAVE>(r, st, g);
-    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv);
 #else
-    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, r.out, flags, q, &r, nxv);
+    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv);
     rg_store_group<P, IX, 1, WAVE>(r, st, g);
 #endif
-    rg_send_serve<P, IX, true, TSW>(st, ins, g, r.out, max_entries, flags, q, it, &r, nxv);
+    rg_send_serve<P, IX, true, TSW>(st, ins, g, sout, max_entries, flags, q, it, &r, nxv);
     rg_store_group<P, IX, 2>(r, st, g);
 }
 

@@ -20,11 +20,12 @@ class EngineError(RuntimeError):
 
 class COL:
     (MATCH, NEXT, PR_COMMIT, PEND_SNAP, PEND_RS, GID, PFLAGS, COMMIT, TERM_LO, TERM_HI, CFG, OUT, RUN_FIRST,
-     RUN_TERM, DUMMY_INDEX, DUMMY_TERM, CUR_TERM) = range(17)
+     RUN_TERM, DUMMY_INDEX, DUMMY_TERM, CUR_TERM, HOST_HINT) = range(18)
     PER_SLOT = (0, 1, 2, 3, 4, 5)
     PER_RUN = (12, 13)
     NAMES = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
-             "term_lo", "term_hi", "cfg", "out", "run_first", "run_term", "dummy_index", "dummy_term", "cur_term")
+             "term_lo", "term_hi", "cfg", "out", "run_first", "run_term", "dummy_index", "dummy_term", "cur_term",
+             "host_hint")
 
 
 TERM_RUNS = 8
@@ -40,7 +41,7 @@ class MF:
 
 
 class OUT:
-    CHANGED, FAULT, TIMEOUT_NOW, APPENDED, BECAME_LEADER = 0x1, 0x2, 0x4, 0x8, 0x10
+    CHANGED, FAULT, TIMEOUT_NOW, APPENDED, BECAME_LEADER, HOST_HINT = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 
     @staticmethod
     def send_append(o):
@@ -75,6 +76,8 @@ class _Config(C.Structure):
                 ("variant", C.c_uint32), ("max_inflight", C.c_uint32)]
 
 
+HOST_HINT_DTYPE = np.dtype([("group", "<u8"), ("slot_mask", "<u4"), ("reserved", "<u4")])
+RESOLVED_HINT_DTYPE = np.dtype([("group", "<u8"), ("index", "<u8"), ("hint", "<u8"), ("slot", "<u4"), ("reserved", "<u4")])
 GROUP_STATUS_DTYPE = np.dtype([("group", "<u8"), ("commit", "<u8"), ("term_lo", "<u8"), ("last_index", "<u8"),
                                ("cfg", "<u4"), ("out", "<u4"), ("match", "<u8", 8), ("next", "<u8", 8),
                                ("pr_commit", "<u8", 8), ("pend_snap", "<u8", 8), ("pend_rs", "<u8", 8),
@@ -212,6 +215,8 @@ SYMBOLS = {
     "rg_heartbeat_commits": (_i, [_vp, _vp, _vp]),
     "rg_step_heartbeat_response": (_i, [_vp, _u64, _u64, _u64, _u64, C.c_uint8]),
     "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rg_host_hints": (_i, [_vp, C.c_void_p, _u64, C.POINTER(_u64)]),
+    "rg_resolve_host_hints": (_i, [_vp, C.c_void_p, _u64, C.c_void_p]),
     "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 5)]),
     "rg_ingest": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_ingest_device": (_i, [_vp, _vp, _u64]),
@@ -382,6 +387,8 @@ class Engine:
             return (self.n_groups, 8), np.uint8
         if col in (COL.CFG, COL.OUT):
             return (self.n_groups,), np.uint32
+        if col == COL.HOST_HINT:
+            return (self.n_groups,), np.uint8
         return (self.n_groups,), np.uint64
 
     def load_column(self, col, arr):
@@ -652,6 +659,24 @@ class Engine:
         a, b = _u64(0), _u64(0)
         self._check(self.L.rg_result_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def host_hints(self):
+        """Groups whose last tick raised RG_OUT_HOST_HINT -> HOST_HINT_DTYPE array (group, slot_mask)."""
+        n = _u64(0)
+        items = np.zeros(256, dtype=HOST_HINT_DTYPE)
+        self._check(self.L.rg_host_hints(self.h, items.ctypes.data, len(items), C.byref(n)))
+        if n.value > len(items):
+            items = np.zeros(n.value, dtype=HOST_HINT_DTYPE)
+            self._check(self.L.rg_host_hints(self.h, items.ctypes.data, len(items), C.byref(n)))
+        return items[:n.value]
+
+    def resolve_host_hints(self, recs):
+        """recs: RESOLVED_HINT_DTYPE array (or [(group, index, hint, slot, 0)]): the host's find_conflict_by_term answers.
+        Returns u8[n]: maybe_decr_to returned true (send_append is due)."""
+        recs = np.ascontiguousarray(np.array(recs, dtype=RESOLVED_HINT_DTYPE))
+        applied = np.zeros(len(recs), dtype=np.uint8)
+        self._check(self.L.rg_resolve_host_hints(self.h, recs.ctypes.data, len(recs), applied.ctypes.data))
+        return applied
 
     def msg_stats(self, dev_m_flags):
         c = (_u64 * 5)()

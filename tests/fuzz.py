@@ -75,16 +75,18 @@ def random_state(rng, st, snapshot_frac=0.05, probe_frac=0.2, small_values=False
     return st
 
 
-def random_term_table(rng, st, term):
-    """Fill st's term-run table (oracle_lib.add_term_table): 0..TERM_RUNS runs of terms OLDER than the leader's `term`
-    right below term_lo (the leader's own entries [term_lo, term_hi] are implicit), the dummy entry below them."""
+def random_term_table(rng, st, term, min_runs=0, max_runs=TERM_RUNS):
+    """Fill st's term-run table (oracle_lib.add_term_table): min_runs..TERM_RUNS runs of terms OLDER than the leader's `term`
+    right below term_lo (the leader's own entries [term_lo, term_hi] are implicit), the dummy entry below them. The table
+    is contiguous: its first run starts right above the dummy entry. (max_runs < TERM_RUNS leaves room for elections: a
+    table that never overflows never hands a reject back to the host.)"""
     G = st["n_groups"]
     st["cur_term"][:] = term
     for g in range(G):
         lo, hi = int(st["term_lo"][g]), int(st["term_hi"][g])
         top = lo if lo <= hi else hi + 1  # first index that is NOT an older entry
         runs, first, t = [], top, term
-        for _ in range(int(rng.integers(0, TERM_RUNS + 1))):
+        for _ in range(int(rng.integers(min_runs, max_runs + 1))):
             if first <= 1 or t <= 1:
                 break
             first = max(1, first - int(rng.integers(1, 6)))

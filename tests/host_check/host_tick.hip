@@ -6,7 +6,7 @@
 #include "../../raft_rs_amd/csrc/rg_send.h"
 
 // state[]: match next pr_commit pend_snap pend_rs gid pflags commit term_lo term_hi cfg out
-//          run_first run_term dummy_index dummy_term cur_term   (17 pointers)
+//          run_first run_term dummy_index dummy_term cur_term host_hint   (18 pointers)
 // msg[]:   m_index m_commit m_hint m_rs m_flags m_logterm       (6 pointers)
 static RgState make_state(void *const *p, u64 G, u64 stride) {
     RgState st;
@@ -15,6 +15,7 @@ static RgState make_state(void *const *p, u64 G, u64 stride) {
     st.lo = (u64 *)p[8]; st.hi = (u64 *)p[9]; st.cfg = (u32 *)p[10]; st.out = (u32 *)p[11];
     st.run_first = (u64 *)p[12]; st.run_term = (u64 *)p[13]; st.dummy_idx = (u64 *)p[14]; st.dummy_term = (u64 *)p[15];
     st.cur_term = (u64 *)p[16];
+    st.hhint = (u8 *)p[17];
     st.G = G; st.stride = stride;
     st.pub = nullptr; st.pub_off_delta = 0; st.pub_cap = 0;
     return st;
@@ -334,5 +335,17 @@ extern "C" int rg_host_check_progress_events(unsigned P, unsigned long G, unsign
     const RgState st = make_state(state, G, stride);
     derive_pending(st, P);
     for (u64 i = 0; i < n; i++) rg_progress_events_at(st, ins_meta, ev, n, P, i);
+    return 0;
+}
+
+
+// rg_resolve_host_hints for the host: the record loop k_resolve_apply runs one lane per record. applied[i] = maybe_decr_to's result.
+extern "C" int rg_host_check_resolve_hints(unsigned P, unsigned long G, unsigned long stride, void *const *state, u32 *ins_meta,
+                                           const rg_resolved_hint *it, unsigned long n, u8 *applied) {
+    if (P < 1 || P > 8) return -1;
+    const RgState st = make_state(state, G, stride);
+    derive_pending(st, P);
+    for (u64 i = 0; i < n; i++)
+        applied[i] = rg_resolve_hint_at(st, ins_meta, it, P, i, [&](u64 g, u32 bits, u32 clear) { st.out[g] = (st.out[g] | bits) & ~clear; }) ? 1 : 0;
     return 0;
 }

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import fuzz
+import hosthints
 import oracle_lib as O
 import sendstage
 
@@ -40,15 +41,18 @@ _ZERO = {}
 
 
 def state_ptrs(st, out):
-    """17 pointers in the order host_tick.hip expects; a zero table when the state has no term-run table."""
+    """18 pointers in the order host_tick.hip expects; a zero table when the state has no term-run table. The
+    RG_COL_HOST_HINT byte column is created in the state dict on first use (st["host_hint"])."""
     key = (st["n_groups"], st["stride"])
     if key not in _ZERO:
         _ZERO[key] = (np.zeros((O.TERM_RUNS, st["stride"]), dtype=np.uint64), np.zeros(st["n_groups"], dtype=np.uint64))
     z4, zg = _ZERO[key]
     table = [st.get("run_first", z4), st.get("run_term", z4), st.get("dummy_index", zg), st.get("dummy_term", zg),
              st.get("cur_term", zg)]
-    cols = [st[k] for k in STATE_ORDER] + [out] + table
-    return (C.c_void_p * 17)(*[c.ctypes.data for c in cols])
+    if "host_hint" not in st:
+        st["host_hint"] = np.zeros(st["n_groups"], dtype=np.uint8)
+    cols = [st[k] for k in STATE_ORDER] + [out] + table + [st["host_hint"]]
+    return (C.c_void_p * 18)(*[c.ctypes.data for c in cols])
 
 
 def msg_ptrs(msgs):
@@ -94,6 +98,21 @@ def host_fused():
 
 def copy_state(st):
     return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+
+
+RESOLVED_DTYPE = np.dtype([("group", "<u8"), ("index", "<u8"), ("hint", "<u8"), ("slot", "<u4"), ("reserved", "<u4")])
+
+
+def twin_resolve(st, out, recs, meta=None):
+    """rg_resolve_host_hints on the host twin: `out` is the twin's RG_COL_OUT (completed in place). Returns applied u8[n]."""
+    fn = C.CDLL(LIB).rg_host_check_resolve_hints
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint, C.c_ulong, C.c_ulong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulong, C.c_void_p]
+    r = np.array(recs, dtype=RESOLVED_DTYPE)
+    applied = np.zeros(len(r), dtype=np.uint8)
+    assert fn(st["n_slots"], st["n_groups"], st["stride"], state_ptrs(st, out), None if meta is None else meta.ctypes.data,
+              r.ctypes.data, len(r), applied.ctypes.data) == 0
+    return applied
 
 
 @pytest.mark.parametrize("gc", [False, True])
@@ -290,7 +309,8 @@ def test_elections_between_and_inside_ticks(host_tick, n_slots):
     """RG_MF_BECOME_LEADER (Raft::reset + become_leader, raft.rs:942-971,1151-1202) on ~15% of the groups per tick,
     several elections per group, together with ordinary traffic of the same tick (acks, rejects with and without
     Message.log_term, heartbeat responses, appends): every column incl. term_lo and the cfg word's transferee, the
-    result word, and the term-run table (pushed by every election, its two oldest runs merged when full)."""
+    result word, and the term-run table (pushed by every election, its oldest run dropped when full -- the oracle keeps
+    its whole log, and the rejects the shortened table cannot answer come back as RG_OUT_HOST_HINT)."""
     rng = np.random.default_rng(4400 + n_slots)
     G, TERM = 4000, 9
     st = O.add_term_table(O.alloc_state(G, n_slots))
@@ -304,14 +324,29 @@ def test_elections_between_and_inside_ticks(host_tick, n_slots):
     gout = np.zeros(G, dtype=np.uint32)
     out = np.zeros(G, dtype=np.uint32)
     elected = np.zeros(G, dtype=np.int64)
+    out2 = np.zeros(G, dtype=np.uint32)
+    settled = 0
+
+    def tick_again(m2):
+        host_tick(eng_st, m2, out2, False)
+        return out2.copy()
+
     for t in range(10):
         cl.store_soa(st)
+        st_before = copy_state(st)
         # stale terms now and then (not above the current one): fault, ignored
         term_t = TERM + 1 + t if t != 6 else TERM
         fuzz.random_msgs(rng, st, msgs, reject_p=0.3, logterm_max=TERM + t, elect_p=0.15, elect_term=term_t)
         host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
         cl.store_soa(st)
+        # rejects whose find_conflict_by_term walk needs terms the bounded table has dropped come back to the host: exactly the
+        # ones the reference's literal walk says, and once the host has resolved them everything equals the oracle again
+        want = hosthints.expected(cl, st_before, st, msgs)
+        flagged = np.nonzero(out & hosthints.OUT_HOST_HINT)[0]
+        assert {int(g): int(eng_st["host_hint"][g]) for g in flagged} == want, t
+        out[:], n = hosthints.settle(cl, msgs, out, eng_st["host_hint"], tick_again)
+        settled += n
         diffs = fuzz.diff_states(st, eng_st, G, n_slots)
         assert not diffs, (t, diffs[:6])
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
@@ -327,6 +362,48 @@ def test_elections_between_and_inside_ticks(host_tick, n_slots):
             assert ((out[flagged & has_self] & 0x10) != 0).all() and ((out[~flagged] & 0x10) == 0).all()
             assert ((st["cfg"][flagged & has_self] >> 20) & 0xf == 0).all(), "abort_leader_transfer"
     assert (elected >= 3).sum() > 50, "some groups saw three and more elections (table overflow path)"
+
+
+
+
+@pytest.mark.parametrize("n_slots", [3, 5, 7])
+def test_log_history_deeper_than_the_term_run_table(host_tick, n_slots):
+    """RaftLog keeps the whole log (raft_log.rs:122-140); the engine's term-run table keeps the newest RG_TERM_RUNS runs of older
+    terms. Groups that start with a FULL table and then see up to nine more elections (9 .. 17 older runs in the oracle's log),
+    rejects whose reject_hint / log_term land anywhere in that history: the engine equals the UNMODIFIED oracle wherever
+    RG_OUT_HOST_HINT is clear, the bit (and RG_COL_HOST_HINT) is set exactly for the rejects whose literal find_conflict_by_term
+    walk (raft_log.rs:209-235) consults a dropped run, and after the host has resolved those against the complete log every
+    column equals the oracle again."""
+    eng = {}
+    out = None
+
+    def load(st):
+        eng["st"] = st
+
+    def tick(m):
+        o = np.zeros(eng["st"]["n_groups"], dtype=np.uint32)
+        host_tick(eng["st"], m, o, False)
+        eng["out"] = o  # (the twin's RG_COL_OUT)
+        return o.copy()
+
+    def resolve(recs):
+        applied = twin_resolve(eng["st"], eng["out"], recs)
+        assert applied.all(), "a reject the tick left to the host was not stale: maybe_decr_to applies"
+        return eng["out"].copy()
+
+    stats = None
+    for step in hosthints.deep_history_run(n_slots, 6100 + n_slots, tick, lambda: eng["st"]["host_hint"], load, resolve=resolve):
+        if isinstance(step, dict):
+            stats = step
+            break
+        cl, st, t = step
+        diffs = fuzz.diff_states(st, eng["st"], st["n_groups"], n_slots)
+        assert not diffs, (t, diffs[:6])
+        for k in ("run_first", "run_term", "cur_term", "dummy_index", "dummy_term"):
+            assert (st[k] == eng["st"][k]).all(), (t, k)
+    assert stats["settled"] > 200, stats       # the corner is really exercised ...
+    assert stats["applied_logterm_rejects"] > 5 * stats["settled"], stats  # ... and stays a corner
+    assert stats["max_runs"] >= 12 and len(stats["depths"]) >= 4, stats
 
 
 @pytest.mark.parametrize("n_slots", [3, 5, 7])
@@ -538,9 +615,20 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, host_tick_send,
         else:
             host_tick(eng_st, msgs, out, False)
         cl.tick_soa(msgs, gout)
+        # (garbage ticks elect: histories outgrow the term-run table) a group with a reject left to the host keeps ALL its sends
+        # until rg_resolve_host_hints has completed its result word -- the stage skips it, the resolve call runs it
+        hinted = (out & hosthints.OUT_HOST_HINT) != 0
+        if hinted.any():
+            seen["hinted"] = seen.get("hinted", 0) + int(hinted.sum())
+            if fused:
+                assert not set(int(g) for g in items["group"]) & set(np.nonzero(hinted)[0].tolist())
+            hosthints.settle(cl, msgs, out, eng_st["host_hint"], resolve=lambda recs: (twin_resolve(eng_st, out, recs, meta), out)[1])
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
         if not fused:
             items = host_send(eng_st, out, meta, head, ring, cap, max_entries, 1 if skip else 0)
+        elif hinted.any():
+            late = host_send(eng_st, np.where(hinted, out, 0).astype(np.uint32), meta, head, ring, cap, max_entries, 1 if skip else 0)
+            items = np.concatenate([items, late])
         omsgs = cl.send_stage_soa(gout, max_entries, skip_bcast_commit=skip)
         got = sendstage.compare_items(items, omsgs)
         apply_snapshots(rng, got, cl, eng_st, meta)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import fuzz
+import hosthints
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -369,6 +370,64 @@ def test_find_conflict_by_term_on_device(rg, n_slots, variant):
     eng.close()
 
 
+@pytest.mark.parametrize("form", ["dense", "sparse", "lds"])
+@pytest.mark.parametrize("n_slots", [3, 5, 7])
+def test_log_history_deeper_than_the_term_run_table(rg, n_slots, form):
+    """RaftLog keeps the whole log (raft_log.rs:122-140), the engine's term-run table the newest RG_TERM_RUNS runs of older terms.
+    Groups that start with a FULL table and see up to nine more elections (9 .. 17 older runs in the oracle's log), rejects whose
+    reject_hint / log_term land anywhere in that history, through the dense tick, the wire-record path and the LDS variant: the
+    engine equals the UNMODIFIED oracle wherever RG_OUT_HOST_HINT is clear, the bit / RG_COL_HOST_HINT / rg_host_hints name exactly
+    the rejects whose literal find_conflict_by_term walk (raft_log.rs:209-235) consults a dropped run, and once the host has
+    answered (a tick of its own, or rg_resolve_host_hints on every other tick) every column equals the oracle again."""
+    from raft_rs_amd.engine import COL, WIRE_DTYPE
+    box = {}
+
+    def load(st):
+        box["eng"] = rg.Engine(st["n_groups"], n_slots, variant=2 if form == "lds" else 1)
+        box["eng"].load_state(st)
+        box["mb"] = rg.MsgBuffers(st["n_groups"], n_slots, box["eng"].stride)
+
+    def tick(m):
+        eng, mb = box["eng"], box["mb"]
+        if form == "sparse":
+            G = m["n_groups"]
+            gs, ps = np.nonzero(m["m_flags"][:, :n_slots])
+            arr = np.zeros(len(gs), dtype=WIRE_DTYPE)
+            arr["group"], arr["slot"], arr["flags"] = gs, ps, m["m_flags"][gs, ps]
+            for k, f in (("m_index", "index"), ("m_commit", "commit"), ("m_hint", "hint"), ("m_rs", "rs"), ("m_logterm", "log_term")):
+                arr[f] = m[k][ps, gs]
+            assert eng.ingest(arr) == 0
+            eng.tick_ingested()
+        else:
+            for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_logterm", "m_flags"):
+                getattr(mb, k)[...] = m[k]
+            eng.tick(mb)
+        return eng.read_column(COL.OUT)
+
+    def resolve(recs):
+        eng = box["eng"]
+        listed = {int(r["group"]): int(r["slot_mask"]) for r in eng.host_hints()}
+        assert listed == {g: sum(1 << r[3] for r in recs if r[0] == g) for g in {r[0] for r in recs}}
+        assert eng.resolve_host_hints(recs).all()
+        return eng.read_column(COL.OUT)
+
+    stats = None
+    for step in hosthints.deep_history_run(n_slots, 7100 + n_slots, tick, lambda: box["eng"].read_column(COL.HOST_HINT), load,
+                                           G=3000, resolve=resolve):
+        if isinstance(step, dict):
+            stats = step
+            break
+        cl, st, t = step
+        got = box["eng"].read_state()
+        diffs = fuzz.diff_states(st, got, st["n_groups"], n_slots)
+        assert not diffs, (form, t, diffs[:6])
+        for col in (COL.RUN_FIRST, COL.RUN_TERM, COL.CUR_TERM, COL.DUMMY_INDEX, COL.DUMMY_TERM):
+            assert (box["eng"].read_column(col) == st[COL.NAMES[col]]).all(), (t, COL.NAMES[col])
+    assert stats["settled"] > 200 and stats["applied_logterm_rejects"] > 5 * stats["settled"], stats
+    assert stats["max_runs"] >= 12 and len(stats["depths"]) >= 4, stats
+    box["eng"].close()
+
+
 @pytest.mark.parametrize("n_slots", [3, 7])
 def test_fused_call_with_log_term_ticks_and_elections(rg, n_slots):
     """rg_tick_device_fused over 6 ticks of which two carry Message.log_term (the library runs those behind their
@@ -380,7 +439,9 @@ def test_fused_call_with_log_term_ticks_and_elections(rg, n_slots):
     st = O.add_term_table(O.alloc_state(G, n_slots))
     st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots)
     fuzz.random_state(rng, st, small_values=True, probe_frac=0.4)
-    fuzz.random_term_table(rng, st, TERM)
+    # (at most 2 + 6 older runs: the table never overflows inside the call, so no reject goes back to the host in the
+    # middle of a fused launch -- tests/test_parity_gpu.py::test_log_history_deeper_than_the_term_run_table has that corner)
+    fuzz.random_term_table(rng, st, TERM, max_runs=2)
     eng = rg.Engine(G, n_slots)
     eng.load_state(st)
     cl = O.Cluster(G)
@@ -438,6 +499,8 @@ def test_garbage_events_on_gpu(rg, n_slots):
                 getattr(mb, k)[...] = msgs[k]
             eng.tick(mb)
             cl.tick_soa(msgs, gout)
+            # (garbage elects about half the groups per tick: histories outgrow the term-run table and some rejects come back)
+            hosthints.settle_engine(eng, cl, msgs)
             assert_same(eng, cl, ref, gout, f"garbage events P={n_slots} variant={variant} tick {t}")
         eng.close()
 

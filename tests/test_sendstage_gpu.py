@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import fuzz
+import hosthints
 import oracle_lib as O
 import sendstage
 
@@ -88,6 +89,66 @@ def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries, fused):
         assert seen["items"] > 1000 and seen["snap"] > 0, seen
     if max_entries and cap > 1:
         assert seen["multi"] > 0, seen
+    eng.close()
+
+
+@pytest.mark.parametrize("form", ["resolve_before_stage", "resolve_after_stage", "one_launch"])
+@pytest.mark.parametrize("n_slots,cap,max_entries", [(3, 2, 1), (5, 4, 0), (7, 3, 2)])
+def test_send_stage_waits_for_host_hints(rg, n_slots, cap, max_entries, form):
+    """Device Inflights and a log deeper than the term-run table: a reject the tick leaves to the host (RG_OUT_HOST_HINT) is
+    processed by the reference BEFORE the group's other sends of the tick (raft.rs:1719 inside the step, the sends after it), so
+    the group's whole send stage waits for rg_resolve_host_hints -- called before rg_send_appends, after it, or after the
+    one-launch form rg_tick_send, whose stage skips the group and which the resolve call then completes. Work items, Progress
+    columns and every ring against the oracle after every tick."""
+    rng = np.random.default_rng(8800 + 31 * n_slots + cap)
+    G, TERM = 4000, 30
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.03)
+    fuzz.random_state(rng, st, probe_frac=0.5, base=200)
+    fuzz.random_term_table(rng, st, TERM, min_runs=O.TERM_RUNS)
+    sendstage.mark_pending_conf(rng, st)
+    eng = rg.Engine(G, n_slots, max_inflight=cap)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM, max_inflight=cap)
+    cl.set_own_inflights(True)
+    msgs = O.alloc_msgs(G, n_slots)
+    mb = rg.MsgBuffers(G, n_slots, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    seen = {"items": 0, "settled": 0, "late_items": 0}
+    for t in range(8):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, valid_p=0.8, reject_p=0.5, rs_p=0.05, sent_p=0.0, heartbeat_p=0.1, logterm_max=TERM + t,
+                         elect_p=0.5, elect_term=TERM + 1 + t)
+        hosthints.spread_reject_hints(rng, st, msgs, TERM + 1 + t)
+        sendstage.prepare_msgs(msgs)
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_logterm", "m_flags"):
+            getattr(mb, k)[...] = msgs[k]
+        skip = t % 2 == 1
+        if form == "one_launch":
+            eng.tick_send(mb, max_entries, skip_bcast_commit=skip)
+        else:
+            eng.tick(mb)
+        cl.tick_soa(msgs, gout)
+        out0 = eng.read_column(rg.COL.OUT)
+        hinted = set(np.nonzero(out0 & hosthints.OUT_HOST_HINT)[0].tolist())
+        if form == "resolve_after_stage":
+            eng.send_appends(max_entries, skip_bcast_commit=skip)
+        if form != "resolve_before_stage":
+            early = eng.send_items()
+            assert not hinted & set(int(g) for g in early["group"]), "the stage served a group that waits for its host hint"
+        seen["settled"] += hosthints.settle_engine(eng, cl, msgs)
+        _, out = eng.results()
+        assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
+        if form == "resolve_before_stage":
+            eng.send_appends(max_entries, skip_bcast_commit=skip)
+        got = eng.send_items()
+        seen["late_items"] += sum(1 for g in got["group"] if int(g) in hinted)
+        items = sendstage.compare_items(got, cl.send_stage_soa(gout, max_entries, skip_bcast_commit=skip))
+        apply_snapshots(rg, eng, cl, st, items)
+        check(rg, eng, cl, st, cap, f"{form} P={n_slots} cap={cap} tick {t}")
+        seen["items"] += len(items)
+    assert seen["settled"] > 100 and seen["late_items"] > 100 and seen["items"] > 1000, seen
     eng.close()
 
 
