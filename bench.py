@@ -246,7 +246,7 @@ def traffic_lookup(key):
     if ent.get("bytes") is None:
         return None, None
     return ent["bytes"], ("profiles/traffic.json[" + key + "]: " + ent.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") +
-                          " -- NOT measured inside this run")
+                          " @ build " + str(ent.get("commit", "unrecorded (before round 4)")) + " -- NOT measured inside this run")
 
 
 def workload_label(workload, n_groups, n_slots, one_engine=False):
@@ -478,6 +478,53 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                                      "understates this mode -- the stage has its own roofline under send_stage"} if inflights else {})}}
 
 
+def by_config_summary(result):
+    """Every configuration this line measured, compact, INSIDE `roofline` (the driver's record keeps that object whole and
+    only the names of the other sub-objects): frac = alg_bytes / us / 8 TB/s can be recomputed from each entry alone.
+    `traffic` = PMC HBM bytes per launch from the committed passes (null where not profiled); `regime` as in `roofline`."""
+    def entry(obj, r=None):
+        r = r or (obj or {}).get("roofline")
+        if not r or "frac" not in r:
+            return {"error": (obj or {}).get("error", "not measured")[:120]}
+        return {"frac": round(r["frac"], 4), "us": round(r["avg_launch_us"], 2), "alg_bytes": int(r["algorithmic_bytes_per_launch"]),
+                "traffic": None if r.get("traffic") is None else int(r["traffic"]), "regime": r.get("regime")}
+    oc = result.get("other_configs") or {}
+    out = {"c2_headline": entry(result)}
+    for name, obj in (("c2_hbm_8M", result.get("out_of_cache")), ("c3_joint", oc.get("configs[2] joint")),
+                      ("c4_shard", oc.get("configs[3] one rank's shard")), ("c5_one_launch", oc.get("configs[4] one launch, class-sorted")),
+                      ("c5_size_class", oc.get("configs[4] size-class engines")), ("c5_one_engine", oc.get("configs[4] one 7-slot engine")),
+                      ("recompute", result.get("recompute_only")), ("recompute_hbm_8M", result.get("recompute_only_out_of_cache"))):
+        if obj is not None:
+            out[name] = entry(obj)
+    for name, key in (("send_two_launch", "configs[1] + send stage"), ("send_one_launch", "configs[1] + send stage, one launch")):
+        obj = oc.get(key)
+        if obj is None:
+            continue
+        e = entry(obj, (obj.get("send_stage") or {}).get("roofline"))  # the stage's OWN byte model
+        if "frac" in e:
+            e["step_us"] = round(obj["us_per_step"], 2)
+            e["frac_by_tick_bytes"] = round(obj["roofline"]["frac"], 4)
+        out[name] = e
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line as N ranks (one per GPU) under
+    torch.distributed.run, --nnodes=1, rendezvous on 127.0.0.1 at a port the OS just handed out. stdout / stderr are the
+    children's (rank 0 prints the JSON line last); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def guarded(fn, *a, **kw):
     """A side measurement must never cost the headline its JSON line: whatever goes wrong in it (a device out of memory on
     a shared box, a fault the stream check raises) is reported in its place."""
@@ -503,8 +550,13 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--publish-every", type=int, default=1,
-                    help="N>1: publish the commit advances every E ticks (and after the last tick); default every tick")
+    ap.add_argument("--publish-every", default="1",
+                    help="N>1: publish the commit advances every E ticks (and after the last tick); default every tick. "
+                         "`auto`: E is picked from the exchange time measured on 8 publications before the timed region "
+                         "(rank 0 decides, the control plane broadcasts it; no extra data-path collective)")
+    ap.add_argument("--total-groups", type=int, default=0,
+                    help="N>1: STRONG scaling -- this many groups in total, split into N disjoint contiguous ranges "
+                         "(sharding.strong_shard); `scaling` is then \"strong\". Default 0 = weak scaling, --groups per GPU")
     ap.add_argument("--publish-raw", action="store_true",
                     help="N>1: publish the full 8 B/group commit column every time (RG_PUBLISH_FULL) instead of the ~1 B/group "
                          "delta slices -- the naive exchange, for comparison")
@@ -533,6 +585,12 @@ def main():
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # The plain command line (`python bench.py --gpus 8 ...`, what works at N = 1) starts its own ranks: one process
+        # per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1 and a free port. Under an external
+        # launcher (WORLD_SIZE set) nothing of this runs.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     import raft_rs_amd as rg
@@ -541,8 +599,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: one rank per GPU, the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # BENCH_SHARE_GPU=1 (test hook): every rank uses GPU 0 and the collective backend is gloo, so the N>1
@@ -561,6 +618,16 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     G, P, W, K = args.groups, args.slots, args.warmup, args.steps
+    strong = args.total_groups > 0
+    if strong:
+        # strong scaling: the SAME total population at every N, rank r holds [r G/N, (r+1) G/N) (sharding.strong_shard). The
+        # publication's all-gather moves equal slices, so the total must divide evenly
+        if args.total_groups % world:
+            raise SystemExit(f"--total-groups {args.total_groups} does not divide into {world} equal ranges")
+        from raft_rs_amd.sharding import strong_shard
+        sh = strong_shard(rank, world, args.total_groups)
+        G = sh.n_groups
+        assert sh.first_group == rank * G
     T = W + K
     if args.side:
         torch.cuda.set_stream(torch.cuda.Stream())
@@ -638,7 +705,9 @@ def main():
     # xGMI) while the next ticks run, and every rank keeps a replica of all commit indices, updated lazily. 1 MB per rank
     # and tick at 1 M groups instead of the 8 MB column: per-tick publication at 8 ranks moves 7 MB into each GPU per
     # ~60 us tick (~120 GB/s of its ~450 GB/s xGMI ingress) instead of 56 MB (~930 GB/s: not feasible).
-    E = max(1, args.publish_every)
+    auto_E = str(args.publish_every).lower() == "auto"
+    E = 1 if auto_E else max(1, int(args.publish_every))
+    auto_note = None
 
     class Dev:  # a device range as a torch tensor (CUDA array interface), for the shared-GPU test transport only
         def __init__(self, ptr, n):
@@ -730,6 +799,42 @@ def main():
                 ev.record(pt.stream)
                 stream.wait_event(ev)
 
+    if distributed and auto_E:
+        # --publish-every auto: how long does ONE exchange take on this fabric, next to one tick? Eight ticks without
+        # publication, then eight back-to-back publications (slices of the real size; what they carry does not change what
+        # travels), each bracketed by a control-plane barrier. Rank 0 decides -- E = ceil(exchange / tick), so that an exchange
+        # is hidden behind the E ticks that follow it -- and broadcasts E over the control plane (gloo): every rank publishes
+        # at the same ticks, and the data path gets no collective of its own for this.
+        def wall_of(fn):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        def eight_publications():
+            for _ in range(8):
+                for pt in parts:
+                    pt.eng.publish_commit()
+            for pt in parts:
+                pt.eng.publish_sync()
+
+        for pt in parts:
+            pt.eng.restore()
+            pt.eng.publish_commit(full=True)
+            pt.eng.publish_sync()
+        n_cal = min(8, T)
+        t_tick = wall_of(lambda: run_ticks(0, n_cal, False)) / n_cal
+        eight_publications()  # (first use of the slices / the communicator: not timed)
+        t_ex = wall_of(eight_publications) / 8
+        box = [max(1, min(32, int(np.ceil(t_ex / t_tick)))), t_tick, t_ex] if rank == 0 else [None, None, None]
+        dist.broadcast_object_list(box, src=0)
+        E = int(box[0])
+        auto_note = {"publish_every": E, "tick_us": round(box[1] * 1e6, 2), "exchange_us": round(box[2] * 1e6, 2),
+                     "rule": "E = ceil(exchange / tick), 1..32; measured on rank 0 over 8 ticks and 8 back-to-back publications "
+                             "before the timed region, broadcast over the control plane"}
+
     # ---- timed region ----
     for pt in parts:
         pt.eng.restore()
@@ -811,7 +916,7 @@ def main():
                            "ms_per_step": float(w2.item()) * 1e3 / K, "value": world * G * K / float(w2.item()),
                            "bytes_per_rank_per_publication": st2["bytes_per_rank_full"] if other else st2["bytes_per_rank_delta"]}
 
-    evals = world * G * K
+    evals = world * G * K  # (strong scaling: world * G = --total-groups)
     value = evals / wall
     timed_bytes = float(np.mean(alg_bytes[W:]))
     per_launch_s = kernel_ms / 1e3 / K  # one step = one launch per size class (1 except config 5)
@@ -832,14 +937,14 @@ def main():
     result = {
         "metric": "raft-group progress+commit evaluations/sec (commit-index recomputes/sec at 1M groups x 5 peers)",
         "value": value, "unit": "group-evals/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": (f"{world * G} groups x 7 peers sharded over {world} GPUs ({G} per GPU), commit indices published "
                                 f"every {'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3]: 8 M x 7 over 8 GPUs"
                                 f"{'' if (world, G) == (8, 1_000_000) else ' -- here at ' + str(world) + ' x ' + str(G)})"
                                 if (args.workload == 2 and P == 7 and distributed) else
                                 workload_label(args.workload, G, P, args.one_engine) +
-                                (f", x {world} ranks (weak scaling), commit indices published every "
+                                (f", x {world} ranks ({'strong scaling: ' + str(world * G) + ' groups in total' if strong else 'weak scaling'}), commit indices published every "
                                  f"{'tick' if E == 1 else str(E) + ' ticks'}" if distributed else "")),
                    "groups_per_gpu": G, "peer_slots": P, "workload_id": args.workload, "seed": hex(args.seed),
                    "acks_per_group": round(A, 3), "rejects_per_group": round(R, 5),
@@ -858,7 +963,8 @@ def main():
                        if distributed else ""),
                    **({"publication": pub_stats,
                        "publication_mode": "raw 8 B/group column every tick (RG_PUBLISH_FULL)" if args.publish_raw else "delta slices (~1 B/group)",
-                       "publication_compare": pub_compare} if distributed else {}),
+                       "publication_compare": pub_compare, "publish_every": E,
+                       **({"publish_every_auto": auto_note} if auto_note else {})} if distributed else {}),
                    "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot,
                      "regime_note": "infinity-cache: the state columns every launch re-reads fit the 256 MB Infinity Cache, so part "
@@ -910,6 +1016,7 @@ def main():
             oc[name] = guarded(run_config, rg, torch, warmup=5, steps=30, seed=args.seed, **kw)
             torch.cuda.empty_cache()
         result["other_configs"] = oc
+        result["roofline"]["by_config"] = by_config_summary(result)
         # the other end of the scale: the round trip of a flush that touches 1 / 10 groups (not a throughput number)
         result["small_batch_latency"] = guarded(small_batch_latency, rg, torch, G, P, args.seed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -370,7 +370,7 @@ extern "C" {
     pub fn rg_step(h: *mut RgEngine, group: u64, m: *const RgAppendResponse) -> i32;
     pub fn rg_step_heartbeat_response(h: *mut RgEngine, group: u64, from: u64, term: u64, commit: u64, ins_full: u8) -> i32;
     pub fn rg_decode_message(bytes: *const u8, len: u64, out: *mut RgDecodedMessage) -> i32;
-    pub fn rg_step_bytes(h: *mut RgEngine, group: u64, bytes: *const u8, len: u64) -> i32;
+    pub fn rg_step_bytes(h: *mut RgEngine, group: u64, bytes: *const u8, len: u64, ins_full: u8) -> i32;
     pub fn rg_entry_size(e: *const RgEntry) -> u64;
     pub fn rg_limit_size(entries: *const RgEntry, n: u64, max_size: u64) -> u64;
     pub fn rg_message_size(m: *const RgMessage, len: *mut u64) -> i32;

@@ -284,7 +284,11 @@ int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word);
  *   RG_EV_SNAPSHOT_FAILURE ... reject = true: snapshot_failure() first, so next = matched + 1
  * A peer that is not in Snapshot ignores both snapshot events; a slot without a Progress (RG_CFG_PRESENT) or beyond the
  * engine's, and a group beyond the shard, are ignored ("no progress available"). With device
- * Inflights the window is reset whenever the state changes. Synchronises (a control-path call, like rg_write_cells). */
+ * Inflights the window is reset whenever the state changes. ORDER with device Inflights: call order is event order, so run
+ * the last tick's send stage (rg_send_appends) BEFORE these calls -- if it has not run, the tick's Inflights effects
+ * (free_to, free_first_one, left Replicate) are applied first and its send requests are dropped, exactly as the next tick
+ * would do with a skipped stage; the event never lands between a tick and that tick's own effects.
+ * Synchronises (a control-path call, like rg_write_cells). */
 typedef struct {
     uint64_t group;
     uint32_t slot;
@@ -415,8 +419,11 @@ int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t from, uint
  * request_snapshot 13; `to`, entries, snapshot, context, priority, commit_term and unknown fields are skipped) and the
  * message is stepped: MsgAppendResponse like rg_step, MsgHeartbeatResponse like rg_step_heartbeat_response, a local
  * message type (is_local_msg, src/raw_node.rs:57-66) is RG_ERR_STEP_LOCAL_MSG, every other type RG_ERR_NOT_ON_PATH (nothing
- * queued), bytes that are not a protobuf message RG_ERR_INVALID_ARG. rg_decode_message is the decoder alone (pure host
- * code: no engine, no device). */
+ * queued), bytes that are not a protobuf message RG_ERR_INVALID_ARG. `ins_full` is the one input of the step that is NOT on
+ * the wire: the caller's Inflights::full() for the sender, exactly as rg_append_response.ins_full and the last argument
+ * of rg_step_heartbeat_response (is_paused of a Replicate peer, src/tracker/progress.rs:209-216; the free_first_one /
+ * `old_paused` decisions of src/raft.rs:1742-1751, :1786-1797) -- leave it 0 when the engine holds the Inflights
+ * (max_inflight > 0). rg_decode_message is the decoder alone (pure host code: no engine, no device). */
 typedef struct {
     uint32_t msg_type; /* eraftpb::MessageType */
     uint32_t reject;   /* Message.reject */
@@ -426,7 +433,7 @@ typedef struct {
     uint32_t context_len;   /* bytes context = 12 */
 } rg_decoded_message;
 int rg_decode_message(const uint8_t *bytes, uint64_t len, rg_decoded_message *out);
-int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len);
+int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len, uint8_t ins_full);
 
 /* ---- the other side of the path: the messages a leader SENDS, as the bytes a transport takes ----
  * The send stage (below) decides WHAT goes to each peer -- `prev_index`, `last_index`, how many messages -- and leaves

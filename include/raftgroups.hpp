@@ -445,7 +445,9 @@ class MultiRaft {
 
     // ---- RawNode::step (raw_node.rs:402-411): local message types and unknown peers are errors; Raft::step's term
     // gate drops a stale term silently and reports a higher one (the host steps down) ----
-    void step(u64 group, const Message &m) {
+    // `ins_full`: with the Inflights on the HOST (max_inflight_msgs == 0) the caller's Inflights::full() for m.from -- the one
+    // input of handle_append_response / handle_heartbeat_response that is neither in the message nor on the device.
+    void step(u64 group, const Message &m, bool ins_full = false) {
         need_boot();
         switch (m.msg_type) {
         case MessageType::MsgAppendResponse: {
@@ -459,11 +461,12 @@ class MultiRaft {
             r.reject_hint = m.reject_hint;
             r.log_term = m.log_term;
             r.request_snapshot = m.request_snapshot;
+            r.ins_full = ins_full ? 1 : 0;
             check(rg_step(h_, group, &r));
             return;
         }
         case MessageType::MsgHeartbeatResponse:
-            check(rg_step_heartbeat_response(h_, group, m.from, m.term, m.commit, 0));
+            check(rg_step_heartbeat_response(h_, group, m.from, m.term, m.commit, ins_full ? 1 : 0));
             return;
         default:
             if (is_local_msg(m.msg_type)) // raw_node.rs:404-406
@@ -473,9 +476,10 @@ class MultiRaft {
     }
     // ... and on the bytes a transport delivers: Message::parse_from_bytes + RawNode::step (rg_step_bytes). A message type
     // outside the path (MsgAppend, votes, ...) is Error{NotOnPath}: the host's own Raft::step takes it.
-    void step(u64 group, const std::uint8_t *bytes, std::size_t len) {
+    // `ins_full`: the caller's Inflights::full() for the sender when the Inflights live on the host (not on the wire).
+    void step(u64 group, const std::uint8_t *bytes, std::size_t len, bool ins_full = false) {
         need_boot();
-        check(rg_step_bytes(h_, group, bytes, len));
+        check(rg_step_bytes(h_, group, bytes, len, ins_full ? 1 : 0));
     }
     // ---- the leader's own events of a batch ----
     void propose(u64 group, u64 n_entries) { // Raft::append_entry (raft.rs:976-991): last_index += n

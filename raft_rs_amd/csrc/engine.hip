@@ -541,7 +541,7 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
 template <int P>
 static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
                                  u32 flags, const RgSendCols &oc) {
-    if (rg_ix32(P, st.stride))
+    if (rg_ix32(st, P))
         hipLaunchKernelGGL((k_send_dense<P, u32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
     else
         hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
@@ -1130,6 +1130,10 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.hhint = (u8 *)rg_col(h, RG_COL_HOST_HINT);
     s.G = h->G;
     s.stride = h->stride;
+    {
+        const char *e = getenv("RG_FORCE_IX64"); // test hook (rg_common.h: rg_ix32), read here and nowhere else
+        s.ix64 = (e && e[0] && e[0] != '0') ? 1u : 0u;
+    }
     s.pub = nullptr;
     s.pub_off_delta = 0;
     s.pub_cap = 0;
@@ -2103,7 +2107,13 @@ extern "C" int rg_progress_events(rg_engine *h, const rg_progress_event *events,
             return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_events: record %llu has kind %u", (unsigned long long)i, events[i].kind);
     if (n == 0) return RG_OK;
     RG_ENTER(h);
-    int rc = rg_stage_records(h, events, (size_t)n * sizeof(rg_progress_event));
+    // Call order is event order: a tick whose send stage has not run yet still owes the windows its free_to / free_first_one /
+    // left-Replicate effects, and they belong BEFORE this event's become_probe (which empties the window) -- the reference
+    // applies everything handle_append_response does before the next local message is stepped. Settled exactly as the next
+    // tick would settle it (effects only: the skipped stage's send requests are dropped, which is what skipping it means).
+    int rc = rg_settle_send(h);
+    if (rc) return rc;
+    rc = rg_stage_records(h, events, (size_t)n * sizeof(rg_progress_event));
     if (rc) return rc;
     hipLaunchKernelGGL(k_progress_events, dim3(rg_grid(n, 256)), dim3(256), 0, h->stream, h->st, h->ins_arena ? h->ins.meta : nullptr,
                        (const rg_progress_event *)h->d_recs, (u64)n, h->P);
@@ -2118,7 +2128,9 @@ extern "C" int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_
     if (kind < RG_EV_UNREACHABLE || kind > RG_EV_SNAPSHOT_FAILURE)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_event_dense: kind %u", kind);
     RG_ENTER(h);
-    int rc = rg_stage_records(h, host_slot_plus1, (size_t)h->G);
+    int rc = rg_settle_send(h); // (as in rg_progress_events: the last tick's Inflights effects come first)
+    if (rc) return rc;
+    rc = rg_stage_records(h, host_slot_plus1, (size_t)h->G);
     if (rc) return rc;
     hipLaunchKernelGGL(k_progress_event_dense, dim3(rg_grid(h->G, 256)), dim3(256), 0, h->stream, h->st,
                        h->ins_arena ? h->ins.meta : nullptr, (const u8 *)h->d_recs, (u32)kind, h->P);
@@ -2615,7 +2627,7 @@ extern "C" int rg_encode_message(const rg_message *m, uint8_t *buf, uint64_t cap
     return RG_OK;
 }
 
-extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len) {
+extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len, uint8_t ins_full) {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_bytes: bad argument");
     rg_decoded_message m;
     int rc = rg_decode_message(bytes, len, &m);
@@ -2634,10 +2646,11 @@ extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes,
         r.reject_hint = m.reject_hint;
         r.log_term = m.log_term;
         r.request_snapshot = m.request_snapshot;
+        r.ins_full = ins_full; // (not on the wire: the caller's Inflights::full() for m.from, as in rg_step)
         return rg_step(h, group, &r);
     }
     case 9: // MsgHeartbeatResponse
-        return rg_step_heartbeat_response(h, group, m.from, m.term, m.commit, 0);
+        return rg_step_heartbeat_response(h, group, m.from, m.term, m.commit, ins_full);
     default:
         return rg_fail(RG_ERR_NOT_ON_PATH, "rg_step_bytes: message type %u is not handled on this path (the host's Raft::step takes it)",
                        m.msg_type);
@@ -3165,11 +3178,15 @@ static int rg_settle_elections(rg_engine *h, bool results_available) {
                 auto it = became.find(groups[i]);
                 if (it != became.end() && (out[i] & RG_OUT_BECAME_LEADER)) it->second = true;
             }
-            for (const auto &e : h->q_elections)
-                if (!became[e.group]) h->terms[e.group] = e.old_term;
+            // (newest first: should a group ever be listed twice, the OLDEST recorded term -- the registered one -- wins;
+            // rg_local_become_leader refuses a second election of a group inside one flush, RG_ERR_SLOT_BUSY)
+            for (auto e = h->q_elections.rbegin(); e != h->q_elections.rend(); ++e)
+                if (!became[e->group]) h->terms[e->group] = e->old_term;
         }
-    } else {
-        for (const auto &e : h->q_elections) h->terms[e.group] = e.old_term; // no verdict: the conservative side
+    }
+    if (!results_available || !h->last_sparse_n || rc != RG_OK) {
+        // no verdict (the flush failed, or its results could not be read): the conservative side -- every gate goes back
+        for (auto e = h->q_elections.rbegin(); e != h->q_elections.rend(); ++e) h->terms[e->group] = e->old_term;
     }
     h->q_elections.clear();
     return rc;

@@ -31,6 +31,7 @@ struct RgState {
     char *pub;          // [RgPubHdr | RgPubOvf list[pub_cap] | u8 delta[Gpad]]
     u64 pub_off_delta;
     u32 pub_cap;
+    u32 ix64; // host side only: this engine's launches take the 64-bit-offset instantiations (rg_ix32; decided once, in rg_create)
 };
 
 struct RgMsgs {
@@ -52,15 +53,11 @@ static inline bool rg_fits_u32_offsets(u64 n_slots, u64 stride) {
     const u64 rows = n_slots > RG_TERM_RUNS ? n_slots : RG_TERM_RUNS;
     return rows * stride * 8 <= 0xffffffffULL;
 }
-// What the launchers ask: 32-bit cell offsets unless the engine is too large -- or RG_FORCE_IX64=1 is set in the
-// environment, a TEST hook that makes every launch take the 64-bit-offset instantiations (k_tick_lane / _list / _fused /
-// _compact <..., u64>, k_send_dense<..., u64>), which no engine a test can afford to build would otherwise reach on a GPU.
-#include <stdlib.h>
-static inline bool rg_ix32(u64 n_slots, u64 stride) {
-    const char *e = getenv("RG_FORCE_IX64"); // (read per launch: a test flips it inside one process)
-    const bool forced64 = e && e[0] && e[0] != '0';
-    return !forced64 && rg_fits_u32_offsets(n_slots, stride);
-}
+// What the launchers ask: 32-bit cell offsets unless the engine is too large -- or was CREATED with RG_FORCE_IX64=1 in the
+// environment, a TEST hook that makes every launch of that engine take the 64-bit-offset instantiations (k_tick_lane / _list /
+// _fused / _compact <..., u64>, k_send_dense<..., u64>), which no engine a test can afford to build would otherwise reach on
+// a GPU. The environment is read once, by rg_create, into RgState::ix64: nothing on a launch path calls getenv.
+static inline bool rg_ix32(const RgState &st, u64 n_slots) { return !st.ix64 && rg_fits_u32_offsets(n_slots, st.stride); }
 template <typename T, typename IX> RG_HD T &rg_at(T *base, IX i) {
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
     return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (IX)(i * (IX)sizeof(T)));

@@ -985,11 +985,11 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
     } else if (variant == RG_VARIANT_COMPACT) {
         const dim3 grid(rg_grid_for(st.G, RG_CPT_BLOCK)), block(RG_CPT_BLOCK);
-        if (rg_ix32(P, st.stride)) hipLaunchKernelGGL((k_tick_compact<P, GC, u32>), grid, block, 0, stream, st, ms);
+        if (rg_ix32(st, P)) hipLaunchKernelGGL((k_tick_compact<P, GC, u32>), grid, block, 0, stream, st, ms);
         else hipLaunchKernelGGL((k_tick_compact<P, GC, u64>), grid, block, 0, stream, st, ms);
     } else {
         // 32-bit cell offsets when every cell a lane addresses is below 4 GiB from its column's start
-        if (rg_ix32(P, st.stride))
+        if (rg_ix32(st, P))
             RG_LAUNCH_LANE(u32);
         else
             RG_LAUNCH_LANE(u64);
@@ -1003,7 +1003,7 @@ template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo) {
     const dim3 grid(rg_grid_for(n_upper, RG_BLOCK)), block(RG_BLOCK);
-    const bool ix32 = rg_ix32(P, st.stride);
+    const bool ix32 = rg_ix32(st, P);
     if (gc) {
         if (ix32) hipLaunchKernelGGL((k_tick_list<P, true, u32>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
         else hipLaunchKernelGGL((k_tick_list<P, true, u64>), grid, block, 0, stream, st, ms, list, n_ptr, mflags_rw, lo);
@@ -1014,7 +1014,7 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
 }
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
-    const bool ix32 = rg_ix32(P, st.stride); // 32-bit cell offsets (rg_launch_tick_t)
+    const bool ix32 = rg_ix32(st, P); // 32-bit cell offsets (rg_launch_tick_t)
     if (gc) {
         if (ix32) hipLaunchKernelGGL((k_tick_fused<P, true, u32>), grid, block, 0, stream, st, fm);
         else hipLaunchKernelGGL((k_tick_fused<P, true, u64>), grid, block, 0, stream, st, fm);
@@ -1027,7 +1027,7 @@ template <int P>
 void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIns &ins, u64 max_entries,
                            u32 flags, const RgSendCols &oc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
-    const bool ix32 = rg_ix32(P, st.stride); // 32-bit cell offsets (rg_launch_tick_t)
+    const bool ix32 = rg_ix32(st, P); // 32-bit cell offsets (rg_launch_tick_t)
     if (gc) {
         if (ix32) hipLaunchKernelGGL((k_tick_send<P, true, u32>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
         else hipLaunchKernelGGL((k_tick_send<P, true, u64>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);

@@ -35,6 +35,22 @@ static inline int rg_pb_child(int schema, rg_wire_u64 field) { // >= 0: length-d
     default: return -1;
     }
 }
+// The wire type the schema declares for `field`: 0 varint (integers, bools, enums), 2 length-delimited (bytes, messages),
+// 9 = a repeated uint64, which parsers take packed (2) or one varint at a time (0); -1 = not a field of the schema (skipped
+// whatever its wire type). A KNOWN field that arrives with another wire type is a parse error in both codecs the reference
+// can be built with -- rust-protobuf 2 raises WireError::UnexpectedWireType from the generated merge_from, prost fails
+// check_wire_type -- so Message::parse_from_bytes never hands such a message to RawNode::step (a mistyped `term` would
+// otherwise decode as 0 and walk past the term gate).
+static inline int rg_pb_declared(int schema, rg_wire_u64 field) {
+    switch (schema) {
+    case RG_PB_MESSAGE: return field == 7 || field == 9 || field == 12 ? 2 : field >= 1 && field <= 15 ? 0 : -1;
+    case RG_PB_ENTRY: return field == 4 || field == 6 ? 2 : field >= 1 && field <= 6 ? 0 : -1;
+    case RG_PB_SNAPSHOT: return field == 1 || field == 2 ? 2 : -1;
+    case RG_PB_SNAPSHOT_META: return field == 1 ? 2 : field == 2 || field == 3 ? 0 : -1;
+    case RG_PB_CONF_STATE: return field >= 1 && field <= 4 ? 9 : field == 5 ? 0 : -1;
+    default: return -1;
+    }
+}
 // Walk one message of `schema` in [p, end): structure only, except for the top-level Message, whose fields land in `out`.
 // `group` != 0: we are inside an unknown GROUP of that field number and stop at its END_GROUP tag.
 static inline bool rg_pb_walk(const uint8_t *&p, const uint8_t *end, int schema, rg_decoded_message *out, rg_wire_u64 group, int depth) {
@@ -46,6 +62,10 @@ static inline bool rg_pb_walk(const uint8_t *&p, const uint8_t *end, int schema,
         const rg_wire_u64 field = key >> 3;
         const uint32_t wt = (uint32_t)(key & 7);
         if (field == 0) return false;
+        if (!group) {
+            const int want = rg_pb_declared(schema, field);
+            if (want >= 0 && !(want == 9 ? (wt == 0 || wt == 2) : wt == (uint32_t)want)) return false;
+        }
         switch (wt) {
         case 0:
             if (!rg_pb_varint(p, end, v)) return false;
@@ -63,7 +83,7 @@ static inline bool rg_pb_walk(const uint8_t *&p, const uint8_t *end, int schema,
                 case 13: out->request_snapshot = v; break;
                 case 14: out->priority = v; break;
                 case 15: out->commit_term = v; break;
-                default: break; // unknown varint field (or a known one of another wire type): skipped, like protobuf does
+                default: break; // unknown varint field: skipped, like protobuf does
                 }
             }
             break;

@@ -246,7 +246,7 @@ SYMBOLS = {
     "rg_quorum_recently_active": (_i, [_vp, _vp]),
     "rg_set_peers": (_i, [_vp, _u64, C.POINTER(_u64), C.c_uint32, _u64]),
     "rg_step": (_i, [_vp, _u64, C.POINTER(AppendResponse)]),
-    "rg_step_bytes": (_i, [_vp, _u64, C.c_char_p, _u64]),
+    "rg_step_bytes": (_i, [_vp, _u64, C.c_char_p, _u64, C.c_uint8]),
     "rg_decode_message": (_i, [C.c_char_p, _u64, C.POINTER(DecodedMessage)]),
     "rg_progress_events": (_i, [_vp, C.c_void_p, _u64]),
     "rg_progress_event_dense": (_i, [_vp, C.c_uint32, C.c_void_p]),
@@ -715,9 +715,9 @@ class Engine:
                            (C.c_uint8 * 6)(), log_term)
         self._check(self.L.rg_step(self.h, group, C.byref(m)))
 
-    def step_bytes(self, group, data):
-        """RawNode::step on one protobuf-encoded eraftpb::Message (bytes)."""
-        self._check(self.L.rg_step_bytes(self.h, group, bytes(data), len(data)))
+    def step_bytes(self, group, data, ins_full=False):
+        """RawNode::step on one protobuf-encoded eraftpb::Message (bytes); ins_full: the caller's Inflights::full() for the sender."""
+        self._check(self.L.rg_step_bytes(self.h, group, bytes(data), len(data), int(ins_full)))
 
     def local_append(self, group, new_last_index):
         self._check(self.L.rg_local_append(self.h, group, new_last_index))

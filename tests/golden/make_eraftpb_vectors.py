@@ -63,6 +63,70 @@ def build_classes(package, enums, messages):
     return {name: message_factory.GetMessageClass(pool.FindMessageTypeByName(f"{package}.{name}")) for name in messages}
 
 
+def mistyped_known_field(data, messages, enums, name="Message"):
+    """Does `data` -- bytes the protobuf runtime ACCEPTS as message `name` -- carry a field of the schema with a wire type
+    other than the declared one (varint for integers / bools / enums, length-delimited for bytes and messages, either for a
+    repeated uint64)? The Python runtime files such a field under the unknown fields and carries on; both codecs the reference
+    can be built with refuse the whole message (rust-protobuf 2: WireError::UnexpectedWireType out of the generated merge_from;
+    prost: check_wire_type), so Message::parse_from_bytes fails and RawNode::step never sees it. Schema-driven (the parsed
+    .proto), recursing into nested messages as a real parser does; inside an unknown group everything is opaque."""
+    decl = {num: (lab.strip() == "repeated", typ) for lab, typ, _, num in messages[name]}
+
+    def rd_varint(b, i):
+        v = s = 0
+        while True:
+            c = b[i]
+            i += 1
+            v |= (c & 0x7f) << s
+            s += 7
+            if not c & 0x80:
+                return v, i
+
+    def skip_group(b, i, field):
+        while True:
+            key, i = rd_varint(b, i)
+            f, wt = key >> 3, key & 7
+            if wt == 4:
+                assert f == field
+                return i
+            if wt == 0:
+                _, i = rd_varint(b, i)
+            elif wt == 1:
+                i += 8
+            elif wt == 2:
+                n, i = rd_varint(b, i)
+                i += n
+            elif wt == 3:
+                i = skip_group(b, i, f)
+            elif wt == 5:
+                i += 4
+
+    i = 0
+    while i < len(data):
+        key, i = rd_varint(data, i)
+        f, wt = key >> 3, key & 7
+        if f in decl:
+            rep, typ = decl[f]
+            is_len = typ in ("bytes", "string") or typ in messages
+            ok = (wt == 2) if is_len else (wt in (0, 2) if rep else wt == 0)
+            if not ok:
+                return True
+        if wt == 0:
+            _, i = rd_varint(data, i)
+        elif wt == 1:
+            i += 8
+        elif wt == 2:
+            n, i = rd_varint(data, i)
+            if f in decl and decl[f][1] in messages and mistyped_known_field(data[i:i + n], messages, enums, decl[f][1]):
+                return True
+            i += n
+        elif wt == 3:
+            i = skip_group(data, i, f)
+        elif wt == 5:
+            i += 4
+    return False
+
+
 def rand_u64(rng):
     k = rng.random()
     if k < 0.15:
@@ -133,6 +197,29 @@ def main():
         except Exception:
             pass
         vectors.append({"hex": bad.hex(), "type": why, "error": True})
+    # A field of the schema with the wrong wire type. HERE the judge is not the Python runtime -- it keeps such a field as an
+    # unknown one and accepts the message -- but the two Rust codecs of the reference, which both refuse it (see
+    # mistyped_known_field): `strict` marks the vectors where the runtimes differ and the decoder follows the reference's.
+    strict_cases = [(b"\x08\x04\x1a\x01\x05\x21" + b"\x00" * 8 + b"\x30\x07", "from as bytes, term as fixed64 (MsgAppendResponse otherwise)"),
+                    (b"\x08\x04\x22\x01\x07", "term length-delimited"), (b"\x0d\x04\x00\x00\x00", "msg_type as fixed32"),
+                    (b"\x38\x05", "entries as a varint"), (b"\x48\x05", "snapshot as a varint"), (b"\x60\x01", "context as a varint"),
+                    (b"\x55\x01\x00\x00\x00", "reject as fixed32"), (b"\x13\x14", "to as a group"),
+                    (b"\x3a\x03\x12\x01\x00", "an entry whose term is length-delimited"), (b"\x3a\x02\x20\x01", "an entry whose data is a varint"),
+                    (b"\x4a\x02\x08\x01", "a snapshot whose data is a varint"), (b"\x4a\x04\x12\x02\x08\x01", "snapshot metadata whose conf_state is a varint"),
+                    (b"\x4a\x09\x12\x07\x0a\x05\x0d\x01\x00\x00\x00", "conf_state voters as fixed32")]
+    for bad, why in strict_cases:
+        Message.FromString(bad)  # (raises if the Python runtime refuses it: then it belongs to bad_cases)
+        assert mistyped_known_field(bad, messages, enums), why
+        vectors.append({"hex": bad.hex(), "type": why, "error": True, "strict": True})
+    # ... and the other side of that rule: a repeated uint64 is accepted packed AND one varint field per element
+    f0 = dict(vectors[0]["fields"])
+    f0["has_snapshot"] = 1
+    for okb, why in ((b"\x4a\x07\x12\x05\x0a\x03\x0a\x01\x09" + base, "conf_state voters packed"),
+                     (b"\x4a\x08\x12\x06\x0a\x04\x08\x09\x08\x0a" + base, "conf_state voters unpacked (one varint field per element)")):
+        m = Message.FromString(okb)
+        assert list(m.snapshot.metadata.conf_state.voters) in ([9], [9, 10]), why
+        assert not mistyped_known_field(okb, messages, enums), why
+        vectors.append({"hex": okb.hex(), "type": why, "fields": f0})
     for v in vectors:
         if not v.get("error"):
             Message.FromString(bytes.fromhex(v["hex"]))  # (raises if the runtime disagrees)

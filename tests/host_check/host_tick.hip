@@ -17,7 +17,7 @@ static RgState make_state(void *const *p, u64 G, u64 stride) {
     st.cur_term = (u64 *)p[16];
     st.hhint = (u8 *)p[17];
     st.G = G; st.stride = stride;
-    st.pub = nullptr; st.pub_off_delta = 0; st.pub_cap = 0;
+    st.pub = nullptr; st.pub_off_delta = 0; st.pub_cap = 0; st.ix64 = 0;
     return st;
 }
 // RG_PF_PEND_SNAP / RG_PF_PEND_RS are engine-owned: the library derives it when the columns are loaded (k_fix_pending); the arrays a test hands

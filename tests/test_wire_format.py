@@ -52,7 +52,10 @@ def test_decoder_matches_every_golden_vector(rg):
         got = decode_message(data)
         assert got == v["fields"], (v["type"], got, v["fields"])
         n_ok += 1
-    assert n_ok >= 242 and n_err >= 11
+    assert n_ok >= 244 and n_err >= 24
+    # (13 of the error vectors are `strict`: a field of the schema with the wrong wire type -- accepted by the Python runtime
+    # as an unknown field, refused by both Rust codecs of the reference, hence by this decoder)
+    assert sum(1 for v in DOC["vectors"] if v.get("strict")) >= 13
     assert decode_message(b"") == {k: 0 for k in DOC["vectors"][0]["fields"]}  # the empty message: every field default
 
 
@@ -114,14 +117,17 @@ def test_decoder_survives_mutated_and_random_bytes(rg):
 def test_decoder_agrees_with_the_protobuf_runtime_on_mutated_bytes(rg):
     """Differential: the protobuf runtime, with descriptors parsed out of the reference's eraftpb.proto, accepts exactly
     the byte strings rg_decode_message accepts, and reads the same fields (nested entries / snapshots are validated, unknown
-    fields and well-formed groups skipped, tags beyond 32 bits refused)."""
+    fields and well-formed groups skipped, tags beyond 32 bits refused) -- with the one rule where the Python runtime and the
+    reference's Rust codecs part: a field of the schema that arrives with another wire type than the declared one is an
+    unknown field to the former and a parse error to the latter (make_eraftpb_vectors.mistyped_known_field), and the decoder
+    sides with the reference."""
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_eraftpb_vectors as M
     from raft_rs_amd.engine import decode_message, EngineError
     package, enums, messages = M.parse_proto(open(M.PROTO, encoding="utf-8").read())
     Message = M.build_classes(package, enums, messages)["Message"]
     rng = np.random.default_rng(4242)
-    n_ok = 0
+    n_ok = n_strict = 0
     for data in _mutations(rng, 20000):
         try:
             m = Message.FromString(data)
@@ -131,8 +137,10 @@ def test_decoder_agrees_with_the_protobuf_runtime_on_mutated_bytes(rg):
             d = decode_message(data)
         except EngineError:
             d = None
-        assert (m is None) == (d is None), (data.hex(), m is None, d is None)
-        if m is None:
+        strict = m is not None and M.mistyped_known_field(data, messages, enums)
+        n_strict += strict
+        assert (m is None or strict) == (d is None), (data.hex(), m is None, strict, d is None)
+        if d is None:
             continue
         want = {"msg_type": int(m.msg_type) & 0xffffffff, "to": m.to, "from": getattr(m, "from"), "term": m.term,
                 "log_term": m.log_term, "index": m.index, "commit": m.commit, "commit_term": m.commit_term,
@@ -141,7 +149,7 @@ def test_decoder_agrees_with_the_protobuf_runtime_on_mutated_bytes(rg):
                 "context_len": len(m.context)}
         assert d == want, (data.hex(), d, want)
         n_ok += 1
-    assert n_ok > 3000
+    assert n_ok > 3000 and n_strict > 100, (n_ok, n_strict)
 
 
 def test_wire_code_is_clean_under_the_sanitisers(tmp_path):
@@ -333,8 +341,11 @@ def test_encode_then_decode_is_the_identity_on_the_scalar_fields(rg):
 @pytest.mark.gpu
 def test_step_bytes_equals_step(rg):
     """Two engines, the same stream: one stepped through rg_step / rg_step_heartbeat_response, the other through
-    rg_step_bytes on the protobuf encoding of the same messages; identical state and results. Plus RawNode::step's
-    error behaviour on bytes: local types, unknown peers, other types, garbage."""
+    rg_step_bytes on the protobuf encoding of the same messages; identical state and results -- with the Inflights on the
+    host (max_inflight = 0), so that the caller's Inflights::full() bit travels beside the bytes (it is not on the wire) and
+    decides is_paused / free_first_one / the `old_paused` re-send exactly as through rg_step. A third engine gets the same
+    bytes WITHOUT the bit and must end somewhere else: the argument is live. Plus RawNode::step's error behaviour on bytes:
+    local types, unknown peers, other types, garbage."""
     import fuzz
     import oracle_lib as O
     from raft_rs_amd.engine import EngineError, ERR
@@ -345,22 +356,25 @@ def test_step_bytes_equals_step(rg):
     fuzz.random_state(rng, st, small_values=True)
     fuzz.random_term_table(rng, st, TERM)
     self_slot = ((st["cfg"] >> 16) & 7).astype(np.int64)
-    a, b = rg.Engine(G, P), rg.Engine(G, P)
-    for eng in (a, b):
+    a, b, c = rg.Engine(G, P), rg.Engine(G, P), rg.Engine(G, P)
+    for eng in (a, b, c):
         eng.load_state(st)
         for g in range(G):
             eng.set_peers(g, [11 * (s + 1) for s in range(P)], TERM)
-    n_app = n_hb = 0
+    n_app = n_hb = blind = 0
     for rnd in range(6):
         for g in range(G):
             for s in range(P):
                 if s == self_slot[g] or rng.random() < 0.4:
                     continue
                 frm = 11 * (s + 1)
+                full = bool(rng.random() < 0.3)  # the host's Inflights::full() for this peer
                 if rng.random() < 0.2:
                     commit = int(rng.integers(0, 50))
-                    a.step_heartbeat_response(g, frm, TERM, commit)
-                    b.step_bytes(g, encode({"msg_type": MT["MsgHeartbeatResponse"], "from": frm, "to": 1, "term": TERM, "commit": commit}))
+                    a.step_heartbeat_response(g, frm, TERM, commit, ins_full=full)
+                    data = encode({"msg_type": MT["MsgHeartbeatResponse"], "from": frm, "to": 1, "term": TERM, "commit": commit})
+                    b.step_bytes(g, data, ins_full=full)
+                    c.step_bytes(g, data)
                     n_hb += 1
                 else:
                     reject = rng.random() < 0.2
@@ -370,17 +384,23 @@ def test_step_bytes_equals_step(rg):
                          "log_term": int(rng.integers(1, TERM)) if reject and rng.random() < 0.5 else 0,
                          "request_snapshot": int(rng.integers(1, 30)) if reject and rng.random() < 0.1 else 0}
                     a.step(g, frm, TERM, idx, commit=f["commit"], reject=reject, reject_hint=f["reject_hint"],
-                           request_snapshot=f["request_snapshot"], log_term=f["log_term"])
-                    b.step_bytes(g, encode(f))
+                           request_snapshot=f["request_snapshot"], log_term=f["log_term"], ins_full=full)
+                    b.step_bytes(g, encode(f), ins_full=full)
+                    c.step_bytes(g, encode(f))
                     n_app += 1
         a.flush()
         b.flush()
+        c.flush()
         ra, rb = a.ingested_results(), b.ingested_results()
         oa, ob = np.argsort(ra[0]), np.argsort(rb[0])
         for x, y in zip(ra, rb):
             assert np.array_equal(x[oa], y[ob]), rnd
         sa, sb = a.read_state(), b.read_state()
         assert not fuzz.diff_states(sa, sb, G, P), rnd
+        rc_ = c.ingested_results()
+        oc_ = np.argsort(rc_[0])
+        blind += int(sum((x[ob] != y[oc_]).sum() for x, y in zip(rb, rc_)))
+    assert blind > 50, "without the Inflights::full() bit the same bytes give other results: the bit is not on the wire"
     assert n_app > 3000 and n_hb > 500
     for typ in ("MsgHup", "MsgBeat", "MsgUnreachable", "MsgSnapStatus", "MsgCheckQuorum"):  # is_local_msg (raw_node.rs:57-66)
         with pytest.raises(EngineError) as e:
@@ -401,3 +421,4 @@ def test_step_bytes_equals_step(rg):
     assert e.value.code == ERR["INVALID_ARG"]
     a.close()
     b.close()
+    c.close()
