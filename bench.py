@@ -249,7 +249,7 @@ def traffic_lookup(key):
                           " @ build " + str(ent.get("commit", "unrecorded (before round 4)")) + " -- NOT measured inside this run")
 
 
-def workload_label(workload, n_groups, n_slots, one_engine=False):
+def workload_label(workload, n_groups, n_slots, one_engine=False, sorted_classes=False):
     m = n_groups // 1_000_000 if n_groups % 1_000_000 == 0 else None
     size = f"{m}M" if m else str(n_groups)
     if workload == 2 and n_slots == 5:
@@ -261,7 +261,8 @@ def workload_label(workload, n_groups, n_slots, one_engine=False):
         return f"{size} groups x {n_slots} slots, joint {{0,1,2}}&&{{1,2,3}} + learner" + (" (BASELINE configs[2])" if (n_groups, n_slots) == (1_000_000, 5) else "")
     if workload == 5:
         return (f"{size} groups mixed 3/5/7 peers + 10% leader-term rollover" + (" (BASELINE configs[4])" if n_groups == 1_000_000 else "") +
-                (f", sizes interleaved in one {n_slots}-slot engine" if one_engine else ", one engine per replica-set size"))
+                (f", placed by size class in ONE {n_slots}-slot engine: one launch per tick (k_tick_classes)" if sorted_classes else
+                 f", sizes interleaved in one {n_slots}-slot engine" if one_engine else ", one engine per replica-set size"))
     return f"{n_groups} groups x {n_slots} slots, workload {workload}"
 
 
@@ -282,18 +283,21 @@ def send_stage_bytes(rg, eng, n_items, with_work=False):
 
 
 def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
-               inflights=0, fused_send=False):
+               inflights=0, fused_send=False, sorted_classes=False):
     """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
     headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
     synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
     checkpoint, and the K recorded ticks are replayed back to back between two HIP events on the engines' streams.
       what == "tick":      the hot path; config 5 runs one engine per replica-set size on its own stream unless one_engine;
                            inflights > 0 adds the send stage (rg_send_appends) after every tick, timed per launch too;
-                           fused_send: the timed replay runs the tick and its stage as ONE launch (rg_tick_device_send)
+                           fused_send: the timed replay runs the tick and its stage as ONE launch (rg_tick_device_send);
+                           sorted_classes (config 5, one engine): the same groups placed by replica-set size class, which the
+                           engine runs as ONE launch whose blocks skip the slots their class does not have (k_tick_classes)
       what == "recompute": K launches of rg_recompute -- Raft::maybe_commit for every group with no messages, literally
                            BASELINE's "commit-index recomputes"
     Returns a dict with its own `roofline` object (bound, regime, achieved, peak, frac, traffic...)."""
     main_stream = torch.cuda.current_stream()
+    one_engine = one_engine or sorted_classes
     if workload == 5 and not one_engine:
         sizes = [(3, n_groups // 3), (5, n_groups // 3), (7, n_groups - 2 * (n_groups // 3))]
     else:
@@ -310,9 +314,12 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt.fixed = slots if (workload == 5 and not one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights)
         pt.eng.set_stream(main_stream.cuda_stream)
-        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed)
+        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=sorted_classes)
         first += n
         parts.append(pt)
+    classes = parts[0].eng.size_classes() if sorted_classes else None
+    if sorted_classes and len(classes) < 2:
+        raise SystemExit(f"side measurement: the class-placed shard was not recognised as one ({classes})")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     extra = {}
     if what == "recompute":
@@ -348,7 +355,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         census = dict(valid=0, rejects=0, elections=0)
         for t in range(T):
             for pt in parts:
-                pt.eng.workload_gen(workload, t, *ptrs(pt, t), seed=seed, first_group=pt.first, fixed_peers=pt.fixed)
+                pt.eng.workload_gen(workload, t, *ptrs(pt, t), seed=seed, first_group=pt.first, fixed_peers=pt.fixed,
+                                    sorted_classes=sorted_classes)
                 if inflights:
                     pt.flags[t] &= 0xE7  # no RG_MF_SENT / RG_MF_INS_FULL: the device owns the send path
                 s = pt.eng.msg_stats(pt.flags[t].data_ptr())
@@ -416,9 +424,11 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                 raise SystemExit("side measurement: the timed replay diverged from the recorded pass")
         nbytes = float(np.mean(alg[warmup:]))
         hot = sum(hot_state_bytes(pt.n, pt.slots, bool(inflights)) for pt in parts)
-        kernel = {2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(variant, "k_tick_lane")
+        if sorted_classes:  # the columns of the slots a class does not have are never touched
+            hot = sum(hot_state_bytes(n, q) for _, n, q in classes)
+        kernel = {2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(variant, "k_tick_classes" if sorted_classes else "k_tick_lane")
         unit = "group-evals/s"
-        key = (f"{workload}:{n_groups}:{n_slots}" + (":one-engine" if (workload == 5 and one_engine) else "") +
+        key = (f"{workload}:{n_groups}:{n_slots}" + (":sorted" if sorted_classes else ":one-engine" if (workload == 5 and one_engine) else "") +
                (f":v{variant}" if variant else "") + (":inflights" if inflights else "") + (":fused-send" if (inflights and fused_send) else ""))
         denom = float(n_groups * steps)
         extra = {"acks_per_group": round(census["valid"] / denom, 3), "rejects_per_group": round(census["rejects"] / denom, 5)}
@@ -462,13 +472,14 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt.eng.close()
     gbs = nbytes / (us * 1e-6) / 1e9
     traffic, traffic_source = traffic_lookup(key)
-    label = (workload_label(workload, n_groups, n_slots, one_engine) if what == "tick" else
+    label = (workload_label(workload, n_groups, n_slots, one_engine, sorted_classes) if what == "tick" else
              f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers")
     if inflights:
         label += (f" + Inflights (cap {inflights}) on the device and the send stage after every tick, " +
                   ("tick and stage as ONE launch (rg_tick_device_send)" if fused_send else "as a launch of its own (rg_send_appends)"))
     return {"workload": label,
             "groups": n_groups, "peer_slots": n_slots, "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
+            **({"size_classes": [{"first_group": f, "groups": n, "slots": q} for f, n, q in classes]} if classes else {}),
             "steps": steps, "warmup": warmup, "us_per_step": us, "value": n_groups / (us * 1e-6), "unit": unit, **extra,
             "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot, "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel": ("k_tick_send" if fused_send else kernel + " + k_send_dense") if inflights else kernel,
@@ -566,6 +577,8 @@ def main():
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
+    ap.add_argument("--sorted", action="store_true",
+                    help="config 5: ONE engine with the groups placed by replica-set size class (one launch per tick, k_tick_classes)")
     ap.add_argument("--inflights", type=int, default=0,
                     help="N > 0: keep the Inflights (cap N) on the device and run the send stage (rg_send_appends: "
                          "maybe_send_append decisions, SURVEY 8f row 3) after every tick, inside the timed region; the "
@@ -584,6 +597,8 @@ def main():
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
+    if args.sorted:
+        args.one_engine = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # The plain command line (`python bench.py --gpus 8 ...`, what works at N = 1) starts its own ranks: one process
@@ -632,7 +647,8 @@ def main():
     if args.side:
         torch.cuda.set_stream(torch.cuda.Stream())
         print(json.dumps(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
-                                    one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send)),
+                                    one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
+                                    sorted_classes=args.sorted)),
               flush=True)
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
@@ -664,7 +680,7 @@ def main():
         pt.fixed = slots if (args.workload == 5 and not args.one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant, max_inflight=args.inflights)
         pt.eng.set_stream(stream.cuda_stream)
-        pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed)
+        pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=args.sorted)
         pt.eng.checkpoint()
         pt.cols = [torch.empty((T, slots, pt.eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
         pt.flags = torch.empty((T, n, 8), dtype=torch.uint8, device="cuda")
@@ -680,7 +696,7 @@ def main():
     for t in range(T):
         for pt in parts:
             pt.eng.workload_gen(args.workload, t, *tick_ptrs(pt, t), seed=args.seed, first_group=pt.first,
-                                fixed_peers=pt.fixed)
+                                fixed_peers=pt.fixed, sorted_classes=args.sorted)
             if args.inflights:
                 pt.flags[t] &= 0xE7  # no RG_MF_SENT / RG_MF_INS_FULL: the device owns the send path
             s = pt.eng.msg_stats(pt.flags[t].data_ptr())
@@ -930,7 +946,7 @@ def main():
     traffic, traffic_source = (None, None)
     if not args.inflights and args.split == 1 and args.fuse == 1:
         traffic, traffic_source = traffic_lookup(
-            f"{args.workload}:{G}:{P}" + (":one-engine" if (args.workload == 5 and args.one_engine) else "") +
+            f"{args.workload}:{G}:{P}" + (":sorted" if args.sorted else ":one-engine" if (args.workload == 5 and args.one_engine) else "") +
             (f":v{args.variant}" if args.variant else ""))
     hot = sum(hot_state_bytes(pt.n, pt.slots, bool(args.inflights)) for pt in parts)
 
@@ -943,7 +959,7 @@ def main():
                                 f"every {'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3]: 8 M x 7 over 8 GPUs"
                                 f"{'' if (world, G) == (8, 1_000_000) else ' -- here at ' + str(world) + ' x ' + str(G)})"
                                 if (args.workload == 2 and P == 7 and distributed) else
-                                workload_label(args.workload, G, P, args.one_engine) +
+                                workload_label(args.workload, G, P, args.one_engine, args.sorted) +
                                 (f", x {world} ranks ({'strong scaling: ' + str(world * G) + ' groups in total' if strong else 'weak scaling'}), commit indices published every "
                                  f"{'tick' if E == 1 else str(E) + ' ticks'}" if distributed else "")),
                    "groups_per_gpu": G, "peer_slots": P, "workload_id": args.workload, "seed": hex(args.seed),
@@ -972,7 +988,7 @@ def main():
                                     "(the honest HBM-regime figure is out_of_cache.roofline.frac); hbm: they do not fit",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_lane")) +
+                     "kernel": ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_classes" if args.sorted else "k_tick_lane")) +
                                (" + k_send_dense" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6,
@@ -1005,6 +1021,7 @@ def main():
         c5v = args.c5_variant
         for name, kw in (("configs[2] joint", dict(n_groups=1_000_000, n_slots=5, workload=3)),
                          ("configs[3] one rank's shard", dict(n_groups=1_000_000, n_slots=7, workload=2)),
+                         ("configs[4] one launch, class-sorted", dict(n_groups=1_000_000, n_slots=7, workload=5, sorted_classes=True)),
                          ("configs[4] size-class engines", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v)),
                          ("configs[4] one 7-slot engine", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v, one_engine=True)),
                          ("configs[1] + send stage", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256)),

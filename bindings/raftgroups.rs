@@ -52,6 +52,7 @@ pub const RG_PUBLISH_FULL: u32 = 0x1;
 pub const RG_WL_MAJORITY: u32 = 2;
 pub const RG_WL_JOINT: u32 = 3;
 pub const RG_WL_MIXED: u32 = 5;
+pub const RG_WL_PLACE_SORTED: u32 = 0x10;
 
 // rg_status
 pub const RG_OK: i32 = 0;
@@ -84,7 +85,8 @@ pub const RG_COL_DUMMY_INDEX: i32 = 14;
 pub const RG_COL_DUMMY_TERM: i32 = 15;
 pub const RG_COL_CUR_TERM: i32 = 16;
 pub const RG_COL_HOST_HINT: i32 = 17;
-pub const RG_COL_COUNT: i32 = 18;
+pub const RG_COL_RUN_COUNT: i32 = 18;
+pub const RG_COL_COUNT: i32 = 19;
 
 pub enum RgEngine {} // opaque
 pub type RgAllgatherFn = Option<unsafe extern "C" fn(*mut c_void, *const c_void, *mut c_void, u64, *mut c_void) -> i32>;
@@ -156,6 +158,14 @@ pub struct RgProgressEvent {
     pub group: u64,
     pub slot: u32,
     pub kind: u32,
+}
+
+#[repr(C)]
+pub struct RgSizeClass {
+    pub first_group: u64,
+    pub n_groups: u64,
+    pub n_slots: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -352,6 +362,7 @@ extern "C" {
     pub fn rg_set_config(h: *mut RgEngine, group: u64, cfg_word: u32) -> i32;
     pub fn rg_progress_events(h: *mut RgEngine, events: *const RgProgressEvent, n: u64) -> i32;
     pub fn rg_progress_event_dense(h: *mut RgEngine, kind: u32, host_slot_plus1: *const u8) -> i32;
+    pub fn rg_size_classes(h: *mut RgEngine, out: *mut RgSizeClass, cap: u32, n: *mut u32) -> i32;
     pub fn rg_tick(h: *mut RgEngine, host_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device(h: *mut RgEngine, dev_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device_fused(h: *mut RgEngine, dev_msgs: *const RgMsgs, n_ticks: u32, dev_out_t: *mut u32, dev_commit_t: *mut u64) -> i32;

@@ -168,7 +168,10 @@ typedef enum {
     RG_COL_HOST_HINT = 17,   /* u8 [G] engine-owned, read-only for the host: bit s = slot s's reject of the last tick was left to
                                 the host (RG_OUT_HOST_HINT). Meaningful only for groups whose RG_COL_OUT word of that tick has the
                                 bit; other bytes are stale. rg_host_hints gathers the flagged groups. */
-    RG_COL_COUNT = 18
+    RG_COL_RUN_COUNT = 18,   /* u8 [G] engine-owned, read-only for the host: how many runs of RG_COL_RUN_FIRST / _TERM are in use
+                                (derived when RG_COL_RUN_FIRST is loaded, kept by the elections): what lets an election file
+                                its run without reading the table */
+    RG_COL_COUNT = 19
 } rg_column;
 #define RG_TERM_RUNS 8
 
@@ -303,6 +306,22 @@ int rg_progress_events(rg_engine *h, const rg_progress_event *events, uint64_t n
  * slot s (values beyond the engine's slots are ignored). 1 B per group over PCIe instead of a 16 B record: 1 M groups in
  * 77 us instead of 5.5 ms (profiles/r03_progress_events.txt). Same arithmetic as rg_progress_events. Synchronises. */
 int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slot_plus1);
+
+/* Size classes: replica sets of different sizes in one shard (BASELINE config 5: 3 / 5 / 7 peers). Peers a group does not
+ * have still occupy cells of the engine's P slots; where the host places groups of one size in CONTIGUOUS ranges, the dense
+ * tick skips the absent slots of a whole range -- their loads, stores and instructions -- in ONE launch (k_tick_classes).
+ * Nothing to declare: the engine derives the ranges from RG_COL_CFG by itself (per 64 groups, the highest slot any cfg word
+ * names; at most 8 ranges, rounded up to 3 / 5 / 7 / P slots), re-derives them after anything wrote the column
+ * (rg_load_column, rg_set_config beyond its block's class, rg_restore, rg_workload_init) and falls back to the plain kernel
+ * wherever the layout does not qualify (sizes interleaved, group commit on, the LDS / compact variants, an engine beyond
+ * 32-bit cell offsets, RG_COL_CFG's device pointer handed out through rg_column_ptr). Results never depend on it.
+ * This call reports what the next dense tick will use: *n = number of ranges (0 = the plain kernel), out[k] for k < cap. */
+typedef struct {
+    uint64_t first_group, n_groups;
+    uint32_t n_slots; /* slots the groups of the range use at most */
+    uint32_t reserved;
+} rg_size_class;
+int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, uint32_t *n);
 
 /* ---- the hot path ---- */
 /* One tick: for every group, apply its <=1 message per slot in slot order exactly as
@@ -719,11 +738,15 @@ int rg_pub_apply_host(uint64_t n_groups, uint32_t overflow_slots, uint32_t world
 typedef struct {
     uint64_t seed;
     uint32_t workload; /* RG_WL_* */
-    uint32_t reserved; /* RG_WL_MIXED only: fixed replica-set size (3/5/7) of a size-class shard, 0 = by group id % 3 */
+    uint32_t reserved; /* RG_WL_MIXED only: bits 0-3 = fixed replica-set size (3/5/7) of a size-class shard, 0 = by group id % 3;
+                          RG_WL_PLACE_SORTED (bit 4): the same groups, placed inside the shard by size class (all ids 0 mod 3
+                          first, then 1 mod 3, then 2 mod 3) instead of interleaved -- contiguous classes let one launch skip the
+                          peer slots a class does not have */
 } rg_workload;
 #define RG_WL_MAJORITY 2u /* BASELINE config 2 (and 1, 4): majority quorum over all P slots */
 #define RG_WL_JOINT 3u    /* config 3: incoming {0,1,2} && outgoing {1,2,3}, slot 4.. learners */
 #define RG_WL_MIXED 5u    /* config 5: P in {3,5,7} by group, 10% groups in post-election probe/reject */
+#define RG_WL_PLACE_SORTED 0x10u /* rg_workload.reserved flag, see there */
 /* Initialise all engine state for the workload (device-side generator). */
 int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t first_group_global);
 /* Generate tick `tick`'s messages from the CURRENT device state into device message columns. */

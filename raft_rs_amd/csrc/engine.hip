@@ -682,6 +682,11 @@ __global__ __launch_bounds__(256) void k_progress_event_dense(RgState st, u32 *i
 
 // RG_PF_PEND_SNAP / RG_PF_PEND_RS (pending_snapshot / pending_request_snapshot != 0) re-derived for every cell: after the
 // flag column or one of the two columns was loaded wholesale.
+// RG_COL_RUN_COUNT from a freshly loaded RG_COL_RUN_FIRST
+__global__ __launch_bounds__(RG_BLOCK) void k_fix_run_count(RgState st) {
+    const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g < st.G) rg_run_n(st)[g] = (u8)rg_count_runs(st, g);
+}
 __global__ __launch_bounds__(RG_BLOCK) void k_fix_pending(RgState st, u32 P) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
@@ -775,10 +780,28 @@ __global__ __launch_bounds__(RG_BLOCK) void k_msg_stats(const u64 *mflags, const
     }
 }
 
+// rg_refresh_classes: per block of RG_BLOCK groups (= one workgroup of the lane kernels), the number of slots the block's cfg
+// words name: 1 + the highest slot that is present, a voter of either majority, the leader's own, or the transferee.
+RG_HD u32 rg_cfg_slots_named(u32 cfg) {
+    const u32 tr = RG_CFG_TRANSFEREE(cfg);
+    const u32 m = RG_CFG_PRESENT(cfg) | RG_CFG_INCOMING(cfg) | RG_CFG_OUTGOING(cfg) | (1u << RG_CFG_SELF(cfg)) | (tr ? 1u << (tr - 1u) : 0u);
+    return 32u - (u32)__builtin_clz(m | 1u);
+}
+__global__ __launch_bounds__(256) void k_block_slots(const u32 *cfg, u64 G, u64 n_blocks, u8 *need) {
+    const u64 b = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n_blocks) return;
+    u32 m = 1;
+    for (u64 g = b * RG_BLOCK; g < (b + 1) * RG_BLOCK && g < G; g++) {
+        const u32 k = rg_cfg_slots_named(cfg[g]);
+        m = k > m ? k : m;
+    }
+    need[b] = (u8)m;
+}
+
 __global__ __launch_bounds__(RG_BLOCK) void k_wl_init(RgState st, u64 seed, u32 workload, u32 P, u64 first) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
-    rg_wl_init_group(seed, workload, P, st.stride, g, first + g, st.match, st.next, st.prc, st.psnap,
+    rg_wl_init_group(seed, workload, P, st.stride, g, first + rg_wl_place(workload, g, st.G), st.match, st.next, st.prc, st.psnap,
                      st.prs, st.gid, reinterpret_cast<u8 *>(st.pflags), st.commit, st.lo, st.hi, st.cfg);
     st.out[g] = 0;
     // the cold log-model columns: nothing compacted, no older runs known, leader term RG_WL_TERM0
@@ -786,6 +809,7 @@ __global__ __launch_bounds__(RG_BLOCK) void k_wl_init(RgState st, u64 seed, u32 
         st.run_first[(u64)k * st.stride + g] = 0;
         st.run_term[(u64)k * st.stride + g] = 0;
     }
+    rg_run_n(st)[g] = 0;
     st.dummy_idx[g] = 0;
     st.dummy_term[g] = 0;
     st.cur_term[g] = RG_WL_TERM0;
@@ -795,7 +819,7 @@ __global__ __launch_bounds__(RG_BLOCK) void k_wl_gen(RgState st, u64 seed, u32 w
                                                      u64 tick, u64 *mi, u64 *mc, u64 *mh, u64 *mrs, u8 *mf) {
     const u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g >= st.G) return;
-    rg_wl_gen_group(seed, workload, P, st.stride, g, first + g, tick, st.match, st.next,
+    rg_wl_gen_group(seed, workload, P, st.stride, g, first + rg_wl_place(workload, g, st.G), tick, st.match, st.next,
                     reinterpret_cast<const u8 *>(st.pflags), st.commit, st.lo, st.hi, mi, mc, mh, mrs, mf);
 }
 
@@ -865,6 +889,10 @@ struct rg_engine {
     std::vector<rg_send_item> host_items; // items of the last stage when rg_flush_send fetched them
     bool host_items_valid;
     char *pin_send;    // pinned host: u32 count | pad | rg_send_item[RG_SEND_SPEC] (small stages: one round trip)
+    // size classes (k_tick_classes): derived from RG_COL_CFG, lazily, by the first dense tick after anything wrote the column
+    RgClasses cls;     // cls.n == 0: not class-placed (or not derivable): the plain kernels run
+    bool cls_stale;    // RG_COL_CFG may have changed since cls was derived
+    bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
@@ -955,7 +983,7 @@ static size_t rg_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t rg_col_elem(int c) {
     if (c == RG_COL_PFLAGS) return 8; // one u64 row per group
     if (c == RG_COL_CFG || c == RG_COL_OUT) return 4;
-    if (c == RG_COL_HOST_HINT) return 1;
+    if (c == RG_COL_HOST_HINT || c == RG_COL_RUN_COUNT) return 1;
     return 8;
 }
 static bool rg_col_per_slot(int c) { return c <= RG_COL_GID; }
@@ -1062,6 +1090,12 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     h->send_ready = false;
+    h->cls.n = 0;
+    h->cls_stale = true;
+    {
+        const char *e = getenv("RG_NO_CLASSES"); // measurement hook (bench.py's A/B of the class-placed layout), read here only
+        h->cls_off = e && e[0] && e[0] != '0';
+    }
     h->stage_max_entries = 0;
     h->stage_flags = 0;
     // Infinity Cache (256 MB on MI355X): when the state a dense tick re-reads (24 P + 40 B per group) and the message columns of
@@ -1130,6 +1164,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.hhint = (u8 *)rg_col(h, RG_COL_HOST_HINT);
     s.G = h->G;
     s.stride = h->stride;
+    // (consecutive byte columns, strides of 256: RG_COL_RUN_COUNT sits `stride` bytes behind RG_COL_HOST_HINT by construction)
+    if ((u8 *)rg_col(h, RG_COL_RUN_COUNT) != rg_run_n(s)) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: column layout");
     {
         const char *e = getenv("RG_FORCE_IX64"); // test hook (rg_common.h: rg_ix32), read here and nowhere else
         s.ix64 = (e && e[0] && e[0] != '0') ? 1u : 0u;
@@ -1225,6 +1261,7 @@ extern "C" int rg_sync(rg_engine *h) {
 extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t bytes) {
     if (!h || !src || c < 0 || c >= RG_COL_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: bad argument");
     if (c == RG_COL_HOST_HINT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: RG_COL_HOST_HINT is written by the ticks only");
+    if (c == RG_COL_RUN_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: RG_COL_RUN_COUNT is derived from RG_COL_RUN_FIRST by the engine");
     if (bytes != rg_column_bytes(h, c))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column(%d): %llu bytes given, %llu expected", c,
                        (unsigned long long)bytes, (unsigned long long)rg_column_bytes(h, c));
@@ -1243,6 +1280,8 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
     if (c == RG_COL_PFLAGS && h->ins_arena) // the FULL bit is the engine's: re-derive it from the windows
         hipLaunchKernelGGL(k_fix_ins_full, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
                            h->st, h->ins, h->P);
+    if (c == RG_COL_RUN_FIRST) // ... and the table's fill count
+        hipLaunchKernelGGL(k_fix_run_count, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st);
     if (c == RG_COL_PFLAGS || c == RG_COL_PEND_SNAP || c == RG_COL_PEND_RS) // ... and so is RG_PF_PENDING
         hipLaunchKernelGGL(k_fix_pending, dim3((unsigned)((h->G + RG_BLOCK - 1) / RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream,
                            h->st, h->P);
@@ -1250,6 +1289,7 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
     if (c == RG_COL_COMMIT && h->pub) h->pub->local_lost = true;
     if (c == RG_COL_CFG) {
         h->host_cfg_valid = false;
+        h->cls_stale = true;
         const u32 *w = static_cast<const u32 *>(src);
         bool any = false;
         for (u64 g = 0; g < h->G && !any; g++) any = (w[g] & RG_CFG_GROUP_COMMIT) != 0;
@@ -1271,6 +1311,7 @@ extern "C" int rg_read_column(rg_engine *h, int c, void *dst, uint64_t bytes) {
 
 extern "C" void *rg_column_ptr(rg_engine *h, int c) {
     if (!h || c < 0 || c >= RG_COL_COUNT) return nullptr;
+    if (c == RG_COL_CFG) h->cls_off = true; // whoever holds this pointer can rewrite cfg words behind the engine's back
     return rg_col(h, c);
 }
 
@@ -1302,6 +1343,7 @@ extern "C" int rg_restore(rg_engine *h) {
     if (h->pub) h->pub->local_lost = true; // the published advances no longer describe this commit column
     h->out_is_dense = true; // RG_COL_OUT is whatever it was at the checkpoint: the next sparse tick clears all of it
     h->host_cfg_valid = false; // RG_COL_CFG came back too: the mirror re-reads its copy
+    h->cls_stale = true;
     if (h->ckpt_any_group_commit) h->any_group_commit = true; // ... and so may group-commit configurations
     if (h->ins_arena && h->ins_ckpt) {
         RG_HIP(hipMemcpyAsync(h->ins_arena, h->ins_ckpt, h->ins_state_bytes, hipMemcpyDeviceToDevice, h->stream));
@@ -1370,6 +1412,13 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
     RG_HIP(hipStreamSynchronize(h->stream));
     if (cfg_word & RG_CFG_GROUP_COMMIT) h->any_group_commit = true; // (stays set: the GC kernel is a superset)
     if (h->host_cfg_valid) h->host_cfg[group] = cfg_word;
+    if (!h->cls_stale && h->cls.n) { // a word that stays inside its block's class changes nothing (the class is an upper bound)
+        const u32 b = (u32)(group / RG_BLOCK);
+        u32 np = h->P;
+        for (int k = RG_MAX_CLASSES - 1; k >= 0; k--)
+            if ((u32)k < h->cls.n && b < h->cls.end_block[k]) np = h->cls.np[k];
+        if (rg_cfg_slots_named(cfg_word) > np) h->cls_stale = true;
+    }
     return RG_OK;
 }
 
@@ -1392,6 +1441,47 @@ static int rg_settle_send(rg_engine *h) {
     h->send_ready = false;
     h->send_bound = 0;
     return rc;
+}
+
+// Size classes of the shard, from RG_COL_CFG as it stands: per block of RG_BLOCK groups the number of slots its cfg words
+// name (k_block_slots), run-length encoded on the host after rounding up to the slot counts k_tick_classes has a body for
+// (3, 5, 7, P). Class-placed shards give a handful of ranges; anything that does not fit RG_MAX_CLASSES ranges (sizes
+// interleaved) or names every slot everywhere runs the plain kernel (cls.n = 0). A control-path step (one small kernel, one
+// copy of G / 64 bytes, one synchronisation) taken by the first dense tick after something wrote the column.
+static int rg_refresh_classes(rg_engine *h) {
+    h->cls.n = 0;
+    h->cls_stale = false;
+    if (h->cls_off || h->P < 4) return RG_OK;
+    const u64 nb = (h->G + RG_BLOCK - 1) / RG_BLOCK;
+    u8 *d_need = reinterpret_cast<u8 *>(h->d_scratch); // (G x 8 B of scratch: nb bytes fit)
+    hipLaunchKernelGGL(k_block_slots, dim3(rg_grid(nb, 256)), dim3(256), 0, h->stream, (const u32 *)h->st.cfg, h->G, nb, d_need);
+    std::vector<u8> need(nb);
+    RG_HIP(hipMemcpyAsync(need.data(), d_need, nb, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    auto body_of = [&](u32 k) -> u32 { // the smallest body that covers k slots
+        const u32 P = h->P;
+        if (P > 3 && k <= 3) return 3;
+        if (P > 5 && k <= 5) return 5;
+        if (P > 7 && k <= 7) return 7;
+        return P;
+    };
+    RgClasses c;
+    c.n = 0;
+    bool any_smaller = false;
+    for (u64 b = 0; b < nb; b++) {
+        const u32 q = body_of(need[b]);
+        if (c.n && c.np[c.n - 1] == q) {
+            c.end_block[c.n - 1] = (u32)(b + 1);
+            continue;
+        }
+        if (c.n == RG_MAX_CLASSES) return RG_OK; // too many ranges: not a class-placed shard
+        c.np[c.n] = q;
+        c.end_block[c.n] = (u32)(b + 1);
+        c.n++;
+        any_smaller = any_smaller || q < h->P;
+    }
+    if (any_smaller) h->cls = c;
+    return RG_OK;
 }
 
 // `send` != NULL: the tick and its send stage as ONE launch (k_tick_send; rg_tick_send / rg_tick_device_send)
@@ -1443,6 +1533,36 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
 #else
 #define RG_TICK_STATE h->st
 #endif
+    // a class-placed shard (replica sets of different sizes in contiguous ranges): ONE launch whose blocks run the tick
+    // instantiated for the slots their groups have (k_tick_classes). Lane variant, no group commit, 32-bit cell offsets.
+    if ((variant & ~RG_VARIANT_NT_MSGS) == RG_VARIANT_LANE && !h->any_group_commit && h->P >= 4 && !h->cls_off && rg_ix32(h->st, h->P)) {
+        if (h->cls_stale) {
+            // (the refresh synchronises: not inside a stream capture -- a captured tick of a stale engine takes the plain kernel)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+            if (cs == hipStreamCaptureStatusNone) {
+                const int crc = rg_refresh_classes(h);
+                if (crc) return crc;
+            }
+        }
+        if (h->cls.n && !h->cls_stale) {
+            switch (h->P) {
+            case 4: rg_launch_tick_classes_t<4>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
+            case 5: rg_launch_tick_classes_t<5>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
+            case 6: rg_launch_tick_classes_t<6>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
+            case 7: rg_launch_tick_classes_t<7>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
+            default: rg_launch_tick_classes_t<8>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
+            }
+            hipError_t ce = hipGetLastError();
+            if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));
+            h->tick_launches++;
+            h->ticked = true;
+            h->out_is_dense = true;
+            h->send_ready = true;
+            h->host_res_valid = false;
+            return RG_OK;
+        }
+    }
     switch (h->P) {
     case 1: rg_launch_tick_t<1>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
     case 2: rg_launch_tick_t<2>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
@@ -1460,6 +1580,29 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
     h->out_is_dense = true;
     h->send_ready = true;
     h->host_res_valid = false;
+    return RG_OK;
+}
+
+extern "C" int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, uint32_t *n) {
+    if (!h || !n || (cap && !out)) return rg_fail(RG_ERR_INVALID_ARG, "rg_size_classes: bad argument");
+    *n = 0;
+    RG_ENTER(h);
+    if (h->cls_stale) {
+        const int rc = rg_refresh_classes(h);
+        if (rc) return rc;
+    }
+    const bool usable = (h->cfg.variant != RG_VARIANT_LDS && h->cfg.variant != RG_VARIANT_LDS_DMA && h->cfg.variant != RG_VARIANT_COMPACT) &&
+                        !h->any_group_commit && !h->cls_off && rg_ix32(h->st, h->P);
+    if (!usable) return RG_OK;
+    *n = h->cls.n;
+    for (u32 k = 0; k < h->cls.n && k < cap; k++) {
+        const u64 first = k ? (u64)h->cls.end_block[k - 1] * RG_BLOCK : 0;
+        const u64 end = rg_min((u64)h->cls.end_block[k] * RG_BLOCK, h->G);
+        out[k].first_group = first;
+        out[k].n_groups = end - first;
+        out[k].n_slots = h->cls.np[k];
+        out[k].reserved = 0;
+    }
     return RG_OK;
 }
 
@@ -3273,7 +3416,8 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
     if (!h || !w) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: bad argument");
     if (w->workload != RG_WL_MAJORITY && w->workload != RG_WL_JOINT && w->workload != RG_WL_MIXED)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: unknown workload %u", w->workload);
-    if (w->reserved > 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: fixed replica-set size %u", w->reserved);
+    if ((w->reserved & 0xfu) > 8 || (w->reserved & ~0x1fu))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: fixed replica-set size %u / flags %#x", w->reserved & 0xfu, w->reserved & ~0xfu);
     RG_ENTER(h);
     hipLaunchKernelGGL(k_wl_init, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
                        w->workload | (w->reserved << 8), h->P, (u64)first);
@@ -3281,6 +3425,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_init: %s", hipGetErrorString(e));
     if (h->pub) h->pub->local_lost = true;
     h->host_cfg_valid = false;
+    h->cls_stale = true;
     return RG_OK;
 }
 
@@ -3298,7 +3443,8 @@ extern "C" int rg_workload_gen(rg_engine *h, const rg_workload *w, uint64_t firs
 extern "C" int rg_workload_init_host(const rg_workload *w, uint64_t first, rg_host_state *s) {
     if (!w || !s || s->n_slots == 0 || s->n_slots > 8) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init_host: bad argument");
     for (u64 g = 0; g < s->n_groups; g++)
-        rg_wl_init_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g, first + g, (u64 *)s->match, (u64 *)s->next,
+        rg_wl_init_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g,
+                         first + rg_wl_place(w->workload | (w->reserved << 8), g, s->n_groups), (u64 *)s->match, (u64 *)s->next,
                          (u64 *)s->pr_commit, (u64 *)s->pend_snap, (u64 *)s->pend_rs, (u64 *)s->gid, s->pflags,
                          (u64 *)s->commit, (u64 *)s->term_lo, (u64 *)s->term_hi, s->cfg);
     return RG_OK;
@@ -3308,7 +3454,8 @@ extern "C" int rg_workload_gen_host(const rg_workload *w, uint64_t first, uint64
                                     uint64_t *mi, uint64_t *mc, uint64_t *mh, uint64_t *mrs, uint8_t *mf) {
     if (!w || !s || !mi || !mc || !mh || !mrs || !mf) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_gen_host: bad argument");
     for (u64 g = 0; g < s->n_groups; g++)
-        rg_wl_gen_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g, first + g, tick, (const u64 *)s->match,
+        rg_wl_gen_group(w->seed, w->workload | (w->reserved << 8), s->n_slots, s->stride, g,
+                        first + rg_wl_place(w->workload | (w->reserved << 8), g, s->n_groups), tick, (const u64 *)s->match,
                         (const u64 *)s->next, s->pflags, (const u64 *)s->commit, (const u64 *)s->term_lo,
                         (const u64 *)s->term_hi, (u64 *)mi,
                         (u64 *)mc, (u64 *)mh, (u64 *)mrs, mf);

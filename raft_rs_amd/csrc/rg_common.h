@@ -26,6 +26,9 @@ struct RgState {
     u64 *run_first, *run_term;                   // [RG_TERM_RUNS][stride] term-run table (cold)
     u64 *dummy_idx, *dummy_term, *cur_term;      // [G] (cold)
     u8 *hhint;                                   // [G] (cold) RG_COL_HOST_HINT: rejects of the last log-term tick left to the host
+                                                 // ... and, `stride` bytes further on, RG_COL_RUN_COUNT (rg_run_n): the two byte columns
+                                                 // share ONE base pointer -- a kernel argument more costs the send-stage and fused
+                                                 // kernels, at the limit of their scalar registers, a spill to scratch
     u64 G, stride;
     // commit publication (rg_publish.h): this rank's slice under construction, nullptr = not publishing
     char *pub;          // [RgPubHdr | RgPubOvf list[pub_cap] | u8 delta[Gpad]]
@@ -33,6 +36,9 @@ struct RgState {
     u32 pub_cap;
     u32 ix64; // host side only: this engine's launches take the 64-bit-offset instantiations (rg_ix32; decided once, in rg_create)
 };
+
+// RG_COL_RUN_COUNT [G]: used runs of the term-run table (engine-owned, derived); laid out right behind RG_COL_HOST_HINT
+static inline __host__ __device__ u8 *rg_run_n(const RgState &st) { return st.hhint + st.stride; }
 
 struct RgMsgs {
     const u64 *mi, *mc, *mh, *mrs; // [P][stride]

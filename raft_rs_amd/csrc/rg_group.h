@@ -85,6 +85,63 @@ template <int P> struct RgQuorum {
 };
 
 // ---------------------------------------------------------------------------------------------
+// The quorum index WHILE acks land one at a time (the exact replay of RgTick::commit_phase): JointConfig::committed_index
+// (src/quorum/joint.rs:47-51) after every single Progress::maybe_update, without re-evaluating the quorum. Per majority
+// config the pair (T, c) is carried along: T = the q-th largest matched index over the voter mask M (what
+// MajorityConfig::committed_index returns, majority.rs:70-101), c = #{j in M : v_j > T}. T is the q-th largest iff
+// c <= q - 1 and #{v_j >= T} >= q. An accepted ack raises ONE v_S from u to v (u < v); that moves T only if the voter sat at or
+// below T and now lies above it (u <= T < v) while q - 1 voters were above T already (c = q - 1): then exactly q voters are
+// above T and the q-th largest is the smallest of them; in every other case T stays and at most c grows by one. So a step
+// costs a few compares, and the O(P) rescan only where the index really moves -- instead of a row + a column of the bit matrix
+// and 2 P popcounts per ack (what made the replay 1 159 VALU per wave, profiles/r03_pmc_sq_c5_kinds.txt). The initial (T, c)
+// come from one ordinary evaluation on the matches as they were before the tick.
+// ---------------------------------------------------------------------------------------------
+template <int P> struct RgRunningQuorum {
+    struct One {   // one majority config (no arrays over the two configs: nothing here may ever be indexed dynamically)
+        u64 T;     // an empty config is u64::MAX for good (majority.rs:71-75)
+        u32 c, q, M;
+    };
+    One in, out; // incoming, outgoing majority
+
+    RG_HD static void init_one(One &o, const RgQuorum<P> &qm, const u64 (&v)[P], u32 mask) {
+        o.M = mask;
+        o.q = (u32)__builtin_popcount(mask) / 2u + 1u;
+        o.T = qm.kth(v, mask);
+        u32 above = 0;
+#pragma unroll
+        for (int j = 0; j < P; j++) above += (((mask >> j) & 1u) && v[j] > o.T) ? 1u : 0u;
+        o.c = above;
+    }
+    RG_HD void init(const RgQuorum<P> &qm, const u64 (&v)[P], u32 incoming, u32 outgoing) {
+        init_one(in, qm, v, incoming);
+        init_one(out, qm, v, outgoing);
+    }
+    // v[S] has just been raised from `u` (v already holds the new value)
+    template <int S> RG_HD static void raise_one(One &o, const u64 (&v)[P], u64 u) {
+        if (!((o.M >> S) & 1u) || !(u <= o.T && v[S] > o.T)) return;
+        if (o.c + 1u < o.q) {
+            o.c += 1u;
+            return;
+        }
+        // q voters lie above T now: the q-th largest is the smallest of them
+        u64 t = ~0ULL;
+#pragma unroll
+        for (int j = 0; j < P; j++)
+            if (((o.M >> j) & 1u) && v[j] > o.T && v[j] < t) t = v[j];
+        u32 above = 0;
+#pragma unroll
+        for (int j = 0; j < P; j++) above += (((o.M >> j) & 1u) && v[j] > t) ? 1u : 0u;
+        o.T = t;
+        o.c = above;
+    }
+    template <int S> RG_HD void raise(const u64 (&v)[P], u64 u) {
+        raise_one<S>(in, v, u);
+        raise_one<S>(out, v, u);
+    }
+    RG_HD u64 mci() const { return in.T < out.T ? in.T : out.T; }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Group commit (src/quorum/majority.rs:99-123), the literal algorithm: stable descending sort by
 // index (voter order = slot order), Q = sorted[q-1], then the scan over sorted order. Ranks replace
 // the sort so that all indexing stays static. Rare path (ProgressTracker.group_commit, tracker.rs:207).
@@ -531,29 +588,32 @@ RG_HD bool rg_log_maybe_commit(u64 mci, u64 &commit, u64 lo, u64 hi) {
 // (RgTick::become_leader). Used runs come first; when all RG_TERM_RUNS are in use the OLDEST run is dropped: the table
 // then starts above the dummy entry, and a find_conflict_by_term walk that would need the dropped terms is handed to
 // the host instead of being answered (RgLogView, RG_OUT_HOST_HINT; include/raftgroups.h: RG_COL_RUN_FIRST).
-template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first, u64 term) {
-    // (loops over the table in memory, four cells per round trip: a rare path that runs behind the group's stores -- no
-    // register array that lives through the tick, so the depth of the table costs the dense kernel nothing)
-    int k = RG_TERM_RUNS;
-#pragma unroll 1
-    for (int b = 0; b < RG_TERM_RUNS && k == RG_TERM_RUNS; b += 4) {
-        u64 rf[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) rf[i] = rg_at(st.run_first, (IX)(b + i) * (IX)st.stride + g);
-#pragma unroll
-        for (int i = 3; i >= 0; i--)
-            if (rf[i] == 0) k = b + i; // first unused run
-    }
-    if (k == RG_TERM_RUNS) { // table full: the oldest run goes
+// `n` = the group's RG_COL_RUN_COUNT byte (how many runs the table holds): an engine-owned count kept beside the table so that
+// filing a run needs no look at the table itself -- round 3 found the first unused run by reading it, two dependent memory
+// round trips at the tail of every wave that holds an electing group (87 % of the waves of BASELINE config 5: 7 us of its
+// 100 us tick, profiles/r04_c5_one_launch.txt). The caller reads the byte (rg_store_group: together with term_lo, ahead of
+// the group's stores); only a FULL table is still read, to move its runs down.
+template <typename IX> RG_HD void rg_push_run(const RgState &st, IX g, u64 first, u64 term, u32 n) {
+    u32 k = n;
+    if (k >= RG_TERM_RUNS) { // table full: the oldest run goes
 #pragma unroll 1
         for (int j = 0; j + 1 < RG_TERM_RUNS; j++) {
             rg_at(st.run_first, (IX)j * (IX)st.stride + g) = rg_at(st.run_first, (IX)(j + 1) * (IX)st.stride + g);
             rg_at(st.run_term, (IX)j * (IX)st.stride + g) = rg_at(st.run_term, (IX)(j + 1) * (IX)st.stride + g);
         }
         k = RG_TERM_RUNS - 1;
+    } else {
+        rg_at(rg_run_n(st), g) = (u8)(k + 1u);
     }
     rg_at(st.run_first, (IX)k * (IX)st.stride + g) = first;
     rg_at(st.run_term, (IX)k * (IX)st.stride + g) = term;
+}
+// What RG_COL_RUN_COUNT holds for a table as loaded (used runs come first): the engine derives it whenever the host loads
+// RG_COL_RUN_FIRST (k_fix_run_count), the host twin of the tests on its way in.
+RG_HD u32 rg_count_runs(const RgState &st, u64 g) {
+    u32 n = 0;
+    for (int k = 0; k < RG_TERM_RUNS; k++) n += st.run_first[(u64)k * st.stride + g] != 0 ? 1u : 0u;
+    return n;
 }
 // RG_NX_PREFETCH: everything a tick may read beyond the bulk columns, decided from the two flag rows and the cfg
 // word alone and requested in ONE batch right behind the bulk loads -- the old `next` of the slots where it can
@@ -704,7 +764,7 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
             if (PREF) { // nothing in this tick reads the table: filed after the group's stores (rg_store_group)
                 r.dirty |= RG_TICK_PUSH; // (r.el_old is their term; term_lo still holds their first index in memory)
             } else {
-                rg_push_run<IX>(st, g, old_lo, old_term);
+                rg_push_run<IX>(st, g, old_lo, old_term, (u32)rg_at(rg_run_n(st), g));
             }
         }
 #pragma unroll
@@ -945,14 +1005,21 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
         }
     }
 
-    // One step of the sequential replay: slot S's accepted ack lands, Raft::maybe_commit runs.
-    template <int S> RG_HD void replay_slot(RgQuorum<P> &qm, u64 (&cur)[P], u64 &commit) {
+    // One step of the sequential replay: slot S's accepted ack lands, Raft::maybe_commit runs. The quorum index is carried
+    // from step to step (RgRunningQuorum); groups with group commit on take the literal evaluation (GC kernels only).
+    template <int S> RG_HD void replay_slot(RgQuorum<P> &qm, RgRunningQuorum<P> &run, u64 (&cur)[P], u64 &commit) {
         if (!((acc >> S) & 1u)) return;
         cur[S] = r.mt[S];
-        qm.template update<S>(cur);
+        u64 mci;
+        if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
+            mci = mci_of(qm, cur);
+        } else {
+            run.template raise<S>(cur, r.mi[S]); // (maybe_update parked the matched index this ack replaced there)
+            mci = run.mci();
+        }
         // last_index as it was when this message was processed: the leader's APPEND lands at its own slot
         const u64 hi_then = (u32)S < self ? last0 : r.hi;
-        if (rg_log_maybe_commit(mci_of(qm, cur), commit, r.lo, hi_then)) out |= RG_OUT_CHANGED;
+        if (rg_log_maybe_commit(mci, commit, r.lo, hi_then)) out |= RG_OUT_CHANGED;
         else if ((acc_oldp >> S) & 1u) out |= 1u << (8 + S); // raft.rs:1749-1751
     }
 
@@ -1000,8 +1067,10 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
             u64 cur[P];
             ((cur[S] = ((acc >> S) & 1u) ? r.mi[S] : r.mt[S]), ...); // (maybe_update parked the old matches)
             qm.init(cur);
+            RgRunningQuorum<P> run;
+            run.init(qm, cur, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg));
             u64 commit = commit0;
-            (replay_slot<S>(qm, cur, commit), ...);
+            (replay_slot<S>(qm, run, cur, commit), ...);
             r.commit = commit;
         }
         if (r.commit != commit0) {

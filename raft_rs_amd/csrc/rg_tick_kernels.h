@@ -99,9 +99,20 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
 // WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
 // stage, which changes both; every other caller stores the group in one go).
 // WAVE_ST (kernels whose lanes hold CONSECUTIVE groups, all lanes of the wave arriving here together): RG_OPT_WAVE_ST
-template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false>
+template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false, bool EARLY_PUSH = false>
 RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
+    // an election's table update (below) needs the previous leader's first index -- still in memory, the register holds the new
+    // term_lo -- and the table's fill count: both are requested HERE, ahead of the group's stores, so that they are on their
+    // way while the stores issue (one round trip at the tail of the wave instead of the three a look at the table cost)
+    // (EARLY_PUSH: the dense lane kernels only; elsewhere -- the send-stage and fused kernels, at their register limit -- the two
+    // loads are issued where they are used, still one round trip)
+    u64 push_first = 0;
+    u32 push_n = 0;
+    if (EARLY_PUSH && (d & RG_TICK_PUSH)) {
+        push_first = rg_at(st.lo, g);
+        push_n = (u32)rg_at(rg_run_n(st), g);
+    }
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
         const u32 ev = r.evm; // slots with a Progress that had an event (RgTick)
@@ -125,17 +136,28 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
         if ((WHICH & 1) && (d & (1u << (16 + p)))) rg_st(rg_at(st.prc, o), r.pc[p], RG_OPT_NT_ALL != 0);
     }
     if ((WHICH & 2) && (d & RG_DIRTY_PF)) rg_at(st.pflags, g) = r.pf;
-    if (!(WHICH & 1)) return;
-    if (d & RG_DIRTY_COMMIT) {
-        if (st.pub) rg_pub_store(st, g, r.adv, r.commit); // commit publication: one byte per advanced group
-        rg_at(st.commit, g) = r.commit;
+    if (WHICH & 1) {
+        if (d & RG_DIRTY_COMMIT) {
+            if (st.pub) rg_pub_store(st, g, r.adv, r.commit); // commit publication: one byte per advanced group
+            rg_at(st.commit, g) = r.commit;
+        }
+        if (d & RG_DIRTY_HI) rg_at(st.hi, g) = r.hi;
+        rg_st(rg_at(st.out, g), r.out, (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
     }
-    if (d & RG_DIRTY_HI) rg_at(st.hi, g) = r.hi;
-    rg_st(rg_at(st.out, g), r.out, (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
-    if (d & (RG_DIRTY_LO | RG_DIRTY_CFG | RG_TICK_PUSH)) { // an election (rare)
+    // (an election's own stores go with part 2: k_tick_send runs its stage -- on the registers, it reads neither term_lo nor the
+    // cfg word nor the table from memory -- between the two parts, where the kernel is at the limit of its scalar registers)
+    if ((WHICH & 2) && (d & (RG_DIRTY_LO | RG_DIRTY_CFG | RG_TICK_PUSH))) { // an election (rare)
         // its table update comes last (it reads the table, and nothing else of the wave should wait for that) but before
         // term_lo is overwritten: the previous leader's first index is taken from there
-        if (d & RG_TICK_PUSH) rg_push_run<IX>(st, g, rg_at(st.lo, g), r.el_old);
+#ifndef RG_NO_PUSH /* (measurement builds only: what the table update at the tail of an electing wave costs) */
+        if (d & RG_TICK_PUSH) {
+            if (!EARLY_PUSH) {
+                push_first = rg_at(st.lo, g);
+                push_n = (u32)rg_at(rg_run_n(st), g);
+            }
+            rg_push_run<IX>(st, g, push_first, r.el_old, push_n);
+        }
+#endif
         if (d & RG_DIRTY_LO) rg_at(st.lo, g) = r.lo;
         if (d & RG_DIRTY_CFG) rg_at(st.cfg, g) = r.cfg;
     }
@@ -169,7 +191,74 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
 #endif
 #endif
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<P, IX, 3, true>(r, st, g);
+    rg_store_group<P, IX, 3, true, true>(r, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the tick over an engine whose groups are placed by SIZE CLASS (BASELINE config 5: replica sets of 3 / 5 / 7)
+// ------------------------------------------------------------------------------------------------
+// Peers a group does not have still occupy cells of an engine with P slots. Where sizes interleave every line of a column holds
+// some group that has the peer, so every line travels (config 5 in one 7-slot engine: 533 MB of HBM traffic for 354 MB of
+// algorithmic bytes, profiles/traffic.json). Where the host places groups of one size in contiguous ranges, whole blocks of 64
+// groups use only the first Q < P slots -- the engine derives that from the cfg words by itself (rg_refresh_classes in
+// engine.hip: per block the highest slot any cfg word of the block names, run-length encoded; up to RG_MAX_CLASSES ranges
+// travel in the kernel arguments, i.e. in SGPRs: a wave knows its Q before its first load) -- and such a block runs the tick
+// INSTANTIATED FOR Q SLOTS over the P-slot columns: no load, no store and no instruction for the absent peers (the quorum
+// matrix alone is 9 / 25 / 49 compares). One launch for the whole shard instead of one engine, stream and launch per size
+// class: the three 333 k-group launches of the size-class layout were tail-bound (154 us of kernel time overlapped into
+// 100 us, profiles/r03_c5_kernel_stats.csv). The register allocation is the largest body's (P = 7: 3 waves per SIMD), code
+// size the sum of the bodies -- what the three kernels running side by side occupied as well.
+// Valid for a block iff every slot its groups' cfg words name (present, voters, self, transferee) is below Q: then the
+// Q-slot tick and the P-slot tick are the same function of the group (slots >= Q carry no Progress and no event is applied
+// to a slot without one). Bodies exist for Q in {3, 5, 7} below P, and P itself.
+#define RG_MAX_CLASSES 8
+struct RgClasses {
+    u32 n;                         // ranges in use (0: not class-placed -- the plain kernel runs)
+    u32 end_block[RG_MAX_CLASSES]; // range k = blocks [end_block[k-1], end_block[k]) of RG_BLOCK groups
+    u32 np[RG_MAX_CLASSES];        // slots the groups of range k name at most
+};
+template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(const RgState &st_in, const RgMsgs &ms, IX g) {
+    // Every body computes its cells' scalar addresses from ITS OWN copy of the stride: with one shared value the compiler
+    // hoists the address arithmetic all bodies have in common above the branch, where it stays live through whichever body
+    // runs -- 18 more SGPR spills, and the VGPRs they are spilled into cost the P = 7 kernel its third wave per SIMD.
+    RgState st = st_in;
+#ifndef RG_CLS_VARIANT
+#define RG_CLS_VARIANT 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#if RG_CLS_VARIANT == 1
+    asm volatile("" : "+s"(st.stride));
+#elif RG_CLS_VARIANT == 2
+    asm volatile("" : "+v"(g));
+#elif RG_CLS_VARIANT == 3
+    asm volatile("" : "+s"(st.stride));
+    asm volatile("" : "+v"(g));
+#endif
+#endif
+    RgGroup<Q> r;
+    rg_load_group<Q, RG_LANE_NX, IX, NTM || (RG_OPT_NT_MSG != 0)>(r, st, ms, g);
+    rg_group_tick<Q, false, RG_LANE_NX, false, IX>(r, st, ms, g);
+    rg_store_group<Q, IX, 3, true, true>(r, st, g);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_endpgm(); // each body ends the wave itself: no common epilogue for the compiler to merge the bodies' stores into
+#endif
+}
+// (the occupancy of the plain kernel with P slots is asked for explicitly: the common prologue of the bodies otherwise costs
+// the allocation a handful of registers, which at P = 7 is the step from 3 waves per SIMD to 2 and at P = 5 from 4 to 3)
+#define RG_CLS_WAVES(P) ((P) <= 5 ? 4 : (P) <= 7 ? 3 : 2)
+template <int P, typename IX, bool NTM>
+__global__ RG_TICK_BOUNDS void k_tick_classes(RgState st, RgMsgs ms, RgClasses cls) {
+    const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g64 >= st.G) return;
+    const IX g = (IX)g64;
+    u32 np = P; // (scalar: the table is in SGPRs, blockIdx is uniform)
+#pragma unroll
+    for (int k = RG_MAX_CLASSES - 1; k >= 0; k--)
+        if ((u32)k < cls.n && blockIdx.x < cls.end_block[k]) np = cls.np[k];
+    if (P > 3 && np <= 3) rg_lane_body<3, IX, NTM>(st, ms, g);
+    else if (P > 5 && np <= 5) rg_lane_body<5, IX, NTM>(st, ms, g);
+    else if (P > 7 && np <= 7) rg_lane_body<7, IX, NTM>(st, ms, g);
+    else rg_lane_body<P, IX, NTM>(st, ms, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -927,6 +1016,8 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
 // ------------------------------------------------------------------------------------------------
 #define RG_VARIANT_NT_MSGS 0x100u /* engine-internal flag on the variant word: stream the message columns (k_tick_lane<.., NTM>) */
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
+// the lane kernel over a class-placed engine (no group commit, 32-bit cell offsets: the caller checks both); P >= 4
+template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool ntm, const RgClasses &cls);
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo);
@@ -999,6 +1090,13 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
     if (gc) rg_launch_tick_gc<P, true>(stream, st, ms, variant);
     else rg_launch_tick_gc<P, false>(stream, st, ms, variant);
 }
+template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool ntm, const RgClasses &cls) {
+    if constexpr (P >= 4) {
+        const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
+        if (ntm) hipLaunchKernelGGL((k_tick_classes<P, u32, true>), grid, block, 0, stream, st, ms, cls);
+        else hipLaunchKernelGGL((k_tick_classes<P, u32, false>), grid, block, 0, stream, st, ms, cls);
+    }
+}
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo) {
@@ -1038,6 +1136,7 @@ void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &
 }
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1045,6 +1144,7 @@ extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1052,6 +1152,7 @@ extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1059,6 +1160,7 @@ extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1066,6 +1168,7 @@ extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1073,6 +1176,7 @@ extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1080,6 +1184,7 @@ extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1087,6 +1192,7 @@ extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
+extern template void rg_launch_tick_classes_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);

@@ -62,6 +62,20 @@ RG_HD RgWlGroup rg_wl_group(u64 seed, u32 workload_word, u32 n_slots, u64 gg) {
     return w;
 }
 
+// RG_WL_SORTED (bit 12 of the workload word; rg_workload.reserved bit 4): the SAME population of groups, placed by
+// replica-set size class -- the local groups of a shard of G are first all those whose global id is 0 mod 3 (3 peers under
+// RG_WL_MIXED), then 1 mod 3 (5), then 2 mod 3 (7), each class in ascending id order. Group placement inside a shard is the
+// host's choice; contiguous classes are what lets ONE launch skip the peer slots a class does not have
+// (k_tick_classes). Returns the offset of local group g's global id from the shard's first id.
+#define RG_WL_SORTED_BIT 0x1000u
+RG_HD u64 rg_wl_place(u32 workload_word, u64 g, u64 G) {
+    if (!(workload_word & RG_WL_SORTED_BIT)) return g;
+    const u64 n0 = (G + 2) / 3, n1 = (G + 1) / 3;
+    if (g < n0) return 3 * g;
+    if (g < n0 + n1) return 3 * (g - n0) + 1;
+    return 3 * (g - n0 - n1) + 2;
+}
+
 // follower p's real log end when a leader whose log ends at `last0` is elected (what a rejected probe reports
 // as hint): up to 31 entries behind
 RG_HD u64 rg_wl_follower_last(u64 seed, u64 gg, u32 p, u64 last0) {

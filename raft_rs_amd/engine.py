@@ -20,12 +20,12 @@ class EngineError(RuntimeError):
 
 class COL:
     (MATCH, NEXT, PR_COMMIT, PEND_SNAP, PEND_RS, GID, PFLAGS, COMMIT, TERM_LO, TERM_HI, CFG, OUT, RUN_FIRST,
-     RUN_TERM, DUMMY_INDEX, DUMMY_TERM, CUR_TERM, HOST_HINT) = range(18)
+     RUN_TERM, DUMMY_INDEX, DUMMY_TERM, CUR_TERM, HOST_HINT, RUN_COUNT) = range(19)
     PER_SLOT = (0, 1, 2, 3, 4, 5)
     PER_RUN = (12, 13)
     NAMES = ("match", "next", "pr_commit", "pend_snap", "pend_rs", "gid", "pflags", "commit",
              "term_lo", "term_hi", "cfg", "out", "run_first", "run_term", "dummy_index", "dummy_term", "cur_term",
-             "host_hint")
+             "host_hint", "run_count")
 
 
 TERM_RUNS = 8
@@ -215,6 +215,7 @@ SYMBOLS = {
     "rg_heartbeat_commits": (_i, [_vp, _vp, _vp]),
     "rg_step_heartbeat_response": (_i, [_vp, _u64, _u64, _u64, _u64, C.c_uint8]),
     "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rg_size_classes": (_i, [_vp, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rg_host_hints": (_i, [_vp, C.c_void_p, _u64, C.POINTER(_u64)]),
     "rg_resolve_host_hints": (_i, [_vp, C.c_void_p, _u64, C.c_void_p]),
     "rg_msg_stats": (_i, [_vp, _vp, C.POINTER(_u64 * 5)]),
@@ -387,7 +388,7 @@ class Engine:
             return (self.n_groups, 8), np.uint8
         if col in (COL.CFG, COL.OUT):
             return (self.n_groups,), np.uint32
-        if col == COL.HOST_HINT:
+        if col in (COL.HOST_HINT, COL.RUN_COUNT):
             return (self.n_groups,), np.uint8
         return (self.n_groups,), np.uint64
 
@@ -660,6 +661,15 @@ class Engine:
         self._check(self.L.rg_result_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def size_classes(self):
+        """rg_size_classes: the ranges of the shard the next dense tick treats as one size class each -> [(first_group, n_groups,
+        n_slots)]; [] = the plain kernel runs."""
+        dt = np.dtype([("first_group", "<u8"), ("n_groups", "<u8"), ("n_slots", "<u4"), ("reserved", "<u4")])
+        out = np.zeros(8, dtype=dt)
+        n = C.c_uint32(0)
+        self._check(self.L.rg_size_classes(self.h, out.ctypes.data, len(out), C.byref(n)))
+        return [(int(r["first_group"]), int(r["n_groups"]), int(r["n_slots"])) for r in out[:n.value]]
+
     def host_hints(self):
         """Groups whose last tick raised RG_OUT_HOST_HINT -> HOST_HINT_DTYPE array (group, slot_mask)."""
         n = _u64(0)
@@ -779,13 +789,13 @@ class Engine:
         return {k: getattr(st, k) for k, _ in PublishStats._fields_}
 
     # ---- synthetic stream --------------------------------------------------------------------
-    def workload_init(self, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0):
-        w = _Workload(seed, workload, fixed_peers)
+    def workload_init(self, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False):
+        w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
         self._check(self.L.rg_workload_init(self.h, C.byref(w), first_group))
 
     def workload_gen(self, workload, tick, m_index, m_commit, m_hint, m_rs, m_flags, seed=0x5EED5EED, first_group=0,
-                     fixed_peers=0):
-        w = _Workload(seed, workload, fixed_peers)
+                     fixed_peers=0, sorted_classes=False):
+        w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
         self._check(self.L.rg_workload_gen(self.h, C.byref(w), first_group, tick, _ptr(m_index), _ptr(m_commit),
                                            _ptr(m_hint), _ptr(m_rs), _ptr(m_flags)))
 
@@ -795,20 +805,23 @@ def _host_state_struct(st):
                       *[st[k].ctypes.data for k in COL.NAMES[:11]])
 
 
-def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0):
+WL_PLACE_SORTED = 0x10  # rg_workload.reserved flag: the groups of a shard placed by replica-set size class (RG_WL_PLACE_SORTED)
+
+
+def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False):
     """Host twin of Engine.workload_init over numpy columns (no GPU)."""
     L = load_library()
-    w = _Workload(seed, workload, fixed_peers)
+    w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
     s = _host_state_struct(st)
     rc = L.rg_workload_init_host(C.byref(w), first_group, C.byref(s))
     if rc:
         raise EngineError(rc, L.rg_last_error().decode())
 
 
-def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, fixed_peers=0):
+def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False):
     """Host twin of Engine.workload_gen: messages of `tick` from the numpy state columns."""
     L = load_library()
-    w = _Workload(seed, workload, fixed_peers)
+    w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
     s = _host_state_struct(st)
     rc = L.rg_workload_gen_host(C.byref(w), first_group, tick, C.byref(s), msgs.m_index.ctypes.data,
                                 msgs.m_commit.ctypes.data, msgs.m_hint.ctypes.data, msgs.m_rs.ctypes.data,

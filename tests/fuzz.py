@@ -224,3 +224,10 @@ def random_progress_events(rng, n_groups, n_slots, n, dup_frac=0.2):
     out.insert(len(out) // 2, (n_groups + 5, 0, 1))  # no such group
     out.insert(len(out) // 3, (0, 8, 2))             # no such slot
     return out
+
+
+def class_placed_cfg(rng, ranges, n_slots, **kw):
+    """cfg words of a shard whose groups are placed by replica-set size class: `ranges` = [(n_groups, q), ...] in placement order,
+    the groups of a range name only slots < q (random_cfg over q slots). Returns u32[sum n]."""
+    parts = [random_cfg(rng, n, min(q, n_slots), **kw) for n, q in ranges]
+    return np.concatenate(parts).astype(np.uint32)

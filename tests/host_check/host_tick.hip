@@ -6,7 +6,7 @@
 #include "../../raft_rs_amd/csrc/rg_send.h"
 
 // state[]: match next pr_commit pend_snap pend_rs gid pflags commit term_lo term_hi cfg out
-//          run_first run_term dummy_index dummy_term cur_term host_hint   (18 pointers)
+//          run_first run_term dummy_index dummy_term cur_term host_hint run_count   (19 pointers)
 // msg[]:   m_index m_commit m_hint m_rs m_flags m_logterm       (6 pointers)
 static RgState make_state(void *const *p, u64 G, u64 stride) {
     RgState st;
@@ -16,6 +16,8 @@ static RgState make_state(void *const *p, u64 G, u64 stride) {
     st.run_first = (u64 *)p[12]; st.run_term = (u64 *)p[13]; st.dummy_idx = (u64 *)p[14]; st.dummy_term = (u64 *)p[15];
     st.cur_term = (u64 *)p[16];
     st.hhint = (u8 *)p[17];
+    // (p[18] = RG_COL_RUN_COUNT: it must sit `stride` bytes behind p[17], as in the engine's arena -- rg_run_n)
+    if ((u8 *)p[18] != (u8 *)p[17] + stride) __builtin_trap();
     st.G = G; st.stride = stride;
     st.pub = nullptr; st.pub_off_delta = 0; st.pub_cap = 0; st.ix64 = 0;
     return st;
@@ -31,6 +33,7 @@ static void derive_pending(const RgState &st, unsigned P) {
             row |= (u64)((st.psnap[o] ? RG_PF_PEND_SNAP : 0u) | (st.prs[o] ? RG_PF_PEND_RS : 0u)) << (8 * p);
         }
         st.pflags[g] = row;
+        rg_run_n(st)[g] = (u8)rg_count_runs(st, g); // RG_COL_RUN_COUNT is engine-owned too (k_fix_run_count)
     }
 }
 

@@ -41,7 +41,7 @@ _ZERO = {}
 
 
 def state_ptrs(st, out):
-    """18 pointers in the order host_tick.hip expects; a zero table when the state has no term-run table. The
+    """19 pointers in the order host_tick.hip expects; a zero table when the state has no term-run table. The
     RG_COL_HOST_HINT byte column is created in the state dict on first use (st["host_hint"])."""
     key = (st["n_groups"], st["stride"])
     if key not in _ZERO:
@@ -49,10 +49,17 @@ def state_ptrs(st, out):
     z4, zg = _ZERO[key]
     table = [st.get("run_first", z4), st.get("run_term", z4), st.get("dummy_index", zg), st.get("dummy_term", zg),
              st.get("cur_term", zg)]
-    if "host_hint" not in st:
-        st["host_hint"] = np.zeros(st["n_groups"], dtype=np.uint8)
-    cols = [st[k] for k in STATE_ORDER] + [out] + table + [st["host_hint"]]
-    return (C.c_void_p * 18)(*[c.ctypes.data for c in cols])
+    if "host_hint" not in st or "run_count" not in st or st["run_count"].ctypes.data != st["host_hint"].ctypes.data + st["stride"]:
+        # RG_COL_HOST_HINT and, `stride` bytes behind it, RG_COL_RUN_COUNT (engine-owned, derived by the twin on its way in): one
+        # allocation, as in the engine's arena (rg_run_n)
+        both = np.zeros(2 * st["stride"], dtype=np.uint8)
+        if "host_hint" in st:
+            both[:st["n_groups"]] = st["host_hint"][:st["n_groups"]]
+        st["_hint_and_count"] = both
+        st["host_hint"] = both[:st["n_groups"]]
+        st["run_count"] = both[st["stride"]:st["stride"] + st["n_groups"]]
+    cols = [st[k] for k in STATE_ORDER] + [out] + table + [st["host_hint"], st["run_count"]]
+    return (C.c_void_p * 19)(*[c.ctypes.data for c in cols])
 
 
 def msg_ptrs(msgs):
@@ -886,3 +893,34 @@ def test_progress_events_on_host_match_the_oracle(n_slots):
             cl.load_soa(st, term=6)
             eng_st = copy_state(st)
     assert n_changed > 500, n_changed
+
+
+@pytest.mark.parametrize("n_slots,q", [(7, 3), (7, 5), (8, 7), (5, 3), (8, 3)])
+def test_tick_for_fewer_slots_is_the_full_tick_where_no_higher_slot_is_named(host_tick, n_slots, q):
+    """What k_tick_classes rests on (one launch over a shard placed by replica-set size class): for a group whose cfg word
+    names only slots < q -- Progress set, both voter sets, the leader's own slot, the transferee -- the tick instantiated for q
+    slots, run over the SAME P-slot columns, is the tick instantiated for P slots: every column, every result word. The
+    messages are random over all P slots (events on slots without a Progress are ignored by both, raft.rs:1663-1673)."""
+    rng = np.random.default_rng(7700 + 10 * n_slots + q)
+    G = 3000
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.class_placed_cfg(rng, [(G, q)], n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True)
+    fuzz.random_term_table(rng, st, 9, max_runs=4)
+    full, few = copy_state(st), copy_state(st)
+    few["n_slots"] = q  # the q-slot instantiation over the P-slot columns (same stride, same pointers)
+    msgs = O.alloc_msgs(G, n_slots)
+    out_full = np.zeros(G, dtype=np.uint32)
+    out_few = np.zeros(G, dtype=np.uint32)
+    for t in range(8):
+        fuzz.random_msgs(rng, full, msgs, reject_p=0.2, heartbeat_p=0.1, malformed_p=0.02 if t == 5 else 0.0,
+                         elect_p=0.1, elect_term=10 + t)
+        host_tick(full, msgs, out_full, False)
+        host_tick(few, msgs, out_few, False)
+        few["n_slots"] = n_slots
+        diffs = fuzz.diff_states(full, few, G, n_slots)
+        few["n_slots"] = q
+        assert not diffs, (t, diffs[:6])
+        assert (out_full == out_few).all(), (t, np.nonzero(out_full != out_few)[0][:5])
+        for k in ("run_first", "run_term", "cur_term"):
+            assert (full[k] == few[k]).all(), (t, k)

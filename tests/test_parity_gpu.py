@@ -661,3 +661,129 @@ def test_fused_and_sparse_kernels_with_64bit_offsets(rg, force_ix64):
     import test_sparse_path_gpu as S
     S.test_sparse_ticks_match_oracle(rg, 5)
     S.test_sparse_ticks_match_oracle(rg, 7)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# shards placed by replica-set size class: ONE launch whose blocks run the tick instantiated for the slots their groups
+# have (k_tick_classes; the engine derives the ranges from RG_COL_CFG by itself, rg_size_classes reports them)
+# ---------------------------------------------------------------------------------------------------------------
+def _run_against_oracle(rg, eng, st, rng, ticks, label, **msg_kw):
+    G, P = st["n_groups"], st["n_slots"]
+    cl = oracle_from_state(st)
+    msgs = O.alloc_msgs(G, P)
+    gout = np.zeros(G, dtype=np.uint32)
+    mb = rg.MsgBuffers(G, P, eng.stride)
+    for t in range(ticks):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, **msg_kw)
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags"):
+            getattr(mb, k)[...] = msgs[k]
+        eng.tick(mb)
+        cl.tick_soa(msgs, gout)
+        assert_same(eng, cl, st, gout, f"{label} tick {t}")
+    return cl
+
+
+@pytest.mark.parametrize("n_slots", [5, 7, 8])
+def test_class_placed_shard_runs_as_one_launch_and_matches_oracle(rg, n_slots):
+    """Groups of 3, 5 and 7 (8) peers in contiguous ranges of one engine -- the boundaries NOT on multiples of 64, so the blocks
+    that straddle one take the larger class. The engine finds the ranges itself; random traffic (rejects, heartbeats, elections,
+    malformed acks, events on slots a group does not have) against the oracle; then rg_set_config grows one group of the
+    3-peer range to the engine's last slot (its block leaves the class), rg_restore brings the old words back (re-derived),
+    and an engine created with RG_NO_CLASSES=1 -- the plain kernel -- ends in the same state."""
+    rng = np.random.default_rng(8800 + n_slots)
+    sizes = [q for q in (3, 5, 7) if q < n_slots] + [n_slots]
+    ranges = [(64 * 20 + 11, sizes[0])] + [(64 * 13 + 5, q) for q in sizes[1:-1]] + [(64 * 9 + 40, sizes[-1])]
+    G = sum(n for n, _ in ranges)
+    st = O.alloc_state(G, n_slots)
+    st["cfg"][:] = fuzz.class_placed_cfg(rng, ranges, n_slots, missing_progress_frac=0.05)
+    fuzz.random_state(rng, st, small_values=True)
+    eng = rg.Engine(G, n_slots)
+    eng.load_state(st)
+    # what the engine derived: one range per size, ends rounded UP to the block that still holds a smaller group
+    cls = eng.size_classes()
+    assert [q for _, _, q in cls] == sizes, cls
+    assert cls[0][0] == 0 and sum(n for _, n, _ in cls) == G
+    first = 0
+    for (f, n, q), (rn, rq) in zip(cls, ranges):
+        assert f == (first // 64) * 64 and q == rq, (cls, ranges)  # a class starts with the block its first group lies in
+        first += rn
+    os.environ["RG_NO_CLASSES"] = "1"
+    try:
+        plain = rg.Engine(G, n_slots)
+    finally:
+        os.environ.pop("RG_NO_CLASSES", None)
+    plain.load_state(st)
+    assert plain.size_classes() == []
+    st_plain = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+    kw = dict(reject_p=0.2, heartbeat_p=0.1, elect_p=0.05, elect_term=50)
+    rng2 = np.random.default_rng(99)
+    _run_against_oracle(rg, eng, st, np.random.default_rng(99), 5, f"classes P={n_slots}", **kw)
+    _run_against_oracle(rg, plain, st_plain, rng2, 5, f"plain P={n_slots}", **kw)
+    a, b = eng.read_state(), plain.read_state()
+    assert not fuzz.diff_states(a, b, G, n_slots)
+    # a conf change that names a slot beyond the group's class: its block leaves the class (more ranges, same results)
+    eng.checkpoint()
+    g = 70
+    full = (1 << n_slots) - 1
+    eng.set_config(g, rg.engine.cfg_make(full, 0, 0, False, 0, full))
+    cls2 = eng.size_classes()
+    assert len(cls2) == len(cls) + 2 and cls2[1] == (64, 64, n_slots), cls2
+    st2 = eng.read_state()
+    # (the oracle restarts from the engine's columns at TERM: no elections here, their terms would no longer line up)
+    _run_against_oracle(rg, eng, st2, np.random.default_rng(5), 3, f"classes after conf change P={n_slots}", reject_p=0.2, heartbeat_p=0.1)
+    eng.restore()
+    assert eng.size_classes() == cls
+    # a conf change INSIDE the class keeps the table
+    eng.set_config(g, int(st["cfg"][g]))
+    assert eng.size_classes() == cls
+    eng.close()
+    plain.close()
+
+
+def test_interleaved_sizes_are_not_a_class_placed_shard(rg):
+    """Sizes alternating group by group (BASELINE config 5's one-engine layout): every block names every slot, the plain kernel
+    runs, nothing else changes."""
+    G = 20000
+    eng = rg.Engine(G, 7)
+    eng.workload_init(5)
+    assert eng.size_classes() == []
+    eng.close()
+
+
+@pytest.mark.parametrize("n_slots", [7, 8])
+def test_sorted_mixed_workload_matches_oracle(rg, n_slots):
+    """BASELINE config 5's population placed by size class (RG_WL_PLACE_SORTED): the same groups as the interleaved layout --
+    group for group, after undoing the placement -- in three ranges the engine runs as one launch; 6 ticks of the rollover
+    stream (elections, rejects, probes) against the oracle, messages from the host twin of the generator."""
+    from raft_rs_amd import engine as E
+    G = 30000 + 77
+    eng = rg.Engine(G, n_slots)
+    eng.workload_init(5, sorted_classes=True)
+    cls = eng.size_classes()
+    assert [q for _, _, q in cls] == [3, 5, 7], cls
+    n0, n1 = (G + 2) // 3, (G + 1) // 3
+    assert cls[1][0] == (n0 // 64) * 64 and cls[2][0] == ((n0 + n1) // 64) * 64
+    st = eng.read_state()
+    # the same population as the interleaved layout
+    ref = rg.Engine(G, n_slots)
+    ref.workload_init(5)
+    st_i = ref.read_state()
+    ref.close()
+    place = np.concatenate([np.arange(0, G, 3), np.arange(1, G, 3), np.arange(2, G, 3)])
+    for k in ("commit", "term_lo", "term_hi", "cfg"):
+        assert (st[k] == st_i[k][place]).all(), k
+    assert (st["match"][:, :G] == st_i["match"][:, :G][:, place]).all()
+    cl = oracle_from_state(st)
+    msgs = rg.MsgBuffers(G, n_slots, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    n_elect = 0
+    for t in range(6):
+        cl.store_soa(st)
+        E.workload_gen_host(st, msgs, 5, t, sorted_classes=True)
+        eng.tick(msgs)
+        cl.tick_soa(msgs.as_dict(), gout)
+        assert_same(eng, cl, st, gout, f"sorted workload 5 P={n_slots} tick {t}")
+        n_elect += int(((gout & 0x10) != 0).sum())
+    assert n_elect > G // 40
+    eng.close()
