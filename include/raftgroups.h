@@ -310,12 +310,14 @@ int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slo
 /* Size classes: replica sets of different sizes in one shard (BASELINE config 5: 3 / 5 / 7 peers). Peers a group does not
  * have still occupy cells of the engine's P slots; where the host places groups of one size in CONTIGUOUS ranges, the dense
  * tick skips the absent slots of a whole range -- their loads, stores and instructions -- in ONE launch (k_tick_classes).
- * Nothing to declare: the engine derives the ranges from RG_COL_CFG by itself (per 64 groups, the highest slot any cfg word
- * names; at most 8 ranges, rounded up to 3 / 5 / 7 / P slots), re-derives them after anything wrote the column
- * (rg_load_column, rg_set_config beyond its block's class, rg_restore, rg_workload_init) and falls back to the plain kernel
- * wherever the layout does not qualify (sizes interleaved, group commit on, the LDS / compact variants, an engine beyond
- * 32-bit cell offsets, RG_COL_CFG's device pointer handed out through rg_column_ptr). Results never depend on it.
- * This call reports what the next dense tick will use: *n = number of ranges (0 = the plain kernel), out[k] for k < cap. */
+ * Nothing to declare: the engine derives it from RG_COL_CFG by itself (per block of 64 groups, the highest slot any cfg word
+ * names, rounded up to 3 / 5 / 7 / P slots: one byte per block, so a conf change that grows one group costs its own block
+ * the shortcut and nobody else), re-derives it after anything wrote the column (rg_load_column, rg_set_config beyond its
+ * block's class, rg_restore, rg_workload_init) and runs the plain kernel wherever the layout does not qualify (every block
+ * names every slot -- sizes interleaved --, group commit on, the LDS / compact variants, an engine beyond 32-bit cell
+ * offsets, RG_COL_CFG's device pointer handed out through rg_column_ptr). Results never depend on it.
+ * This call reports what the next dense tick will use, as ranges of equal blocks: *n = number of ranges (0 = the plain
+ * kernel; it may exceed cap), out[k] for k < cap. */
 typedef struct {
     uint64_t first_group, n_groups;
     uint32_t n_slots; /* slots the groups of the range use at most */

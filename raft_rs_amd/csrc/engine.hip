@@ -787,7 +787,9 @@ RG_HD u32 rg_cfg_slots_named(u32 cfg) {
     const u32 m = RG_CFG_PRESENT(cfg) | RG_CFG_INCOMING(cfg) | RG_CFG_OUTGOING(cfg) | (1u << RG_CFG_SELF(cfg)) | (tr ? 1u << (tr - 1u) : 0u);
     return 32u - (u32)__builtin_clz(m | 1u);
 }
-__global__ __launch_bounds__(256) void k_block_slots(const u32 *cfg, u64 G, u64 n_blocks, u8 *need) {
+// the smallest body k_tick_classes<P> has for k slots (3, 5, 7 below P; P)
+RG_HD u32 rg_class_body(u32 k, u32 P) { return (P > 3 && k <= 3) ? 3u : (P > 5 && k <= 5) ? 5u : (P > 7 && k <= 7) ? 7u : P; }
+__global__ __launch_bounds__(256) void k_block_slots(const u32 *cfg, u64 G, u64 n_blocks, u32 P, u8 *need) {
     const u64 b = (u64)blockIdx.x * 256 + threadIdx.x;
     if (b >= n_blocks) return;
     u32 m = 1;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) void k_block_slots(const u32 *cfg, u64 G, u64 
         const u32 k = rg_cfg_slots_named(cfg[g]);
         m = k > m ? k : m;
     }
-    need[b] = (u8)m;
+    need[b] = (u8)rg_class_body(m, P);
 }
 
 __global__ __launch_bounds__(RG_BLOCK) void k_wl_init(RgState st, u64 seed, u32 workload, u32 P, u64 first) {
@@ -890,8 +892,10 @@ struct rg_engine {
     bool host_items_valid;
     char *pin_send;    // pinned host: u32 count | pad | rg_send_item[RG_SEND_SPEC] (small stages: one round trip)
     // size classes (k_tick_classes): derived from RG_COL_CFG, lazily, by the first dense tick after anything wrote the column
-    RgClasses cls;     // cls.n == 0: not class-placed (or not derivable): the plain kernels run
-    bool cls_stale;    // RG_COL_CFG may have changed since cls was derived
+    u8 *cls_need;      // device: one byte per block of RG_BLOCK groups (k_block_slots), padded to whole words
+    std::vector<u8> cls_host; // its host copy
+    bool cls_on;       // some block names fewer slots than the engine has: the dense lane tick runs k_tick_classes
+    bool cls_stale;    // RG_COL_CFG may have changed since the bytes were derived
     bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool send_ready;   // a tick ran since the last rg_send_appends
@@ -1090,7 +1094,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     h->send_ready = false;
-    h->cls.n = 0;
+    h->cls_need = nullptr;
+    h->cls_on = false;
     h->cls_stale = true;
     {
         const char *e = getenv("RG_NO_CLASSES"); // measurement hook (bench.py's A/B of the class-placed layout), read here only
@@ -1220,6 +1225,7 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->pub) (void)rg_comm_destroy(h);
     if (h->arena) (void)hipFree(h->arena);
     if (h->ckpt) (void)hipFree(h->ckpt);
+    if (h->cls_need) (void)hipFree(h->cls_need);
     if (h->ins_arena) (void)hipFree(h->ins_arena);
     if (h->ins_ckpt) (void)hipFree(h->ins_ckpt);
     if (h->esz) (void)hipFree(h->esz);
@@ -1412,13 +1418,8 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
     RG_HIP(hipStreamSynchronize(h->stream));
     if (cfg_word & RG_CFG_GROUP_COMMIT) h->any_group_commit = true; // (stays set: the GC kernel is a superset)
     if (h->host_cfg_valid) h->host_cfg[group] = cfg_word;
-    if (!h->cls_stale && h->cls.n) { // a word that stays inside its block's class changes nothing (the class is an upper bound)
-        const u32 b = (u32)(group / RG_BLOCK);
-        u32 np = h->P;
-        for (int k = RG_MAX_CLASSES - 1; k >= 0; k--)
-            if ((u32)k < h->cls.n && b < h->cls.end_block[k]) np = h->cls.np[k];
-        if (rg_cfg_slots_named(cfg_word) > np) h->cls_stale = true;
-    }
+    // (a word that stays inside its block's class changes nothing: the class is an upper bound)
+    if (!h->cls_stale && h->cls_on && rg_cfg_slots_named(cfg_word) > h->cls_host[group / RG_BLOCK]) h->cls_stale = true;
     return RG_OK;
 }
 
@@ -1444,43 +1445,24 @@ static int rg_settle_send(rg_engine *h) {
 }
 
 // Size classes of the shard, from RG_COL_CFG as it stands: per block of RG_BLOCK groups the number of slots its cfg words
-// name (k_block_slots), run-length encoded on the host after rounding up to the slot counts k_tick_classes has a body for
-// (3, 5, 7, P). Class-placed shards give a handful of ranges; anything that does not fit RG_MAX_CLASSES ranges (sizes
-// interleaved) or names every slot everywhere runs the plain kernel (cls.n = 0). A control-path step (one small kernel, one
-// copy of G / 64 bytes, one synchronisation) taken by the first dense tick after something wrote the column.
+// name, rounded up to the slot counts k_tick_classes has a body for (k_block_slots) -- one byte per block, kept in device
+// memory for the kernel and copied to the host, where the engine decides whether the layout pays (some block below P) and
+// rg_size_classes reports it as ranges. A control-path step (one small kernel, one copy of G / 64 bytes, one
+// synchronisation) taken by the first dense tick after something wrote the column.
 static int rg_refresh_classes(rg_engine *h) {
-    h->cls.n = 0;
+    h->cls_on = false;
     h->cls_stale = false;
     if (h->cls_off || h->P < 4) return RG_OK;
     const u64 nb = (h->G + RG_BLOCK - 1) / RG_BLOCK;
-    u8 *d_need = reinterpret_cast<u8 *>(h->d_scratch); // (G x 8 B of scratch: nb bytes fit)
-    hipLaunchKernelGGL(k_block_slots, dim3(rg_grid(nb, 256)), dim3(256), 0, h->stream, (const u32 *)h->st.cfg, h->G, nb, d_need);
-    std::vector<u8> need(nb);
-    RG_HIP(hipMemcpyAsync(need.data(), d_need, nb, hipMemcpyDeviceToHost, h->stream));
-    RG_HIP(hipStreamSynchronize(h->stream));
-    auto body_of = [&](u32 k) -> u32 { // the smallest body that covers k slots
-        const u32 P = h->P;
-        if (P > 3 && k <= 3) return 3;
-        if (P > 5 && k <= 5) return 5;
-        if (P > 7 && k <= 7) return 7;
-        return P;
-    };
-    RgClasses c;
-    c.n = 0;
-    bool any_smaller = false;
-    for (u64 b = 0; b < nb; b++) {
-        const u32 q = body_of(need[b]);
-        if (c.n && c.np[c.n - 1] == q) {
-            c.end_block[c.n - 1] = (u32)(b + 1);
-            continue;
-        }
-        if (c.n == RG_MAX_CLASSES) return RG_OK; // too many ranges: not a class-placed shard
-        c.np[c.n] = q;
-        c.end_block[c.n] = (u32)(b + 1);
-        c.n++;
-        any_smaller = any_smaller || q < h->P;
+    if (!h->cls_need) {
+        RG_HIP(hipMalloc(&h->cls_need, (nb + 3) & ~(u64)3));
+        RG_HIP(hipMemsetAsync(h->cls_need, 0, (nb + 3) & ~(u64)3, h->stream));
     }
-    if (any_smaller) h->cls = c;
+    hipLaunchKernelGGL(k_block_slots, dim3(rg_grid(nb, 256)), dim3(256), 0, h->stream, (const u32 *)h->st.cfg, h->G, nb, h->P, h->cls_need);
+    h->cls_host.resize(nb);
+    RG_HIP(hipMemcpyAsync(h->cls_host.data(), h->cls_need, nb, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    for (u64 b = 0; b < nb && !h->cls_on; b++) h->cls_on = h->cls_host[b] < h->P;
     return RG_OK;
 }
 
@@ -1545,13 +1527,15 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
                 if (crc) return crc;
             }
         }
-        if (h->cls.n && !h->cls_stale) {
+        if (h->cls_on && !h->cls_stale) {
+            RgClasses cls;
+            cls.need = reinterpret_cast<const u32 *>(h->cls_need);
             switch (h->P) {
-            case 4: rg_launch_tick_classes_t<4>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
-            case 5: rg_launch_tick_classes_t<5>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
-            case 6: rg_launch_tick_classes_t<6>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
-            case 7: rg_launch_tick_classes_t<7>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
-            default: rg_launch_tick_classes_t<8>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, h->cls); break;
+            case 4: rg_launch_tick_classes_t<4>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
+            case 5: rg_launch_tick_classes_t<5>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
+            case 6: rg_launch_tick_classes_t<6>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
+            case 7: rg_launch_tick_classes_t<7>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
+            default: rg_launch_tick_classes_t<8>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
             }
             hipError_t ce = hipGetLastError();
             if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));
@@ -1594,15 +1578,22 @@ extern "C" int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, u
     const bool usable = (h->cfg.variant != RG_VARIANT_LDS && h->cfg.variant != RG_VARIANT_LDS_DMA && h->cfg.variant != RG_VARIANT_COMPACT) &&
                         !h->any_group_commit && !h->cls_off && rg_ix32(h->st, h->P);
     if (!usable) return RG_OK;
-    *n = h->cls.n;
-    for (u32 k = 0; k < h->cls.n && k < cap; k++) {
-        const u64 first = k ? (u64)h->cls.end_block[k - 1] * RG_BLOCK : 0;
-        const u64 end = rg_min((u64)h->cls.end_block[k] * RG_BLOCK, h->G);
-        out[k].first_group = first;
-        out[k].n_groups = end - first;
-        out[k].n_slots = h->cls.np[k];
-        out[k].reserved = 0;
+    if (!h->cls_on) return RG_OK;
+    u32 k = 0; // run-length encode the per-block bytes
+    const u64 nb = h->cls_host.size();
+    for (u64 b = 0; b < nb;) {
+        u64 e = b + 1;
+        while (e < nb && h->cls_host[e] == h->cls_host[b]) e++;
+        if (k < cap) {
+            out[k].first_group = b * RG_BLOCK;
+            out[k].n_groups = rg_min(e * RG_BLOCK, h->G) - b * RG_BLOCK;
+            out[k].n_slots = h->cls_host[b];
+            out[k].reserved = 0;
+        }
+        k++;
+        b = e;
     }
+    *n = k;
     return RG_OK;
 }
 

@@ -201,8 +201,11 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
 // some group that has the peer, so every line travels (config 5 in one 7-slot engine: 533 MB of HBM traffic for 354 MB of
 // algorithmic bytes, profiles/traffic.json). Where the host places groups of one size in contiguous ranges, whole blocks of 64
 // groups use only the first Q < P slots -- the engine derives that from the cfg words by itself (rg_refresh_classes in
-// engine.hip: per block the highest slot any cfg word of the block names, run-length encoded; up to RG_MAX_CLASSES ranges
-// travel in the kernel arguments, i.e. in SGPRs: a wave knows its Q before its first load) -- and such a block runs the tick
+// engine.hip: per block the highest slot any cfg word of the block names, one byte per block in device memory; a wave reads
+// its byte with ONE scalar load before its first vector load. A table of ranges in the kernel arguments was tried first: its
+// 17 SGPRs, live at the top of the kernel together with every column pointer, pushed 16 of those pointers into spill lanes
+// for good -- 1 566 v_readlane / v_writelane in the code, ~250 executed per wave -- and it capped the layout at 8 ranges,
+// which one conf change in the middle of a class breaks) -- and such a block runs the tick
 // INSTANTIATED FOR Q SLOTS over the P-slot columns: no load, no store and no instruction for the absent peers (the quorum
 // matrix alone is 9 / 25 / 49 compares). One launch for the whole shard instead of one engine, stream and launch per size
 // class: the three 333 k-group launches of the size-class layout were tail-bound (154 us of kernel time overlapped into
@@ -211,54 +214,44 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
 // Valid for a block iff every slot its groups' cfg words name (present, voters, self, transferee) is below Q: then the
 // Q-slot tick and the P-slot tick are the same function of the group (slots >= Q carry no Progress and no event is applied
 // to a slot without one). Bodies exist for Q in {3, 5, 7} below P, and P itself.
-#define RG_MAX_CLASSES 8
 struct RgClasses {
-    u32 n;                         // ranges in use (0: not class-placed -- the plain kernel runs)
-    u32 end_block[RG_MAX_CLASSES]; // range k = blocks [end_block[k-1], end_block[k]) of RG_BLOCK groups
-    u32 np[RG_MAX_CLASSES];        // slots the groups of range k name at most
+    const u32 *need; // byte b = slots the groups of block b (RG_BLOCK groups) name at most, rounded up to a body (3, 5, 7, P);
+                     // padded to whole words. nullptr on the host side: not class-placed -- the plain kernel runs
 };
-template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(const RgState &st_in, const RgMsgs &ms, IX g) {
-    // Every body computes its cells' scalar addresses from ITS OWN copy of the stride: with one shared value the compiler
-    // hoists the address arithmetic all bodies have in common above the branch, where it stays live through whichever body
-    // runs -- 18 more SGPR spills, and the VGPRs they are spilled into cost the P = 7 kernel its third wave per SIMD.
-    RgState st = st_in;
-#ifndef RG_CLS_VARIANT
-#define RG_CLS_VARIANT 1
-#endif
+// The kernel's arguments as ONE struct, so that a body can find them in the kernarg segment by itself (below).
+struct RgClassArgs {
+    RgState st;
+    RgMsgs ms;
+    RgClasses cls;
+};
+// Every body reads the column pointers from the kernarg segment ITSELF, through its own opaque copy of the segment pointer.
+// Taken from the kernel's parameters instead, all of them are loaded at the top of the kernel and stay live through
+// whichever body runs; what does not fit the scalar registers there is spilled to VGPR lanes for good and read back at every
+// use -- 1 500 v_readlane / v_writelane in the code, ~250 executed per wave, in bodies (3 and 5 slots) that compiled on their
+// own spill nothing. A scalar load that hits the constant cache costs the VALU nothing.
+template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(IX g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#if RG_CLS_VARIANT == 1
-    asm volatile("" : "+s"(st.stride));
-#elif RG_CLS_VARIANT == 2
-    asm volatile("" : "+v"(g));
-#elif RG_CLS_VARIANT == 3
-    asm volatile("" : "+s"(st.stride));
-    asm volatile("" : "+v"(g));
-#endif
-#endif
+    typedef const __attribute__((address_space(4))) RgClassArgs *KArgs;
+    KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka)); // (opaque per body: nothing of this can be hoisted above the dispatch or shared between bodies)
+    const RgState st = ka->st;
+    const RgMsgs ms = ka->ms;
     RgGroup<Q> r;
     rg_load_group<Q, RG_LANE_NX, IX, NTM || (RG_OPT_NT_MSG != 0)>(r, st, ms, g);
     rg_group_tick<Q, false, RG_LANE_NX, false, IX>(r, st, ms, g);
     rg_store_group<Q, IX, 3, true, true>(r, st, g);
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_endpgm(); // each body ends the wave itself: no common epilogue for the compiler to merge the bodies' stores into
 #endif
 }
-// (the occupancy of the plain kernel with P slots is asked for explicitly: the common prologue of the bodies otherwise costs
-// the allocation a handful of registers, which at P = 7 is the step from 3 waves per SIMD to 2 and at P = 5 from 4 to 3)
-#define RG_CLS_WAVES(P) ((P) <= 5 ? 4 : (P) <= 7 ? 3 : 2)
-template <int P, typename IX, bool NTM>
-__global__ RG_TICK_BOUNDS void k_tick_classes(RgState st, RgMsgs ms, RgClasses cls) {
+template <int P, typename IX, bool NTM> __global__ RG_TICK_BOUNDS void k_tick_classes(RgClassArgs a) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (g64 >= st.G) return;
+    if (g64 >= a.st.G) return;
     const IX g = (IX)g64;
-    u32 np = P; // (scalar: the table is in SGPRs, blockIdx is uniform)
-#pragma unroll
-    for (int k = RG_MAX_CLASSES - 1; k >= 0; k--)
-        if ((u32)k < cls.n && blockIdx.x < cls.end_block[k]) np = cls.np[k];
-    if (P > 3 && np <= 3) rg_lane_body<3, IX, NTM>(st, ms, g);
-    else if (P > 5 && np <= 5) rg_lane_body<5, IX, NTM>(st, ms, g);
-    else if (P > 7 && np <= 7) rg_lane_body<7, IX, NTM>(st, ms, g);
-    else rg_lane_body<P, IX, NTM>(st, ms, g);
+    // (scalar: blockIdx is uniform, so this is one s_load_dword of the word that holds the block's byte)
+    const u32 np = (a.cls.need[blockIdx.x >> 2] >> (8u * (blockIdx.x & 3u))) & 0xffu;
+    if (P > 3 && np <= 3) rg_lane_body<3, IX, NTM>(g);
+    else if (P > 5 && np <= 5) rg_lane_body<5, IX, NTM>(g);
+    else if (P > 7 && np <= 7) rg_lane_body<7, IX, NTM>(g);
+    else rg_lane_body<P, IX, NTM>(g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -281,15 +274,38 @@ template <int P> struct RgSendWin {
 
 // WAVE: the lanes of the calling wave hold consecutive groups and arrive together (k_tick_send): whole-line accesses
 // (rg_wave_any); the small-batch flush, whose lanes hold unrelated groups, passes false.
-template <int P, bool GC, typename IX, bool WAVE = (RG_SEND_WAVE_LINES != 0)>
-RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, const RgIns &ins, IX g, u64 max_entries,
-                              u32 flags, RgSendRegs<P> &it, const RgSendWin<P> *win = nullptr, u32 lane = 0) {
+// Where the column pointers come from. A: every phase of the launch asks for the structs it needs when it starts --
+// RgTsDirect hands out the caller's (the small-batch flush, the host twin of the tests); k_tick_send's provider re-reads them
+// from the kernarg segment (RgTsKernarg, below), so that the stage's pointers are not live during the tick nor the messages'
+// during the stage: the kernel names ~40 columns, twice what the scalar registers hold, and kept 428 v_readlane / v_writelane
+// (9 % of its vector instructions) busy moving them in and out of spill lanes.
+struct RgTsDirect {
+    const RgState &s;
+    const RgMsgs &m;
+    const RgIns &i;
+    RG_HD RgState st() const { return s; }
+    RG_HD RgMsgs ms() const { return m; }
+    RG_HD RgIns ins() const { return i; }
+};
+template <int P, bool GC, typename IX, bool WAVE, typename A>
+RG_HD void rg_group_tick_send_a(RgGroup<P> &r, const A &a, IX g, u64 max_entries, u32 flags, RgSendRegs<P> &it,
+                                const RgSendWin<P> *win = nullptr, u32 lane = 0) {
     RgSendOps<P> q;
     constexpr bool PRE = RG_TS_SPEC != 0;
     constexpr bool TSW = WAVE; // (on the host rg_wave_any is the lane's own answer)
-    if (RG_TS_SPEC == 1 || (RG_TS_SPEC == 2 && !win)) rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
-    if (RG_TS_SPEC == 2 && win) q.first_index = rg_at(st.dummy_idx, g) + 1;
-    rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    {   // ---- phase 1: the tick ----
+        const RgState st = a.st();
+        const RgMsgs ms = a.ms();
+        if (RG_TS_SPEC == 1 || (RG_TS_SPEC == 2 && !win)) {
+            const RgIns ins = a.ins();
+            rg_send_prefetch<P, IX>(st, ins, g, q); // (behind the group's own loads, which the caller has issued)
+        }
+        if (RG_TS_SPEC == 2 && win) q.first_index = rg_at(st.dummy_idx, g) + 1;
+        rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
+    }
+    // ---- phase 2: the stage, on the registers the tick leaves ----
+    const RgState st = a.st();
+    const RgIns ins = a.ins();
     // A reject of this group waits for the host's log (RG_OUT_HOST_HINT, rg_resolve_host_hints): its send_append belongs BEFORE
     // the group's other sends of the tick, so the whole group's stage waits with it -- that call runs it. The stage below sees an
     // empty result word: no Inflights effect, no work item; the real word goes to RG_COL_OUT as always.
@@ -320,6 +336,12 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
     rg_send_serve<P, IX, true, TSW>(st, ins, g, sout, max_entries, flags, q, it, &r, nxv);
     rg_store_group<P, IX, 2>(r, st, g);
 }
+template <int P, bool GC, typename IX, bool WAVE = (RG_SEND_WAVE_LINES != 0)>
+RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, const RgIns &ins, IX g, u64 max_entries,
+                              u32 flags, RgSendRegs<P> &it, const RgSendWin<P> *win = nullptr, u32 lane = 0) {
+    const RgTsDirect a = {st, ms, ins};
+    rg_group_tick_send_a<P, GC, IX, WAVE>(r, a, g, max_entries, flags, it, win, lane);
+}
 
 // The work items of a dense stage into their peer-major columns (k_send_dense, k_tick_send).
 template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P> &it, const RgSendCols &oc, u64 stride, IX g) {
@@ -345,9 +367,37 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
 #ifndef RG_TS_WAVES
 #define RG_TS_WAVES 1 /* minimum waves per SIMD k_tick_send is compiled for (experiment knob) */
 #endif
+struct RgTickSendArgs { // k_tick_send's arguments as ONE struct: a phase finds them in the kernarg segment by itself
+    RgState st;
+    RgMsgs ms;
+    RgIns ins;
+    u64 max_entries;
+    u32 flags;
+    RgSendCols oc;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+struct RgTsKernarg { // (each call is opaque to the others: a phase's scalar loads cannot be hoisted into an earlier phase)
+    typedef const __attribute__((address_space(4))) RgTickSendArgs *KA;
+    RG_D static KA ptr() {
+        KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        return ka;
+    }
+    RG_D RgState st() const { return ptr()->st; }
+    RG_D RgMsgs ms() const { return ptr()->ms; }
+    RG_D RgIns ins() const { return ptr()->ins; }
+};
+#else
+struct RgTsKernarg { // (never used on the host)
+    RgState st() const { return RgState(); }
+    RgMsgs ms() const { return RgMsgs(); }
+    RgIns ins() const { return RgIns(); }
+};
+#endif
 template <int P, bool GC, typename IX>
-__global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgState st, RgMsgs ms, RgIns ins, u64 max_entries, u32 flags,
-                                                                     RgSendCols oc) {
+__global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgTickSendArgs ka_) {
+    const RgState &st = ka_.st; // (the prologue below; the phases go through RgTsKernarg)
+    const RgIns &ins = ka_.ins;
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
 #if RG_TS_SPEC == 2
     // The stage's window columns (meta 4 B, oldest / newest inflight 8 B each, per slot and group) travel straight from
@@ -378,17 +428,27 @@ __global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgState st,
         }
     }
 #endif
+    (void)ins;
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
+    const RgTsKernarg a;
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, IX, true>(r, st, ms, g); // (message columns streamed: an engine with device Inflights is past the cache at any size that matters)
+    {
+        const RgState st1 = a.st();
+        const RgMsgs ms1 = a.ms();
+        rg_load_group<P, RG_LANE_NX, IX, true>(r, st1, ms1, g); // (message columns streamed: an engine with device Inflights is past the cache at any size that matters)
+    }
     RgSendRegs<P> it;
 #if RG_TS_SPEC == 2
-    rg_group_tick_send<P, GC, IX>(r, st, ms, ins, g, max_entries, flags, it, &win, lane);
+    rg_group_tick_send_a<P, GC, IX, (RG_SEND_WAVE_LINES != 0)>(r, a, g, ka_.max_entries, ka_.flags, it, &win, lane);
 #else
-    rg_group_tick_send<P, GC, IX>(r, st, ms, ins, g, max_entries, flags, it);
+    rg_group_tick_send_a<P, GC, IX, (RG_SEND_WAVE_LINES != 0)>(r, a, g, ka_.max_entries, ka_.flags, it);
 #endif
-    rg_store_send_items<P, IX>(it, oc, st.stride, g);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const RgSendCols oc = RgTsKernarg::ptr()->oc;
+    const u64 stride = RgTsKernarg::ptr()->st.stride;
+    rg_store_send_items<P, IX>(it, oc, stride, g);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,8 +1153,12 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
 template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool ntm, const RgClasses &cls) {
     if constexpr (P >= 4) {
         const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
-        if (ntm) hipLaunchKernelGGL((k_tick_classes<P, u32, true>), grid, block, 0, stream, st, ms, cls);
-        else hipLaunchKernelGGL((k_tick_classes<P, u32, false>), grid, block, 0, stream, st, ms, cls);
+        RgClassArgs a;
+        a.st = st;
+        a.ms = ms;
+        a.cls = cls;
+        if (ntm) hipLaunchKernelGGL((k_tick_classes<P, u32, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_tick_classes<P, u32, false>), grid, block, 0, stream, a);
     }
 }
 template <int P>
@@ -1126,12 +1190,19 @@ void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &
                            u32 flags, const RgSendCols &oc) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
     const bool ix32 = rg_ix32(st, P); // 32-bit cell offsets (rg_launch_tick_t)
+    RgTickSendArgs ta;
+    ta.st = st;
+    ta.ms = ms;
+    ta.ins = ins;
+    ta.max_entries = max_entries;
+    ta.flags = flags;
+    ta.oc = oc;
     if (gc) {
-        if (ix32) hipLaunchKernelGGL((k_tick_send<P, true, u32>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
-        else hipLaunchKernelGGL((k_tick_send<P, true, u64>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
+        if (ix32) hipLaunchKernelGGL((k_tick_send<P, true, u32>), grid, block, 0, stream, ta);
+        else hipLaunchKernelGGL((k_tick_send<P, true, u64>), grid, block, 0, stream, ta);
     } else {
-        if (ix32) hipLaunchKernelGGL((k_tick_send<P, false, u32>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
-        else hipLaunchKernelGGL((k_tick_send<P, false, u64>), grid, block, 0, stream, st, ms, ins, max_entries, flags, oc);
+        if (ix32) hipLaunchKernelGGL((k_tick_send<P, false, u32>), grid, block, 0, stream, ta);
+        else hipLaunchKernelGGL((k_tick_send<P, false, u64>), grid, block, 0, stream, ta);
     }
 }
 #else

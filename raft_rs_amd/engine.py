@@ -665,9 +665,12 @@ class Engine:
         """rg_size_classes: the ranges of the shard the next dense tick treats as one size class each -> [(first_group, n_groups,
         n_slots)]; [] = the plain kernel runs."""
         dt = np.dtype([("first_group", "<u8"), ("n_groups", "<u8"), ("n_slots", "<u4"), ("reserved", "<u4")])
-        out = np.zeros(8, dtype=dt)
+        out = np.zeros(64, dtype=dt)
         n = C.c_uint32(0)
         self._check(self.L.rg_size_classes(self.h, out.ctypes.data, len(out), C.byref(n)))
+        if n.value > len(out):
+            out = np.zeros(n.value, dtype=dt)
+            self._check(self.L.rg_size_classes(self.h, out.ctypes.data, len(out), C.byref(n)))
         return [(int(r["first_group"]), int(r["n_groups"]), int(r["n_slots"])) for r in out[:n.value]]
 
     def host_hints(self):
