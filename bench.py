@@ -988,7 +988,8 @@ def main():
                                     "(the honest HBM-regime figure is out_of_cache.roofline.frac); hbm: they do not fit",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_classes" if args.sorted else "k_tick_lane")) +
+                     "kernel": "k_tick_send" if (args.inflights and args.fused_send) else
+                               ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_classes" if args.sorted else "k_tick_lane")) +
                                (" + k_send_dense" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
                      "avg_launch_us": per_launch_s * 1e6,

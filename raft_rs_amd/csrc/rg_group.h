@@ -438,18 +438,23 @@ template <int P> struct RgGroup {
     // reject hints (after find_conflict_by_term where the pre-pass ran) and what an election reads from the cold
     // columns. A wave then pays one memory round trip however many of its lanes take a rare path.
     u64 hint[P];
+    u32 el_n;           // an election: the term-run table's fill count (RG_COL_RUN_COUNT) -- with it rg_push_run files the previous
+                        // leader's run on the spot, two stores and no look at the table (round 3 read the table for the first
+                        // unused run, behind the group's stores: two dependent round trips at the tail of every wave that holds
+                        // an electing group, 7 of config 5's 100 us)
     u64 el_old;         // an election: the current term (the new one comes in hint[self]) = the term of the previous
-                        // leader's entries, which rg_push_run files in the term-run table after the group's stores
-                        // (RG_TICK_PUSH: from memory, behind everything else -- round 2 requested the table's cells early, into
-                        // the registers the dead message columns leave; with RG_TERM_RUNS = 8 that cost the dense kernel a wave
-                        // of occupancy at P = 5, the late reads cost config 5 nothing measurable, profiles/r03_*)
+                        // leader's entries, the run rg_push_run files (round 2 requested the table's CELLS early, into the
+                        // registers the dead message columns leave: with RG_TERM_RUNS = 8 that cost the dense kernel a wave of
+                        // occupancy at P = 5; the count is one register that is dead again before the slots are walked)
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 // The value stays what it is, but the compiler may not look through: without this it computes `hint + 1` (and the
 // election's term comparison) inside the very branch that issued the prefetch, i.e. waits for the load on the spot.
 #define RG_OPAQUE64(x) asm volatile("" : "+v"(x))
+#define RG_OPAQUE32(x) asm volatile("" : "+v"(x))
 #else
 #define RG_OPAQUE64(x) (void)(x)
+#define RG_OPAQUE32(x) (void)(x)
 #endif
 // How a tick gets at Progress.next_idx (and the other rarely needed operands):
 #define RG_NX_LOADED 0   /* the caller loaded r.nx[] for every slot (LDS-staged variants) */
@@ -462,7 +467,6 @@ template <int P> struct RgGroup {
 #define RG_DIRTY_LO (1u << 27)      /* term_lo changed (an election) */
 #define RG_DIRTY_CFG (1u << 28)     /* the cfg word changed (an election aborts a leader transfer) */
 #define RG_TICK_ELECTED (1u << 29)  /* not a store bit: RG_MF_BECOME_LEADER was applied in THIS tick */
-#define RG_TICK_PUSH (1u << 30)     /* RG_NX_PREFETCH: ... and the previous leader's run still has to enter the term-run table */
 
 // RawNode::report_unreachable / report_snapshot (src/raw_node.rs:692-709) on ONE Progress cell: handle_unreachable
 // (src/raft.rs:1931-1954) and handle_snapshot_status (:1891-1929). `pf` is the cell's flag byte. Returns whether
@@ -629,7 +633,11 @@ template <int P, typename IX> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const R
     const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
     const bool elect = rg_has_election(r.mf, cfg, P);
     r.el_old = 0;
-    if (elect) r.el_old = rg_at(st.cur_term, g); // (the new term arrives in r.hint[self], below)
+    r.el_n = 0;
+    if (elect) {
+        r.el_old = rg_at(st.cur_term, g); // (the new term arrives in r.hint[self], below)
+        r.el_n = (u32)rg_at(rg_run_n(st), g);
+    }
 #pragma unroll
     for (int i = 0; i < P; i++) {
         const u32 f = (u32)(r.mf >> (8 * i)) & 0xffu, pb = (u32)(r.pf >> (8 * i)) & 0xffu;
@@ -761,11 +769,11 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
         const u64 old_lo = r.lo, old_hi = r.hi;
         rg_at(st.cur_term, g) = new_term;
         if (old_lo <= old_hi) { // the previous leader's entries become one more run of an older term
-            if (PREF) { // nothing in this tick reads the table: filed after the group's stores (rg_store_group)
-                r.dirty |= RG_TICK_PUSH; // (r.el_old is their term; term_lo still holds their first index in memory)
-            } else {
-                rg_push_run<IX>(st, g, old_lo, old_term, (u32)rg_at(rg_run_n(st), g));
-            }
+            // (PREF: the fill count came with the prefetch batch -- the stores go out here and now, nothing waits for them)
+            u32 n = r.el_n;
+            if (PREF) RG_OPAQUE32(n);
+            else n = (u32)rg_at(rg_run_n(st), g);
+            rg_push_run<IX>(st, g, old_lo, old_term, n);
         }
 #pragma unroll
         for (int i = 0; i < P; i++) {

@@ -99,20 +99,9 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
 // WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
 // stage, which changes both; every other caller stores the group in one go).
 // WAVE_ST (kernels whose lanes hold CONSECUTIVE groups, all lanes of the wave arriving here together): RG_OPT_WAVE_ST
-template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false, bool EARLY_PUSH = false>
+template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false>
 RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
-    // an election's table update (below) needs the previous leader's first index -- still in memory, the register holds the new
-    // term_lo -- and the table's fill count: both are requested HERE, ahead of the group's stores, so that they are on their
-    // way while the stores issue (one round trip at the tail of the wave instead of the three a look at the table cost)
-    // (EARLY_PUSH: the dense lane kernels only; elsewhere -- the send-stage and fused kernels, at their register limit -- the two
-    // loads are issued where they are used, still one round trip)
-    u64 push_first = 0;
-    u32 push_n = 0;
-    if (EARLY_PUSH && (d & RG_TICK_PUSH)) {
-        push_first = rg_at(st.lo, g);
-        push_n = (u32)rg_at(rg_run_n(st), g);
-    }
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
         const u32 ev = r.evm; // slots with a Progress that had an event (RgTick)
@@ -146,18 +135,7 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     }
     // (an election's own stores go with part 2: k_tick_send runs its stage -- on the registers, it reads neither term_lo nor the
     // cfg word nor the table from memory -- between the two parts, where the kernel is at the limit of its scalar registers)
-    if ((WHICH & 2) && (d & (RG_DIRTY_LO | RG_DIRTY_CFG | RG_TICK_PUSH))) { // an election (rare)
-        // its table update comes last (it reads the table, and nothing else of the wave should wait for that) but before
-        // term_lo is overwritten: the previous leader's first index is taken from there
-#ifndef RG_NO_PUSH /* (measurement builds only: what the table update at the tail of an electing wave costs) */
-        if (d & RG_TICK_PUSH) {
-            if (!EARLY_PUSH) {
-                push_first = rg_at(st.lo, g);
-                push_n = (u32)rg_at(rg_run_n(st), g);
-            }
-            rg_push_run<IX>(st, g, push_first, r.el_old, push_n);
-        }
-#endif
+    if ((WHICH & 2) && (d & (RG_DIRTY_LO | RG_DIRTY_CFG))) { // an election (rare)
         if (d & RG_DIRTY_LO) rg_at(st.lo, g) = r.lo;
         if (d & RG_DIRTY_CFG) rg_at(st.cfg, g) = r.cfg;
     }
@@ -191,7 +169,7 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
 #endif
 #endif
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<P, IX, 3, true, true>(r, st, g);
+    rg_store_group<P, IX, 3, true>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -239,7 +217,7 @@ template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(IX g) {
     RgGroup<Q> r;
     rg_load_group<Q, RG_LANE_NX, IX, NTM || (RG_OPT_NT_MSG != 0)>(r, st, ms, g);
     rg_group_tick<Q, false, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<Q, IX, 3, true, true>(r, st, g);
+    rg_store_group<Q, IX, 3, true>(r, st, g);
 #endif
 }
 template <int P, typename IX, bool NTM> __global__ RG_TICK_BOUNDS void k_tick_classes(RgClassArgs a) {
@@ -498,6 +476,11 @@ template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u6
     f(i++, r.lo);
     f(i++, r.hi);
     f(i++, r.el_old);
+    {
+        u64 n64 = r.el_n;
+        f(i++, n64);
+        r.el_n = (u32)n64;
+    }
     f(i++, cfg_adv);
     f(i++, g64);
 }
@@ -517,7 +500,7 @@ RG_D void rg_lds_barrier() {
 #endif
 template <int P, bool GC, typename IX>
 __global__ RG_CPT_BOUNDS void k_tick_compact(RgState st, RgMsgs ms) {
-    constexpr int NF = 6 * P + 8;
+    constexpr int NF = 6 * P + 9;
     __shared__ u64 x_rare[NF][RG_CPT_CAP];  // rare groups handed over by the natural waves
     __shared__ u64 x_disp[NF][RG_CPT_CAP];  // steady groups the designated wave gives away in exchange
     __shared__ u32 cnt[2];                  // [0] rare lanes of the natural waves, [1] steady lanes of the designated wave
