@@ -895,6 +895,7 @@ struct rg_engine {
     u8 *cls_need;      // device: one byte per block of RG_BLOCK groups (k_block_slots), padded to whole words
     std::vector<u8> cls_host; // its host copy
     bool cls_on;       // some block names fewer slots than the engine has: the dense lane tick runs k_tick_classes
+    u32 cls_ways;      // launch order of that kernel: the shard dealt out in this many equal parts (RgClasses::ways)
     bool cls_stale;    // RG_COL_CFG may have changed since the bytes were derived
     bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
@@ -1096,6 +1097,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_ready = false;
     h->cls_need = nullptr;
     h->cls_on = false;
+    h->cls_ways = 1;
     h->cls_stale = true;
     {
         const char *e = getenv("RG_NO_CLASSES"); // measurement hook (bench.py's A/B of the class-placed layout), read here only
@@ -1463,6 +1465,11 @@ static int rg_refresh_classes(rg_engine *h) {
     RG_HIP(hipMemcpyAsync(h->cls_host.data(), h->cls_need, nb, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     for (u64 b = 0; b < nb && !h->cls_on; b++) h->cls_on = h->cls_host[b] < h->P;
+    // launch order: one part per range of equal blocks (at most 4; RG_CLASS_WAYS in the environment overrides: measurement hook)
+    u32 ranges = 1;
+    for (u64 b = 1; b < nb && ranges < 5; b++) ranges += h->cls_host[b] != h->cls_host[b - 1];
+    h->cls_ways = ranges > 4 ? 1u : ranges;
+    if (const char *e = getenv("RG_CLASS_WAYS")) h->cls_ways = (u32)atoi(e) > 0 ? (u32)atoi(e) : 1u;
     return RG_OK;
 }
 
@@ -1530,6 +1537,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
         if (h->cls_on && !h->cls_stale) {
             RgClasses cls;
             cls.need = reinterpret_cast<const u32 *>(h->cls_need);
+            cls.ways = h->cls_ways;
+            cls.per_way = (u32)(((h->G + RG_BLOCK - 1) / RG_BLOCK + cls.ways - 1) / cls.ways);
             switch (h->P) {
             case 4: rg_launch_tick_classes_t<4>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
             case 5: rg_launch_tick_classes_t<5>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
