@@ -291,8 +291,18 @@ class Dev:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
-calls = []
+calls, sends, recvs = [], set(), set()
+DELTA, FULL = rg.engine.pub_bytes_per_rank(G), None
 def allgather(dev_send, dev_recv, nbytes, stream):
+    # What the library hands its all-gather is, argument for argument, what ncclAllGather(sendbuff, recvbuff, sendcount,
+    # ncclUint8, comm, stream) takes when this callback is not installed (rg_pub_allgather): the N-rank SHAPE of the exchange is
+    # checked here, so that RCCL itself is the only thing this box cannot run at N > 1. One slice of `nbytes` in, `world` slices
+    # out, rank r's at recvbuff + r * nbytes (all_gather_into_tensor below has that very contract); the two ranges are
+    # disjoint device allocations of the engine, whole cache lines apart; the count is one of the two slice sizes.
+    assert nbytes == DELTA or nbytes % 8 == 0 and nbytes >= 8 * G, (nbytes, DELTA)
+    assert dev_send % 256 == 0 and dev_recv % 256 == 0, (hex(dev_send), hex(dev_recv))
+    assert dev_send + nbytes <= dev_recv or dev_recv + world * nbytes <= dev_send
+    sends.add((dev_send, nbytes)); recvs.add((dev_recv, nbytes))
     torch.cuda.synchronize()
     send = torch.as_tensor(Dev(dev_send, nbytes), device="cuda").cpu()
     out = torch.empty(world * nbytes, dtype=torch.uint8)
@@ -331,7 +341,14 @@ assert all(exact_at[:6]), exact_at
 assert not all(exact_at[6:6 + 2 * RING + 1]) and all(exact_at[6 + 2 * RING + 1:]), exact_at
 assert st["full_publications"] == 2, st          # rg_comm_init's and the resynchronisation
 assert calls.count(st["bytes_per_rank_full"]) == 2 and calls.count(st["bytes_per_rank_delta"]) == TICKS - 1, (calls, st)
-assert st["bytes_per_rank_delta"] < 1.1 * G + 4096
+assert st["bytes_per_rank_delta"] < 1.1 * G + 4096 and st["bytes_per_rank_delta"] == DELTA
+# a collective: every rank passed the SAME count at the SAME call -- also across the loss / full-snapshot protocol, which each
+# rank decides on its own from the gathered headers
+every = [None] * world
+dist.all_gather_object(every, calls)
+assert all(c == every[0] for c in every), every
+# the engine rotates 4 send slices and RING gathered slots per slice size (+ one full-size pair)
+assert len({p for p, n in sends if n == DELTA}) <= 4 and len({p for p, n in recvs if n == DELTA}) <= RING, (len(sends), len(recvs))
 if rank == 0:
     print("PUBLISH8_OK", world, st["bytes_per_rank_delta"], st["bytes_per_rank_full"], exact_at.count(False))
 dist.barrier()
@@ -375,3 +392,31 @@ def test_bench_line_of_eight_ranks_sharing_the_gpu(rg):
     assert cfg["publication_mode"].startswith("delta") and cfg["publication_compare"]["mode"].startswith("raw")
     assert cfg["publication_compare"]["bytes_per_rank_per_publication"] == pub["bytes_per_rank_full"]
     assert line["roofline"]["regime"] in ("infinity-cache", "hbm") and line["cpu_baseline"] is None
+
+
+def test_bench_starts_its_own_ranks_with_strong_scaling_and_an_automatic_cadence(rg):
+    """The PLAIN command line -- `python bench.py --gpus 2 ...`, no launcher, what the driver runs at N = 1 -- starts its own
+    ranks (torch.distributed.run underneath, rendezvous on 127.0.0.1 at a free port); `--total-groups` splits one population
+    into equal contiguous ranges (strong scaling) and `--publish-every auto` picks the cadence from a measured exchange
+    (rank 0 decides, the control plane broadcasts). Two ranks share the GPU (BENCH_SHARE_GPU=1: gloo moves the slices)."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-groups", "262144", "--steps", "6", "--warmup", "2",
+           "--publish-every", "auto", "--no-publish-compare"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["groups_per_gpu"] == 131072
+    assert line["value"] == pytest.approx(262144 * 6 / (line["ms_per_step"] * 6 / 1e3), rel=1e-6)
+    auto = line["config"]["publish_every_auto"]
+    assert 1 <= auto["publish_every"] <= 32 and auto["publish_every"] == line["config"]["publish_every"]
+    assert auto["tick_us"] > 0 and auto["exchange_us"] > 0
+    # (through the host transport an exchange is far slower than a tick: the rule must have picked a cadence above 1)
+    assert abs(auto["publish_every"] - min(32, int(np.ceil(auto["exchange_us"] / auto["tick_us"])))) <= 1  # (the note rounds to 0.01 us)
+    pub = line["config"]["publication"]
+    assert pub["publications"] >= 1 + 6 // auto["publish_every"]
+    # an uneven split is refused, loudly
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-groups", "262145", "--steps", "2",
+                          "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+    assert bad.returncode != 0 and "does not divide" in bad.stderr
