@@ -64,9 +64,33 @@ static inline bool rg_fits_u32_offsets(u64 n_slots, u64 stride) {
 // _fused / _compact <..., u64>, k_send_dense<..., u64>), which no engine a test can afford to build would otherwise reach on
 // a GPU. The environment is read once, by rg_create, into RgState::ix64: nothing on a launch path calls getenv.
 static inline bool rg_ix32(const RgState &st, u64 n_slots) { return !st.ix64 && rg_fits_u32_offsets(n_slots, st.stride); }
+// rg_u32o: a 32-bit cell index whose BYTE OFFSET is made opaque right before every access (rg_at below). `base + zext(offset)`
+// then stays in the block of the access, where instruction selection turns it into the SGPR-base + VGPR-offset addressing
+// mode; left alone, the compiler hoists the 64-bit sum out of the branches and keeps a VGPR address PAIR per cell alive
+// (118 v_lshl_add_u64 in k_tick_lane<5>). Register allocation with the opaque form: lane<5> 123 -> 101 VGPRs, lane<7>
+// 162 -> 135, fused<5> 156 -> 115 (3 -> 4 waves per SIMD), fused<7> 201 -> 145 (2 -> 3). Measured on one box
+// (profiles/calls/gpu_r04_g.sh): the fused kernels gain 10-12 % (their occupancy step), the single-tick lane kernels, whose
+// occupancy does not change, lose 0-3 % (the asm statements pin the order of the accesses) -- so it is the FUSED kernel's
+// index type and nobody else's.
+struct rg_u32o {
+    u32 v;
+    RG_HD rg_u32o() {}
+    RG_HD rg_u32o(u64 x) : v((u32)x) {}
+    RG_HD operator u32() const { return v; }
+    friend RG_HD rg_u32o operator*(rg_u32o a, rg_u32o b) { return rg_u32o((u64)(a.v * b.v)); }
+    friend RG_HD rg_u32o operator+(rg_u32o a, rg_u32o b) { return rg_u32o((u64)(a.v + b.v)); }
+};
 template <typename T, typename IX> RG_HD T &rg_at(T *base, IX i) {
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
-    return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (IX)(i * (IX)sizeof(T)));
+    if constexpr (std::is_same<IX, rg_u32o>::value) {
+        u32 off = i.v * (u32)sizeof(T);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(off));
+#endif
+        return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + off);
+    } else {
+        return *reinterpret_cast<T *>(reinterpret_cast<B *>(base) + (IX)(i * (IX)sizeof(T)));
+    }
 }
 
 RG_HD u64 rg_min(u64 a, u64 b) { return a < b ? a : b; }

@@ -1169,10 +1169,10 @@ template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
     const bool ix32 = rg_ix32(st, P); // 32-bit cell offsets (rg_launch_tick_t)
     if (gc) {
-        if (ix32) hipLaunchKernelGGL((k_tick_fused<P, true, u32>), grid, block, 0, stream, st, fm);
+        if (ix32) hipLaunchKernelGGL((k_tick_fused<P, true, rg_u32o>), grid, block, 0, stream, st, fm);
         else hipLaunchKernelGGL((k_tick_fused<P, true, u64>), grid, block, 0, stream, st, fm);
     } else {
-        if (ix32) hipLaunchKernelGGL((k_tick_fused<P, false, u32>), grid, block, 0, stream, st, fm);
+        if (ix32) hipLaunchKernelGGL((k_tick_fused<P, false, rg_u32o>), grid, block, 0, stream, st, fm);
         else hipLaunchKernelGGL((k_tick_fused<P, false, u64>), grid, block, 0, stream, st, fm);
     }
 }
