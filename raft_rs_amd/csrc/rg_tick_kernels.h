@@ -53,6 +53,9 @@ template <typename T> RG_HD void rg_st(T &dst, T v, bool nt) {
 #else
 #define RG_BLOCK 256
 #endif
+#ifndef RG_LANE_IX32 /* the 32-bit cell index of the single-tick lane kernels: u32, or rg_u32o (opaque offsets, rg_common.h: experiment) */
+#define RG_LANE_IX32 u32
+#endif
 #ifdef RG_MIN_WAVES /* experiment: minimum waves per SIMD the register allocator must leave room for */
 #define RG_TICK_BOUNDS __launch_bounds__(RG_BLOCK, RG_MIN_WAVES)
 #else
@@ -1132,7 +1135,7 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
     } else {
         // 32-bit cell offsets when every cell a lane addresses is below 4 GiB from its column's start
         if (rg_ix32(st, P))
-            RG_LAUNCH_LANE(u32);
+            RG_LAUNCH_LANE(RG_LANE_IX32);
         else
             RG_LAUNCH_LANE(u64);
     }
@@ -1148,8 +1151,8 @@ template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState
         a.st = st;
         a.ms = ms;
         a.cls = cls;
-        if (ntm) hipLaunchKernelGGL((k_tick_classes<P, u32, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_tick_classes<P, u32, false>), grid, block, 0, stream, a);
+        if (ntm) hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, false>), grid, block, 0, stream, a);
     }
 }
 template <int P>
