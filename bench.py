@@ -16,8 +16,11 @@ index (maybe_commit), i.e. one *evaluation* per group per step (BASELINE.md sect
 Workload at N=1: BASELINE.json configs[1] = 1,000,000 groups x 5 peers, majority quorum, synthetic
 AppendResponse stream (seed 0x5EED5EED). Weak scaling: every rank holds its own 1M-group shard
 (disjoint global group ids); the only exchange is the publication of commit indices, natively behind the C ABI
-(rg_comm_init / rg_publish_commit: ncclAllGather over xGMI of the ~1 B/group slices the ticks produce), after EVERY
-tick by default. `--gpus N --slots 7` is BASELINE configs[3] (8 M x 7 over 8 GPUs at N = 8).
+(rg_comm_init / rg_publish_commit: ncclAllGather over xGMI of the ~1 B/group slices the ticks produce), after every
+tick wherever an exchange fits behind a tick (`--publish-every auto`, the default: measured before the timed region,
+reported as config.publish_every_auto; `--publish-every 1` forces every tick). `--gpus N --slots 7` is BASELINE
+configs[3] (8 M x 7 over 8 GPUs at N = 8); `--total-groups G` is strong scaling; `python bench.py --gpus N` without a
+launcher starts its own ranks.
 
 Procedure: the W+K ticks of messages are generated on the device from the evolving state in an
 untimed pass (generate -> tick -> generate ...), the engine state is restored from a checkpoint,
@@ -561,10 +564,11 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--publish-every", default="1",
-                    help="N>1: publish the commit advances every E ticks (and after the last tick); default every tick. "
-                         "`auto`: E is picked from the exchange time measured on 8 publications before the timed region "
-                         "(rank 0 decides, the control plane broadcasts it; no extra data-path collective)")
+    ap.add_argument("--publish-every", default="auto",
+                    help="N>1: publish the commit advances every E ticks (and after the last tick). Default `auto`: E is picked "
+                         "from the exchange time measured on 8 publications before the timed region -- E = ceil(exchange / "
+                         "tick), 1 (= every tick) wherever an exchange fits behind a tick; rank 0 decides, the control plane "
+                         "broadcasts it, no extra data-path collective. `1` forces every tick.")
     ap.add_argument("--total-groups", type=int, default=0,
                     help="N>1: STRONG scaling -- this many groups in total, split into N disjoint contiguous ranges "
                          "(sharding.strong_shard); `scaling` is then \"strong\". Default 0 = weak scaling, --groups per GPU")

@@ -379,7 +379,7 @@ def test_bench_line_of_eight_ranks_sharing_the_gpu(rg):
     env = dict(os.environ, BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", "29579", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--slots", "7", "--groups", "131072",
-           "--steps", "6", "--warmup", "2"]
+           "--steps", "6", "--warmup", "2", "--publish-every", "1"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
