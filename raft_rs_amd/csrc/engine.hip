@@ -538,11 +538,14 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
     rg_group_send<P, IX, RG_SEND_SPEC_LOADS != 0, RG_SEND_WAVE_LINES != 0>(st, ins, g, out, max_entries, flags, it); // (unconditional: its loads ride with `out`)
     rg_store_send_items<P, IX>(it, oc, st.stride, g);
 }
+#ifndef RG_SEND_IX32 /* the dense send stage's 32-bit cell index (rg_u32o measured: 125 -> 123 VGPRs, nothing else: profiles/r04_addressing.txt) */
+#define RG_SEND_IX32 u32
+#endif
 template <int P>
 static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
                                  u32 flags, const RgSendCols &oc) {
     if (rg_ix32(st, P))
-        hipLaunchKernelGGL((k_send_dense<P, u32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
+        hipLaunchKernelGGL((k_send_dense<P, RG_SEND_IX32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
     else
         hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
 }
