@@ -898,7 +898,7 @@ struct rg_engine {
     u8 *cls_need;      // device: one byte per block of RG_BLOCK groups (k_block_slots), padded to whole words
     std::vector<u8> cls_host; // its host copy
     bool cls_on;       // some block names fewer slots than the engine has: the dense lane tick runs k_tick_classes
-    u32 cls_ways;      // launch order of that kernel: the shard dealt out in this many equal parts (RgClasses::ways)
+    u32 *cls_order;    // device: one word per workgroup of that kernel, in launch order: block | slots << 28 (RgClasses::order)
     bool cls_stale;    // RG_COL_CFG may have changed since the bytes were derived
     bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
@@ -1100,7 +1100,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_ready = false;
     h->cls_need = nullptr;
     h->cls_on = false;
-    h->cls_ways = 1;
+    h->cls_order = nullptr;
     h->cls_stale = true;
     {
         const char *e = getenv("RG_NO_CLASSES"); // measurement hook (bench.py's A/B of the class-placed layout), read here only
@@ -1231,6 +1231,7 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->arena) (void)hipFree(h->arena);
     if (h->ckpt) (void)hipFree(h->ckpt);
     if (h->cls_need) (void)hipFree(h->cls_need);
+    if (h->cls_order) (void)hipFree(h->cls_order);
     if (h->ins_arena) (void)hipFree(h->ins_arena);
     if (h->ins_ckpt) (void)hipFree(h->ins_ckpt);
     if (h->esz) (void)hipFree(h->esz);
@@ -1468,11 +1469,28 @@ static int rg_refresh_classes(rg_engine *h) {
     RG_HIP(hipMemcpyAsync(h->cls_host.data(), h->cls_need, nb, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     for (u64 b = 0; b < nb && !h->cls_on; b++) h->cls_on = h->cls_host[b] < h->P;
-    // launch order: one part per range of equal blocks (at most 4; RG_CLASS_WAYS in the environment overrides: measurement hook)
-    u32 ranges = 1;
-    for (u64 b = 1; b < nb && ranges < 5; b++) ranges += h->cls_host[b] != h->cls_host[b - 1];
-    h->cls_ways = ranges > 4 ? 1u : ranges;
-    if (const char *e = getenv("RG_CLASS_WAYS")) h->cls_ways = (u32)atoi(e) > 0 ? (u32)atoi(e) : 1u;
+    if (!h->cls_on) return RG_OK;
+    // launch order (RgClasses::order): the ranges of equal blocks dealt out proportionally -- block i of a range of n blocks sorts
+    // by (i + 1/2) / n, ties by block index. RG_CLASS_ORDER=0 in the environment keeps block order (measurement hook).
+    if (nb >= (1ull << 28)) { // (the word holds 28 bits of block index)
+        h->cls_on = false;
+        return RG_OK;
+    }
+    std::vector<std::pair<double, u32>> key(nb);
+    const char *eo = getenv("RG_CLASS_ORDER");
+    const bool deal = !(eo && eo[0] == '0');
+    for (u64 b = 0; b < nb;) {
+        u64 e = b + 1;
+        while (e < nb && h->cls_host[e] == h->cls_host[b]) e++;
+        for (u64 i = b; i < e; i++) key[i] = {deal ? ((double)(i - b) + 0.5) / (double)(e - b) : 0.0, (u32)i};
+        b = e;
+    }
+    std::stable_sort(key.begin(), key.end(), [](const std::pair<double, u32> &x, const std::pair<double, u32> &y) { return x.first < y.first; });
+    std::vector<u32> order(nb);
+    for (u64 w = 0; w < nb; w++) order[w] = key[w].second | ((u32)h->cls_host[key[w].second] << 28);
+    if (!h->cls_order) RG_HIP(hipMalloc(&h->cls_order, nb * 4));
+    RG_HIP(hipMemcpyAsync(h->cls_order, order.data(), nb * 4, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream)); // (`order` is a local)
     return RG_OK;
 }
 
@@ -1539,9 +1557,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
         }
         if (h->cls_on && !h->cls_stale) {
             RgClasses cls;
-            cls.need = reinterpret_cast<const u32 *>(h->cls_need);
-            cls.ways = h->cls_ways;
-            cls.per_way = (u32)(((h->G + RG_BLOCK - 1) / RG_BLOCK + cls.ways - 1) / cls.ways);
+            cls.order = h->cls_order;
             switch (h->P) {
             case 4: rg_launch_tick_classes_t<4>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
             case 5: rg_launch_tick_classes_t<5>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;

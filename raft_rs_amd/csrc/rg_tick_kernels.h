@@ -196,14 +196,17 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
 // Q-slot tick and the P-slot tick are the same function of the group (slots >= Q carry no Progress and no event is applied
 // to a slot without one). Bodies exist for Q in {3, 5, 7} below P, and P itself.
 struct RgClasses {
-    const u32 *need; // byte b = slots the groups of block b (RG_BLOCK groups) name at most, rounded up to a body (3, 5, 7, P);
-                     // padded to whole words. nullptr on the host side: not class-placed -- the plain kernel runs
-    // Launch order: workgroup w runs block (w % ways) * per_way + w / ways -- the shard cut into `ways` equal parts, dealt out
-    // in turn. Placed by class, the shard would otherwise be swept class by class: first every CU holds 3-slot waves (short,
-    // bandwidth-hungry), at the end every CU holds 7-slot waves (three per SIMD, long, instruction- and latency-bound under
-    // rollover). Dealt out in turn, both kinds are resident side by side for the whole launch. ways = 1: launch order = block
-    // order. The grid is ways x per_way workgroups; the few beyond the last block leave at once.
-    u32 ways, per_way;
+    // One word per WORKGROUP, in launch order: the block of RG_BLOCK groups it runs (bits 0-27) and the slots that block's
+    // groups name at most, rounded up to a body -- 3, 5, 7 or P -- (bits 28-31). nullptr on the host side: not class-placed,
+    // the plain kernel runs. A wave reads its word with one scalar load before its first vector load.
+    // Launch order: the ranges of equal blocks are dealt out PROPORTIONALLY (block i of a range of n sorts by (i + 1/2) / n), so
+    // that at any moment the resident waves are a cross-section of the shard. Placed by class and launched in block order the
+    // shard would be swept class by class: first every CU holds 3-slot waves (short, bandwidth-hungry), at the end every CU
+    // holds 7-slot waves (three per SIMD, long, instruction- and latency-bound under rollover): 98 us instead of 85-90 for
+    // config 5. (A fixed `(w % ways) * per_way + w / ways` deal was the first form: as good while the parts coincide with the
+    // classes -- 3, 9, 12, 30 parts of three equal classes: 85 us --, worse than no deal at all when they do not -- 4 parts:
+    // 107 us; profiles/calls/gpu_r04_f.sh, gpu_r04_i.sh.)
+    const u32 *order;
 };
 // The kernel's arguments as ONE struct, so that a body can find them in the kernarg segment by itself (below).
 struct RgClassArgs {
@@ -230,13 +233,11 @@ template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(IX g) {
 #endif
 }
 template <int P, typename IX, bool NTM> __global__ RG_TICK_BOUNDS void k_tick_classes(RgClassArgs a) {
-    const u32 w = blockIdx.x, ways = a.cls.ways;
-    const u32 blk = ways > 1 ? (w % ways) * a.cls.per_way + w / ways : w; // (scalar)
+    const u32 e = a.cls.order[blockIdx.x]; // (scalar: blockIdx is uniform -- one s_load_dword)
+    const u32 blk = e & 0x0fffffffu, np = e >> 28;
     const u64 g64 = (u64)blk * RG_BLOCK + threadIdx.x;
     if (g64 >= a.st.G) return;
     const IX g = (IX)g64;
-    // (scalar: the block index is uniform, so this is one s_load_dword of the word that holds the block's byte)
-    const u32 np = (a.cls.need[blk >> 2] >> (8u * (blk & 3u))) & 0xffu;
     if (P > 3 && np <= 3) rg_lane_body<3, IX, NTM>(g);
     else if (P > 5 && np <= 5) rg_lane_body<5, IX, NTM>(g);
     else if (P > 7 && np <= 7) rg_lane_body<7, IX, NTM>(g);
@@ -1146,7 +1147,7 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
 }
 template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool ntm, const RgClasses &cls) {
     if constexpr (P >= 4) {
-        const dim3 grid(cls.ways > 1 ? cls.ways * cls.per_way : rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
+        const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
         RgClassArgs a;
         a.st = st;
         a.ms = ms;
