@@ -93,6 +93,11 @@ template <typename T, typename IX> RG_HD T &rg_at(T *base, IX i) {
     }
 }
 
+RG_HD void rg_swap64(u64 &a, u64 &b) {
+    const u64 t = a;
+    a = b;
+    b = t;
+}
 RG_HD u64 rg_min(u64 a, u64 b) { return a < b ? a : b; }
 RG_HD u64 rg_max(u64 a, u64 b) { return a > b ? a : b; }
 

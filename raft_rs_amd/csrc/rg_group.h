@@ -1015,14 +1015,22 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
 
     // One step of the sequential replay: slot S's accepted ack lands, Raft::maybe_commit runs. The quorum index is carried
     // from step to step (RgRunningQuorum); groups with group commit on take the literal evaluation (GC kernels only).
-    template <int S> RG_HD void replay_slot(RgQuorum<P> &qm, RgRunningQuorum<P> &run, u64 (&cur)[P], u64 &commit) {
+    // The replay walks the matches IN PLACE: before it r.mt / r.mi of every accepted slot are swapped (r.mt = the matches as
+    // they were before the tick, r.mi = the acked values), each step swaps its slot back, so at the end r.mt holds the new
+    // matches and r.mi the parked old ones again -- no second copy of the matches in registers (P u64 less in the region
+    // that carries the running quorum state as well).
+    template <int S> RG_HD void replay_slot(RgQuorum<P> &qm, RgRunningQuorum<P> &run, u64 &commit) {
         if (!((acc >> S) & 1u)) return;
-        cur[S] = r.mt[S];
+        {
+            const u64 old = r.mt[S];
+            r.mt[S] = r.mi[S];
+            r.mi[S] = old;
+        }
         u64 mci;
         if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
-            mci = mci_of(qm, cur);
+            mci = mci_of(qm, r.mt);
         } else {
-            run.template raise<S>(cur, r.mi[S]); // (maybe_update parked the matched index this ack replaced there)
+            run.template raise<S>(r.mt, r.mi[S]); // (the matched index this ack replaced)
             mci = run.mci();
         }
         // last_index as it was when this message was processed: the leader's APPEND lands at its own slot
@@ -1072,13 +1080,13 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
             }
         }
         if (replay) {
-            u64 cur[P];
-            ((cur[S] = ((acc >> S) & 1u) ? r.mi[S] : r.mt[S]), ...); // (maybe_update parked the old matches)
-            qm.init(cur);
+            // (maybe_update parked the old matches in r.mi: swap them in, the replay swaps them back slot by slot)
+            ((((acc >> S) & 1u) ? (void)rg_swap64(r.mt[S], r.mi[S]) : (void)0), ...);
+            qm.init(r.mt);
             RgRunningQuorum<P> run;
-            run.init(qm, cur, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg));
+            run.init(qm, r.mt, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg));
             u64 commit = commit0;
-            (replay_slot<S>(qm, run, cur, commit), ...);
+            (replay_slot<S>(qm, run, commit), ...);
             r.commit = commit;
         }
         if (r.commit != commit0) {
