@@ -317,7 +317,9 @@ int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slo
  * names every slot -- sizes interleaved --, group commit on, the LDS / compact variants, an engine beyond 32-bit cell
  * offsets, RG_COL_CFG's device pointer handed out through rg_column_ptr). Results never depend on it.
  * This call reports what the next dense tick will use, as ranges of equal blocks: *n = number of ranges (0 = the plain
- * kernel; it may exceed cap), out[k] for k < cap. */
+ * kernel; it may exceed cap), out[k] for k < cap. Re-deriving synchronises, so it cannot happen inside a stream capture: a
+ * tick captured into a hipGraph while RG_COL_CFG has changed since the last derivation runs the plain kernel -- call this
+ * (or run one tick) before the capture begins. */
 typedef struct {
     uint64_t first_group, n_groups;
     uint32_t n_slots; /* slots the groups of the range use at most */

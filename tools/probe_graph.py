@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Can a stream of rg_tick_device launches be captured into a hipGraph and replayed? (torch.cuda.graph drives
 hipStreamBeginCapture / hipGraphLaunch; the engine runs on the capture stream.) Small shards, where a tick is shorter than a
-launch: K recorded ticks eagerly vs as one graph replay. Usage: python tools/probe_graph.py [groups] [ticks]"""
+launch: K recorded ticks eagerly vs as one graph replay. Usage: python tools/probe_graph.py [groups] [ticks] [classes]
+(`classes`: BASELINE config 5 placed by replica-set size class in a 7-slot engine -- the captured launches are k_tick_classes)"""
 import os
 import sys
 import time
@@ -15,11 +16,12 @@ import raft_rs_amd as rg  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-P = 5
+PLACED = len(sys.argv) > 3 and sys.argv[3] == "classes"
+P, WL = (7, 5) if PLACED else (5, 2)
 side = torch.cuda.Stream()
 eng = rg.Engine(G, P)
 eng.set_stream(side.cuda_stream)
-eng.workload_init(2)
+eng.workload_init(WL, sorted_classes=PLACED)
 cols = [torch.empty((K, P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
 flags = torch.empty((K, G, 8), dtype=torch.uint8, device="cuda")
 
@@ -30,7 +32,7 @@ def ptrs(t):
 
 eng.checkpoint()
 for t in range(K):  # record the stream from the evolving state
-    eng.workload_gen(2, t, *ptrs(t))
+    eng.workload_gen(WL, t, *ptrs(t), sorted_classes=PLACED)
     eng.tick_device(*ptrs(t))
 eng.sync()
 ref = eng.results()
@@ -60,6 +62,10 @@ assert np.array_equal(c, ref[0]) and np.array_equal(o, ref[1])
 
 eng.restore()
 eng.sync()
+if PLACED:
+    # rg_restore brought RG_COL_CFG back, so the size classes are re-derived by the next dense tick -- a synchronising step that
+    # cannot run inside a capture (a captured tick of a stale engine takes the plain kernel): ask for them first
+    assert [q for _, _, q in eng.size_classes()] == [3, 5, 7]
 graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph, stream=side):
     eager()
@@ -80,6 +86,6 @@ assert np.array_equal(c, ref[0]) and np.array_equal(o, ref[1])
 st = eng.read_state()
 for k in ("match", "next", "pr_commit", "commit", "pflags"):
     assert np.array_equal(st[k], ref_state[k]), k
-print(f"{G} groups x {P} peers, {K} ticks: eager {us_eager:.1f} us ({us_eager / K:.2f} us per tick), "
+print(f"{G} groups x {P} {'slots, placed by size class' if PLACED else 'peers'}, {K} ticks: eager {us_eager:.1f} us ({us_eager / K:.2f} us per tick), "
       f"one hipGraph replay {us_graph:.1f} us ({us_graph / K:.2f} us per tick); results identical")
 print("GRAPH_OK")
