@@ -486,6 +486,22 @@ def scenario_send_append_for_progress(B):
         assert ld.propose() == []
 
 
+def scenario_progress_paused(B):
+    """test_raft.rs:349-366 test_progress_paused: a fresh leader of {1, 2} (become_leader: the follower is in Probe at
+    next = last_index + 1, its own noop appended) takes three MsgPropose in a row -- read_messages() holds ONE MsgAppend: the
+    first proposal's bcast_append probes, Progress::update_state pauses the peer (progress.rs:238), the other two find it paused."""
+    ld = B(1, 1, [1, 2], log=[(1, 1)], committed=0, next_idx=1, max_inflight=256)
+    ld.set_progress(1, match=1, next=2, state=REPLICATE)
+    ld.set_progress(2, match=0, next=1, state=PROBE, paused=False)
+    ms = []
+    for _ in range(3):
+        ms += ld.propose()
+    assert len(ms) == 1 and ms[0][0] == 2, ms
+    assert ms[0][2] == 0 and ms[0][3] == 2, "prev_index 0, the noop and the first proposal in one message"
+    pr = ld.progress(2)
+    assert pr["paused"] and pr["next"] == 1
+
+
 def scenario_progress_flow_control(B):
     """test_raft.rs:369-435 test_progress_flow_control: max_inflight_msgs = 3, max_size_per_msg = 2048 with
     1000-byte proposals = two entries per MsgAppend. Probe sends one message; its ack switches to Replicate and
@@ -690,7 +706,7 @@ def scenario_unreachable_resets_the_window(B, cap=4):
 
 
 FLOW = [scenario_unreachable_resets_the_window, scenario_leader_start_replication, scenario_request_snapshot_unavailable, scenario_request_snapshot_through_send_path, scenario_sending_snapshot_set_pending_snapshot, scenario_leader_increase_next, scenario_skip_bcast_commit, scenario_progress_flow_control, scenario_progress_flow_control_bytes, scenario_msg_append_response_wait_reset, scenario_msg_app_flow_control_full, scenario_msg_app_flow_control_move_forward,
-        scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress]
+        scenario_msg_app_flow_control_recv_heartbeat, scenario_send_append_for_progress, scenario_progress_paused]
 
 ALL = [scenario_test_commit, scenario_test_group_commit, scenario_test_group_commit_consistent,
        scenario_test_leader_append_response, scenario_leader_only_commits_log_from_current_term,

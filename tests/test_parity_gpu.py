@@ -57,20 +57,27 @@ def test_workload_stream_matches_oracle(rg, variant, workload, n_slots):
     eng.close()
 
 
-def test_device_generator_equals_host_generator(rg):
+@pytest.mark.parametrize("P,placed", [(5, False), (7, True)])
+def test_device_generator_equals_host_generator(rg, P, placed):
+    """The synthetic stream on the device (what bench.py records) and its host twin (what the parity tests feed the oracle),
+    interleaved sizes and groups placed by size class (RG_WL_PLACE_SORTED), the initial state through the host twin as well."""
     import torch
-    G, P = 5000, 5
+    G = 5000
     eng = rg.Engine(G, P)
-    eng.workload_init(5)
+    eng.workload_init(5, sorted_classes=placed)
     st = eng.read_state()
+    st_h = O.alloc_state(G, P)
+    from raft_rs_amd import engine as E0
+    E0.workload_init_host(st_h, 5, sorted_classes=placed)
+    assert not fuzz.diff_states(st_h, st, G, P), "rg_workload_init_host builds the state rg_workload_init builds"
     dev = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
     dflags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
     from raft_rs_amd import engine as E
     host = rg.MsgBuffers(G, P, eng.stride)
     for t in range(3):
-        eng.workload_gen(5, t, *[d.data_ptr() for d in dev], dflags.data_ptr())
+        eng.workload_gen(5, t, *[d.data_ptr() for d in dev], dflags.data_ptr(), sorted_classes=placed)
         eng.sync()
-        E.workload_gen_host(st, host, 5, t)
+        E.workload_gen_host(st, host, 5, t, sorted_classes=placed)
         present = (st["cfg"] >> 24) & 0xff
         for name, d in zip(("m_index", "m_commit", "m_hint", "m_rs"), dev):
             got = d.cpu().numpy().view(np.uint64)
