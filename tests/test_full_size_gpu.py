@@ -23,11 +23,13 @@ TERM = 5  # RG_WL_TERM0 of the generator
 MSG_KEYS = ("m_index", "m_commit", "m_hint", "m_rs")
 
 
-def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_peers=0, variant=0):
+def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_peers=0, variant=0, placed=False):
     import torch
     threads = os.cpu_count() or 8
     eng = rg.Engine(n_groups, n_slots, variant=variant)
-    eng.workload_init(workload, first_group=first_group, fixed_peers=fixed_peers)
+    eng.workload_init(workload, first_group=first_group, fixed_peers=fixed_peers, sorted_classes=placed)
+    if placed:  # three ranges, one launch per tick (k_tick_classes)
+        assert [q for _, _, q in eng.size_classes()] == [3, 5, 7]
     st = eng.read_state()
     cl = O.Cluster(n_groups)
     cl.load_soa(st, term=TERM)
@@ -38,7 +40,7 @@ def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_
     seen = {"changed": 0, "rejects": 0, "elections": 0, "valid": 0}
     for t in range(ticks):
         eng.workload_gen(workload, t, *[d.data_ptr() for d in dev], dflags.data_ptr(), first_group=first_group,
-                         fixed_peers=fixed_peers)
+                         fixed_peers=fixed_peers, sorted_classes=placed)
         eng.sync()
         for k, d in zip(MSG_KEYS, dev):
             msgs[k] = np.ascontiguousarray(d.cpu().numpy().view(np.uint64))
@@ -79,6 +81,14 @@ def test_one_million_groups_match_the_oracle(rg, workload, n_slots, name):
 def test_config5_one_engine_matches_the_oracle(rg):
     """1 M groups of 3 / 5 / 7 peers interleaved in one 7-slot engine, elections on every tick."""
     seen = _run_full_size(rg, 5, 1_000_000, 7, ticks=5)
+    assert seen["elections"] > 5 * 1_000_000 / 32 * 0.9 and seen["rejects"] > 300_000, seen
+
+
+def test_config5_placed_by_size_class_one_launch_matches_the_oracle(rg):
+    """bench.py --workload 5 --slots 7 --sorted: the same 1 M groups placed by replica-set size class in ONE 7-slot engine,
+    one launch per tick whose blocks run the tick instantiated for 3, 5 or 7 slots (k_tick_classes): every group, every
+    column, five ticks of the rollover stream."""
+    seen = _run_full_size(rg, 5, 1_000_000, 7, ticks=5, placed=True)
     assert seen["elections"] > 5 * 1_000_000 / 32 * 0.9 and seen["rejects"] > 300_000, seen
 
 
