@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 4, final evidence on build 184bf12: the whole GPU suite, smoke(), the driver's bench command, the secondary configurations
+# Round 4, final evidence on build d35d657: the whole GPU suite, smoke(), the driver's bench command, the secondary configurations
 set -u
 cd $GRAFT_REPO_ROOT
 R=$PWD
 O=$R/gpurun_out/r04z
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-echo 184bf12 > $O/build_commit.txt
+echo d35d657 > $O/build_commit.txt
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep "passed\|failed\|error" | tail -3 > $O/tests_gpu.txt
 cat $O/tests_gpu.txt
 timeout 300 python -c "import __graft_entry__ as e; e.smoke(); print('SMOKE_OK')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
@@ -23,12 +23,13 @@ for cfg in "" "--slots 7"; do
 done
 BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 --groups 500000 --no-cpu-baseline >> $O/bench_dist_share2.jsonl 2>> $O/bench_dist.err
 ls $O
-python - <<'PY'
+python - <<"PY" || true
 import json
 d=json.loads(open('gpurun_out/r04z/bench_n1.json').read().strip().splitlines()[-1])
 print(d['value']/1e9, d['ms_per_step']*1e3, d['roofline']['frac'])
 for k,v in d['roofline']['by_config'].items(): print(k, v.get('frac'), v.get('us'))
 for f in ('gpurun_out/r04z/bench_dist_ws1.jsonl','gpurun_out/r04z/bench_dist_share2.jsonl'):
     for l in open(f):
+        if not l.startswith('{"metric"'): continue
         d=json.loads(l); c=d['config']; print(f[-22:], d['n_gpus'], round(d['ms_per_step']*1e3,1), c.get('publish_every'), c.get('publish_every_auto'))
 PY
