@@ -1533,16 +1533,6 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
     // needed when some group has ProgressTracker.group_commit set
     const u32 variant = ((h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
                              ? h->cfg.variant : RG_VARIANT_LANE) | (h->nt_msgs ? RG_VARIANT_NT_MSGS : 0u);
-#ifdef RG_CPT_MEASURE /* measurement builds only: see k_tick_compact */
-    RgState st_m = h->st;
-    if (!st_m.pub) {
-        const char *e = getenv("RG_MEASURE_DROP");
-        st_m.pub_cap = e ? (u32)atoi(e) : 0u;
-    }
-#define RG_TICK_STATE st_m
-#else
-#define RG_TICK_STATE h->st
-#endif
     // a class-placed shard (replica sets of different sizes in contiguous ranges): ONE launch whose blocks run the tick
     // instantiated for the slots their groups have (k_tick_classes). Lane variant, no group commit, 32-bit cell offsets.
     if ((variant & ~RG_VARIANT_NT_MSGS) == RG_VARIANT_LANE && !h->any_group_commit && h->P >= 4 && !h->cls_off && rg_ix32(h->st, h->P)) {
@@ -1559,11 +1549,11 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             RgClasses cls;
             cls.order = h->cls_order;
             switch (h->P) {
-            case 4: rg_launch_tick_classes_t<4>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
-            case 5: rg_launch_tick_classes_t<5>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
-            case 6: rg_launch_tick_classes_t<6>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
-            case 7: rg_launch_tick_classes_t<7>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
-            default: rg_launch_tick_classes_t<8>(h->stream, RG_TICK_STATE, ms, h->nt_msgs, cls); break;
+            case 4: rg_launch_tick_classes_t<4>(h->stream, h->st, ms, h->nt_msgs, cls); break;
+            case 5: rg_launch_tick_classes_t<5>(h->stream, h->st, ms, h->nt_msgs, cls); break;
+            case 6: rg_launch_tick_classes_t<6>(h->stream, h->st, ms, h->nt_msgs, cls); break;
+            case 7: rg_launch_tick_classes_t<7>(h->stream, h->st, ms, h->nt_msgs, cls); break;
+            default: rg_launch_tick_classes_t<8>(h->stream, h->st, ms, h->nt_msgs, cls); break;
             }
             hipError_t ce = hipGetLastError();
             if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));
@@ -1576,14 +1566,14 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
         }
     }
     switch (h->P) {
-    case 1: rg_launch_tick_t<1>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    case 2: rg_launch_tick_t<2>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    case 3: rg_launch_tick_t<3>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    case 4: rg_launch_tick_t<4>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    case 5: rg_launch_tick_t<5>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    case 6: rg_launch_tick_t<6>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    case 7: rg_launch_tick_t<7>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
-    default: rg_launch_tick_t<8>(h->stream, RG_TICK_STATE, ms, variant, h->any_group_commit); break;
+    case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 3: rg_launch_tick_t<3>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 4: rg_launch_tick_t<4>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 5: rg_launch_tick_t<5>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 6: rg_launch_tick_t<6>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    case 7: rg_launch_tick_t<7>(h->stream, h->st, ms, variant, h->any_group_commit); break;
+    default: rg_launch_tick_t<8>(h->stream, h->st, ms, variant, h->any_group_commit); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));

@@ -532,22 +532,6 @@ __global__ RG_CPT_BOUNDS void k_tick_compact(RgState st, RgMsgs ms) {
     if (valid) rg_load_group<P, RG_NX_PREFETCH, IX>(r, st, ms, (IX)g64);
     rg_lds_barrier(); // the counters are zero
     const bool rare = valid && rg_is_rare(r.mf, r.pf, r.cfg, P);
-#if defined(RG_CPT_MEASURE) && defined(__HIP_DEVICE_COMPILE__)
-    // measurement builds only (results wrong): RG_MEASURE_DROP=1 in the environment makes the rare lanes leave here,
-    // 2 the steady ones -- what each class costs on its own (rg_tick_impl passes the value in the unused pub_cap)
-    if (!st.pub && st.pub_cap) {
-        const u32 mode = st.pub_cap;
-        if (mode == 1 ? rare : !rare) return;
-        if (mode >= 3) { // only ONE kind of rare group stays (in place): 3 elections, 4 rejects, 5 Probe / Snapshot acks, 6 full windows
-            const u64 L = 0x0101010101010101ULL;
-            const u64 v = r.mf & L, rj = (r.mf >> 1) & L, fl = ((r.mf >> 3) | (r.pf >> 4)) & L;
-            const u64 nr = ((r.pf & L) ^ L) | ((r.pf >> 1) & L);
-            const bool e = rg_has_election(r.mf, r.cfg, P);
-            const bool kr = !e && (v & rj) != 0, kt = !e && !kr && (v & nr) != 0, kf = !e && !kr && !kt && (v & fl) != 0;
-            if (!(mode == 3 ? e : mode == 4 ? kr : mode == 5 ? kt : kf)) return;
-        }
-    }
-#endif
     const bool cand = wave == wd ? (valid && !rare) : rare;
 #if defined(__HIP_DEVICE_COMPILE__)
     const u64 bal = __ballot(cand);
