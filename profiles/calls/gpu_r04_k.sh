@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, call k: is the slow mode of k_tick_send a matter of where the work-item columns sit relative to the window columns?
+# (the RG_SEND_PAD hook -- a padding in front of the work-item columns, read in rg_create -- existed only in the build of this call)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04k
 O=gpurun_out/r04k/pad.txt; : > $O
