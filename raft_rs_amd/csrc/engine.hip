@@ -902,6 +902,7 @@ struct rg_engine {
     bool cls_stale;    // RG_COL_CFG may have changed since the bytes were derived
     bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
+    bool nt_all;       // ... and the state columns, loads and stores: the state ALONE is far beyond the cache
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
     u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
@@ -1113,6 +1114,19 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     // (with the Inflights on the device a step also touches the window and work-item columns: 40 P B per group more)
     h->nt_msgs = (double)h->G * (double)(40u * h->P + 48u + (cfg->max_inflight ? 40u * h->P : 0u)) > 256.0 * 1024.0 * 1024.0;
     if (const char *e = getenv("RG_NT_MSGS")) h->nt_msgs = atoi(e) != 0; // (measurement hook)
+    // The third regime: the state a dense tick re-reads (24 P + 40 B per group) alone is more than 1.5 x the Infinity Cache --
+    // by the time a launch comes back to a line the cache has turned over, so allocating there only costs. Everything is then
+    // streamed, loads and stores. The window is measured (profiles/r04_nt_state.txt, 5 slots): it pays from 2.4 M groups
+    // (384 MB of state: 153 -> 148 us) through 8 M (528 -> 483, fraction 0.68 -> 0.75) to 12 M (803 -> 778); below it a
+    // good part of the state still survives from launch to launch (2 M: 106 -> 126), and from 16 M groups (2.5 GB of state) on
+    // the plain accesses are the faster ones again (1034-1067 -> 1085-1135 us), so the regime has an upper end as well.
+    // RG_NT_ALL: test / measurement hook.
+    {
+        const double state = (double)h->G * (double)(24u * h->P + 40u), mall = 256.0 * 1024.0 * 1024.0;
+        h->nt_all = !cfg->max_inflight && state > 1.5 * mall && state <= 7.5 * mall;
+    }
+    if (const char *e = getenv("RG_NT_ALL")) h->nt_all = atoi(e) != 0;
+    if (h->nt_all) h->nt_msgs = true;
     h->send_bound = 0;
     h->pin_send = nullptr;
     h->host_items_valid = false;
@@ -1532,10 +1546,10 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
     const u32 variant = ((h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
-                             ? h->cfg.variant : RG_VARIANT_LANE) | (h->nt_msgs ? RG_VARIANT_NT_MSGS : 0u);
+                             ? h->cfg.variant : RG_VARIANT_LANE) | (h->nt_msgs ? RG_VARIANT_NT_MSGS : 0u) | (h->nt_all ? RG_VARIANT_NT_ALL : 0u);
     // a class-placed shard (replica sets of different sizes in contiguous ranges): ONE launch whose blocks run the tick
     // instantiated for the slots their groups have (k_tick_classes). Lane variant, no group commit, 32-bit cell offsets.
-    if ((variant & ~RG_VARIANT_NT_MSGS) == RG_VARIANT_LANE && !h->any_group_commit && h->P >= 4 && !h->cls_off && rg_ix32(h->st, h->P)) {
+    if ((variant & ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL)) == RG_VARIANT_LANE && !h->any_group_commit && h->P >= 4 && !h->cls_off && rg_ix32(h->st, h->P)) {
         if (h->cls_stale) {
             // (the refresh synchronises: not inside a stream capture -- a captured tick of a stale engine takes the plain kernel)
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1549,11 +1563,11 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             RgClasses cls;
             cls.order = h->cls_order;
             switch (h->P) {
-            case 4: rg_launch_tick_classes_t<4>(h->stream, h->st, ms, h->nt_msgs, cls); break;
-            case 5: rg_launch_tick_classes_t<5>(h->stream, h->st, ms, h->nt_msgs, cls); break;
-            case 6: rg_launch_tick_classes_t<6>(h->stream, h->st, ms, h->nt_msgs, cls); break;
-            case 7: rg_launch_tick_classes_t<7>(h->stream, h->st, ms, h->nt_msgs, cls); break;
-            default: rg_launch_tick_classes_t<8>(h->stream, h->st, ms, h->nt_msgs, cls); break;
+            case 4: rg_launch_tick_classes_t<4>(h->stream, h->st, ms, h->nt_all ? 2 : h->nt_msgs ? 1 : 0, cls); break;
+            case 5: rg_launch_tick_classes_t<5>(h->stream, h->st, ms, h->nt_all ? 2 : h->nt_msgs ? 1 : 0, cls); break;
+            case 6: rg_launch_tick_classes_t<6>(h->stream, h->st, ms, h->nt_all ? 2 : h->nt_msgs ? 1 : 0, cls); break;
+            case 7: rg_launch_tick_classes_t<7>(h->stream, h->st, ms, h->nt_all ? 2 : h->nt_msgs ? 1 : 0, cls); break;
+            default: rg_launch_tick_classes_t<8>(h->stream, h->st, ms, h->nt_all ? 2 : h->nt_msgs ? 1 : 0, cls); break;
             }
             hipError_t ce = hipGetLastError();
             if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));

@@ -37,12 +37,14 @@
 // bit5: the lane kernels rewrite a slot's `matched` / `committed_index` cell in EVERY lane of a wave as soon as one lane
 // changed it (both are in registers anyway): whole 128-B lines instead of lane-masked ones (tools/microbench/send_shape.hip)
 #define RG_OPT_WAVE_ST (RG_OPT & 32)
-template <typename T> RG_HD void rg_st(T &dst, T v, bool nt) {
+// (NT is a TEMPLATE argument on purpose: as a function argument the two stores of `nt ? nontemporal : plain` are merged into one
+// plain store when this function is simplified on its own, before it is inlined and the flag folds -- which of the two happens
+// first depends on what else the translation unit holds; round 4 found the kernels of tick_inst.hip without a single `nt` store)
+template <bool NT, typename T> RG_HD void rg_st(T &dst, T v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (nt) __builtin_nontemporal_store(v, &dst);
+    if constexpr (NT) __builtin_nontemporal_store(v, &dst);
     else dst = v;
 #else
-    (void)nt;
     dst = v;
 #endif
 }
@@ -77,22 +79,26 @@ template <bool NTM = (RG_OPT_NT_MSG != 0), typename T> RG_HD T rg_ld_stream(cons
 
 // The flag rows and the cfg word go first: rg_prefetch_rare decides from them alone, so its loads can be issued
 // while the bulk loads below are still in flight (memory returns a wave's loads in order).
-template <int P, int NXM, typename IX, bool NTM = (RG_OPT_NT_MSG != 0)>
+// NTS: the STATE columns streamed as well (loads here, stores in rg_store_group) -- the third memory regime, for engines whose
+// state alone is far beyond the Infinity Cache: nothing a launch touches is touched again before the cache has turned over,
+// so nothing should be allocated there. Only together do the two halves pay (8 M x 5, one box: loads alone 525 -> 616 us,
+// stores alone 534, both 485: profiles/r04_nt_state.txt).
+template <int P, int NXM, typename IX, bool NTM = (RG_OPT_NT_MSG != 0), bool NTS = false>
 RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
     constexpr bool LOAD_NX = NXM == RG_NX_LOADED;
     r.mf = rg_ld_stream<NTM>(&rg_at(ms.mflags, g));
-    r.pf = rg_at(st.pflags, g);
-    r.cfg = rg_at(st.cfg, g);
-    r.commit = rg_at(st.commit, g);
-    r.lo = rg_at(st.lo, g);
-    r.hi = rg_at(st.hi, g);
+    r.pf = rg_ld_stream<NTS>(&rg_at(st.pflags, g));
+    r.cfg = rg_ld_stream<NTS>(&rg_at(st.cfg, g));
+    r.commit = rg_ld_stream<NTS>(&rg_at(st.commit, g));
+    r.lo = rg_ld_stream<NTS>(&rg_at(st.lo, g));
+    r.hi = rg_ld_stream<NTS>(&rg_at(st.hi, g));
     r.adv = rg_pub_load(st, g);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const IX o = (IX)p * (IX)st.stride + g;
-        r.mt[p] = rg_at(st.match, o);
+        r.mt[p] = rg_ld_stream<NTS>(&rg_at(st.match, o));
         if (LOAD_NX) r.nx[p] = rg_at(st.next, o);
-        r.pc[p] = rg_at(st.prc, o);
+        r.pc[p] = rg_ld_stream<NTS>(&rg_at(st.prc, o));
         r.mi[p] = rg_ld_stream<NTM>(&rg_at(ms.mi, o));
         r.mc[p] = rg_ld_stream<NTM>(&rg_at(ms.mc, o));
     }
@@ -102,7 +108,7 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
 // WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
 // stage, which changes both; every other caller stores the group in one go).
 // WAVE_ST (kernels whose lanes hold CONSECUTIVE groups, all lanes of the wave arriving here together): RG_OPT_WAVE_ST
-template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false>
+template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false, bool NTS = false>
 RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
@@ -123,9 +129,9 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const IX o = (IX)p * (IX)st.stride + g;
-        if ((WHICH & 1) && (d & (1u << p))) rg_st(rg_at(st.match, o), r.mt[p], RG_OPT_NT_ALL != 0);
-        if ((WHICH & 2) && (d & (1u << (8 + p)))) rg_st(rg_at(st.next, o), r.nx[p], (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
-        if ((WHICH & 1) && (d & (1u << (16 + p)))) rg_st(rg_at(st.prc, o), r.pc[p], RG_OPT_NT_ALL != 0);
+        if ((WHICH & 1) && (d & (1u << p))) rg_st<(RG_OPT_NT_ALL != 0 || NTS)>(rg_at(st.match, o), r.mt[p]);
+        if ((WHICH & 2) && (d & (1u << (8 + p)))) rg_st<((RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0 || NTS)>(rg_at(st.next, o), r.nx[p]);
+        if ((WHICH & 1) && (d & (1u << (16 + p)))) rg_st<(RG_OPT_NT_ALL != 0 || NTS)>(rg_at(st.prc, o), r.pc[p]);
     }
     if ((WHICH & 2) && (d & RG_DIRTY_PF)) rg_at(st.pflags, g) = r.pf;
     if (WHICH & 1) {
@@ -134,7 +140,7 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
             rg_at(st.commit, g) = r.commit;
         }
         if (d & RG_DIRTY_HI) rg_at(st.hi, g) = r.hi;
-        rg_st(rg_at(st.out, g), r.out, (RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0);
+        rg_st<((RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0 || NTS)>(rg_at(st.out, g), r.out);
     }
     // (an election's own stores go with part 2: k_tick_send runs its stage -- on the registers, it reads neither term_lo nor the
     // cfg word nor the table from memory -- between the two parts, where the kernel is at the limit of its scalar registers)
@@ -146,8 +152,9 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
 
 template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u64 &cfg_adv, F &&f);
 // IX = u32 when every cell of the engine's columns lies within 4 GiB of its column's start (rg_launch_tick_t decides).
-// NTM: the read-once message columns as non-temporal loads (rg_ld_stream; decided per launch from the engine's footprint)
-template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
+// NTM: 1 = the read-once message columns as non-temporal loads (rg_ld_stream), 2 = the state columns as well, loads and stores
+// (rg_load_group: NTS); decided per launch from the engine's footprint (rg_create)
+template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
@@ -156,7 +163,7 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
     asm volatile("" ::"v"((u32)(uintptr_t)&occ_pad[threadIdx.x]));
 #endif
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, IX, NTM || (RG_OPT_NT_MSG != 0)>(r, st, ms, g);
+    rg_load_group<P, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2>(r, st, ms, g);
 #if defined(RG_LANE_FENCE) && defined(__HIP_DEVICE_COMPILE__) /* experiment: keep the compiler from interleaving the tick with the loads */
 #if RG_LANE_FENCE == 1
     asm volatile("" ::: "memory");
@@ -172,7 +179,7 @@ template <int P, bool GC, typename IX, bool NTM = false> __global__ RG_TICK_BOUN
 #endif
 #endif
     rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<P, IX, 3, true>(r, st, g);
+    rg_store_group<P, IX, 3, true, NTM == 2>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -219,7 +226,7 @@ struct RgClassArgs {
 // whichever body runs; what does not fit the scalar registers there is spilled to VGPR lanes for good and read back at every
 // use -- 1 500 v_readlane / v_writelane in the code, ~250 executed per wave, in bodies (3 and 5 slots) that compiled on their
 // own spill nothing. A scalar load that hits the constant cache costs the VALU nothing.
-template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(IX g) {
+template <int Q, typename IX, int NTM> RG_D void rg_lane_body(IX g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) RgClassArgs *KArgs;
     KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -227,12 +234,12 @@ template <int Q, typename IX, bool NTM> RG_D void rg_lane_body(IX g) {
     const RgState st = ka->st;
     const RgMsgs ms = ka->ms;
     RgGroup<Q> r;
-    rg_load_group<Q, RG_LANE_NX, IX, NTM || (RG_OPT_NT_MSG != 0)>(r, st, ms, g);
+    rg_load_group<Q, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2>(r, st, ms, g);
     rg_group_tick<Q, false, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<Q, IX, 3, true>(r, st, g);
+    rg_store_group<Q, IX, 3, true, NTM == 2>(r, st, g);
 #endif
 }
-template <int P, typename IX, bool NTM> __global__ RG_TICK_BOUNDS void k_tick_classes(RgClassArgs a) {
+template <int P, typename IX, int NTM> __global__ RG_TICK_BOUNDS void k_tick_classes(RgClassArgs a) {
     const u32 e = a.cls.order[blockIdx.x]; // (scalar: blockIdx is uniform -- one s_load_dword)
     const u32 blk = e & 0x0fffffffu, np = e >> 28;
     const u64 g64 = (u64)blk * RG_BLOCK + threadIdx.x;
@@ -339,7 +346,7 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
     for (int s = 0; s < P; s++) {
         const IX o = (IX)s * (IX)stride + g;
         const u32 nk = rg_send_nk<P>(it, s);
-        rg_st(rg_at(oc.n, o), nk, RG_SEND_NT_ITEMS != 0); // every cell, every stage: 0 = nothing for this peer
+        rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.n, o), nk); // every cell, every stage: 0 = nothing for this peer
         // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
         // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -348,8 +355,8 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
         const bool any = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
 #endif
         if (any) {
-            rg_st(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0, RG_SEND_NT_ITEMS != 0);
-            rg_st(rg_at(oc.last, o), nk ? it.last[s] : (u64)0, RG_SEND_NT_ITEMS != 0);
+            rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0);
+            rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.last, o), nk ? it.last[s] : (u64)0);
         }
     }
 }
@@ -1053,10 +1060,11 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-#define RG_VARIANT_NT_MSGS 0x100u /* engine-internal flag on the variant word: stream the message columns (k_tick_lane<.., NTM>) */
+#define RG_VARIANT_NT_MSGS 0x100u /* engine-internal flag on the variant word: stream the message columns (k_tick_lane<.., NTM = 1>) */
+#define RG_VARIANT_NT_ALL 0x200u  /* ... and the state columns, loads and stores (NTM = 2): engines far beyond the Infinity Cache */
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
 // the lane kernel over a class-placed engine (no group commit, 32-bit cell offsets: the caller checks both); P >= 4
-template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool ntm, const RgClasses &cls);
+template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, int ntm, const RgClasses &cls);
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo);
@@ -1099,14 +1107,16 @@ void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs
 // (the group-commit instantiation has no streaming twin: it is the rare kernel and twice the code)
 #define RG_LAUNCH_LANE(IXT)                                                                                                       \
     do {                                                                                                                          \
-        if (ntm && !GC)                                                                                                           \
-            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, !GC>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+        if (ntm == 2 && !GC)                                                                                                      \
+            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, GC ? 0 : 2>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+        else if (ntm && !GC)                                                                                                      \
+            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, GC ? 0 : 1>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
         else                                                                                                                      \
-            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, false>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, 0>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
     } while (0)
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
-    const bool ntm = (variant & RG_VARIANT_NT_MSGS) != 0;
-    variant &= ~RG_VARIANT_NT_MSGS;
+    const int ntm = (variant & RG_VARIANT_NT_ALL) ? 2 : (variant & RG_VARIANT_NT_MSGS) ? 1 : 0;
+    variant &= ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL);
     if (variant == RG_VARIANT_LDS) {
         hipLaunchKernelGGL((k_tick_lds<P, GC, false>), dim3(rg_grid_for(st.G, RG_LDS_BATCH * RG_LDS_WAVES)),
                            dim3(64 * RG_LDS_WAVES), 0, stream, st, ms);
@@ -1129,15 +1139,16 @@ template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, co
     if (gc) rg_launch_tick_gc<P, true>(stream, st, ms, variant);
     else rg_launch_tick_gc<P, false>(stream, st, ms, variant);
 }
-template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool ntm, const RgClasses &cls) {
+template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, int ntm, const RgClasses &cls) {
     if constexpr (P >= 4) {
         const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
         RgClassArgs a;
         a.st = st;
         a.ms = ms;
         a.cls = cls;
-        if (ntm) hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, false>), grid, block, 0, stream, a);
+        if (ntm == 2) hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 2>), grid, block, 0, stream, a);
+        else if (ntm) hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 0>), grid, block, 0, stream, a);
     }
 }
 template <int P>
@@ -1186,7 +1197,7 @@ void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &
 }
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<1>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1194,7 +1205,7 @@ extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<2>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1202,7 +1213,7 @@ extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<3>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1210,7 +1221,7 @@ extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<4>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1218,7 +1229,7 @@ extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<5>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1226,7 +1237,7 @@ extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<6>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1234,7 +1245,7 @@ extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<7>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1242,7 +1253,7 @@ extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, co
 extern template void rg_launch_flush_small_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
-extern template void rg_launch_tick_classes_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgClasses &);
+extern template void rg_launch_tick_classes_t<8>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);

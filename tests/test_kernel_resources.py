@@ -33,8 +33,13 @@ def _resource_usage(p):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         return None
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(ROOT, "raft_rs_amd", "csrc", "tick_inst.hip"),
-           "-o", os.devnull, "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage", f"-DRG_P={p}"]
+    import tempfile
+    asm = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    # device code only, as assembly: the remarks come from the same compile, and the text says which stores kept their
+    # non-temporal bit (test_streamed_stores_are_streamed)
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+           os.path.join(ROOT, "raft_rs_amd", "csrc", "tick_inst.hip"),
+           "-o", asm, "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage", f"-DRG_P={p}"]
     err = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True).stderr
     rows, cur = {}, None
     for line in err.splitlines():
@@ -47,13 +52,26 @@ def _resource_usage(p):
         elif cur is not None and ":" in txt:
             k, v = txt.split(":", 1)
             cur[k.strip()] = v.strip()
+    name = None
+    try:
+        with open(asm) as f:
+            for line in f:
+                m = re.match(r"(_Z\w+):", line)
+                if m:
+                    name = m.group(1)
+                elif name in rows and re.search(r"\bglobal_store_\w+ .* nt\b", line):
+                    rows[name]["nt stores"] = rows[name].get("nt stores", 0) + 1
+                elif name in rows and re.search(r"\bglobal_load_\w+ .* nt\b", line):
+                    rows[name]["nt loads"] = rows[name].get("nt loads", 0) + 1
+    finally:
+        os.unlink(asm)
     return rows
 
 
 def test_tick_kernels_keep_their_register_budget():
     rows = resource_usage(5)
-    lane = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLb0EE" in k)    # 32-bit cell offsets: what the bench runs
-    lane64 = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EmLb0EE" in k)  # engines beyond 4 GiB per column
+    lane = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLi0EE" in k)    # 32-bit cell offsets: what the bench runs
+    lane64 = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EmLi0EE" in k)  # engines beyond 4 GiB per column
     lst = next(v for k, v in rows.items() if "k_tick_listILi5ELb0E" in k)
     fused = next(v for k, v in rows.items() if "k_tick_fusedILi5ELb0E7rg_u32oE" in k)
     # the dense sweep is the bandwidth-bound kernel: 4 waves/SIMD. (Round 2 added the election event, the publication
@@ -61,8 +79,10 @@ def test_tick_kernels_keep_their_register_budget():
     # the `SGPR base + 32-bit offset` addressing of rg_at paid for their registers: profiles/r02_*.)
     assert int(lane["VGPRs"]) <= 128 and int(lane["Occupancy [waves/SIMD]"]) >= 4, lane
     assert int(lane64["Occupancy [waves/SIMD]"]) >= 3, lane64
-    lane_nt = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLb1EE" in k)  # message columns streamed (large engines)
+    lane_nt = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLi1EE" in k)  # message columns streamed (large engines)
     assert int(lane_nt["VGPRs"]) <= 128 and int(lane_nt["ScratchSize [bytes/lane]"]) == 0, lane_nt
+    lane_all = next(v for k, v in rows.items() if "k_tick_laneILi5ELb0EjLi2EE" in k)  # everything streamed (engines far beyond the cache)
+    assert int(lane_all["VGPRs"]) <= 128 and int(lane_all["ScratchSize [bytes/lane]"]) == 0, lane_all
     # the sparse-path kernel carries the list / result pointers on top; round 3 (the term-run table read from memory
     # behind the stores instead of prefetched into registers) brought it to 4 waves as well
     assert int(lst["VGPRs"]) <= 128 and int(lst["Occupancy [waves/SIMD]"]) >= 4, lst
@@ -79,7 +99,7 @@ def test_tick_kernels_keep_their_register_budget():
     # kernel's occupancy (its bodies do the same: the first form carried 1 566 spill-lane instructions)
     send = next(v for k, v in rows.items() if "k_tick_sendILi5ELb0EjE" in k)
     assert int(send["VGPRs"]) <= 128 and int(send["Occupancy [waves/SIMD]"]) >= 4 and int(send["ScratchSize [bytes/lane]"]) == 0, send
-    cls = next(v for k, v in rows.items() if "k_tick_classesILi5EjLb0EE" in k)
+    cls = next(v for k, v in rows.items() if "k_tick_classesILi5EjLi0EE" in k)
     assert int(cls["VGPRs"]) <= 128 and int(cls["Occupancy [waves/SIMD]"]) >= 4 and int(cls["ScratchSize [bytes/lane]"]) == 0, cls
 
 
@@ -87,11 +107,31 @@ def test_occupancy_of_the_other_slot_counts():
     # P = 3 runs at 5 waves/SIMD, P = 7 (config 4's shard) at 3
     for p, waves in ((3, 5), (7, 3)):
         rows = resource_usage(p)
-        lane = next(v for k, v in rows.items() if f"k_tick_laneILi{p}ELb0EjLb0EE" in k)
+        lane = next(v for k, v in rows.items() if f"k_tick_laneILi{p}ELb0EjLi0EE" in k)
         assert int(lane["Occupancy [waves/SIMD]"]) >= waves and int(lane["ScratchSize [bytes/lane]"]) == 0, (p, lane)
         for name in (f"k_tick_sendILi{p}ELb0EjE", f"k_tick_listILi{p}ELb0EjE"):  # no scratch at any slot count
             r = next(v for k, v in rows.items() if name in k)
             assert int(r["ScratchSize [bytes/lane]"]) == 0, (p, name, r)
     # config 5's one launch: the 7-slot body sets the allocation of every class -- three waves per SIMD, not two
-    cls7 = next(v for k, v in resource_usage(7).items() if "k_tick_classesILi7EjLb0EE" in k)
+    cls7 = next(v for k, v in resource_usage(7).items() if "k_tick_classesILi7EjLi0EE" in k)
     assert int(cls7["VGPRs"]) <= 168 and int(cls7["Occupancy [waves/SIMD]"]) >= 3 and int(cls7["ScratchSize [bytes/lane]"]) == 0, cls7
+
+
+def test_streamed_stores_are_streamed():
+    """The non-temporal bit of the stores the design streams is IN the ISA. Round 4 found it was not: rg_st took the choice as
+    a run-time bool that was constant at every call site, and after inlining LLVM merged the two stores of the if/else into
+    one plain store -- k_tick_send wrote its item columns through the cache since round 3 (the run-to-run bimodality of the
+    one-launch send form), and the first all-streamed build had streamed loads only (profiles/r04_nt_state.txt)."""
+    rows = resource_usage(5)
+    def one(tag):
+        return next(v for k, v in rows.items() if tag in k)
+    plain = one("k_tick_laneILi5ELb0EjLi0EE")
+    assert plain.get("nt stores", 0) == 0 and plain.get("nt loads", 0) == 0, plain
+    msgs = one("k_tick_laneILi5ELb0EjLi1EE")      # messages streamed: 11 loads (5 slots x 2 + the election word), no store
+    assert msgs.get("nt loads", 0) >= 11 and msgs.get("nt stores", 0) == 0, msgs
+    alls = one("k_tick_laneILi5ELb0EjLi2EE")      # everything streamed: every state store of the dense path (3 P + 1 at least)
+    assert alls.get("nt stores", 0) >= 16 and alls.get("nt loads", 0) >= 11 + 15, alls
+    cls = one("k_tick_classesILi5EjLi2EE")
+    assert cls.get("nt stores", 0) >= 16, cls
+    send = one("k_tick_sendILi5ELb0EjE")          # the item columns and the ring cells
+    assert send.get("nt stores", 0) >= 12, send

@@ -661,6 +661,29 @@ def test_random_streams_match_oracle_with_64bit_offsets(rg, force_ix64, n_slots)
     test_random_streams_match_oracle(rg, 5, n_slots)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the third memory regime (k_tick_lane / k_tick_classes <.., NTM = 2>: state columns streamed too, loads and stores) is what
+# engines far beyond the Infinity Cache run; RG_NT_ALL=1 at rg_create makes a small engine take it
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def force_nt_all():
+    os.environ["RG_NT_ALL"] = "1"
+    yield
+    os.environ.pop("RG_NT_ALL", None)
+
+
+@pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (3, 5), (5, 7)])
+def test_workload_stream_matches_oracle_with_everything_streamed(rg, force_nt_all, workload, n_slots):
+    test_workload_stream_matches_oracle(rg, 1, workload, n_slots)
+
+
+def test_random_and_class_placed_streams_with_everything_streamed(rg, force_nt_all):
+    for n_slots in (4, 7, 8):
+        test_random_streams_match_oracle(rg, 1, n_slots)
+    test_class_placed_shard_runs_as_one_launch_and_matches_oracle(rg, 7)
+    test_sorted_mixed_workload_matches_oracle(rg, 7)
+
+
 def test_fused_and_sparse_kernels_with_64bit_offsets(rg, force_ix64):
     """k_tick_fused<..., u64> and k_tick_list<..., u64> on the GPU."""
     test_fused_launch_equals_sequential_ticks(rg, 2, 5, 4)
