@@ -991,6 +991,7 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k_tick_send" if (args.inflights and args.fused_send) else
+                               "k_tick_fused" if (args.fuse > 1 and not distributed and not args.inflights) else
                                ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_classes" if args.sorted else "k_tick_lane")) +
                                (" + k_send_dense" if args.inflights else ""),
                      "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
