@@ -199,6 +199,24 @@ template <int P> struct RgSendOps {
     bool bcast, serve, elected;
 };
 
+// The window columns (meta, head, tail: 20 B per Progress, read and rewritten by every stage) go past the Infinity Cache, loads
+// and stores (RG_SEND_NT_WIN = 1; 2 = head and tail only; 0 = through the cache, as up to round 3): what the cache is for in
+// a send engine is the tick's state, which the NEXT launch re-reads, and 20 P B per group of window columns competed with it.
+// profiles/r04_send_window.txt: faster or equal at every engine size tried -- 1 M x 5 one launch -3..-5 %, 1.25 M x 5 -12 %,
+// 2 M x 5 as two launches -15 %, 1 M x 7 -14 %, 1 M x 3 -10 %, 500 k x 5 -1..-4 %.
+// (The choice is a template argument: see rg_st in rg_tick_kernels.h for what a run-time one costs.)
+#ifndef RG_SEND_NT_WIN
+#define RG_SEND_NT_WIN 1
+#endif
+template <int K, typename T> RG_HD T rg_wld(const T &c) {
+    if constexpr (RG_SEND_NT_WIN == 1 || (RG_SEND_NT_WIN == 2 && K == 1)) return __builtin_nontemporal_load(&c);
+    else return c;
+}
+template <int K, typename T, typename V> RG_HD void rg_wst(T &c, V v) {
+    if constexpr (RG_SEND_NT_WIN == 1 || (RG_SEND_NT_WIN == 2 && K == 1)) __builtin_nontemporal_store((T)v, &c);
+    else c = (T)v;
+}
+
 // Part 0 (k_tick_send with RG_TS_SPEC): the window columns of EVERY slot and first_index requested together with the
 // group's own loads, before the tick has run -- the stage then needs no second memory round trip (after a dense tick nearly
 // every follower is in the work set anyway); rg_send_request<.., PRE = true> skips what is already on its way.
@@ -207,9 +225,9 @@ template <int P, typename IX> RG_HD void rg_send_prefetch(const RgState &st, con
 #pragma unroll
     for (int s = 0; s < P; s++) {
         const IX o = (IX)s * (IX)st.stride + g;
-        q.meta_v[s] = rg_at(ins.meta, o);
-        q.head_v[s] = rg_at(ins.head, o);
-        q.tail_v[s] = rg_at(ins.tail, o);
+        q.meta_v[s] = rg_wld<0>(rg_at(ins.meta, o));
+        q.head_v[s] = rg_wld<1>(rg_at(ins.head, o));
+        q.tail_v[s] = rg_wld<1>(rg_at(ins.tail, o));
     }
 }
 
@@ -234,9 +252,9 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
 #pragma unroll
         for (int s = 0; s < P; s++) {
             const IX o = (IX)s * (IX)st.stride + g;
-            q.meta_v[s] = rg_at(ins.meta, o);
-            q.head_v[s] = rg_at(ins.head, o);
-            q.tail_v[s] = rg_at(ins.tail, o);
+            q.meta_v[s] = rg_wld<0>(rg_at(ins.meta, o));
+            q.head_v[s] = rg_wld<1>(rg_at(ins.head, o));
+            q.tail_v[s] = rg_wld<1>(rg_at(ins.tail, o));
             q.next_v[s] = rg_at(st.next, o);
             q.prs_v[s] = rg_at(st.prs, o); // (the flag row is not known yet)
             q.match_v[s] = rg_at(st.match, o);
@@ -273,9 +291,9 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
             q.meta_v[s] = 0u;
             q.head_v[s] = q.tail_v[s] = 0ULL;
             if (wv) {
-                q.meta_v[s] = rg_at(ins.meta, o);
-                q.head_v[s] = rg_at(ins.head, o);
-                q.tail_v[s] = rg_at(ins.tail, o);
+                q.meta_v[s] = rg_wld<0>(rg_at(ins.meta, o));
+                q.head_v[s] = rg_wld<1>(rg_at(ins.head, o));
+                q.tail_v[s] = rg_wld<1>(rg_at(ins.tail, o));
             }
         }
         if (FUSED) {
@@ -318,9 +336,9 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             // WAVE: another lane of the wave works on this slot -- this one rewrites what it loaded, so that the wave's
             // stores cover whole lines
             if (WAVE && ((q.wv >> s) & 1u)) {
-                rg_at(ins.meta, o) = q.meta_v[s];
-                rg_at(ins.head, o) = q.head_v[s];
-                rg_at(ins.tail, o) = q.tail_v[s];
+                rg_wst<0>(rg_at(ins.meta, o), q.meta_v[s]);
+                rg_wst<1>(rg_at(ins.head, o), q.head_v[s]);
+                rg_wst<1>(rg_at(ins.tail, o), q.tail_v[s]);
                 if (!FUSED && ((q.sv >> s) & 1u)) rg_at(st.next, o) = q.next_v[s];
             }
             continue;
@@ -473,10 +491,10 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
         // RG_SEND_WHOLE_LINES: every cell of the work set is rewritten, changed or not -- whole 128-B lines instead of
         // lane-masked partial ones, which the memory side has to read before it can merge them (the tick kernel's
         // RG_OPT bit 1, same reason)
-        if (RG_SEND_WHOLE_LINES || meta != meta0) rg_at(ins.meta, o) = meta;
+        if (RG_SEND_WHOLE_LINES || meta != meta0) rg_wst<0>(rg_at(ins.meta, o), meta);
         // (an empty window's two cells keep whatever they held: rewritten with the value just read)
-        if (RG_SEND_WHOLE_LINES || (head != head0 && count)) rg_at(ins.head, o) = count ? head : head0;
-        if (RG_SEND_WHOLE_LINES || (tail != tail0 && count)) rg_at(ins.tail, o) = count ? tail : tail0;
+        if (RG_SEND_WHOLE_LINES || (head != head0 && count)) rg_wst<1>(rg_at(ins.head, o), count ? head : head0);
+        if (RG_SEND_WHOLE_LINES || (tail != tail0 && count)) rg_wst<1>(rg_at(ins.tail, o), count ? tail : tail0);
     }
     if (row != row0) {
         if (FUSED) {
