@@ -903,6 +903,7 @@ struct rg_engine {
     bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool nt_all;       // ... and the state columns, loads and stores: the state ALONE is far beyond the cache
+    u64 nt_resident;   // ... except those of the first nt_resident workgroups' groups, which stay in the cache (k_tick_split); 0 = off
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
     u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
@@ -1127,6 +1128,20 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     }
     if (const char *e = getenv("RG_NT_ALL")) h->nt_all = atoi(e) != 0;
     if (h->nt_all) h->nt_msgs = true;
+    // Partial residency (k_tick_split): a leading range of the groups keeps its state in the cache, the rest is streamed.
+    // Measured (profiles/r04_resident.txt): with 176 MB of state resident 2.4 M x 5 runs in 134 us instead of 150 (all
+    // streamed; 155 plain) and 4 M x 5 in 233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that
+    // long the resident lines are gone before the next one comes back to them, and a miss that allocates costs more than a
+    // streamed access. So: only up to 2.5 x the cache. RG_NT_RESIDENT_MB / RG_NT_RESIDENT_BLOCKS: measurement / test hooks
+    // (the size of the range in MB of state / in workgroups; 0 = off).
+    h->nt_resident = 0;
+    if (!cfg->max_inflight) {
+        const double per_block = (double)(24u * h->P + 40u) * RG_BLOCK, mall = 256.0 * 1024.0 * 1024.0;
+        if (h->nt_all && (double)h->G * (double)(24u * h->P + 40u) <= 2.5 * mall) h->nt_resident = (u64)(176.0 * 1024.0 * 1024.0 / per_block);
+        if (const char *e = getenv("RG_NT_RESIDENT_MB")) h->nt_resident = (u64)(atof(e) * 1024.0 * 1024.0 / per_block);
+        if (const char *e = getenv("RG_NT_RESIDENT_BLOCKS")) h->nt_resident = (u64)atoll(e);
+        if (!h->nt_all) h->nt_resident = 0;
+    }
     h->send_bound = 0;
     h->pin_send = nullptr;
     h->host_items_valid = false;
@@ -1579,6 +1594,18 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             return RG_OK;
         }
     }
+    if (h->nt_resident && variant == (RG_VARIANT_LANE | RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL) && !h->any_group_commit && rg_ix32(h->st, h->P)) {
+        switch (h->P) {
+        case 1: rg_launch_tick_split_t<1>(h->stream, h->st, ms, h->nt_resident); break;
+        case 2: rg_launch_tick_split_t<2>(h->stream, h->st, ms, h->nt_resident); break;
+        case 3: rg_launch_tick_split_t<3>(h->stream, h->st, ms, h->nt_resident); break;
+        case 4: rg_launch_tick_split_t<4>(h->stream, h->st, ms, h->nt_resident); break;
+        case 5: rg_launch_tick_split_t<5>(h->stream, h->st, ms, h->nt_resident); break;
+        case 6: rg_launch_tick_split_t<6>(h->stream, h->st, ms, h->nt_resident); break;
+        case 7: rg_launch_tick_split_t<7>(h->stream, h->st, ms, h->nt_resident); break;
+        default: rg_launch_tick_split_t<8>(h->stream, h->st, ms, h->nt_resident); break;
+        }
+    } else
     switch (h->P) {
     case 1: rg_launch_tick_t<1>(h->stream, h->st, ms, variant, h->any_group_commit); break;
     case 2: rg_launch_tick_t<2>(h->stream, h->st, ms, variant, h->any_group_commit); break;

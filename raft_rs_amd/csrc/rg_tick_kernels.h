@@ -251,6 +251,29 @@ template <int P, typename IX, int NTM> __global__ RG_TICK_BOUNDS void k_tick_cla
     else rg_lane_body<P, IX, NTM>(g);
 }
 
+// The lane kernel over an engine whose state is PARTLY RESIDENT in the Infinity Cache (round 4). Beyond the cache a launch
+// either allocates every state line there (and finds none of them again: LRU over more than the cache holds) or streams
+// them all (k_tick_lane<.., 2>: the whole state from HBM, every tick). This kernel does both, by group range: the first
+// `resident_blocks` workgroups run the body that goes through the cache (messages streamed), the rest the all-streamed body.
+// What the resident groups re-read is then always a cache hit, whatever the size of the engine, and nothing else competes
+// for those lines: every other access of the launch carries the non-temporal hint. rg_create sizes the range
+// (profiles/r04_resident.txt). One launch, two bodies of the same register footprint (the hint is a bit of the instruction).
+struct RgSplitArgs {
+    RgState st;
+    RgMsgs ms; // (st and ms where RgClassArgs has them: the bodies find them in the kernarg segment by themselves)
+    u64 resident_blocks;
+};
+static_assert(offsetof(RgSplitArgs, st) == offsetof(RgClassArgs, st) && offsetof(RgSplitArgs, ms) == offsetof(RgClassArgs, ms) &&
+                  sizeof(RgSplitArgs) >= sizeof(RgClassArgs),
+              "rg_lane_body reads st and ms through an RgClassArgs view of the kernarg segment");
+template <int P, typename IX> __global__ RG_TICK_BOUNDS void k_tick_split(RgSplitArgs a) {
+    const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
+    if (g64 >= a.st.G) return;
+    const IX g = (IX)g64;
+    if ((u64)blockIdx.x < a.resident_blocks) rg_lane_body<P, IX, 1>(g);
+    else rg_lane_body<P, IX, 2>(g);
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels: the tick AND its send stage in one launch (rg_tick_device_send; engines with device Inflights)
 // ------------------------------------------------------------------------------------------------
@@ -904,6 +927,11 @@ __global__ __launch_bounds__(RG_INGEST_BLOCK) void k_mailbox(RgState st, RgMsgs 
 // plus 1/T of the state read+write. Every tick's result word (and, optionally, commit index) is still
 // produced. Bit-identical to T launches of k_tick_lane (tests). For backlogs / replay, not for latency.
 #define RG_MAX_FUSE 8
+#ifndef RG_FUSED_NT /* 1: the T message sets (read once) and the per-tick result columns (written once) go past the Infinity
+                       Cache, so that what stays there from launch to launch is the state. profiles/r04_fused_nt.txt: 8 ticks per
+                       launch at 1 M x 5 29.6 -> 28.1 us per tick, 4 ticks 33.5 -> 30.9; never slower (2 M, 8 M, 7 slots, config 5) */
+#define RG_FUSED_NT 1
+#endif
 struct RgFused {
     RgMsgs m[RG_MAX_FUSE];
     u32 *out_t;    // [T][G] result word of every tick
@@ -934,16 +962,16 @@ template <int P, bool GC, typename IX> __global__ RG_TICK_BOUNDS void k_tick_fus
     r.adv = rg_pub_load(st, g); // commit publication: the launch's total advance lands in the group's byte (rg_store_group)
     for (u32 t = 0; t < fm.n_ticks; t++) {
         const RgMsgs &ms = fm.m[t];
-        r.mf = rg_ld_stream(&rg_at(ms.mflags, g));
+        r.mf = rg_ld_stream<(RG_FUSED_NT != 0)>(&rg_at(ms.mflags, g));
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const IX o = (IX)p * (IX)st.stride + g;
-            r.mi[p] = rg_ld_stream(&rg_at(ms.mi, o));
-            r.mc[p] = rg_ld_stream(&rg_at(ms.mc, o));
+            r.mi[p] = rg_ld_stream<(RG_FUSED_NT != 0)>(&rg_at(ms.mi, o));
+            r.mc[p] = rg_ld_stream<(RG_FUSED_NT != 0)>(&rg_at(ms.mc, o));
         }
         rg_group_tick<P, GC, RG_NX_LAZY, true, IX>(r, st, ms, g);
-        fm.out_t[(u64)t * st.G + g64] = r.out;
-        if (fm.commit_t) fm.commit_t[(u64)t * st.G + g64] = r.commit;
+        rg_st<(RG_FUSED_NT != 0)>(fm.out_t[(u64)t * st.G + g64], r.out);
+        if (fm.commit_t) rg_st<(RG_FUSED_NT != 0)>(fm.commit_t[(u64)t * st.G + g64], r.commit);
     }
     // `next` cells that were only fetched (never needed a write) are harmlessly rewritten with their value
     rg_store_group<P, IX>(r, st, g);
@@ -1065,6 +1093,8 @@ __global__ __launch_bounds__(64 * RG_LDS_WAVES) void k_tick_lds(RgState st, RgMs
 template <int P> void rg_launch_tick_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant, bool gc);
 // the lane kernel over a class-placed engine (no group commit, 32-bit cell offsets: the caller checks both); P >= 4
 template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, int ntm, const RgClasses &cls);
+// the lane kernel with the first resident_blocks workgroups' state kept in the Infinity Cache (no group commit, 32-bit cell offsets)
+template <int P> void rg_launch_tick_split_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u64 resident_blocks);
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo);
@@ -1151,6 +1181,13 @@ template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState
         else hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 0>), grid, block, 0, stream, a);
     }
 }
+template <int P> void rg_launch_tick_split_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u64 resident_blocks) {
+    RgSplitArgs a;
+    a.st = st;
+    a.ms = ms;
+    a.resident_blocks = resident_blocks;
+    hipLaunchKernelGGL((k_tick_split<P, RG_LANE_IX32>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, a);
+}
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,
                            const u32 *n_ptr, u64 n_upper, u64 *mflags_rw, const RgListOut &lo) {
@@ -1198,6 +1235,7 @@ void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &
 #else
 extern template void rg_launch_tick_t<1>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<1>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<1>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1206,6 +1244,7 @@ extern template void rg_launch_flush_small_send_t<1>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<2>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<2>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<2>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1214,6 +1253,7 @@ extern template void rg_launch_flush_small_send_t<2>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<3>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<3>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<3>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1222,6 +1262,7 @@ extern template void rg_launch_flush_small_send_t<3>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<4>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<4>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<4>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1230,6 +1271,7 @@ extern template void rg_launch_flush_small_send_t<4>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<5>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<5>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<5>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1238,6 +1280,7 @@ extern template void rg_launch_flush_small_send_t<5>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<6>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<6>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<6>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1246,6 +1289,7 @@ extern template void rg_launch_flush_small_send_t<6>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<7>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<7>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<7>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
@@ -1254,6 +1298,7 @@ extern template void rg_launch_flush_small_send_t<7>(hipStream_t, const RgState 
 extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
 extern template void rg_launch_tick_t<8>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 extern template void rg_launch_tick_classes_t<8>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+extern template void rg_launch_tick_split_t<8>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
 extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);

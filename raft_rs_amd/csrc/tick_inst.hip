@@ -7,6 +7,7 @@
 
 template void rg_launch_tick_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, u32, bool);
 template void rg_launch_tick_classes_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, int, const RgClasses &);
+template void rg_launch_tick_split_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, u64);
 template void rg_launch_tick_list_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64,
                                           u64 *, const RgListOut &);
 template void rg_launch_tick_fused_t<RG_P>(hipStream_t, const RgState &, const RgFused &, bool);

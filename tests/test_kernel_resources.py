@@ -133,6 +133,8 @@ def test_streamed_stores_are_streamed():
     assert alls.get("nt stores", 0) >= 16 and alls.get("nt loads", 0) >= 11 + 15, alls
     cls = one("k_tick_classesILi5EjLi2EE")
     assert cls.get("nt stores", 0) >= 16, cls
+    split = one("k_tick_splitILi5EjE")            # both bodies in one kernel: the streamed one's stores, at the lane kernel's budget
+    assert split.get("nt stores", 0) >= 16 and int(split["VGPRs"]) <= 128 and int(split["ScratchSize [bytes/lane]"]) == 0, split
     send = one("k_tick_sendILi5ELb0EjE")          # the item columns (3 x 5) and the window columns (3 x 5, stored at two places);
     assert send.get("nt stores", 0) >= 45, send   # loads: the messages (11) and the window columns (15)
     assert send.get("nt loads", 0) >= 26, send

@@ -684,6 +684,28 @@ def test_random_and_class_placed_streams_with_everything_streamed(rg, force_nt_a
     test_sorted_mixed_workload_matches_oracle(rg, 7)
 
 
+@pytest.fixture(params=[1, 7])
+def force_resident(request):
+    """k_tick_split: the first `param` workgroups' groups keep their state in the cache, the rest is streamed (both bodies in one
+    launch; engines beyond the Infinity Cache). The engines of these tests have a few hundred to a few thousand groups: with 1 and
+    7 resident workgroups both bodies run in every one of them."""
+    os.environ["RG_NT_ALL"] = "1"
+    os.environ["RG_NT_RESIDENT_BLOCKS"] = str(request.param)
+    yield
+    os.environ.pop("RG_NT_ALL", None)
+    os.environ.pop("RG_NT_RESIDENT_BLOCKS", None)
+
+
+@pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (3, 5), (5, 7)])
+def test_workload_stream_matches_oracle_partly_resident(rg, force_resident, workload, n_slots):
+    test_workload_stream_matches_oracle(rg, 1, workload, n_slots)
+
+
+def test_random_streams_partly_resident(rg, force_resident):
+    for n_slots in (4, 7, 8):
+        test_random_streams_match_oracle(rg, 1, n_slots)
+
+
 def test_fused_and_sparse_kernels_with_64bit_offsets(rg, force_ix64):
     """k_tick_fused<..., u64> and k_tick_list<..., u64> on the GPU."""
     test_fused_launch_equals_sequential_ticks(rg, 2, 5, 4)
