@@ -23,6 +23,7 @@
 #include <string>
 #include <unordered_map>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "rg_group.h"
@@ -31,6 +32,9 @@
 #include "rg_workload.h"
 
 #include "rg_tick_kernels.h"
+
+// engines of this process whose leading group range is resident in the Infinity Cache (k_tick_split): at most one
+static std::atomic<int> g_resident_claims{0};
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -904,6 +908,7 @@ struct rg_engine {
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool nt_all;       // ... and the state columns, loads and stores: the state ALONE is far beyond the cache
     u64 nt_resident;   // ... except those of the first nt_resident workgroups' groups, which stay in the cache (k_tick_split); 0 = off
+    bool resident_claim; // this engine holds the process' one claim on the cache (g_resident_claims)
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
     u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
@@ -1019,6 +1024,12 @@ extern "C" uint64_t rg_column_bytes(const rg_engine *h, int c) {
 
 static void *rg_col(rg_engine *h, int c) { return h->arena + h->col_off[c]; }
 
+// (rg_create's failure paths and rg_destroy: the claim on the cache goes back with the engine)
+static void rg_drop(rg_engine *h) {
+    if (h->resident_claim) g_resident_claims.fetch_sub(1);
+    delete h;
+}
+
 extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (!cfg || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: null argument");
     if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
@@ -1130,17 +1141,30 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (h->nt_all) h->nt_msgs = true;
     // Partial residency (k_tick_split): a leading range of the groups keeps its state in the cache, the rest is streamed.
     // Measured (profiles/r04_resident.txt): with 176 MB of state resident 2.4 M x 5 runs in 134 us instead of 150 (all
-    // streamed; 155 plain) and 4 M x 5 in 233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that
+    // streamed; 155 plain) and 4 M x 5 in 227-233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that
     // long the resident lines are gone before the next one comes back to them, and a miss that allocates costs more than a
-    // streamed access. So: only up to 2.5 x the cache. RG_NT_RESIDENT_MB / RG_NT_RESIDENT_BLOCKS: measurement / test hooks
-    // (the size of the range in MB of state / in workgroups; 0 = off).
+    // streamed access. At 2 M x 5 (1.2 x the cache) it equals the plain kernel. So: 1.3 x cache < state <= 2.5 x cache.
+    // The cache is ONE per device: the engines of a process share one claim (three size-class engines with 176 MB each
+    // turned config 5 at 8 M groups from 724 into 893 us); an engine that finds it taken runs by the rules above.
+    // RG_NT_RESIDENT_MB / RG_NT_RESIDENT_BLOCKS: measurement / test hooks (the size of the range in MB of state / in
+    // workgroups; 0 = off); RG_NT_ALL=0 switches this off as well.
     h->nt_resident = 0;
+    h->resident_claim = false;
     if (!cfg->max_inflight) {
         const double per_block = (double)(24u * h->P + 40u) * RG_BLOCK, mall = 256.0 * 1024.0 * 1024.0;
-        if (h->nt_all && (double)h->G * (double)(24u * h->P + 40u) <= 2.5 * mall) h->nt_resident = (u64)(176.0 * 1024.0 * 1024.0 / per_block);
+        const double state = (double)h->G * (double)(24u * h->P + 40u);
+        if (state > 1.3 * mall && state <= 2.5 * mall) {
+            if (g_resident_claims.fetch_add(1) == 0) {
+                h->resident_claim = true;
+                h->nt_resident = (u64)(176.0 * 1024.0 * 1024.0 / per_block);
+            } else {
+                g_resident_claims.fetch_sub(1);
+            }
+        }
+        // (the hooks set the range whatever the claims say)
         if (const char *e = getenv("RG_NT_RESIDENT_MB")) h->nt_resident = (u64)(atof(e) * 1024.0 * 1024.0 / per_block);
         if (const char *e = getenv("RG_NT_RESIDENT_BLOCKS")) h->nt_resident = (u64)atoll(e);
-        if (!h->nt_all) h->nt_resident = 0;
+        if (const char *e = getenv("RG_NT_ALL")) if (!atoi(e)) h->nt_resident = 0;
     }
     h->send_bound = 0;
     h->pin_send = nullptr;
@@ -1148,7 +1172,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->ckpt_send_ready = false;
     h->ckpt_any_group_commit = false;
     if (cfg->max_inflight > 65535u) {
-        delete h;
+        rg_drop(h);
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: max_inflight=%u, at most 65535", cfg->max_inflight);
     }
     size_t off = 0;
@@ -1163,7 +1187,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     const size_t zero_bytes = rg_align((size_t)h->P * h->stride * 8);
     hipError_t e = hipMalloc(&h->arena, off + 2 * zero_bytes + 256 + rg_align(h->stride * 8));
     if (e != hipSuccess) {
-        delete h;
+        rg_drop(h);
         return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
     }
     e = hipMemset(h->arena, 0, off + 2 * zero_bytes + 256 + rg_align(h->stride * 8));
@@ -1174,7 +1198,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         (void)hipFree(h->arena);
-        delete h;
+        rg_drop(h);
         return rg_fail(RG_ERR_NO_DEVICE, "rg_create: hipMemset failed: %s", hipGetErrorString(e));
     }
     h->dev.engine_bytes = off + 2 * zero_bytes + 256 + rg_align(h->stride * 8);
@@ -1225,7 +1249,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         if (e != hipSuccess) {
             if (h->ins_arena) (void)hipFree(h->ins_arena);
             (void)hipFree(h->arena);
-            delete h;
+            rg_drop(h);
             return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_create: %zu bytes of Inflights (cap %u): %s", meta_b + ring_b + items_b + cols_b,
                            cfg->max_inflight, hipGetErrorString(e));
         }
@@ -1274,7 +1298,7 @@ extern "C" void rg_destroy(rg_engine *h) {
     if (h->pin_send) (void)hipHostFree(h->pin_send);
     if (h->d_packed) (void)hipFree(h->d_packed);
     if (h->pin_packed) (void)hipHostFree(h->pin_packed);
-    delete h;
+    rg_drop(h);
 }
 
 extern "C" uint64_t rg_stride(const rg_engine *h) { return h ? h->stride : 0; }
@@ -1594,7 +1618,7 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             return RG_OK;
         }
     }
-    if (h->nt_resident && variant == (RG_VARIANT_LANE | RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL) && !h->any_group_commit && rg_ix32(h->st, h->P)) {
+    if (h->nt_resident && (variant & ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL)) == RG_VARIANT_LANE && !h->any_group_commit && rg_ix32(h->st, h->P)) {
         switch (h->P) {
         case 1: rg_launch_tick_split_t<1>(h->stream, h->st, ms, h->nt_resident); break;
         case 2: rg_launch_tick_split_t<2>(h->stream, h->st, ms, h->nt_resident); break;
