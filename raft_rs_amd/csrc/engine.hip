@@ -33,8 +33,9 @@
 
 #include "rg_tick_kernels.h"
 
-// engines of this process whose leading group range is resident in the Infinity Cache (k_tick_split): at most one
-static std::atomic<int> g_resident_claims{0};
+// live engines of this process: the Infinity Cache is one per device, and a range of ONE engine can only stay resident there
+// (k_tick_split) while no other engine's traffic goes through it
+static std::atomic<int> g_live_engines{0};
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -908,7 +909,8 @@ struct rg_engine {
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool nt_all;       // ... and the state columns, loads and stores: the state ALONE is far beyond the cache
     u64 nt_resident;   // ... except those of the first nt_resident workgroups' groups, which stay in the cache (k_tick_split); 0 = off
-    bool resident_claim; // this engine holds the process' one claim on the cache (g_resident_claims)
+    bool resident_forced; // nt_resident comes from a test / measurement hook: it holds whatever else lives in the process
+    bool counted_live;   // this engine is in g_live_engines
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
     u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
@@ -1024,9 +1026,9 @@ extern "C" uint64_t rg_column_bytes(const rg_engine *h, int c) {
 
 static void *rg_col(rg_engine *h, int c) { return h->arena + h->col_off[c]; }
 
-// (rg_create's failure paths and rg_destroy: the claim on the cache goes back with the engine)
+// (rg_create's failure paths and rg_destroy)
 static void rg_drop(rg_engine *h) {
-    if (h->resident_claim) g_resident_claims.fetch_sub(1);
+    if (h->counted_live) g_live_engines.fetch_sub(1);
     delete h;
 }
 
@@ -1144,28 +1146,23 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     // streamed; 155 plain) and 4 M x 5 in 227-233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that
     // long the resident lines are gone before the next one comes back to them, and a miss that allocates costs more than a
     // streamed access. At 2 M x 5 (1.2 x the cache) it equals the plain kernel. So: 1.3 x cache < state <= 2.5 x cache.
-    // The cache is ONE per device: the engines of a process share one claim (three size-class engines with 176 MB each
-    // turned config 5 at 8 M groups from 724 into 893 us); an engine that finds it taken runs by the rules above.
+    // The cache is ONE per device: the range is only used while this is the ONLY live engine of the process (checked at every
+    // launch: three size-class engines of config 5 at 8 M groups, two of them with a resident range, took 893 us instead of
+    // 724; with one range next to the other engines' traffic still 821). Several engines on one device run by the rules above.
     // RG_NT_RESIDENT_MB / RG_NT_RESIDENT_BLOCKS: measurement / test hooks (the size of the range in MB of state / in
-    // workgroups; 0 = off); RG_NT_ALL=0 switches this off as well.
+    // workgroups; 0 = off; they hold whatever else lives in the process); RG_NT_ALL=0 switches this off as well.
     h->nt_resident = 0;
-    h->resident_claim = false;
+    h->resident_forced = false;
     if (!cfg->max_inflight) {
         const double per_block = (double)(24u * h->P + 40u) * RG_BLOCK, mall = 256.0 * 1024.0 * 1024.0;
         const double state = (double)h->G * (double)(24u * h->P + 40u);
-        if (state > 1.3 * mall && state <= 2.5 * mall) {
-            if (g_resident_claims.fetch_add(1) == 0) {
-                h->resident_claim = true;
-                h->nt_resident = (u64)(176.0 * 1024.0 * 1024.0 / per_block);
-            } else {
-                g_resident_claims.fetch_sub(1);
-            }
-        }
-        // (the hooks set the range whatever the claims say)
-        if (const char *e = getenv("RG_NT_RESIDENT_MB")) h->nt_resident = (u64)(atof(e) * 1024.0 * 1024.0 / per_block);
-        if (const char *e = getenv("RG_NT_RESIDENT_BLOCKS")) h->nt_resident = (u64)atoll(e);
+        if (state > 1.3 * mall && state <= 2.5 * mall) h->nt_resident = (u64)(176.0 * 1024.0 * 1024.0 / per_block);
+        if (const char *e = getenv("RG_NT_RESIDENT_MB")) h->nt_resident = (u64)(atof(e) * 1024.0 * 1024.0 / per_block), h->resident_forced = true;
+        if (const char *e = getenv("RG_NT_RESIDENT_BLOCKS")) h->nt_resident = (u64)atoll(e), h->resident_forced = true;
         if (const char *e = getenv("RG_NT_ALL")) if (!atoi(e)) h->nt_resident = 0;
     }
+    g_live_engines.fetch_add(1);
+    h->counted_live = true;
     h->send_bound = 0;
     h->pin_send = nullptr;
     h->host_items_valid = false;
@@ -1618,7 +1615,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             return RG_OK;
         }
     }
-    if (h->nt_resident && (variant & ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL)) == RG_VARIANT_LANE && !h->any_group_commit && rg_ix32(h->st, h->P)) {
+    if (h->nt_resident && (h->resident_forced || g_live_engines.load(std::memory_order_relaxed) == 1) &&
+        (variant & ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL)) == RG_VARIANT_LANE && !h->any_group_commit && rg_ix32(h->st, h->P)) {
         switch (h->P) {
         case 1: rg_launch_tick_split_t<1>(h->stream, h->st, ms, h->nt_resident); break;
         case 2: rg_launch_tick_split_t<2>(h->stream, h->st, ms, h->nt_resident); break;
