@@ -504,7 +504,8 @@ def by_config_summary(result):
                 "traffic": None if r.get("traffic") is None else int(r["traffic"]), "regime": r.get("regime")}
     oc = result.get("other_configs") or {}
     out = {"c2_headline": entry(result)}
-    for name, obj in (("c2_hbm_8M", result.get("out_of_cache")), ("c3_joint", oc.get("configs[2] joint")),
+    for name, obj in (("c2_hbm_8M", result.get("out_of_cache")), ("c2_resident_2_4M", result.get("between_regimes")),
+                      ("c3_joint", oc.get("configs[2] joint")),
                       ("c4_shard", oc.get("configs[3] one rank's shard")), ("c5_one_launch", oc.get("configs[4] one launch, class-sorted")),
                       ("c5_size_class", oc.get("configs[4] size-class engines")), ("c5_one_engine", oc.get("configs[4] one 7-slot engine")),
                       ("recompute", result.get("recompute_only")), ("recompute_hbm_8M", result.get("recompute_only_out_of_cache"))):
@@ -1018,6 +1019,9 @@ def main():
                                                            what="recompute")
         # the headline configuration beyond the 256 MB Infinity Cache (state + one tick of messages >> cache)
         result["out_of_cache"] = guarded(run_config, rg, torch, args.out_of_cache_groups, P, wl, 3, 12, args.seed)
+        # ... and just beyond it (1.3 - 2.5 x the cache): a leading range of the groups stays resident, the rest is streamed,
+        # one launch (k_tick_split; the engine is alone in the process here: the headline's engines are closed)
+        result["between_regimes"] = guarded(run_config, rg, torch, 2_400_000, P, wl, 3, 20, args.seed)
         # every other BASELINE configuration that fits one GPU, each with its own roofline object (driver-timed like the
         # headline): configs[2] joint, one rank's shard of configs[3], configs[4] in both layouts, and configs[1] with the
         # Inflights on the device and the send stage after every tick
