@@ -6,7 +6,7 @@
                     [--inflights CAP] [--no-extras] [--c5-variant V]
 
 The default (N = 1) line also carries, as sub-objects with their own `roofline` (each labelled with its memory regime):
-`recompute_only` (+ `_out_of_cache`), `out_of_cache`, `other_configs` (every other BASELINE configuration that fits one
+`recompute_only` (+ `_out_of_cache`), `out_of_cache`, `between_regimes` (2.4 M groups), `other_configs` (every other BASELINE configuration that fits one
 GPU, and the headline with the send stage), `small_batch_latency`, `cpu_baseline`.
 
 One "step" = one tick of the hot path over every raft group of the shard: apply each group's
