@@ -32,12 +32,27 @@ pub const RG_OUT_APPENDED: u32 = 0x8;
 pub const RG_OUT_BECAME_LEADER: u32 = 0x10;
 pub const RG_OUT_HOST_HINT: u32 = 0x20;
 pub const RG_TERM_RUNS: u32 = 8;
+pub const RG_CACHE_AUTO: u32 = 0;
+pub const RG_CACHE_PLAIN: u32 = 1;
+pub const RG_CACHE_STREAM_MSGS: u32 = 2;
+pub const RG_CACHE_STREAM_ALL: u32 = 3;
+pub const RG_CACHE_RESIDENT: u32 = 4;
+pub const RG_CFGF_NO_SIZE_CLASSES: u32 = 0x1;
+pub const RG_CFGF_CLASS_BLOCK_ORDER: u32 = 0x2;
+pub const RG_CFGF_IX64: u32 = 0x4;
 pub const RG_VARIANT_DEFAULT: u32 = 0;
 pub const RG_VARIANT_LANE: u32 = 1;
 pub const RG_VARIANT_LDS: u32 = 2;
 pub const RG_VARIANT_LDS_DMA: u32 = 4;
 pub const RG_VARIANT_COMPACT: u32 = 5;
 pub const RG_VARIANT_COOP: u32 = 3;
+pub const RG_KERNEL_NONE: u32 = 0;
+pub const RG_KERNEL_LANE: u32 = 1;
+pub const RG_KERNEL_CLASSES: u32 = 2;
+pub const RG_KERNEL_SPLIT: u32 = 3;
+pub const RG_KERNEL_LDS: u32 = 4;
+pub const RG_KERNEL_COMPACT: u32 = 5;
+pub const RG_KERNEL_TICK_SEND: u32 = 6;
 pub const RG_EV_UNREACHABLE: u32 = 1;
 pub const RG_EV_SNAPSHOT_FINISH: u32 = 2;
 pub const RG_EV_SNAPSHOT_FAILURE: u32 = 3;
@@ -108,6 +123,9 @@ pub struct RgConfig {
     pub device: i32,
     pub variant: u32,
     pub max_inflight: u32,
+    pub cache_policy: u32,
+    pub flags: u32,
+    pub cache_resident_groups: u64,
 }
 
 #[repr(C)]
@@ -119,6 +137,11 @@ pub struct RgDeviceInfo {
     pub hbm_bytes: u64,
     pub l2_bytes: u64,
     pub engine_bytes: u64,
+    pub cache_policy: u32,
+    pub engines_on_device: u32,
+    pub resident_groups: u64,
+    pub last_tick_kernel: u32,
+    pub last_tick_streaming: u32,
 }
 
 #[repr(C)]

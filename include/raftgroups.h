@@ -195,7 +195,37 @@ typedef struct {
     uint32_t max_inflight; /* 0 = Inflights stay with the host (RG_MF_INS_FULL in, RG_OUT_FREE_TO out);
                               1..65535 = Config::max_inflight_msgs (src/config.rs:112): one ring of that many u64
                               per Progress lives in HBM and rg_send_appends runs the send decision on the device */
+    /* ---- how the dense ticks go through the 256 MB Infinity Cache (all zero = the engine decides; zero-initialised
+     *      rg_config structs of older callers keep meaning what they meant). Decided ONCE, here: nothing outside this struct
+     *      -- no environment variable, no other engine created or destroyed later -- changes which kernel a live engine
+     *      runs; rg_get_device_info reports the decision. ---- */
+    uint32_t cache_policy;          /* RG_CACHE_* */
+    uint32_t flags;                 /* RG_CFGF_* */
+    uint64_t cache_resident_groups; /* RG_CACHE_RESIDENT: the state of the first this-many groups (rounded down to whole
+                                       workgroups of 256) stays in the cache, the rest is streamed; 0 = the engine's own
+                                       sizing (176 MB of state). Ignored by the other policies. */
 } rg_config;
+
+/* rg_config.cache_policy. What a dense tick re-reads on every launch is its STATE (24 P + 40 bytes per group); the message
+ * columns (16 P + 8) are read once. Measured windows (profiles/r04_nt_state.txt, r04_resident.txt at 5 slots;
+ * profiles/r05_cache_policy_sweep.txt at 3 and 7): */
+#define RG_CACHE_AUTO 0u        /* by footprint: PLAIN while state + one tick of messages fit the cache; STREAM_MSGS beyond;
+                                   RESIDENT where 1.3 x cache < state <= 2.5 x cache and no other engine lives on the device
+                                   at rg_create (the cache is one per device); STREAM_ALL where 1.5 x cache < state <= 7.5 x
+                                   cache; engines with device Inflights: PLAIN / STREAM_MSGS only */
+#define RG_CACHE_PLAIN 1u       /* every access allocates in the cache */
+#define RG_CACHE_STREAM_MSGS 2u /* the read-once message columns are streamed past it (non-temporal loads) */
+#define RG_CACHE_STREAM_ALL 3u  /* ... and the state columns, loads and stores: nothing of the launch is allocated */
+#define RG_CACHE_RESIDENT 4u    /* STREAM_ALL except for a leading range of groups whose state stays resident (one launch,
+                                   two bodies: k_tick_split); needs max_inflight = 0, no group commit, the lane variant --
+                                   where those do not hold the launch falls back to STREAM_ALL and the report says so */
+/* rg_config.flags */
+#define RG_CFGF_NO_SIZE_CLASSES 0x1u   /* a shard placed by replica-set size class runs the plain kernel (rg_size_classes
+                                          reports 0 ranges): the A/B switch of the class-placed layout */
+#define RG_CFGF_CLASS_BLOCK_ORDER 0x2u /* k_tick_classes launches its workgroups in block order instead of dealing the
+                                          classes out proportionally (measurement) */
+#define RG_CFGF_IX64 0x4u              /* 64-bit cell offsets on an engine small enough for 32-bit ones: the instantiations
+                                          only engines beyond 4 GiB per column reach otherwise (tests run both widths) */
 
 #define RG_VARIANT_DEFAULT 0u
 #define RG_VARIANT_LANE 1u /* one lane per group, columns straight into registers */
@@ -229,7 +259,23 @@ typedef struct {
     uint64_t hbm_bytes;       /* totalGlobalMem */
     uint64_t l2_bytes;        /* l2CacheSize (one XCD's L2) */
     uint64_t engine_bytes;    /* device memory this engine allocated in rg_create */
+    /* the cache policy rg_create settled on (never RG_CACHE_AUTO) and why */
+    uint32_t cache_policy;      /* RG_CACHE_PLAIN .. RG_CACHE_RESIDENT */
+    uint32_t engines_on_device; /* live engines of this process on the engine's device when it was created, itself included
+                                   (AUTO grants a resident range only to an engine that is alone) */
+    uint64_t resident_groups;   /* RG_CACHE_RESIDENT: groups whose state stays in the cache (a multiple of 256), else 0 */
+    /* the dense tick kernel of the LAST rg_tick / rg_tick_device(_send) launch (0 before the first): what actually ran */
+    uint32_t last_tick_kernel;  /* RG_KERNEL_* */
+    uint32_t last_tick_streaming; /* 0 = plain accesses, 1 = message columns streamed, 2 = state columns too
+                                     (RG_KERNEL_SPLIT: 2 beyond the resident range, 1 inside) */
 } rg_device_info;
+#define RG_KERNEL_NONE 0u
+#define RG_KERNEL_LANE 1u      /* k_tick_lane: one lane per group */
+#define RG_KERNEL_CLASSES 2u   /* k_tick_classes: the lane kernel, workgroups instantiated per replica-set size class */
+#define RG_KERNEL_SPLIT 3u     /* k_tick_split: the lane kernel with a cache-resident leading range */
+#define RG_KERNEL_LDS 4u       /* k_tick_lds (RG_VARIANT_LDS / _LDS_DMA) */
+#define RG_KERNEL_COMPACT 5u   /* k_tick_compact (RG_VARIANT_COMPACT) */
+#define RG_KERNEL_TICK_SEND 6u /* k_tick_send: the tick and its send stage in one launch */
 int rg_get_device_info(const rg_engine *h, rg_device_info *info);
 /* Run all engine work on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
 int rg_set_stream(rg_engine *h, void *hip_stream);

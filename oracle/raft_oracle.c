@@ -1013,6 +1013,27 @@ size_t ro_ins_contents(ro_cluster *c, size_t g, uint64_t id, uint64_t *buf, size
     return pr->ins.count;
 }
 
+size_t ro_ins_export_soa(ro_cluster *c, size_t n_slots, size_t stride, uint32_t *counts, uint64_t *first_k, size_t k) {
+    size_t max_count = 0;
+    for (size_t g = 0; g < c->n; g++) {
+        for (size_t p = 0; p < n_slots; p++) {
+            ro_progress *pr = pmap_get(&c->g[g].progress, p + 1);
+            uint64_t *dst = first_k + (g * n_slots + p) * k;
+            for (size_t i = 0; i < k; i++) dst[i] = 0;
+            counts[p * stride + g] = 0;
+            if (!pr) continue;
+            counts[p * stride + g] = (uint32_t)pr->ins.count;
+            if (pr->ins.count > max_count) max_count = pr->ins.count;
+            size_t idx = pr->ins.start;
+            for (size_t i = 0; i < pr->ins.count && i < k; i++) {
+                dst[i] = pr->ins.buffer[idx];
+                if (++idx >= pr->ins.cap) idx -= pr->ins.cap;
+            }
+        }
+    }
+    return max_count;
+}
+
 /* prepare_send_snapshot (raft.rs:664-712) up to the point where the snapshot is fetched */
 static bool ro_decide_send_snapshot(const ro_progress *pr) {
     return pr->recent_active; /* :665-672 "ignore sending snapshot ... not recently active" */

@@ -8,8 +8,9 @@ importing `raft_rs_amd.engine` raises.
 """
 from .engine import (Engine, EngineError, MsgBuffers, load_library, LIB_PATH,  # noqa: F401
                      COL, MF, PF, OUT, cfg_make, WL_MAJORITY, WL_JOINT, WL_MIXED,
-                     VARIANT_DEFAULT, VARIANT_LANE, VARIANT_LDS, VARIANT_COOP, VARIANT_LDS_DMA, VARIANT_COMPACT)
+                     VARIANT_DEFAULT, VARIANT_LANE, VARIANT_LDS, VARIANT_COOP, VARIANT_LDS_DMA, VARIANT_COMPACT,
+                     CACHE, CFGF, KERNEL)
 
 __all__ = ["Engine", "EngineError", "MsgBuffers", "load_library", "LIB_PATH", "COL", "MF", "PF", "OUT",
            "cfg_make", "WL_MAJORITY", "WL_JOINT", "WL_MIXED", "VARIANT_DEFAULT", "VARIANT_LANE",
-           "VARIANT_LDS", "VARIANT_COOP", "VARIANT_LDS_DMA", "VARIANT_COMPACT"]
+           "VARIANT_LDS", "VARIANT_COOP", "VARIANT_LDS_DMA", "VARIANT_COMPACT", "CACHE", "CFGF", "KERNEL"]

@@ -24,6 +24,7 @@
 #include <unordered_map>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "rg_group.h"
@@ -33,9 +34,13 @@
 
 #include "rg_tick_kernels.h"
 
-// live engines of this process: the Infinity Cache is one per device, and a range of ONE engine can only stay resident there
-// (k_tick_split) while no other engine's traffic goes through it
-static std::atomic<int> g_live_engines{0};
+// live engines of this process PER DEVICE: the Infinity Cache is one per device, and a range of ONE engine only stays
+// resident there (k_tick_split) while no other engine's traffic goes through it. Looked at ONCE, by rg_create, when the cache
+// policy of the new engine is decided (RG_CACHE_AUTO grants a resident range only to an engine that is alone on its device);
+// a live engine's kernel never changes because another engine comes or goes.
+#define RG_MAX_DEVICES 64
+static std::mutex g_live_mu;
+static int g_live_on_device[RG_MAX_DEVICES];
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -905,12 +910,12 @@ struct rg_engine {
     bool cls_on;       // some block names fewer slots than the engine has: the dense lane tick runs k_tick_classes
     u32 *cls_order;    // device: one word per workgroup of that kernel, in launch order: block | slots << 28 (RgClasses::order)
     bool cls_stale;    // RG_COL_CFG may have changed since the bytes were derived
-    bool cls_off;      // never use them: RG_NO_CLASSES=1 at rg_create (measurement hook), or the cfg column's device pointer was handed out
+    bool cls_off;      // never use them: RG_CFGF_NO_SIZE_CLASSES at rg_create, or the cfg column's device pointer was handed out
     bool nt_msgs;      // dense ticks stream their message columns (non-temporal loads): state + one tick's messages > Infinity Cache
     bool nt_all;       // ... and the state columns, loads and stores: the state ALONE is far beyond the cache
     u64 nt_resident;   // ... except those of the first nt_resident workgroups' groups, which stay in the cache (k_tick_split); 0 = off
-    bool resident_forced; // nt_resident comes from a test / measurement hook: it holds whatever else lives in the process
-    bool counted_live;   // this engine is in g_live_engines
+    bool counted_live;   // this engine is in g_live_on_device
+    bool cls_block_order; // RG_CFGF_CLASS_BLOCK_ORDER
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
     u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
@@ -1028,7 +1033,10 @@ static void *rg_col(rg_engine *h, int c) { return h->arena + h->col_off[c]; }
 
 // (rg_create's failure paths and rg_destroy)
 static void rg_drop(rg_engine *h) {
-    if (h->counted_live) g_live_engines.fetch_sub(1);
+    if (h->counted_live) {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live_on_device[h->cfg.device]--;
+    }
     delete h;
 }
 
@@ -1038,10 +1046,13 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: n_groups=%llu n_slots=%u out of range",
                        (unsigned long long)cfg->n_groups, cfg->n_slots);
     if (cfg->variant > RG_VARIANT_COMPACT) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown variant %u", cfg->variant);
+    if (cfg->cache_policy > RG_CACHE_RESIDENT) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown cache_policy %u", cfg->cache_policy);
+    if (cfg->flags & ~(RG_CFGF_NO_SIZE_CLASSES | RG_CFGF_CLASS_BLOCK_ORDER | RG_CFGF_IX64))
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_create: unknown flags %#x", cfg->flags);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return rg_fail(RG_ERR_NO_DEVICE, "rg_create: no HIP device visible (this engine has no CPU fallback)");
-    if (cfg->device < 0 || cfg->device >= ndev)
+    if (cfg->device < 0 || cfg->device >= ndev || cfg->device >= RG_MAX_DEVICES)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: device %d of %d", cfg->device, ndev);
     RG_HIP(hipSetDevice(cfg->device));
     hipDeviceProp_t prop;
@@ -1117,52 +1128,63 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->cls_on = false;
     h->cls_order = nullptr;
     h->cls_stale = true;
-    {
-        const char *e = getenv("RG_NO_CLASSES"); // measurement hook (bench.py's A/B of the class-placed layout), read here only
-        h->cls_off = e && e[0] && e[0] != '0';
-    }
+    h->cls_off = (cfg->flags & RG_CFGF_NO_SIZE_CLASSES) != 0;
+    h->cls_block_order = (cfg->flags & RG_CFGF_CLASS_BLOCK_ORDER) != 0;
     h->stage_max_entries = 0;
     h->stage_flags = 0;
-    // Infinity Cache (256 MB on MI355X): when the state a dense tick re-reads (24 P + 40 B per group) and the message columns of
-    // ONE tick (16 P + 8 B per group, read once) do not fit together, the messages are streamed past it
-    // (with the Inflights on the device a step also touches the window and work-item columns: 40 P B per group more)
-    h->nt_msgs = (double)h->G * (double)(40u * h->P + 48u + (cfg->max_inflight ? 40u * h->P : 0u)) > 256.0 * 1024.0 * 1024.0;
-    if (const char *e = getenv("RG_NT_MSGS")) h->nt_msgs = atoi(e) != 0; // (measurement hook)
-    // The third regime: the state a dense tick re-reads (24 P + 40 B per group) alone is more than 1.5 x the Infinity Cache --
-    // by the time a launch comes back to a line the cache has turned over, so allocating there only costs. Everything is then
-    // streamed, loads and stores. The window is measured (profiles/r04_nt_state.txt, 5 slots): it pays from 2.4 M groups
-    // (384 MB of state: 153 -> 148 us) through 8 M (528 -> 483, fraction 0.68 -> 0.75) to 12 M (803 -> 778); below it a
-    // good part of the state still survives from launch to launch (2 M: 106 -> 126), and from 16 M groups (2.5 GB of state) on
-    // the plain accesses are the faster ones again (1034-1067 -> 1085-1135 us), so the regime has an upper end as well.
-    // RG_NT_ALL: test / measurement hook.
+    // ---- cache policy (rg_config.cache_policy; include/raftgroups.h: RG_CACHE_*), decided here and nowhere else ----
+    // Infinity Cache (256 MB on MI355X). AUTO, by footprint:
+    //  * STREAM_MSGS when the state a dense tick re-reads (24 P + 40 B per group) and the message columns of ONE tick
+    //    (16 P + 8 B per group, read once) do not fit together (with the Inflights on the device a step also touches the
+    //    window and work-item columns: 40 P B per group more);
+    //  * STREAM_ALL when the state alone is more than 1.5 x the cache -- by the time a launch comes back to a line the cache
+    //    has turned over, so allocating there only costs. The window is measured (profiles/r04_nt_state.txt, 5 slots;
+    //    profiles/r05_cache_policy_sweep.txt, 3 and 7): it pays from 2.4 M x 5 (384 MB of state: 153 -> 148 us) through 8 M
+    //    (528 -> 483, fraction 0.68 -> 0.75) to 12 M (803 -> 778); below it a good part of the state still survives from
+    //    launch to launch (2 M: 106 -> 126), and from 16 M groups (2.5 GB of state) on the plain accesses are the faster ones
+    //    again (1034-1067 -> 1085-1135 us), so the regime has an upper end as well: 1.5 x cache < state <= 7.5 x cache;
+    //  * RESIDENT (k_tick_split): a leading range of the groups keeps its state in the cache, the rest is streamed. Measured
+    //    (profiles/r04_resident.txt): with 176 MB of state resident 2.4 M x 5 runs in 134 us instead of 150 (all streamed; 155
+    //    plain) and 4 M x 5 in 227-233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that long the
+    //    resident lines are gone before the next one comes back to them. At 2 M x 5 (1.2 x the cache) it equals the plain
+    //    kernel. So: 1.3 x cache < state <= 2.5 x cache. The cache is ONE per device: three size-class engines of config 5 at
+    //    8 M groups, two of them with a resident range, took 893 us instead of 724 -- so AUTO grants the range only to an
+    //    engine that is ALONE on its device when it is created (engines_on_device == 1 in rg_device_info); a later engine on the
+    //    same device gets STREAM_ALL by the rule above and the first one keeps what it was given. A host that knows better says
+    //    so: an explicit policy is honoured as given.
     {
-        const double state = (double)h->G * (double)(24u * h->P + 40u), mall = 256.0 * 1024.0 * 1024.0;
-        h->nt_all = !cfg->max_inflight && state > 1.5 * mall && state <= 7.5 * mall;
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        h->dev.engines_on_device = (uint32_t)++g_live_on_device[cfg->device];
+        h->counted_live = true;
     }
-    if (const char *e = getenv("RG_NT_ALL")) h->nt_all = atoi(e) != 0;
-    if (h->nt_all) h->nt_msgs = true;
-    // Partial residency (k_tick_split): a leading range of the groups keeps its state in the cache, the rest is streamed.
-    // Measured (profiles/r04_resident.txt): with 176 MB of state resident 2.4 M x 5 runs in 134 us instead of 150 (all
-    // streamed; 155 plain) and 4 M x 5 in 227-233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that
-    // long the resident lines are gone before the next one comes back to them, and a miss that allocates costs more than a
-    // streamed access. At 2 M x 5 (1.2 x the cache) it equals the plain kernel. So: 1.3 x cache < state <= 2.5 x cache.
-    // The cache is ONE per device: the range is only used while this is the ONLY live engine of the process (checked at every
-    // launch: three size-class engines of config 5 at 8 M groups, two of them with a resident range, took 893 us instead of
-    // 724; with one range next to the other engines' traffic still 821). Several engines on one device run by the rules above.
-    // RG_NT_RESIDENT_MB / RG_NT_RESIDENT_BLOCKS: measurement / test hooks (the size of the range in MB of state / in
-    // workgroups; 0 = off; they hold whatever else lives in the process); RG_NT_ALL=0 switches this off as well.
-    h->nt_resident = 0;
-    h->resident_forced = false;
-    if (!cfg->max_inflight) {
-        const double per_block = (double)(24u * h->P + 40u) * RG_BLOCK, mall = 256.0 * 1024.0 * 1024.0;
-        const double state = (double)h->G * (double)(24u * h->P + 40u);
-        if (state > 1.3 * mall && state <= 2.5 * mall) h->nt_resident = (u64)(176.0 * 1024.0 * 1024.0 / per_block);
-        if (const char *e = getenv("RG_NT_RESIDENT_MB")) h->nt_resident = (u64)(atof(e) * 1024.0 * 1024.0 / per_block), h->resident_forced = true;
-        if (const char *e = getenv("RG_NT_RESIDENT_BLOCKS")) h->nt_resident = (u64)atoll(e), h->resident_forced = true;
-        if (const char *e = getenv("RG_NT_ALL")) if (!atoi(e)) h->nt_resident = 0;
+    {
+        const double mall = 256.0 * 1024.0 * 1024.0;
+        const double per_group = (double)(24u * h->P + 40u), state = (double)h->G * per_group;
+        const double with_msgs = (double)h->G * (double)(40u * h->P + 48u + (cfg->max_inflight ? 40u * h->P : 0u));
+        const bool lane = cfg->variant == RG_VARIANT_DEFAULT || cfg->variant == RG_VARIANT_LANE || cfg->variant == RG_VARIANT_COOP;
+        u32 pol = cfg->cache_policy;
+        if (pol == RG_CACHE_AUTO) {
+            pol = with_msgs > mall ? RG_CACHE_STREAM_MSGS : RG_CACHE_PLAIN;
+            if (!cfg->max_inflight && state > 1.5 * mall && state <= 7.5 * mall) pol = RG_CACHE_STREAM_ALL;
+            if (!cfg->max_inflight && lane && state > 1.3 * mall && state <= 2.5 * mall && h->dev.engines_on_device == 1)
+                pol = RG_CACHE_RESIDENT;
+        }
+        if (cfg->max_inflight && pol > RG_CACHE_STREAM_MSGS) { // (k_tick_send / k_send_dense have no all-streamed form)
+            rg_drop(h);
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_create: cache_policy %u needs max_inflight = 0 (engines with device Inflights: "
+                                               "RG_CACHE_PLAIN or RG_CACHE_STREAM_MSGS)", pol);
+        }
+        h->nt_msgs = pol >= RG_CACHE_STREAM_MSGS;
+        h->nt_all = pol >= RG_CACHE_STREAM_ALL;
+        h->nt_resident = 0;
+        if (pol == RG_CACHE_RESIDENT) {
+            const u64 groups = cfg->cache_resident_groups ? cfg->cache_resident_groups : (u64)(176.0 * 1024.0 * 1024.0 / per_group);
+            h->nt_resident = rg_min(groups, h->G) / RG_BLOCK;
+            if (h->nt_resident == 0) pol = RG_CACHE_STREAM_ALL; // (less than one workgroup: nothing to keep)
+        }
+        h->dev.cache_policy = pol;
+        h->dev.resident_groups = h->nt_resident * RG_BLOCK;
     }
-    g_live_engines.fetch_add(1);
-    h->counted_live = true;
     h->send_bound = 0;
     h->pin_send = nullptr;
     h->host_items_valid = false;
@@ -1225,11 +1247,12 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     s.G = h->G;
     s.stride = h->stride;
     // (consecutive byte columns, strides of 256: RG_COL_RUN_COUNT sits `stride` bytes behind RG_COL_HOST_HINT by construction)
-    if ((u8 *)rg_col(h, RG_COL_RUN_COUNT) != rg_run_n(s)) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: column layout");
-    {
-        const char *e = getenv("RG_FORCE_IX64"); // test hook (rg_common.h: rg_ix32), read here and nowhere else
-        s.ix64 = (e && e[0] && e[0] != '0') ? 1u : 0u;
+    if ((u8 *)rg_col(h, RG_COL_RUN_COUNT) != rg_run_n(s)) {
+        (void)hipFree(h->arena);
+        rg_drop(h);
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_create: column layout");
     }
+    s.ix64 = (cfg->flags & RG_CFGF_IX64) ? 1u : 0u; // (rg_common.h: rg_ix32)
     s.pub = nullptr;
     s.pub_off_delta = 0;
     s.pub_cap = 0;
@@ -1521,14 +1544,13 @@ static int rg_refresh_classes(rg_engine *h) {
     for (u64 b = 0; b < nb && !h->cls_on; b++) h->cls_on = h->cls_host[b] < h->P;
     if (!h->cls_on) return RG_OK;
     // launch order (RgClasses::order): the ranges of equal blocks dealt out proportionally -- block i of a range of n blocks sorts
-    // by (i + 1/2) / n, ties by block index. RG_CLASS_ORDER=0 in the environment keeps block order (measurement hook).
+    // by (i + 1/2) / n, ties by block index. RG_CFGF_CLASS_BLOCK_ORDER keeps block order (measurement).
     if (nb >= (1ull << 28)) { // (the word holds 28 bits of block index)
         h->cls_on = false;
         return RG_OK;
     }
     std::vector<std::pair<double, u32>> key(nb);
-    const char *eo = getenv("RG_CLASS_ORDER");
-    const bool deal = !(eo && eo[0] == '0');
+    const bool deal = !h->cls_block_order;
     for (u64 b = 0; b < nb;) {
         u64 e = b + 1;
         while (e < nb && h->cls_host[e] == h->cls_host[b]) e++;
@@ -1565,6 +1587,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick + send stage launch failed: %s", hipGetErrorString(e));
+        h->dev.last_tick_kernel = RG_KERNEL_TICK_SEND;
+        h->dev.last_tick_streaming = 1u; // (k_tick_send streams its message columns at any size)
         h->tick_launches++;
         h->ticked = true;
         h->out_is_dense = true;
@@ -1607,6 +1631,8 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             }
             hipError_t ce = hipGetLastError();
             if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));
+            h->dev.last_tick_kernel = RG_KERNEL_CLASSES;
+            h->dev.last_tick_streaming = h->nt_all ? 2u : h->nt_msgs ? 1u : 0u;
             h->tick_launches++;
             h->ticked = true;
             h->out_is_dense = true;
@@ -1615,8 +1641,11 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
             return RG_OK;
         }
     }
-    if (h->nt_resident && (h->resident_forced || g_live_engines.load(std::memory_order_relaxed) == 1) &&
-        (variant & ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL)) == RG_VARIANT_LANE && !h->any_group_commit && rg_ix32(h->st, h->P)) {
+    u32 kernel = (variant & ~(RG_VARIANT_NT_MSGS | RG_VARIANT_NT_ALL)) == RG_VARIANT_LANE ? RG_KERNEL_LANE
+                 : (variant & 0xffu) == RG_VARIANT_COMPACT                                 ? RG_KERNEL_COMPACT
+                                                                                           : RG_KERNEL_LDS;
+    if (h->nt_resident && kernel == RG_KERNEL_LANE && !h->any_group_commit && rg_ix32(h->st, h->P)) {
+        kernel = RG_KERNEL_SPLIT;
         switch (h->P) {
         case 1: rg_launch_tick_split_t<1>(h->stream, h->st, ms, h->nt_resident); break;
         case 2: rg_launch_tick_split_t<2>(h->stream, h->st, ms, h->nt_resident); break;
@@ -1640,6 +1669,9 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
+    h->dev.last_tick_kernel = kernel;
+    // (the group-commit instantiation and the LDS / compact variants have no streaming twins: rg_launch_tick_gc)
+    h->dev.last_tick_streaming = kernel == RG_KERNEL_SPLIT ? 2u : (kernel == RG_KERNEL_LANE && !h->any_group_commit) ? (h->nt_all ? 2u : h->nt_msgs ? 1u : 0u) : 0u;
     h->tick_launches++;
     h->ticked = true;
     h->out_is_dense = true;
@@ -3613,7 +3645,11 @@ static int rg_publish_impl(rg_engine *h, bool force_full) {
     const u64 i = p->n_pub;
     const int b = (int)(i % RG_PUB_SEND);
     const double t0 = rg_now_us();
+#ifdef RG_PUB_DEBUG_BUILD /* measurement builds only (python -m raft_rs_amd.build --exp pubdbg -DRG_PUB_DEBUG_BUILD=1): the default library reads no environment */
     static const int dbg = getenv("RG_PUB_DEBUG") ? atoi(getenv("RG_PUB_DEBUG")) : 0; // measurement knobs (profiles/)
+#else
+    const int dbg = 0;
+#endif
 
     // Loss protocol. Every `ring` publications is a CHECK POINT (the same publication numbers on every rank): all
     // buffered slices are folded into the replica first -- the update kernel raises d_lost for a slice that carries
@@ -3765,7 +3801,11 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
     // with a kernel of this device; a host transport synchronises the device itself), so the system-scope fence a
     // recorded event normally implies -- an L2 write-back worth ~2 us per tick -- is not needed
     // (RG_PUB_DEBUG & 4 keeps it, for A/B measurements: profiles/r02_publish_overhead.txt)
+#ifdef RG_PUB_DEBUG_BUILD
     const unsigned evf = hipEventDisableTiming | ((getenv("RG_PUB_DEBUG") && (atoi(getenv("RG_PUB_DEBUG")) & 4)) ? 0 : hipEventDisableSystemFence);
+#else
+    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+#endif
     for (int k = 0; k < RG_PUB_SEND; k++) {
         RG_PUB_TRY(hipMalloc(&p->send[k], p->lay.bytes_per_rank));
         RG_PUB_TRY(hipMemsetAsync(p->send[k], 0, p->lay.bytes_per_rank, h->stream));

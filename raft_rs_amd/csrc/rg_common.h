@@ -59,10 +59,10 @@ static inline bool rg_fits_u32_offsets(u64 n_slots, u64 stride) {
     const u64 rows = n_slots > RG_TERM_RUNS ? n_slots : RG_TERM_RUNS;
     return rows * stride * 8 <= 0xffffffffULL;
 }
-// What the launchers ask: 32-bit cell offsets unless the engine is too large -- or was CREATED with RG_FORCE_IX64=1 in the
-// environment, a TEST hook that makes every launch of that engine take the 64-bit-offset instantiations (k_tick_lane / _list /
-// _fused / _compact <..., u64>, k_send_dense<..., u64>), which no engine a test can afford to build would otherwise reach on
-// a GPU. The environment is read once, by rg_create, into RgState::ix64: nothing on a launch path calls getenv.
+// What the launchers ask: 32-bit cell offsets unless the engine is too large -- or was CREATED with RG_CFGF_IX64 in
+// rg_config.flags, which makes every launch of that engine take the 64-bit-offset instantiations (k_tick_lane / _list /
+// _fused / _compact <..., u64>, k_send_dense<..., u64>) that no engine a test can afford to build would otherwise reach on
+// a GPU. Decided once, by rg_create, into RgState::ix64.
 static inline bool rg_ix32(const RgState &st, u64 n_slots) { return !st.ix64 && rg_fits_u32_offsets(n_slots, st.stride); }
 // rg_u32o: a 32-bit cell index whose BYTE OFFSET is made opaque right before every access (rg_at below). `base + zext(offset)`
 // then stays in the block of the access, where instruction selection turns it into the SGPR-base + VGPR-offset addressing

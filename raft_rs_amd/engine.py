@@ -73,7 +73,25 @@ def cfg_make(incoming, outgoing=0, self_slot=0, group_commit=False, transferee_p
 
 class _Config(C.Structure):
     _fields_ = [("n_groups", C.c_uint64), ("n_slots", C.c_uint32), ("device", C.c_int32),
-                ("variant", C.c_uint32), ("max_inflight", C.c_uint32)]
+                ("variant", C.c_uint32), ("max_inflight", C.c_uint32),
+                ("cache_policy", C.c_uint32), ("flags", C.c_uint32), ("cache_resident_groups", C.c_uint64)]
+
+
+class CACHE:
+    """rg_config.cache_policy (include/raftgroups.h: RG_CACHE_*)."""
+    AUTO, PLAIN, STREAM_MSGS, STREAM_ALL, RESIDENT = range(5)
+    NAMES = ("auto", "plain", "stream_msgs", "stream_all", "resident")
+
+
+class CFGF:
+    """rg_config.flags (RG_CFGF_*)."""
+    NO_SIZE_CLASSES, CLASS_BLOCK_ORDER, IX64 = 0x1, 0x2, 0x4
+
+
+class KERNEL:
+    """rg_device_info.last_tick_kernel (RG_KERNEL_*)."""
+    NONE, LANE, CLASSES, SPLIT, LDS, COMPACT, TICK_SEND = range(7)
+    NAMES = ("none", "k_tick_lane", "k_tick_classes", "k_tick_split", "k_tick_lds", "k_tick_compact", "k_tick_send")
 
 
 HOST_HINT_DTYPE = np.dtype([("group", "<u8"), ("slot_mask", "<u4"), ("reserved", "<u4")])
@@ -88,7 +106,23 @@ assert GROUP_STATUS_DTYPE.itemsize == 376
 class DeviceInfo(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("wavefront", C.c_uint32),
                 ("lds_per_workgroup", C.c_uint64), ("hbm_bytes", C.c_uint64), ("l2_bytes", C.c_uint64),
-                ("engine_bytes", C.c_uint64)]
+                ("engine_bytes", C.c_uint64), ("cache_policy", C.c_uint32), ("engines_on_device", C.c_uint32),
+                ("resident_groups", C.c_uint64), ("last_tick_kernel", C.c_uint32), ("last_tick_streaming", C.c_uint32)]
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def config_defaults(**kw):
+    """Every Engine created inside the block gets these rg_config fields unless it names them itself."""
+    old = dict(Engine._defaults)
+    Engine._defaults.update(kw)
+    try:
+        yield
+    finally:
+        Engine._defaults.clear()
+        Engine._defaults.update(old)
 
 
 class _Msgs(C.Structure):
@@ -339,11 +373,24 @@ class MsgBuffers:
 class Engine:
     """One shard of raft groups resident on one MI355X (rg_engine)."""
 
-    def __init__(self, n_groups, n_slots, device=0, variant=VARIANT_DEFAULT, max_inflight=0):
-        """max_inflight > 0: Inflights rings of that capacity live on the device (send_appends after each tick)."""
+    # what Engine() passes for the rg_config fields a caller leaves out (config_defaults: the tests run whole suites of
+    # engines under one cache policy / offset width this way -- through the config struct, not through the environment)
+    _defaults = {"cache_policy": CACHE.AUTO, "flags": 0, "cache_resident_groups": 0}
+
+    def __init__(self, n_groups, n_slots, device=0, variant=VARIANT_DEFAULT, max_inflight=0, cache_policy=None,
+                 flags=None, cache_resident_groups=None):
+        """max_inflight > 0: Inflights rings of that capacity live on the device (send_appends after each tick).
+        cache_policy / cache_resident_groups / flags: rg_config's (CACHE.*, CFGF.*); device_info() reports the decision."""
         self.L = load_library()
         self.h = _vp()
-        cfg = _Config(n_groups, n_slots, device, variant, max_inflight)
+        d = Engine._defaults
+        from_default = cache_policy is None
+        cache_policy = d["cache_policy"] if cache_policy is None else cache_policy
+        flags = d["flags"] if flags is None else flags
+        cache_resident_groups = d["cache_resident_groups"] if cache_resident_groups is None else cache_resident_groups
+        if max_inflight and cache_policy > CACHE.STREAM_MSGS and from_default:
+            cache_policy = CACHE.STREAM_MSGS  # (a suite-wide default the send-stage engines cannot take: rg_create refuses it)
+        cfg = _Config(n_groups, n_slots, device, variant, max_inflight, cache_policy, flags, cache_resident_groups)
         self._check(self.L.rg_create(C.byref(cfg), C.byref(self.h)))
         self.n_groups, self.n_slots, self.device, self.max_inflight = n_groups, n_slots, device, max_inflight
         self.stride = self.L.rg_stride(self.h)
@@ -377,7 +424,9 @@ class Engine:
         self._check(self.L.rg_get_device_info(self.h, C.byref(d)))
         return {"arch": d.arch.decode(), "compute_units": d.compute_units, "wavefront": d.wavefront,
                 "lds_per_workgroup": d.lds_per_workgroup, "hbm_bytes": d.hbm_bytes, "l2_bytes": d.l2_bytes,
-                "engine_bytes": d.engine_bytes}
+                "engine_bytes": d.engine_bytes, "cache_policy": CACHE.NAMES[d.cache_policy],
+                "engines_on_device": d.engines_on_device, "resident_groups": d.resident_groups,
+                "last_tick_kernel": KERNEL.NAMES[d.last_tick_kernel], "last_tick_streaming": d.last_tick_streaming}
 
     def column_shape_dtype(self, col):
         if col in COL.PER_SLOT:

@@ -145,6 +145,7 @@ def lib():
         "ro_set_limit_bytes": (None, [vp, C.c_bool]),
         "ro_group_append_entry_sizes": (None, [vp, sz, u64, vp, sz]),
         "ro_ins_contents": (sz, [vp, sz, u64, C.POINTER(u64), sz]),
+        "ro_ins_export_soa": (sz, [vp, sz, sz, vp, vp, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -271,6 +272,13 @@ class Cluster:
         buf = (C.c_uint64 * cap)()
         n = self.L.ro_ins_contents(self.h, g, pid, buf, cap)
         return [int(buf[i]) for i in range(min(n, cap))]
+
+    def ins_export(self, n_slots, stride, k=16):
+        """Every window of the cluster at once: (counts u32 [P][stride], first_k u64 [n][P][k], largest count)."""
+        counts = np.zeros((n_slots, stride), dtype=np.uint32)
+        first_k = np.zeros((self.n, n_slots, k), dtype=np.uint64)
+        mx = self.L.ro_ins_export_soa(self.h, n_slots, stride, counts.ctypes.data, first_k.ctypes.data, k)
+        return counts, first_k, int(mx)
 
     def tick_soa_mt(self, msgs, gout, n_threads):
         m = _soa_msgs_struct(msgs)

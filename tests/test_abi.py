@@ -1,6 +1,7 @@
 """CPU-only: the C-ABI library loads and exports every symbol include/raftgroups.h declares; the bit
 layouts the oracle's SoA adapter uses are the header's; without a GPU the engine fails loudly."""
 import ctypes
+import ctypes as C
 import os
 import re
 
@@ -72,6 +73,20 @@ def test_engine_fails_loudly_without_a_gpu(rg):
     with pytest.raises(rg.EngineError) as ei:
         rg.Engine(16, 3)
     assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_library_reads_no_environment(rg):
+    """Which kernel an engine runs is decided by rg_config alone: the shipped library neither imports getenv nor carries the
+    name of one of the old measurement hooks (RG_NT_*, RG_NO_CLASSES, ...; the experiment builds of raft_rs_amd.build --exp
+    may, under their own macros)."""
+    import subprocess
+    undefined = subprocess.run(["nm", "-D", "-u", rg.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    blob = open(rg.LIB_PATH, "rb").read()
+    for name in (b"RG_NT_", b"RG_NO_CLASSES", b"RG_CLASS_ORDER", b"RG_FORCE_IX64", b"RG_PUB_DEBUG"):
+        assert name not in blob, name
+    from raft_rs_amd import engine as E
+    assert C.sizeof(E._Config) == 40 and C.sizeof(E.DeviceInfo) == 96
 
 
 def test_product_package_never_touches_the_oracle():

@@ -639,14 +639,14 @@ def test_fused_launch_applies_elections(rg):
 
 # ---------------------------------------------------------------------------------------------------------------
 # the 64-bit-offset instantiations (k_tick_lane / _list / _fused / _compact <..., u64>): engines beyond 4 GiB per column
-# run them; RG_FORCE_IX64=1 (rg_common.h: rg_ix32) makes every launch of a small engine take them, so the device code
-# objects that ship are the ones that are tested
+# run them; rg_config.flags = RG_CFGF_IX64 (rg_common.h: rg_ix32) makes every launch of a small engine take them, so the
+# device code objects that ship are the ones that are tested
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.fixture
 def force_ix64():
-    os.environ["RG_FORCE_IX64"] = "1"
-    yield
-    os.environ.pop("RG_FORCE_IX64", None)
+    from raft_rs_amd import engine as E
+    with E.config_defaults(flags=E.CFGF.IX64):
+        yield
 
 
 @pytest.mark.parametrize("variant", [1, 5])
@@ -663,13 +663,13 @@ def test_random_streams_match_oracle_with_64bit_offsets(rg, force_ix64, n_slots)
 
 # ---------------------------------------------------------------------------------------------------------------
 # the third memory regime (k_tick_lane / k_tick_classes <.., NTM = 2>: state columns streamed too, loads and stores) is what
-# engines far beyond the Infinity Cache run; RG_NT_ALL=1 at rg_create makes a small engine take it
+# engines far beyond the Infinity Cache run; rg_config.cache_policy = RG_CACHE_STREAM_ALL makes a small engine take it
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.fixture
 def force_nt_all():
-    os.environ["RG_NT_ALL"] = "1"
-    yield
-    os.environ.pop("RG_NT_ALL", None)
+    from raft_rs_amd import engine as E
+    with E.config_defaults(cache_policy=E.CACHE.STREAM_ALL):
+        yield
 
 
 @pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (3, 5), (5, 7)])
@@ -689,11 +689,9 @@ def force_resident(request):
     """k_tick_split: the first `param` workgroups' groups keep their state in the cache, the rest is streamed (both bodies in one
     launch; engines beyond the Infinity Cache). The engines of these tests have a few hundred to a few thousand groups: with 1 and
     7 resident workgroups both bodies run in every one of them."""
-    os.environ["RG_NT_ALL"] = "1"
-    os.environ["RG_NT_RESIDENT_BLOCKS"] = str(request.param)
-    yield
-    os.environ.pop("RG_NT_ALL", None)
-    os.environ.pop("RG_NT_RESIDENT_BLOCKS", None)
+    from raft_rs_amd import engine as E
+    with E.config_defaults(cache_policy=E.CACHE.RESIDENT, cache_resident_groups=256 * request.param):
+        yield
 
 
 @pytest.mark.parametrize("workload,n_slots", [(2, 3), (2, 5), (3, 5), (5, 7)])
@@ -742,7 +740,7 @@ def test_class_placed_shard_runs_as_one_launch_and_matches_oracle(rg, n_slots):
     that straddle one take the larger class. The engine finds the ranges itself; random traffic (rejects, heartbeats, elections,
     malformed acks, events on slots a group does not have) against the oracle; then rg_set_config grows one group of the
     3-peer range to the engine's last slot (its block leaves the class), rg_restore brings the old words back (re-derived),
-    and an engine created with RG_NO_CLASSES=1 -- the plain kernel -- ends in the same state."""
+    and an engine created with RG_CFGF_NO_SIZE_CLASSES -- the plain kernel -- ends in the same state."""
     rng = np.random.default_rng(8800 + n_slots)
     sizes = [q for q in (3, 5, 7) if q < n_slots] + [n_slots]
     ranges = [(64 * 20 + 11, sizes[0])] + [(64 * 13 + 5, q) for q in sizes[1:-1]] + [(64 * 9 + 40, sizes[-1])]
@@ -760,11 +758,7 @@ def test_class_placed_shard_runs_as_one_launch_and_matches_oracle(rg, n_slots):
     for (f, n, q), (rn, rq) in zip(cls, ranges):
         assert f == (first // 64) * 64 and q == rq, (cls, ranges)  # a class starts with the block its first group lies in
         first += rn
-    os.environ["RG_NO_CLASSES"] = "1"
-    try:
-        plain = rg.Engine(G, n_slots)
-    finally:
-        os.environ.pop("RG_NO_CLASSES", None)
+    plain = rg.Engine(G, n_slots, flags=rg.CFGF.NO_SIZE_CLASSES)
     plain.load_state(st)
     assert plain.size_classes() == []
     st_plain = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}

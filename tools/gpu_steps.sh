@@ -1,0 +1,36 @@
+#!/bin/bash
+# The box side of tools/gpu_call.sh: gpu_steps.sh <label> <step> ... (see there). Every step is bounded by its own timeout.
+label=$1; shift
+cd "$GRAFT_REPO_ROOT" || exit 9
+export TMPDIR=/tmp
+O=gpurun_out/$label; mkdir -p "$O"
+sp() { echo "${1//,/ }"; }
+for step in "$@"; do
+  IFS=: read -r kind a b c <<< "$step"
+  echo "=== $step" | tee -a "$O/steps.txt"
+  case $kind in
+  tests)
+    files=$(sp "${b:-tests}")
+    if [ -n "$a" ] && [ "$a" != "-" ]; then timeout 1500 python -m pytest $files -m gpu -x -q -k "$(sp "$a")" 2>&1 | grep -v "^E    .*match\[" | tail -15 > "$O/tests_${c:-0}.txt"
+    else timeout 1500 python -m pytest $files -m gpu -x -q 2>&1 | grep -v "^E    .*match\[" | tail -15 > "$O/tests_${c:-0}.txt"; fi
+    tail -4 "$O/tests_${c:-0}.txt" ;;
+  bench)
+    timeout 900 python bench.py $(sp "$a") 2> "$O/bench_err.txt" | tail -1 >> "$O/bench.jsonl"
+    tail -1 "$O/bench.jsonl" | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); r=d.get('roofline',{})
+    print('%s | %.2f G/s  %.1f us  frac %.3f' % (d.get('config',{}).get('workload', d.get('workload','?'))[:70], d['value']/1e9, d.get('ms_per_step', d.get('us_per_step',0)/1e3)*1e3, r.get('frac',0)))
+except Exception as e: print('??', e)"
+    tail -2 "$O/bench_err.txt" ;;
+  prof)
+    rm -rf /tmp/prof_$a; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$a -o $a --output-format csv -- python "$GRAFT_REPO_ROOT/bench.py" $(sp "$b") > "$GRAFT_REPO_ROOT/$O/prof_$a.log" 2>&1 )
+    f=$(find /tmp/prof_$a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/${a}_kernel_stats.csv" && head -6 "$O/${a}_kernel_stats.csv" | cut -c1-200 ;;
+  pmc)
+    bash tools/pmc_traffic.sh "${a//+/:}" "$b" $(sp "$c") > "$O/pmc_${a//+/_}.txt" 2>&1; tail -3 "$O/pmc_${a//+/_}.txt" ;;
+  py)
+    timeout 1200 python "$a" $(sp "$b") > "$O/$(basename "$a" .py)${c:+_$c}.txt" 2>&1; tail -40 "$O/$(basename "$a" .py)${c:+_$c}.txt" ;;
+  sh)
+    timeout 1200 bash -c "$(sp "$a")" 2>&1 | tail -40 ;;
+  esac
+done
