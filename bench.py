@@ -239,17 +239,32 @@ def hot_state_bytes(n_groups, n_slots, inflights=False):
     return n_groups * (24 * n_slots + 40 + (40 * n_slots if inflights else 0))
 
 
+def csrc_sha16():
+    """What the kernels of this run were built from: sha256 over raft_rs_amd/csrc/* and include/raftgroups.h (file names and
+    contents, sorted), first 16 hex digits. The GPU box has no .git, so this -- not a commit -- is what ties a PMC pass to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raft_rs_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "raftgroups.h")]:
+        path = os.path.join(d, f)
+        if os.path.isfile(path):
+            h.update(os.path.basename(f).encode() + b"\0")
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_lookup(key):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), or (None, None)."""
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json) -> (bytes, source, stale). `stale`: the
+    passes were taken on kernels built from other sources than this run's (csrc_sha16 differs or was not recorded)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             ent = json.load(f).get(key, {})
     except (OSError, ValueError):
-        return None, None
+        return None, None, None
     if ent.get("bytes") is None:
-        return None, None
-    return ent["bytes"], ("profiles/traffic.json[" + key + "]: " + ent.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes") +
-                          " @ build " + str(ent.get("commit", "unrecorded (before round 4)")) + " -- NOT measured inside this run")
+        return None, None, None
+    src = f"profiles/traffic.json[{key}]@{ent.get('commit', '?')} csrc {ent.get('csrc_sha16', 'unrecorded')}"
+    return ent["bytes"], src[:120], ent.get("csrc_sha16") != csrc_sha16()
 
 
 def workload_label(workload, n_groups, n_slots, one_engine=False, sorted_classes=False):
@@ -285,8 +300,11 @@ def send_stage_bytes(rg, eng, n_items, with_work=False):
     return (b, n_work) if with_work else b
 
 
+SIDE_REPEATS = 3  # timed regions per side measurement (median reported, min / max beside it)
+
+
 def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
-               inflights=0, fused_send=False, sorted_classes=False):
+               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS):
     """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
     headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
     synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
@@ -334,13 +352,16 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
             pt.eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
         for _ in range(warmup):
             pt.eng.recompute()
-        torch.cuda.synchronize()
-        e0.record(main_stream)
-        for _ in range(steps):
-            pt.eng.recompute()
-        e1.record(main_stream)
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / steps
+        us_all = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            e0.record(main_stream)
+            for _ in range(steps):
+                pt.eng.recompute()
+            e1.record(main_stream)
+            torch.cuda.synchronize()
+            us_all.append(e0.elapsed_time(e1) * 1e3 / steps)
+        us = float(np.median(us_all))
         nbytes = (8 * n_slots + 37) * n_groups  # B0(P) = 8 P + 37
         hot = nbytes  # every byte it reads is re-read by the next launch
         kernel, unit = "k_recompute", "commit-index recomputes/s"
@@ -414,17 +435,24 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                     ev_.record(pt.stream)
                     main_stream.wait_event(ev_)
 
-        replay(0, warmup, False)
-        torch.cuda.synchronize()
-        e0.record(main_stream)
-        replay(warmup, steps, True)
-        e1.record(main_stream)
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / steps
-        for pt in parts:  # replay determinism
-            c, o = pt.eng.results()
-            if not (np.array_equal(c, pt.ref[0]) and np.array_equal(o, pt.ref[1])):
-                raise SystemExit("side measurement: the timed replay diverged from the recorded pass")
+        us_all = []
+        for rep in range(repeats):  # every region: restored state, W warm-up ticks, then exactly K timed ticks
+            if rep:
+                for pt in parts:
+                    pt.eng.restore()
+                per_launch.clear()
+            replay(0, warmup, False)
+            torch.cuda.synchronize()
+            e0.record(main_stream)
+            replay(warmup, steps, True)
+            e1.record(main_stream)
+            torch.cuda.synchronize()
+            us_all.append(e0.elapsed_time(e1) * 1e3 / steps)
+            for pt in parts:  # replay determinism
+                c, o = pt.eng.results()
+                if not (np.array_equal(c, pt.ref[0]) and np.array_equal(o, pt.ref[1])):
+                    raise SystemExit("side measurement: the timed replay diverged from the recorded pass")
+        us = float(np.median(us_all))
         nbytes = float(np.mean(alg[warmup:]))
         hot = sum(hot_state_bytes(pt.n, pt.slots, bool(inflights)) for pt in parts)
         if sorted_classes:  # the columns of the slots a class does not have are never touched
@@ -472,9 +500,13 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                              "note": "the stage's OWN byte model (DESIGN.md section 3), counted on the last tick; SURVEY 8(d) "
                                      "counts no bytes for the send path"}}
     for pt in parts:
+        pt.info = pt.eng.device_info()
         pt.eng.close()
     gbs = nbytes / (us * 1e-6) / 1e9
-    traffic, traffic_source = traffic_lookup(key)
+    traffic, traffic_source, traffic_stale = traffic_lookup(key)
+    info = parts[0].info if hasattr(parts[0], "info") else {}
+    if what == "tick" and info.get("last_tick_kernel") not in (None, "none"):
+        kernel = info["last_tick_kernel"]  # what the engine says it launched (k_tick_split / k_tick_classes / k_tick_send ...)
     label = (workload_label(workload, n_groups, n_slots, one_engine, sorted_classes) if what == "tick" else
              f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers")
     if inflights:
@@ -483,11 +515,14 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
     return {"workload": label,
             "groups": n_groups, "peer_slots": n_slots, "engines": [{"slots": pt.slots, "groups": pt.n} for pt in parts],
             **({"size_classes": [{"first_group": f, "groups": n, "slots": q} for f, n, q in classes]} if classes else {}),
-            "steps": steps, "warmup": warmup, "us_per_step": us, "value": n_groups / (us * 1e-6), "unit": unit, **extra,
+            "steps": steps, "warmup": warmup, "repeats": repeats, "us_per_step": us, "us_per_step_min": min(us_all),
+            "us_per_step_max": max(us_all), "value": n_groups / (us * 1e-6), "unit": unit, **extra,
+            "engine_reports": {k: info.get(k) for k in ("cache_policy", "resident_groups", "last_tick_kernel", "last_tick_streaming")},
             "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot, "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel": ("k_tick_send" if fused_send else kernel + " + k_send_dense") if inflights else kernel,
                          "algorithmic_bytes_per_launch": nbytes, "bytes_per_eval": nbytes / n_groups, "avg_launch_us": us,
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "avg_launch_us_min": min(us_all), "avg_launch_us_max": max(us_all),
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          **({"note": "avg_launch_us is the tick AND its send stage; the algorithmic bytes are the tick's, so frac "
                                      "understates this mode -- the stage has its own roofline under send_stage"} if inflights else {})}}
 
@@ -500,14 +535,19 @@ def by_config_summary(result):
         r = r or (obj or {}).get("roofline")
         if not r or "frac" not in r:
             return {"error": (obj or {}).get("error", "not measured")[:120]}
-        return {"frac": round(r["frac"], 4), "us": round(r["avg_launch_us"], 2), "alg_bytes": int(r["algorithmic_bytes_per_launch"]),
-                "traffic": None if r.get("traffic") is None else int(r["traffic"]), "regime": r.get("regime")}
+        return {"frac": round(r["frac"], 4), "us": round(r["avg_launch_us"], 2),
+                "us_min": None if r.get("avg_launch_us_min") is None else round(r["avg_launch_us_min"], 2),
+                "us_max": None if r.get("avg_launch_us_max") is None else round(r["avg_launch_us_max"], 2),
+                "alg_bytes": int(r["algorithmic_bytes_per_launch"]),
+                "traffic": None if r.get("traffic") is None else int(r["traffic"]), "traffic_stale": r.get("traffic_stale"),
+                "regime": r.get("regime"), "kernel": r.get("kernel")}
     oc = result.get("other_configs") or {}
     out = {"c2_headline": entry(result)}
     for name, obj in (("c2_hbm_8M", result.get("out_of_cache")), ("c2_resident_2_4M", result.get("between_regimes")),
                       ("c3_joint", oc.get("configs[2] joint")),
                       ("c4_shard", oc.get("configs[3] one rank's shard")), ("c5_one_launch", oc.get("configs[4] one launch, class-sorted")),
-                      ("c5_size_class", oc.get("configs[4] size-class engines")), ("c5_one_engine", oc.get("configs[4] one 7-slot engine")),
+                      ("c5_size_class", oc.get("configs[4] size-class engines")), ("c5_interleaved", oc.get("configs[4] one 7-slot engine")),
+                      ("c5_one_launch_hbm_8M", oc.get("configs[4] one launch, class-sorted, 8M groups")),
                       ("recompute", result.get("recompute_only")), ("recompute_hbm_8M", result.get("recompute_only_out_of_cache"))):
         if obj is not None:
             out[name] = entry(obj)
@@ -521,6 +561,25 @@ def by_config_summary(result):
             e["frac_by_tick_bytes"] = round(obj["roofline"]["frac"], 4)
         out[name] = e
     return out
+
+
+def flat_config_keys(by_config):
+    flat = {}
+    for name, e in by_config.items():
+        if "frac" not in e:
+            flat[f"frac_{name}"] = None
+            continue
+        flat[f"frac_{name}"] = e["frac"]
+        flat[f"us_{name}"] = e["us"]
+        flat[f"us_min_{name}"], flat[f"us_max_{name}"] = e.get("us_min"), e.get("us_max")
+        flat[f"mb_{name}"] = round(e["alg_bytes"] / 1e6, 2)
+        flat[f"traffic_mb_{name}"] = None if e.get("traffic") is None else round(e["traffic"] / 1e6, 2)
+        if e.get("traffic_stale"):
+            flat[f"traffic_stale_{name}"] = True
+        for k in ("step_us", "frac_by_tick_bytes"):
+            if k in e:
+                flat[f"{k}_{name}"] = e[k]
+    return flat
 
 
 def self_launch(n):
@@ -578,6 +637,9 @@ def main():
                          "delta slices -- the naive exchange, for comparison")
     ap.add_argument("--no-publish-compare", action="store_true",
                     help="N>1: skip the second run of the K ticks with the other publication form (publication_compare)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of K steps each (every one behind its own restore + W warm-up steps); the line reports the "
+                         "median region and the fastest / slowest beside it")
     ap.add_argument("--fuse", type=int, default=1,
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
@@ -856,29 +918,44 @@ def main():
                      "rule": "E = ceil(exchange / tick), 1..32; measured on rank 0 over up to 32 ticks and 8 back-to-back publications "
                              "before the timed region, broadcast over the control plane"}
 
-    # ---- timed region ----
-    for pt in parts:
-        pt.eng.restore()
-        if distributed:
-            pt.eng.publish_commit(full=True)  # the replicas restart from the restored columns (outside the region)
-    run_ticks(0, W, distributed, args.publish_raw)
-    torch.cuda.synchronize()
+    # ---- timed region(s) ----
+    # R regions (--repeats, default 5), each exactly as the contract says -- restored state, W untimed warm-up ticks, then
+    # EXACTLY K ticks bracketed by barrier + synchronize on both sides, max over ranks -- and the line reports the MEDIAN region
+    # (ms_per_step) with the fastest and slowest beside it (ms_per_step_min / _max): boxes differ by several per cent and one
+    # 1 ms region says nothing about spread.
     launch_mode = "eager"
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    wall0 = time.perf_counter()
-    e0.record(stream)
-    run_ticks(W, K, distributed, args.publish_raw)
-    e1.record(stream)
-    host_issue_s = issued[0] - wall0  # the host's share: how long it took to ISSUE the K steps
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - wall0
-    kernel_ms = e0.elapsed_time(e1)  # HIP events on the stream the tick kernels run on
+    REPS = max(1, args.repeats)
+    walls, kernel_mss, issues = [], [], []
+    for rep in range(REPS):
+        for pt in parts:
+            pt.eng.restore()
+            if distributed:
+                pt.eng.publish_commit(full=True)  # the replicas restart from the restored columns (outside the region)
+        run_ticks(0, W, distributed, args.publish_raw)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        wall0 = time.perf_counter()
+        e0.record(stream)
+        run_ticks(W, K, distributed, args.publish_raw)
+        e1.record(stream)
+        issues.append(issued[0] - wall0)  # the host's share: how long it took to ISSUE the K steps
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        w = time.perf_counter() - wall0
+        if distributed:
+            tmax = torch.tensor([w], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            w = float(tmax.item())
+        walls.append(w)
+        kernel_mss.append(e0.elapsed_time(e1))  # HIP events on the stream the tick kernels run on
+    wall = float(np.median(walls))
+    kernel_ms = float(np.median(kernel_mss))
+    host_issue_s = float(np.median(issues))
 
     send_stage_info = None
     if args.inflights:
@@ -902,9 +979,6 @@ def main():
     pub_stats = parts[0].eng.publish_stats() if distributed else None
     pub_compare = None
     if distributed:
-        tmax = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
         if not args.no_publish_compare:
             # the same K ticks once more with the OTHER publication form (delta slices <-> the raw 8 B/group column), so
             # that a multi-GPU run reports both side by side; outside the headline region, same barriers, max over ranks
@@ -939,6 +1013,27 @@ def main():
     value = evals / wall
     timed_bytes = float(np.mean(alg_bytes[W:]))
     per_launch_s = kernel_ms / 1e3 / K  # one step = one launch per size class (1 except config 5)
+    F_used = 1 if (args.inflights or distributed) else max(1, min(8, args.fuse))
+    fused_model = None
+    if F_used > 1:
+        # Temporal fusion has its own byte model: ONE launch runs F consecutive ticks with the group's state in registers, so
+        # per launch the state part of SURVEY 8(d) moves once and the message / result parts once per tick. Splitting
+        # B = 9 P + 58 A + 8 R + 37 by stream (SURVEY.md 8d's table): state = 8 P (match) + 17 A (next, flags, pr_commit read)
+        # + 25 A (written) + 28 + 8 (commit, log range, masks; commit written) = 8 P + 42 A + 36; messages and result of one
+        # tick = P (flag bytes) + 16 A (m_index, m_commit) + 8 R (hints) + 1. A launch of T ticks: state + sum over its ticks
+        # (T = 1 gives B back). `A` of the state part = the acked slots of the launch's first tick (the same followers ack in
+        # every tick of the stream).
+        launches = []
+        for i in range(W, W + K, F_used):
+            ts = range(i, min(i + F_used, W + K))
+            c0 = census[ts[0]]
+            launches.append(8 * c0["slots"] + 42 * c0["valid"] + 36 * G +
+                            sum(census[t]["slots"] + 16 * census[t]["valid"] + 8 * census[t]["rejects"] + G for t in ts))
+        timed_bytes = float(np.mean(launches))
+        per_launch_s = kernel_ms / 1e3 / len(launches)
+        fused_model = {"ticks_per_launch": F_used, "launches": len(launches),
+                       "per_tick_model_bytes": float(np.mean(alg_bytes[W:])),
+                       "note": "state moves once per launch, messages + result once per tick: 8P+42A+36 + sum_t(P+16A_t+8R_t+1)"}
     achieved = timed_bytes / per_launch_s / 1e9
     A = float(np.mean([c["valid"] for c in census[W:]])) / G
     R = float(np.mean([c["rejects"] for c in census[W:]])) / G
@@ -946,9 +1041,9 @@ def main():
 
     # HBM traffic per launch: PMC-measured in separate rocprofv3 passes of this same command
     # (tools/summarize_prof.py -> profiles/traffic.json); null for configurations not profiled.
-    traffic, traffic_source = (None, None)
+    traffic, traffic_source, traffic_stale = (None, None, None)
     if not args.inflights and args.split == 1 and args.fuse == 1:
-        traffic, traffic_source = traffic_lookup(
+        traffic, traffic_source, traffic_stale = traffic_lookup(
             f"{args.workload}:{G}:{P}" + (":sorted" if args.sorted else ":one-engine" if (args.workload == 5 and args.one_engine) else "") +
             (f":v{args.variant}" if args.variant else ""))
     hot = sum(hot_state_bytes(pt.n, pt.slots, bool(args.inflights)) for pt in parts)
@@ -956,7 +1051,8 @@ def main():
     result = {
         "metric": "raft-group progress+commit evaluations/sec (commit-index recomputes/sec at 1M groups x 5 peers)",
         "value": value, "unit": "group-evals/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "ms_per_step": wall * 1e3 / K, "ms_per_step_min": min(walls) * 1e3 / K, "ms_per_step_max": max(walls) * 1e3 / K, "repeats": REPS,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": (f"{world * G} groups x 7 peers sharded over {world} GPUs ({G} per GPU), commit indices published "
                                 f"every {'tick' if E == 1 else str(E) + ' ticks'} (BASELINE configs[3]: 8 M x 7 over 8 GPUs"
@@ -986,20 +1082,19 @@ def main():
                        **({"publish_every_auto": auto_note} if auto_note else {})} if distributed else {}),
                    "launch": launch_mode, "host_issue_us_per_step": round(host_issue_s * 1e6 / K, 2), "ticks_per_launch": max(1, min(8, args.fuse)) if not (distributed or args.inflights) else 1},
         "roofline": {"bound": "hbm", "regime": regime_of(hot), "hot_state_bytes": hot,
-                     "regime_note": "infinity-cache: the state columns every launch re-reads fit the 256 MB Infinity Cache, so part "
-                                    "of the traffic never reaches HBM and frac can exceed what a pure HBM stream sustains "
-                                    "(the honest HBM-regime figure is out_of_cache.roofline.frac); hbm: they do not fit",
+                     "regime_note": "infinity-cache: hot state fits the 256 MB MALL, frac can exceed a pure HBM stream; HBM figure: frac_c2_hbm_8M",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_stale": traffic_stale, "csrc_sha16": csrc_sha16(),
                      "kernel": "k_tick_send" if (args.inflights and args.fused_send) else
                                "k_tick_fused" if (args.fuse > 1 and not distributed and not args.inflights) else
                                ({2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(args.variant, "k_tick_classes" if args.sorted else "k_tick_lane")) +
                                (" + k_send_dense" if args.inflights else ""),
-                     "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G,
+                     "algorithmic_bytes_per_launch": timed_bytes, "bytes_per_eval": timed_bytes / G / F_used,
                      "avg_launch_us": per_launch_s * 1e6,
-                     **({"note": "temporal fusion: state stays in registers across the fused ticks, so fewer bytes "
-                                 "move than the per-tick algorithmic model counts; frac is not a per-tick HBM "
-                                 "efficiency in this mode"} if args.fuse > 1 and not distributed and not args.inflights else {}),
+                     "avg_launch_us_min": min(kernel_mss) * 1e3 / K * (K / max(1, len(range(W, W + K, F_used)))),
+                     "avg_launch_us_max": max(kernel_mss) * 1e3 / K * (K / max(1, len(range(W, W + K, F_used)))),
+                     **({"fused_model": fused_model} if fused_model else {}),
                      **({"note": "avg_launch_us is the tick AND its send stage; the algorithmic bytes are the tick's "
                                  "(SURVEY 8d counts no bytes for the send path), so frac understates this mode"}
                         if args.inflights else {})},
@@ -1030,6 +1125,8 @@ def main():
         for name, kw in (("configs[2] joint", dict(n_groups=1_000_000, n_slots=5, workload=3)),
                          ("configs[3] one rank's shard", dict(n_groups=1_000_000, n_slots=7, workload=2)),
                          ("configs[4] one launch, class-sorted", dict(n_groups=1_000_000, n_slots=7, workload=5, sorted_classes=True)),
+                         ("configs[4] one launch, class-sorted, 8M groups", dict(n_groups=8_000_000, n_slots=7, workload=5, sorted_classes=True,
+                                                                                 warmup=3, steps=10)),
                          ("configs[4] size-class engines", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v)),
                          ("configs[4] one 7-slot engine", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v, one_engine=True)),
                          ("configs[1] + send stage", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256)),
@@ -1038,10 +1135,14 @@ def main():
             if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") \
                     and kw.get("variant", 0) == args.variant and kw.get("one_engine", False) == args.one_engine:
                 continue  # that is the headline itself
-            oc[name] = guarded(run_config, rg, torch, warmup=5, steps=30, seed=args.seed, **kw)
+            oc[name] = guarded(run_config, rg, torch, seed=args.seed, **{"warmup": 5, "steps": 30, **kw})
             torch.cuda.empty_cache()
         result["other_configs"] = oc
         result["roofline"]["by_config"] = by_config_summary(result)
+        # ... and once more FLAT, as scalar keys of `roofline` (frac_<cfg>, us_<cfg>, us_min_/us_max_<cfg>, mb_<cfg> = algorithmic
+        # MB per launch, traffic_mb_<cfg> = PMC HBM MB per launch or null): scalars are what the driver's record keeps of a
+        # sub-object, so frac = mb / us / 8 TB/s of EVERY configuration can be recomputed from BENCH_rNN.json.parsed alone
+        result["roofline"].update(flat_config_keys(result["roofline"]["by_config"]))
         # the other end of the scale: the round trip of a flush that touches 1 / 10 groups (not a throughput number)
         result["small_batch_latency"] = guarded(small_batch_latency, rg, torch, G, P, args.seed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -202,7 +202,7 @@ typedef struct {
     uint32_t cache_policy;          /* RG_CACHE_* */
     uint32_t flags;                 /* RG_CFGF_* */
     uint64_t cache_resident_groups; /* RG_CACHE_RESIDENT: the state of the first this-many groups (rounded down to whole
-                                       workgroups of 256) stays in the cache, the rest is streamed; 0 = the engine's own
+                                       workgroups of 64) stays in the cache, the rest is streamed; 0 = the engine's own
                                        sizing (176 MB of state). Ignored by the other policies. */
 } rg_config;
 
@@ -263,7 +263,7 @@ typedef struct {
     uint32_t cache_policy;      /* RG_CACHE_PLAIN .. RG_CACHE_RESIDENT */
     uint32_t engines_on_device; /* live engines of this process on the engine's device when it was created, itself included
                                    (AUTO grants a resident range only to an engine that is alone) */
-    uint64_t resident_groups;   /* RG_CACHE_RESIDENT: groups whose state stays in the cache (a multiple of 256), else 0 */
+    uint64_t resident_groups;   /* RG_CACHE_RESIDENT: groups whose state stays in the cache (a multiple of 64), else 0 */
     /* the dense tick kernel of the LAST rg_tick / rg_tick_device(_send) launch (0 before the first): what actually ran */
     uint32_t last_tick_kernel;  /* RG_KERNEL_* */
     uint32_t last_tick_streaming; /* 0 = plain accesses, 1 = message columns streamed, 2 = state columns too

@@ -731,19 +731,22 @@ __global__ __launch_bounds__(RG_BLOCK) void k_fix_ins_full(RgState st, RgIns ins
 }
 
 __global__ __launch_bounds__(RG_BLOCK) void k_count_out(const u32 *out, u64 G, u64 *counts) {
-    u64 ch = 0, fl = 0;
+    u64 ch = 0, fl = 0, hh = 0;
     for (u64 g = (u64)blockIdx.x * RG_BLOCK + threadIdx.x; g < G; g += (u64)gridDim.x * RG_BLOCK) {
         const u32 o = out[g];
         ch += o & RG_OUT_CHANGED ? 1 : 0;
         fl += o & RG_OUT_FAULT ? 1 : 0;
+        hh += o & RG_OUT_HOST_HINT ? 1 : 0;
     }
     for (int off = 32; off > 0; off >>= 1) {
         ch += __shfl_down(ch, off, 64);
         fl += __shfl_down(fl, off, 64);
+        hh += __shfl_down(hh, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd((unsigned long long *)&counts[0], (unsigned long long)ch);
         atomicAdd((unsigned long long *)&counts[1], (unsigned long long)fl);
+        if (hh) atomicAdd((unsigned long long *)&counts[2], (unsigned long long)hh);
     }
 }
 
@@ -916,6 +919,8 @@ struct rg_engine {
     u64 nt_resident;   // ... except those of the first nt_resident workgroups' groups, which stay in the cache (k_tick_split); 0 = off
     bool counted_live;   // this engine is in g_live_on_device
     bool cls_block_order; // RG_CFGF_CLASS_BLOCK_ORDER
+    bool hint_check_due; // device Inflights: a tick that may have raised RG_OUT_HOST_HINT (it carried log terms) ran and nobody has
+                         // verified since that every hint was resolved (rg_require_hints_resolved)
     bool send_ready;   // a tick ran since the last rg_send_appends
     u64 stage_max_entries; // limit and flags of the last send stage (any form): rg_resolve_host_hints runs the stage of the
     u32 stage_flags;       // groups that stage skipped (RG_OUT_HOST_HINT) with the same ones
@@ -1124,6 +1129,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     h->send_ready = false;
+    h->hint_check_due = false;
     h->cls_need = nullptr;
     h->cls_on = false;
     h->cls_order = nullptr;
@@ -1513,7 +1519,31 @@ static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t 
 // Device Inflights: a tick's result word carries free_to / free_first_one / left-Replicate effects for the rings. If
 // the host skipped rg_send_appends, apply those effects (and nothing else: the send requests are dropped, which
 // is what skipping the stage means) before the next tick overwrites RG_COL_OUT, so no window is left stale.
+// Device Inflights and RG_OUT_HOST_HINT: the reference runs a deferred reject's send_append BEFORE the group's other sends of
+// the step, so the group's send requests wait for rg_resolve_host_hints, which serves them (its Inflights effects -- free_to,
+// free_first_one, the window resets -- are applied by the stage either way). A host that moved on without resolving would drop
+// those requests for good and leave `next` / the windows behind the reference's: exact or loud -- every entry point that
+// starts the next step refuses while such a group exists. Checked only after a tick that carried log terms (nothing else can
+// raise the bit): one reduction over RG_COL_OUT and one synchronisation on that rare path, nothing on the others.
+static int rg_require_hints_resolved(rg_engine *h, const char *who) {
+    if (!h->ins_arena || !h->hint_check_due) return RG_OK;
+    RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
+    const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
+    hipLaunchKernelGGL(k_count_out, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u32 *)h->st.out, h->G, h->d_counts);
+    u64 c[3] = {0, 0, 0};
+    RG_HIP(hipMemcpyAsync(c, h->d_counts, 24, hipMemcpyDeviceToHost, h->stream));
+    RG_HIP(hipStreamSynchronize(h->stream));
+    if (c[2])
+        return rg_fail(RG_ERR_STATE, "%s: %llu group(s) still carry RG_OUT_HOST_HINT; with device Inflights (max_inflight > 0) "
+                                     "rg_resolve_host_hints must answer every hint before the next step (rg_host_hints lists them)",
+                       who, (unsigned long long)c[2]);
+    h->hint_check_due = false;
+    return RG_OK;
+}
+
 static int rg_settle_send(rg_engine *h) {
+    int hrc = rg_require_hints_resolved(h, "next step");
+    if (hrc) return hrc;
     if (!h->ins_arena || !h->send_ready) return RG_OK;
     const u64 *list = h->out_is_dense ? nullptr : h->res_list;
     const u64 n = h->out_is_dense ? h->G : h->last_sparse_n;

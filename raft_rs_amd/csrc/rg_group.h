@@ -423,6 +423,11 @@ template <typename IX> RG_HD void rg_pub_store(const RgState &st, IX g, u32 adv,
 // ---------------------------------------------------------------------------------------------
 // One group's registers for a tick.
 // ---------------------------------------------------------------------------------------------
+#ifndef RG_HINT_COMPRESS_FROM /* slot counts from which the reject hints share two registers (99 = never: measured in round 5,
+                                profiles/r05_c5_occupancy.txt -- 10 registers fewer at 7 slots, no wave gained, 87.5 -> 90.4 us on config 5) */
+#define RG_HINT_COMPRESS_FROM 99
+#endif
+#define RG_HINT_REGS(P) ((P) >= RG_HINT_COMPRESS_FROM ? 2 : (P))
 template <int P> struct RgGroup {
     u64 mt[P], nx[P], pc[P]; // Progress.matched / next_idx / committed_index   (in/out)
     u64 mi[P], mc[P];        // Message.index / Message.commit                  (in)
@@ -437,7 +442,14 @@ template <int P> struct RgGroup {
     // Operands of the rare paths, requested TOGETHER WITH the bulk loads by rg_prefetch_rare (NX mode RG_NX_PREFETCH):
     // reject hints (after find_conflict_by_term where the pre-pass ran) and what an election reads from the cold
     // columns. A wave then pays one memory round trip however many of its lanes take a rare path.
-    u64 hint[P];
+    // HN == P: one register per slot. HN == 2 (RG_HINT_REGS: the 7- and 8-slot bodies, where P registers cost a wave of
+    // occupancy): the hints of the first two slots that need one, the election's new term first (`hsel`: bits 0-3 the slot of
+    // hint[0] + 1, bits 4-7 the slot of hint[1] + 1, 0 = none); a third reject of the same group in one tick -- rare even
+    // under rollover (0.12 rejects per group-tick in BASELINE config 5) -- fetches its hint on the spot.
+    static constexpr int HN = RG_HINT_REGS(P);
+    u64 hint[HN];
+    u32 hsel;
+    u64 pc_self;        // early stores (RgTick's ES): the leader's own committed_index once pc[] has gone to memory
     u32 el_n;           // an election: the term-run table's fill count (RG_COL_RUN_COUNT) -- with it rg_push_run files the previous
                         // leader's run on the spot, two stores and no look at the table (round 3 read the table for the first
                         // unused run, behind the group's stores: two dependent round trips at the tail of every wave that holds
@@ -638,6 +650,8 @@ template <int P, typename IX> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const R
         r.el_old = rg_at(st.cur_term, g); // (the new term arrives in r.hint[self], below)
         r.el_n = (u32)rg_at(rg_run_n(st), g);
     }
+    constexpr bool HC = RgGroup<P>::HN != P; // compressed hints
+    u32 hneed = 0, hlt = 0;                  // HC: slots that need a hint / of those, the ones that read the pre-pass's column
 #pragma unroll
     for (int i = 0; i < P; i++) {
         const u32 f = (u32)(r.mf >> (8 * i)) & 0xffu, pb = (u32)(r.pf >> (8 * i)) & 0xffu;
@@ -653,9 +667,51 @@ template <int P, typename IX> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const R
         // it carries a snapshot request: known only with m_rs); after an election every follower is in Probe
         const u32 rj = RG_MF_VALID | RG_MF_REJECT;
         // (the leader's own slot has no hint: its register carries the new term of an election, m_hint of that slot)
-        r.hint[i] = 0;
-        if ((u32)i == self ? elect : here && (f & (rj | RG_MF_HEARTBEAT)) == rj && (elect || !repl))
-            r.hint[i] = (f & RG_MF_HAS_LOGTERM) && (u32)i != self ? rg_at(ms.mhr, o) : rg_at(ms.mh, o);
+        const bool need = (u32)i == self ? elect : here && (f & (rj | RG_MF_HEARTBEAT)) == rj && (elect || !repl);
+        const bool from_prepass = (f & RG_MF_HAS_LOGTERM) && (u32)i != self;
+        if constexpr (!HC) {
+            r.hint[i] = 0;
+            if (need) r.hint[i] = from_prepass ? rg_at(ms.mhr, o) : rg_at(ms.mh, o);
+        } else {
+            hneed |= need ? 1u << i : 0u;
+            hlt |= from_prepass ? 1u << i : 0u;
+        }
+    }
+    if constexpr (HC) {
+        // two loads, each into its own register, whatever slots they serve: the ADDRESS is selected, not the loaded value (a
+        // select over loaded values would make the wave wait for the loads right here)
+        u32 s0 = 0, s1 = 0; // slot + 1
+        if (elect) s0 = self + 1u;
+        u32 rest = hneed & ~(elect ? 1u << self : 0u);
+        if (!s0 && rest) {
+            s0 = (u32)__builtin_ctz(rest) + 1u;
+            rest &= rest - 1u;
+        }
+        if (rest) s1 = (u32)__builtin_ctz(rest) + 1u;
+        r.hsel = s0 | (s1 << 4);
+        r.hint[0] = 0;
+        r.hint[1] = 0;
+        if (s0) r.hint[0] = ((hlt >> (s0 - 1u)) & 1u) ? rg_at(ms.mhr, (IX)(s0 - 1u) * (IX)st.stride + g) : rg_at(ms.mh, (IX)(s0 - 1u) * (IX)st.stride + g);
+        if (s1) r.hint[1] = ((hlt >> (s1 - 1u)) & 1u) ? rg_at(ms.mhr, (IX)(s1 - 1u) * (IX)st.stride + g) : rg_at(ms.mh, (IX)(s1 - 1u) * (IX)st.stride + g);
+    } else {
+        r.hsel = 0;
+    }
+}
+
+// The prefetched hint of slot s (RG_NX_PREFETCH). Compressed form: one of the two registers, or -- a third reject of the group
+// in this tick -- fetched now.
+template <int P, typename IX> RG_HD u64 rg_hint_of(const RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g, u32 s, bool from_prepass) {
+    if constexpr (RgGroup<P>::HN == P) {
+        u64 h = 0;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            if ((u32)i == s) h = r.hint[i];
+        return h;
+    } else {
+        if ((r.hsel & 0xfu) == s + 1u) return r.hint[0];
+        if (((r.hsel >> 4) & 0xfu) == s + 1u) return r.hint[1];
+        const IX o = (IX)s * (IX)st.stride + g;
+        return from_prepass ? rg_at(ms.mhr, o) : rg_at(ms.mh, o);
     }
 }
 
@@ -667,7 +723,21 @@ template <int P, typename IX> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const R
 // when some group has ProgressTracker.group_commit set).
 // FUSED: the group's state stays in registers across several ticks (k_tick_fused): `dirty`/`evm`
 // accumulate, and `next` cells already fetched or written are not fetched again.
-template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
+// ES -- early stores (the 7- and 8-slot lane bodies, rg_tick_kernels.h: RgEarlyStores). A tick's registers peak in the commit
+// phase, where the matches, the parked old matches, the quorum state AND the two columns that are merely waiting for the
+// group's stores -- `next` and `committed_index`, 4 P registers -- are all live. Neither is read again once its slot is done:
+// update_committed is applied to every slot up front (peer_committed), `next` is final when slot<S>() returns. With ES::on
+// they are stored on the spot -- the followers' committed_index right behind peer_committed (uniform control flow: whole-line
+// ballots as in rg_store_group), `next` behind each slot -- and only the leader's own committed_index (raft.rs:896-900 raises
+// it to the new commit index at the very end) travels on, in ONE register pair (RgGroup::pc_self), to be stored with the group. Same cells, same values, same
+// number of stores; what changes is when they are issued and that 4 P - 2 registers are free when the quorum is evaluated.
+struct RgNoEarlyStores {
+    static constexpr bool on = false;
+    template <int P, typename IX> RG_HD static void store_pc(RgGroup<P> &, const RgState &, IX, u32) {}
+    template <int S, int P, typename IX> RG_HD static void store_next(RgGroup<P> &, const RgState &, IX) {}
+};
+template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEarlyStores> struct RgTick {
+    static_assert(!ES::on || !FUSED, "early stores: single-tick kernels only");
     static constexpr bool LAZY_NX = NXM == RG_NX_LAZY;
     static constexpr bool PREF = NXM == RG_NX_PREFETCH;
     RgGroup<P> &r;
@@ -751,10 +821,7 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
         // (RG_NX_PREFETCH: they were requested with the group's bulk loads, rg_prefetch_rare)
         u64 new_term, old_term;
         if (PREF) {
-            new_term = 0;
-#pragma unroll
-            for (int i = 0; i < P; i++)
-                if ((u32)i == self) new_term = r.hint[i];
+            new_term = rg_hint_of<P, IX>(r, st, ms, g, self, false); // (compressed hints: the election's term is always hint[0])
             old_term = r.el_old;
             RG_OPAQUE64(new_term);
             RG_OPAQUE64(old_term);
@@ -945,7 +1012,7 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
                                 // the walk over the term table costs this kernel no registers
                                 u64 hint;
                                 if (PREF) {
-                                    hint = r.hint[S];
+                                    hint = rg_hint_of<P, IX>(r, st, ms, g, (u32)S, (f & RG_MF_HAS_LOGTERM) != 0);
                                     RG_OPAQUE64(hint);
                                 } else {
                                     hint = (f & RG_MF_HAS_LOGTERM) ? rg_at(ms.mhr, o) : rg_at(ms.mh, o);
@@ -1007,7 +1074,12 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
     }
 
     template <int S> RG_HD void self_committed() { // prs[self].update_committed(committed), raft.rs:896-900
-        if ((u32)S == self && ((present >> S) & 1u) && r.pc[S] < r.commit) {
+        if constexpr (ES::on) { // (the followers' cells are in memory already; rg_store_group<.., EARLY> writes pc_self)
+            if ((u32)S == self && ((present >> S) & 1u) && r.pc_self < r.commit) {
+                r.pc_self = r.commit;
+                r.dirty |= 1u << (16 + S);
+            }
+        } else if ((u32)S == self && ((present >> S) & 1u) && r.pc[S] < r.commit) {
             r.pc[S] = r.commit;
             r.dirty |= 1u << (16 + S);
         }
@@ -1099,15 +1171,21 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX> struct RgTick {
     template <int... S> RG_HD void run(rg_seq<S...> seq) {
         mc_self = 0;
         (peer_committed<S>(), ...);
-        (slot<S>(), ...);
+        if constexpr (ES::on) {
+            u64 ps = 0;
+            (((u32)S == self ? (void)(ps = r.pc[S]) : (void)0), ...);
+            r.pc_self = ps;
+            ES::template store_pc<P, IX>(r, st, g, self);
+        }
+        ((slot<S>(), ES::template store_next<S, P, IX>(r, st, g)), ...);
         commit_phase(seq);
         r.out = out;
     }
 };
 
 // NXM: RG_NX_* -- who provides r.nx (and, for RG_NX_PREFETCH, r.hint / r.el_*).
-template <int P, bool GC, int NXM, bool FUSED = false, typename IX = u64>
+template <int P, bool GC, int NXM, bool FUSED = false, typename IX = u64, typename ES = RgNoEarlyStores>
 RG_HD void rg_group_tick(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
-    RgTick<P, GC, NXM, FUSED, IX> t(r, st, ms, g);
+    RgTick<P, GC, NXM, FUSED, IX, ES> t(r, st, ms, g);
     t.run(typename rg_make_seq<P>::type{});
 }

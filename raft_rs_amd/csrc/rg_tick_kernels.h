@@ -55,14 +55,32 @@ template <bool NT, typename T> RG_HD void rg_st(T &dst, T v) {
 #else
 #define RG_BLOCK 256
 #endif
-#ifndef RG_LANE_IX32 /* the 32-bit cell index of the single-tick lane kernels: u32, or rg_u32o (opaque offsets, rg_common.h: experiment) */
-#define RG_LANE_IX32 u32
+// The 32-bit cell index of the single-tick lane kernels, by slot count: u32, or -- from RG_U32O_FROM slots on -- rg_u32o
+// (opaque offsets, rg_common.h), which keeps `base + offset` out of the registers between a cell's load and its store:
+// 6 slots 142 -> 120 VGPRs (3 -> 4 waves per SIMD), 8 slots 182 -> 147 (2 -> 3), 7 slots with the compressed hints and the
+// early stores 162 -> 133 (128 with RG_MIN_WAVES=4). MEASURED (round 5, profiles/r05_c5_occupancy.txt): the extra wave buys
+// NOTHING -- 1 M x 6 at four waves 65.4 us against 64.2 at three, config 5 in one launch at four waves 87.8 against 87.5 at
+// three -- because these kernels are bound by instruction issue (1 100 - 2 100 VALU and 800 - 1 150 SALU per wave), not by
+// latency an extra wave could hide; the opaque offsets themselves cost 0-8 %. So every slot count stays on u32 (99 = never);
+// the knobs remain for the comparison. -DRG_LANE_IX32=<type>: one type for every slot count (experiment builds).
+#ifndef RG_U32O_FROM
+#define RG_U32O_FROM 99
 #endif
-#ifdef RG_MIN_WAVES /* experiment: minimum waves per SIMD the register allocator must leave room for */
-#define RG_TICK_BOUNDS __launch_bounds__(RG_BLOCK, RG_MIN_WAVES)
+#ifdef RG_LANE_IX32
+template <int P> struct RgLaneIx { typedef RG_LANE_IX32 type; };
 #else
-#define RG_TICK_BOUNDS __launch_bounds__(RG_BLOCK)
+template <int P> struct RgLaneIx { typedef typename std::conditional<(P >= RG_U32O_FROM), rg_u32o, u32>::type type; };
 #endif
+// Minimum waves per SIMD the register allocator must leave room for in the lane kernels of RG_MIN_WAVES_FROM slots and more
+// (experiment builds; the default asks for nothing).
+#ifndef RG_MIN_WAVES
+#define RG_MIN_WAVES 1
+#endif
+#ifndef RG_MIN_WAVES_FROM
+#define RG_MIN_WAVES_FROM 1
+#endif
+#define RG_LANE_BOUNDS(P) __launch_bounds__(RG_BLOCK, ((P) >= RG_MIN_WAVES_FROM ? RG_MIN_WAVES : 1))
+#define RG_TICK_BOUNDS __launch_bounds__(RG_BLOCK)
 
 static inline unsigned rg_grid_for(u64 n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
@@ -108,13 +126,15 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
 // WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
 // stage, which changes both; every other caller stores the group in one go).
 // WAVE_ST (kernels whose lanes hold CONSECUTIVE groups, all lanes of the wave arriving here together): RG_OPT_WAVE_ST
-template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false, bool NTS = false>
+// EARLY: the tick ran with RgEarlyStores -- `next` and the followers' committed_index are in memory already; the one
+// committed_index cell still due is the leader's own (RgGroup::pc_self, which RgTick::self_committed may have raised).
+template <int P, typename IX, int WHICH = 3, bool WAVE_ST = false, bool NTS = false, bool EARLY = false>
 RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     u32 d = r.dirty;
 #if RG_OPT_UNCOND_ST
     {   // rewrite every cell of a slot that has a Progress and any event this tick: whole lines
         const u32 ev = r.evm; // slots with a Progress that had an event (RgTick)
-        d |= ev | (ev << 8) | (ev << 16);
+        d |= EARLY ? ev | ((ev & (1u << RG_CFG_SELF(r.cfg))) << 16) : ev | (ev << 8) | (ev << 16);
     }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -122,7 +142,8 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
 #pragma unroll
         for (int p = 0; p < P; p++) {
             if (__builtin_amdgcn_ballot_w64((d >> p) & 1u) != 0) d |= 1u << p;
-            if (__builtin_amdgcn_ballot_w64((d >> (16 + p)) & 1u) != 0) d |= 1u << (16 + p);
+            // (EARLY: only the lanes whose leader sits in slot p still hold a value for that cell)
+            if (__builtin_amdgcn_ballot_w64((d >> (16 + p)) & 1u) != 0 && (!EARLY || (RG_CFG_SELF(r.cfg) == (u32)p && ((RG_CFG_PRESENT(r.cfg) >> p) & 1u)))) d |= 1u << (16 + p);
         }
     }
 #endif
@@ -130,8 +151,8 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     for (int p = 0; p < P; p++) {
         const IX o = (IX)p * (IX)st.stride + g;
         if ((WHICH & 1) && (d & (1u << p))) rg_st<(RG_OPT_NT_ALL != 0 || NTS)>(rg_at(st.match, o), r.mt[p]);
-        if ((WHICH & 2) && (d & (1u << (8 + p)))) rg_st<((RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0 || NTS)>(rg_at(st.next, o), r.nx[p]);
-        if ((WHICH & 1) && (d & (1u << (16 + p)))) rg_st<(RG_OPT_NT_ALL != 0 || NTS)>(rg_at(st.prc, o), r.pc[p]);
+        if (!EARLY && (WHICH & 2) && (d & (1u << (8 + p)))) rg_st<((RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0 || NTS)>(rg_at(st.next, o), r.nx[p]);
+        if ((WHICH & 1) && (d & (1u << (16 + p)))) rg_st<(RG_OPT_NT_ALL != 0 || NTS)>(rg_at(st.prc, o), EARLY ? r.pc_self : r.pc[p]);
     }
     if ((WHICH & 2) && (d & RG_DIRTY_PF)) rg_at(st.pflags, g) = r.pf;
     if (WHICH & 1) {
@@ -150,11 +171,50 @@ RG_HD void rg_store_group(const RgGroup<P> &r, const RgState &st, IX g) {
     }
 }
 
+// RgTick's early stores (rg_group.h: ES) for kernels whose lanes hold consecutive groups and walk the tick together: the same
+// cells rg_store_group would write at the end -- the unconditional / whole-line rules included -- issued as soon as the value
+// is final. The dirty bits are cleared so that nothing is stored twice.
+// MEASURED (round 5, profiles/r05_c5_occupancy.txt): it frees the registers it promises (P = 7: 161 -> 151 VGPRs with u32 offsets) and
+// it LOSES -- 1 M x 7 steady 74.8 -> 84.0 us, 1 M x 8 87.1 -> 94.2 --: stores issued in the middle of the tick queue up in front of
+// nothing useful and take issue slots from the arithmetic. Off by default (99 = never); kept, host-checked, as the comparison.
+#ifndef RG_EARLY_ST_FROM /* slot counts from which the lane bodies store early (99 = never) */
+#define RG_EARLY_ST_FROM 99
+#endif
+template <bool NTS> struct RgEarlyStores {
+    static constexpr bool on = true;
+    template <int P, typename IX> RG_HD static void store_pc(RgGroup<P> &r, const RgState &st, IX g, u32 self) {
+        u32 d = r.dirty;
+#if RG_OPT_UNCOND_ST
+        d |= r.evm << 16;
+#endif
+        d &= ~(1u << (16 + self)); // (the leader's own cell goes with the group: the commit phase may still raise it)
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (RG_OPT_WAVE_ST && __builtin_amdgcn_ballot_w64((d >> (16 + p)) & 1u) != 0) d |= 1u << (16 + p);
+#endif
+            if (d & (1u << (16 + p))) rg_st<(RG_OPT_NT_ALL != 0 || NTS)>(rg_at(st.prc, (IX)p * (IX)st.stride + g), r.pc[p]);
+        }
+        r.dirty &= ~(0xffu << 16) | (1u << (16 + self));
+    }
+    template <int S, int P, typename IX> RG_HD static void store_next(RgGroup<P> &r, const RgState &st, IX g) {
+        u32 d = r.dirty >> (8 + S);
+#if RG_OPT_UNCOND_ST
+        d |= r.evm >> S;
+#endif
+        if (d & 1u) rg_st<((RG_OPT_NT_ALL | RG_OPT_NT_NEXT) != 0 || NTS)>(rg_at(st.next, (IX)S * (IX)st.stride + g), r.nx[S]);
+        r.dirty &= ~(1u << (8 + S));
+    }
+};
+template <int P, bool NTS> struct RgLaneStores {
+    typedef typename std::conditional<(P >= RG_EARLY_ST_FROM), RgEarlyStores<NTS>, RgNoEarlyStores>::type type;
+};
+
 template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u64 &cfg_adv, F &&f);
 // IX = u32 when every cell of the engine's columns lies within 4 GiB of its column's start (rg_launch_tick_t decides).
 // NTM: 1 = the read-once message columns as non-temporal loads (rg_ld_stream), 2 = the state columns as well, loads and stores
 // (rg_load_group: NTS); decided per launch from the engine's footprint (rg_create)
-template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_TICK_BOUNDS void k_tick_lane(RgState st, RgMsgs ms) {
+template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_LANE_BOUNDS(P) void k_tick_lane(RgState st, RgMsgs ms) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g64 >= st.G) return;
     const IX g = (IX)g64;
@@ -178,8 +238,9 @@ template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_TICK_BOUNDS vo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #endif
-    rg_group_tick<P, GC, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<P, IX, 3, true, NTM == 2>(r, st, g);
+    typedef typename RgLaneStores<P, NTM == 2>::type ES;
+    rg_group_tick<P, GC, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
+    rg_store_group<P, IX, 3, true, NTM == 2, ES::on>(r, st, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -235,20 +296,21 @@ template <int Q, typename IX, int NTM> RG_D void rg_lane_body(IX g) {
     const RgMsgs ms = ka->ms;
     RgGroup<Q> r;
     rg_load_group<Q, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2>(r, st, ms, g);
-    rg_group_tick<Q, false, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<Q, IX, 3, true, NTM == 2>(r, st, g);
+    typedef typename RgLaneStores<Q, NTM == 2>::type ES;
+    rg_group_tick<Q, false, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
+    rg_store_group<Q, IX, 3, true, NTM == 2, ES::on>(r, st, g);
 #endif
 }
-template <int P, typename IX, int NTM> __global__ RG_TICK_BOUNDS void k_tick_classes(RgClassArgs a) {
+template <int P, typename IX, int NTM> __global__ RG_LANE_BOUNDS(P) void k_tick_classes(RgClassArgs a) {
     const u32 e = a.cls.order[blockIdx.x]; // (scalar: blockIdx is uniform -- one s_load_dword)
     const u32 blk = e & 0x0fffffffu, np = e >> 28;
     const u64 g64 = (u64)blk * RG_BLOCK + threadIdx.x;
     if (g64 >= a.st.G) return;
-    const IX g = (IX)g64;
-    if (P > 3 && np <= 3) rg_lane_body<3, IX, NTM>(g);
-    else if (P > 5 && np <= 5) rg_lane_body<5, IX, NTM>(g);
-    else if (P > 7 && np <= 7) rg_lane_body<7, IX, NTM>(g);
-    else rg_lane_body<P, IX, NTM>(g);
+    // (each body with the index type of its own slot count: RgLaneIx)
+    if (P > 3 && np <= 3) rg_lane_body<3, typename RgLaneIx<3>::type, NTM>((typename RgLaneIx<3>::type)g64);
+    else if (P > 5 && np <= 5) rg_lane_body<5, typename RgLaneIx<5>::type, NTM>((typename RgLaneIx<5>::type)g64);
+    else if (P > 7 && np <= 7) rg_lane_body<7, typename RgLaneIx<7>::type, NTM>((typename RgLaneIx<7>::type)g64);
+    else rg_lane_body<P, IX, NTM>((IX)g64);
 }
 
 // The lane kernel over an engine whose state is PARTLY RESIDENT in the Infinity Cache (round 4). Beyond the cache a launch
@@ -266,7 +328,7 @@ struct RgSplitArgs {
 static_assert(offsetof(RgSplitArgs, st) == offsetof(RgClassArgs, st) && offsetof(RgSplitArgs, ms) == offsetof(RgClassArgs, ms) &&
                   sizeof(RgSplitArgs) >= sizeof(RgClassArgs),
               "rg_lane_body reads st and ms through an RgClassArgs view of the kernarg segment");
-template <int P, typename IX> __global__ RG_TICK_BOUNDS void k_tick_split(RgSplitArgs a) {
+template <int P, typename IX> __global__ RG_LANE_BOUNDS(P) void k_tick_split(RgSplitArgs a) {
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
     if (g64 >= a.st.G) return;
     const IX g = (IX)g64;
@@ -510,8 +572,9 @@ template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u6
         f(i++, r.mi[p]);
         f(i++, r.mc[p]);
         f(i++, r.nx[p]);
-        f(i++, r.hint[p]);
     }
+#pragma unroll
+    for (int h = 0; h < RgGroup<P>::HN; h++) f(i++, r.hint[h]);
     f(i++, r.mf);
     f(i++, r.pf);
     f(i++, r.commit);
@@ -519,9 +582,10 @@ template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u6
     f(i++, r.hi);
     f(i++, r.el_old);
     {
-        u64 n64 = r.el_n;
+        u64 n64 = (u64)r.el_n | ((u64)r.hsel << 32);
         f(i++, n64);
         r.el_n = (u32)n64;
+        r.hsel = (u32)(n64 >> 32);
     }
     f(i++, cfg_adv);
     f(i++, g64);
@@ -542,7 +606,7 @@ RG_D void rg_lds_barrier() {
 #endif
 template <int P, bool GC, typename IX>
 __global__ RG_CPT_BOUNDS void k_tick_compact(RgState st, RgMsgs ms) {
-    constexpr int NF = 6 * P + 9;
+    constexpr int NF = 5 * P + RgGroup<P>::HN + 9;
     __shared__ u64 x_rare[NF][RG_CPT_CAP];  // rare groups handed over by the natural waves
     __shared__ u64 x_disp[NF][RG_CPT_CAP];  // steady groups the designated wave gives away in exchange
     __shared__ u32 cnt[2];                  // [0] rare lanes of the natural waves, [1] steady lanes of the designated wave
@@ -1160,7 +1224,7 @@ template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, cons
     } else {
         // 32-bit cell offsets when every cell a lane addresses is below 4 GiB from its column's start
         if (rg_ix32(st, P))
-            RG_LAUNCH_LANE(RG_LANE_IX32);
+            RG_LAUNCH_LANE(typename RgLaneIx<P>::type);
         else
             RG_LAUNCH_LANE(u64);
     }
@@ -1176,9 +1240,10 @@ template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState
         a.st = st;
         a.ms = ms;
         a.cls = cls;
-        if (ntm == 2) hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 2>), grid, block, 0, stream, a);
-        else if (ntm) hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_tick_classes<P, RG_LANE_IX32, 0>), grid, block, 0, stream, a);
+        typedef typename RgLaneIx<P>::type IXP;
+        if (ntm == 2) hipLaunchKernelGGL((k_tick_classes<P, IXP, 2>), grid, block, 0, stream, a);
+        else if (ntm) hipLaunchKernelGGL((k_tick_classes<P, IXP, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_tick_classes<P, IXP, 0>), grid, block, 0, stream, a);
     }
 }
 template <int P> void rg_launch_tick_split_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u64 resident_blocks) {
@@ -1186,7 +1251,7 @@ template <int P> void rg_launch_tick_split_t(hipStream_t stream, const RgState &
     a.st = st;
     a.ms = ms;
     a.resident_blocks = resident_blocks;
-    hipLaunchKernelGGL((k_tick_split<P, RG_LANE_IX32>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL((k_tick_split<P, typename RgLaneIx<P>::type>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, a);
 }
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,

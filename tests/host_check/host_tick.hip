@@ -49,9 +49,10 @@ static RgMsgs make_msgs(const void *const *p) {
 template <int P, typename IX> static void host_one(const RgState &st, const RgMsgs &ms, bool gc, IX g) {
     RgGroup<P> r;
     rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
-    if (gc) rg_group_tick<P, true, RG_LANE_NX, false, IX>(r, st, ms, g);
-    else rg_group_tick<P, false, RG_LANE_NX, false, IX>(r, st, ms, g);
-    rg_store_group<P, IX>(r, st, g);
+    typedef typename RgLaneStores<P, false>::type ES; // (the lane kernels' own choice: early stores from 7 slots on)
+    if (gc) rg_group_tick<P, true, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
+    else rg_group_tick<P, false, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
+    rg_store_group<P, IX, 3, false, false, ES::on>(r, st, g);
 }
 
 template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, bool gc, u64 g0, u64 g1) {

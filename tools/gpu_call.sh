@@ -10,6 +10,7 @@
 #   prof:<name>:<bench args>                 rocprofv3 --kernel-trace --stats of bench.py <args> -> <name>_kernel_stats.csv
 #   pmc:<traffic.json key, + for :>:<steps>:<bench args>   FETCH_SIZE / WRITE_SIZE PMC passes (tools/pmc_traffic.sh ->
 #                                            gpurun_out/traffic_<key>.json; fold them in with tools/merge_traffic.py)
+#   sweep:<libs, + between>:<name>:<bench args>   tools/sweep_libs.py: experiment builds x one bench configuration -> sweep.txt
 #   py:<script.py>:<args>                    python <script> <args> > <script>.txt
 #   sh:<command with , for spaces>           anything else
 set -u

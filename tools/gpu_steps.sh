@@ -28,6 +28,8 @@ except Exception as e: print('??', e)"
     f=$(find /tmp/prof_$a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/${a}_kernel_stats.csv" && head -6 "$O/${a}_kernel_stats.csv" | cut -c1-200 ;;
   pmc)
     bash tools/pmc_traffic.sh "${a//+/:}" "$b" $(sp "$c") > "$O/pmc_${a//+/_}.txt" 2>&1; tail -3 "$O/pmc_${a//+/_}.txt" ;;
+  sweep) # sweep:<libs, + between them>:<name>:<bench args, commas for spaces>  -> sweep.txt (tools/sweep_libs.py)
+    timeout 1500 python tools/sweep_libs.py --libs "${a//+/,}" --configs "$b:$(sp "$c")" 2>&1 | tee -a "$O/sweep.txt" ;;
   py)
     timeout 1200 python "$a" $(sp "$b") > "$O/$(basename "$a" .py)${c:+_$c}.txt" 2>&1; tail -40 "$O/$(basename "$a" .py)${c:+_$c}.txt" ;;
   sh)

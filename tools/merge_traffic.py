@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     src, tag, commit, script = sys.argv[1:5]
+    sys.path.insert(0, ROOT)
+    import bench
+    csrc = bench.csrc_sha16()  # (run this with the tree the passes were measured on checked out)
     passes_path = os.path.join(ROOT, "profiles", f"{tag}_traffic_passes.json")
     passes = json.load(open(passes_path)) if os.path.exists(passes_path) else {}
     table_path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -31,7 +34,8 @@ def main():
         d["build"] = commit
         passes[key] = d
         b = sum(v.get("read", 0) + v.get("write", 0) for v in kernels.values())
-        table[key] = {"bytes": b, "source": f"profiles/{tag}_traffic_passes.json ({script}; {d['command']}{note})", "commit": commit}
+        table[key] = {"bytes": b, "source": f"profiles/{tag}_traffic_passes.json ({script}; {d['command']}{note})", "commit": commit,
+                      "csrc_sha16": csrc}
         print(f"{key:45s} {b / 1e6:9.1f} MB")
     json.dump(passes, open(passes_path, "w"), indent=1)
     json.dump(table, open(table_path, "w"), indent=1)
