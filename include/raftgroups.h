@@ -129,7 +129,13 @@ typedef enum {
                                  against its own log and steps the same reject again with RG_MF_HAS_LOGTERM clear (log_term = 0)
                                  and WITHOUT RG_MF_SENT (a SENT event of the slot was applied). Which slots: RG_COL_HOST_HINT /
                                  rg_host_hints. A reject touches only its own peer's Progress and never `matched`, so taking it
-                                 after the other messages of the tick changes no other result. */
+                                 after the other messages of the tick changes no other result.
+                                 Engines with device Inflights (max_inflight > 0): the re-step form is NOT available there -- the
+                                 reference sends the deferred reject's MsgAppend before the group's other sends of the step, so the
+                                 group's send requests wait for rg_resolve_host_hints, which serves them; the tick's Inflights
+                                 effects (free_to, free_first_one, window resets) are applied by the stage either way. Until every
+                                 flagged (group, slot) has been answered, every call that would start the next step (a tick, a
+                                 flush, rg_progress_events ...) fails with RG_ERR_STATE and changes nothing. */
 #define RG_OUT_SEND_APPEND(o) (((uint32_t)(o) >> 8) & 0xffu) /* per slot: send_append(from) (raft.rs:1719, :1750) */
 #define RG_OUT_SEND_MORE(o) (((uint32_t)(o) >> 16) & 0xffu)  /* per slot: the maybe_send_append loop (raft.rs:1761) */
 #define RG_OUT_FREE_TO(o) (((uint32_t)(o) >> 24) & 0xffu)    /* per slot: ins.free_to(m.index) (raft.rs:1742) */
@@ -286,7 +292,10 @@ int rg_sync(rg_engine *h);
 uint64_t rg_column_bytes(const rg_engine *h, int column);
 int rg_load_column(rg_engine *h, int column, const void *host_src, uint64_t bytes);
 int rg_read_column(rg_engine *h, int column, void *host_dst, uint64_t bytes);
-/* Device address of a column (for zero-copy consumers, e.g. an RCCL all-gather of RG_COL_COMMIT). */
+/* Device address of a column (for zero-copy READERS, e.g. an RCCL all-gather of RG_COL_COMMIT). Writing through it bypasses
+ * what rg_load_column derives on the way in -- the engine-owned flag bits, RG_COL_RUN_COUNT from RG_COL_RUN_FIRST, the size
+ * classes from RG_COL_CFG (handing out that column's pointer switches k_tick_classes off for good) -- so state goes in
+ * through rg_load_column / rg_write_cells. */
 void *rg_column_ptr(rg_engine *h, int column);
 /* Snapshot / restore the complete device state inside the engine (bench replays, rollbacks). */
 int rg_checkpoint(rg_engine *h);
@@ -390,7 +399,10 @@ int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
  * BEFORE that tick, so the library runs it as a single-tick launch (behind its pre-pass) between the fused launches of the
  * ticks around it -- same results, same arrays. With commit publication active (rg_comm_init) the call's total advance of
  * every group lands in its publication byte, exactly as n_ticks single launches without a publication in between would
- * leave it. Not available with device Inflights (rg_send_appends has to follow every tick).
+ * leave it. A log-term tick that raises RG_OUT_HOST_HINT reports it in its row of dev_out_t ONLY (RG_COL_OUT / RG_COL_HOST_HINT
+ * hold the last tick's): the later ticks of the call run with that reject unapplied, exactly as if the host had stepped them
+ * before answering -- a host whose term-run tables may be non-contiguous does not fuse log-term ticks.
+ * Not available with device Inflights (rg_send_appends has to follow every tick).
  * Asynchronous. Use it to
  * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
 #define RG_MAX_FUSE 8
@@ -426,8 +438,9 @@ int rg_host_hints(rg_engine *h, rg_host_hint *host_items, uint64_t cap, uint64_t
  * device cell -- Progress::maybe_decr_to(index, hint, 0) (src/tracker/progress.rs:168-206) with `hint` =
  * find_conflict_by_term(reject_hint, log_term).0 from the host's log (src/raft.rs:1657-1660), become_probe when that leaves
  * Replicate -- and the group's RG_COL_OUT word completed: RG_OUT_SEND_APPEND(slot) where maybe_decr_to returned true
- * (host_applied[i] = 1, may be NULL), RG_OUT_HOST_HINT cleared. Pass all rejects of a group in one call, before anything
- * else touches the group. With device Inflights the order of the reference is kept by making the GROUP's sends wait for
+ * (host_applied[i] = 1, may be NULL); the group's RG_OUT_HOST_HINT bit falls with the LAST of its flagged slots
+ * (bit s of RG_COL_HOST_HINT[g] is cleared per record; a record for a slot that is not waiting changes nothing). Pass the rejects
+ * of a group before anything else touches the group. With device Inflights the order of the reference is kept by making the GROUP's sends wait for
  * this call: after rg_tick(_device) call it BEFORE rg_send_appends; the one-launch forms (rg_tick_send, rg_tick_device_send,
  * rg_flush_send) do not run the stage of a group that raised the bit -- this call runs it, with the limit and flags of that
  * launch, and appends the work items to the compact list (rg_send_items; rg_send_columns then no longer holds everything).

@@ -70,6 +70,7 @@ static int rg_fail(int code, const char *fmt, ...) {
 
 struct rg_engine;
 static int rg_mailbox_quiesce(rg_engine *h);
+static int rg_require_hints_resolved(rg_engine *h, const char *who);
 // Every entry point that puts work on the engine's stream starts here: select the device and, if the resident mailbox
 // kernel is on the stream (rg_mailbox_start), tell it to leave -- stream order would make the call wait for it anyway
 // (until its idle timeout), this makes the wait a few microseconds.
@@ -677,10 +678,17 @@ __global__ __launch_bounds__(256) void k_progress_events(RgState st, u32 *ins_me
 __global__ __launch_bounds__(256) void k_resolve_apply(RgState st, u32 *ins_meta, const rg_resolved_hint *it, u64 n, u32 P, u8 *applied) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const bool dec = rg_resolve_hint_at(st, ins_meta, it, P, i, [&](u64 g, u32 bits, u32 clear) {
-        if (bits) atomicOr(&st.out[g], bits);
-        atomicAnd(&st.out[g], ~clear);
-    });
+    const bool dec = rg_resolve_hint_at(
+        st, ins_meta, it, P, i,
+        [&](u64 g, u32 s) { // (byte g of the column lives in the aligned word g / 4; the column is padded to a multiple of 256)
+            u32 *w = reinterpret_cast<u32 *>(st.hhint) + (g >> 2);
+            const u32 sh = 8u * (u32)(g & 3u);
+            return (atomicAnd(w, ~(1u << (sh + s))) >> sh) & 0xffu;
+        },
+        [&](u64 g, u32 bits, u32 clear) {
+            if (bits) atomicOr(&st.out[g], bits);
+            if (clear) atomicAnd(&st.out[g], ~clear);
+        });
     applied[i] = dec ? 1 : 0;
 }
 
@@ -1513,8 +1521,7 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
 // ------------------------------------------------------------------------------------------------
 static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, const u64 *list, u64 n,
                            const u32 *n_ptr);
-#define RG_SEND_EFFECTS_ONLY 0x80000000u /* internal: apply the tick's Inflights effects, serve no send request */
-#define RG_SEND_APPEND_LIST 0x40000000u  /* internal: the stage's work items are appended to the compact list (the counter is not reset) */
+// (RG_SEND_EFFECTS_ONLY / _APPEND_LIST / _REQUESTS_ONLY: rg_send.h)
 
 // Device Inflights: a tick's result word carries free_to / free_first_one / left-Replicate effects for the rings. If
 // the host skipped rg_send_appends, apply those effects (and nothing else: the send requests are dropped, which
@@ -1749,6 +1756,10 @@ static int rg_send_check(rg_engine *h, uint32_t flags, const char *who) {
 
 static int rg_tick_device_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     RG_ENTER(h);
+    {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
+        const int hrc__ = rg_require_hints_resolved(h, "rg_tick_device");
+        if (hrc__) return hrc__;
+    }
     RgMsgs ms;
     ms.mi = (const u64 *)m->m_index;
     ms.mc = (const u64 *)m->m_commit;
@@ -1762,7 +1773,9 @@ static int rg_tick_device_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *
                            h->rhint);
         ms.mhr = h->rhint;
     }
-    return rg_tick_impl(h, ms, send);
+    const int trc = rg_tick_impl(h, ms, send);
+    if (trc == RG_OK && m->m_logterm) h->hint_check_due = true; // (rg_require_hints_resolved: this tick can have raised RG_OUT_HOST_HINT)
+    return trc;
 }
 
 extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
@@ -1876,6 +1889,10 @@ static int rg_ensure_msg_arena(rg_engine *h) {
 
 static int rg_tick_host_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     RG_ENTER(h);
+    {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
+        const int hrc__ = rg_require_hints_resolved(h, "rg_tick");
+        if (hrc__) return hrc__;
+    }
     int rc = rg_ensure_msg_arena(h);
     if (rc) return rc;
     const size_t colb = (size_t)h->P * h->stride * 8;
@@ -1897,6 +1914,7 @@ static int rg_tick_host_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *se
     }
     rc = rg_tick_impl(h, ms, send);
     if (rc) return rc;
+    if (m->m_logterm) h->hint_check_due = true;
     // the engine-owned message columns must read "no events" outside a tick (sparse-path invariant)
     RG_HIP(hipMemsetAsync((void *)h->staged.mflags, 0, h->stride * 8, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // caller-owned host buffers may be reused after return
@@ -1968,6 +1986,10 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     if (n_duplicates) *n_duplicates = 0;
     if (n == 0) return RG_OK;
     RG_ENTER(h);
+    {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
+        const int hrc__ = rg_require_hints_resolved(h, "rg_ingest");
+        if (hrc__) return hrc__;
+    }
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     if (n > h->d_records_cap) {
@@ -1998,6 +2020,10 @@ extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, ui
     if (!h || (!dev_records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest_device: bad argument");
     if (n == 0) return RG_OK;
     RG_ENTER(h);
+    {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
+        const int hrc__ = rg_require_hints_resolved(h, "rg_ingest_device");
+        if (hrc__) return hrc__;
+    }
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     hipLaunchKernelGGL(k_ingest, dim3(rg_grid(n, RG_INGEST_BLOCK)), dim3(RG_INGEST_BLOCK), 0, h->stream,
@@ -2039,6 +2065,7 @@ static int rg_sparse_enqueue(rg_engine *h, u64 upper, char *packed, bool any_log
     h->last_sparse_n = 0;
     h->host_res_valid = false;
     if (!upper) return RG_OK;
+    if (any_logterm) h->hint_check_due = true; // (rg_require_hints_resolved)
     RgMsgs ms = h->staged;
     ms.mhr = ms.mh;
     u64 *mf = (u64 *)h->staged.mflags;
@@ -2120,6 +2147,10 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_ingested: null engine");
     if (n_groups) *n_groups = 0;
     RG_ENTER(h);
+    {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
+        const int hrc__ = rg_require_hints_resolved(h, "rg_tick_ingested");
+        if (hrc__) return hrc__;
+    }
     int rc = rg_ensure_sparse(h);
     if (rc) return rc;
     const u64 upper = h->ingested_upper < h->G ? h->ingested_upper : h->G;
@@ -2196,6 +2227,10 @@ template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *
 extern "C" int rg_recompute(rg_engine *h) {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_recompute: null engine");
     RG_ENTER(h);
+    {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
+        const int hrc__ = rg_require_hints_resolved(h, "rg_recompute");
+        if (hrc__) return hrc__;
+    }
     int rc = rg_settle_send(h);
     if (rc) return rc;
     rc = rg_recompute_impl<true>(h, nullptr, nullptr);
@@ -2240,7 +2275,7 @@ static int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t 
     const bool append = (flags & RG_SEND_APPEND_LIST) != 0; // (rg_resolve_host_hints: the list keeps what it holds)
     flags &= ~RG_SEND_APPEND_LIST;
     h->stage_max_entries = max_entries_per_msg;
-    h->stage_flags = flags;
+    h->stage_flags = flags & ~RG_SEND_REQUESTS_ONLY;
     h->send_cols_fresh = false;
     h->send_last_dense = false;
     if (!list && !n_ptr && n == h->G) { // every group: work items into the peer-major columns, no list
@@ -2675,7 +2710,8 @@ extern "C" int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items
         h->send_last_dense = false;
         rc = rg_stage_records(h, groups.data(), groups.size() * 8);
         if (rc) return rc;
-        rc = rg_send_enqueue(h, h->stage_max_entries, h->stage_flags | RG_SEND_APPEND_LIST, (const u64 *)h->d_recs,
+        // (requests only: that stage applied the groups' Inflights effects when it skipped their requests)
+        rc = rg_send_enqueue(h, h->stage_max_entries, h->stage_flags | RG_SEND_APPEND_LIST | RG_SEND_REQUESTS_ONLY, (const u64 *)h->d_recs,
                              groups.size(), nullptr);
         if (rc) return rc;
         h->send_bound += groups.size() * h->P;
@@ -3042,7 +3078,14 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served,
 static int rg_sparse_roundtrip(rg_engine *h, const rg_wire_msg *recs, u64 n, bool any_logterm, u32 *dup_out,
                                const rg_send_req *send = nullptr) {
     RG_HIP(hipSetDevice(h->cfg.device)); // (not RG_ENTER: this is the one path the resident mailbox kernel serves)
-    int rc = rg_ensure_sparse(h);
+    int rc;
+    if (h->ins_arena && h->hint_check_due) { // (rare: a log-term tick came before; the check needs the stream to itself)
+        rc = rg_mailbox_quiesce(h);
+        if (rc) return rc;
+        rc = rg_require_hints_resolved(h, "rg_flush / rg_ingest_tick");
+        if (rc) return rc;
+    }
+    rc = rg_ensure_sparse(h);
     if (rc) return rc;
     if (recs && n > RG_ROUNDTRIP_MAX) return rg_sparse_threecall(h, recs, n, dup_out, send);
     if (!recs) {
@@ -3320,6 +3363,8 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served,
     // earlier tick left to settle (that one needs a launch), and a limit the request word can carry
     u32 lim = 0;
     if (h->ins_arena) {
+        // (a tick that can raise RG_OUT_HOST_HINT, or one that follows such a tick, takes the launch path: rg_require_hints_resolved)
+        if (any_logterm || h->hint_check_due) return RG_OK;
         if (!send || h->send_ready) return RG_OK;
         if (send->max_entries == ~0ULL) lim = 0xffffffffu;
         else if (send->max_entries >= 0xffffffffULL) return RG_OK;

@@ -560,13 +560,21 @@ RG_HD bool rg_apply_resolved_reject(u64 match, u64 &next, u64 &psnap, u32 &pf, u
 }
 
 // Record i of an rg_resolve_host_hints batch against the columns (k_resolve_apply: one lane per record; tests/host_check: a loop).
-// `orw(g, bits, clear)`: out[g] = (out[g] | bits) & ~clear, atomically on the device (records of one group may sit in different lanes).
-template <typename ORW>
-RG_HD bool rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolved_hint *it, u32 P, u64 i, ORW &&orw) {
+// A record answers ONE deferred reject: bit `slot` of the group's RG_COL_HOST_HINT byte. A record for a (group, slot) that is
+// not waiting -- never flagged, or answered already -- changes nothing (returns false). The group's RG_OUT_HOST_HINT bit, which
+// holds back the group's send requests on an engine with device Inflights, falls only when its LAST waiting slot is answered:
+// a host that passes some of a group's rejects now and the rest later releases the stage with the last of them.
+// `take(g, s)`: atomically clear bit s of hhint[g] and return the byte as it was (records of one group may sit in different
+// lanes); `orw(g, bits, clear)`: out[g] = (out[g] | bits) & ~clear, atomically on the device.
+template <typename TAKE, typename ORW>
+RG_HD bool rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolved_hint *it, u32 P, u64 i, TAKE &&take, ORW &&orw) {
     const u64 g = it[i].group;
     const u32 s = it[i].slot;
     if (g >= st.G || s >= P) return false;
     if (!((RG_CFG_PRESENT(st.cfg[g]) >> s) & 1u)) return false;
+    if (!(st.out[g] & RG_OUT_HOST_HINT)) return false; // (the byte is only meaningful under the bit: raftgroups.h)
+    const u32 before = take(g, s);
+    if (!((before >> s) & 1u)) return false;
     const u64 o = (u64)s * st.stride + g;
     u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + g * 8 + s;
     u32 pf = *pfb;
@@ -585,7 +593,8 @@ RG_HD bool rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolve
         }
         *pfb = (u8)pf;
     }
-    orw(g, dec ? 1u << (8 + s) : 0u, (u32)RG_OUT_HOST_HINT);
+    const bool last = (before & ~(1u << s) & 0xffu) == 0;
+    orw(g, dec ? 1u << (8 + s) : 0u, last ? (u32)RG_OUT_HOST_HINT : 0u);
     return dec;
 }
 

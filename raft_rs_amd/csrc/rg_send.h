@@ -18,6 +18,9 @@
 #ifndef RG_SEND_WHOLE_LINES
 #define RG_SEND_WHOLE_LINES 1
 #endif
+#define RG_SEND_EFFECTS_ONLY 0x80000000u  /* engine-internal stage flags (never part of the C ABI's RG_SEND_*) */
+#define RG_SEND_APPEND_LIST 0x40000000u   /* the stage's work items are appended to the compact list (the counter is not reset) */
+#define RG_SEND_REQUESTS_ONLY 0x20000000u
 #ifndef RG_SEND_WAVE_LINES /* the dense kernels: a cell one lane of a wave needs is loaded and rewritten by all of them (rg_wave_any) */
 #define RG_SEND_WAVE_LINES 1
 #endif
@@ -263,8 +266,10 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
     const u32 present = RG_CFG_PRESENT(q.cfg), self = RG_CFG_SELF(q.cfg);
     // bcast_append: the leader appended entries (a proposal, raft.rs:2049-2053), or the commit index moved and
     // should_bcast_commit() (raft.rs:1745-1748, :2684-2686: !skip_bcast_commit || has_pending_conf())
-    // RG_SEND_EFFECTS_ONLY (engine-internal, a skipped stage being settled): only the Inflights effects below
-    q.serve = !(flags & 0x80000000u);
+    // RG_SEND_EFFECTS_ONLY (engine-internal: a skipped stage being settled, a group that waits for its host hint): only the
+    // Inflights effects below. (RG_SEND_REQUESTS_ONLY, rg_resolve_host_hints completing such a group: rg_group_send masks the
+    // effect bits out of the result word it passes.)
+    q.serve = !(flags & RG_SEND_EFFECTS_ONLY);
     q.bcast = q.serve && (out & RG_OUT_APPENDED) != 0;
     if (q.serve && (out & RG_OUT_CHANGED))
         q.bcast = q.bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((q.row0 >> (8 * self)) & RG_PF_PENDING_CONF);
@@ -511,9 +516,13 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
 template <int P, typename IX = u64, bool SPEC = false, bool WAVE = false>
 RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64 max_entries, u32 flags,
                          RgSendRegs<P> &it) {
-    // a group that waits for the host's answer to RG_OUT_HOST_HINT keeps ALL its requests for the stage that
-    // rg_resolve_host_hints runs (the deferred reject's send_append comes before the group's other sends of the tick)
-    if (out & RG_OUT_HOST_HINT) out = 0;
+    // a group that waits for the host's answer to RG_OUT_HOST_HINT keeps its send REQUESTS for the stage that
+    // rg_resolve_host_hints runs (the deferred reject's send_append comes before the group's other sends of the tick); the
+    // tick's Inflights EFFECTS -- free_to, free_first_one, the window resets -- are applied here and now, once, whatever the host
+    // does next (round 4 dropped them with the requests: a host that moved on without resolving left the windows stale)
+    if ((out & RG_OUT_HOST_HINT) && (flags & RG_SEND_REQUESTS_ONLY)) out = 0; // (still waiting for more answers; its effects are done)
+    else if (out & RG_OUT_HOST_HINT) flags |= RG_SEND_EFFECTS_ONLY;
+    else if (flags & RG_SEND_REQUESTS_ONLY) out &= ~(0xff000000u | (u32)RG_OUT_BECAME_LEADER); // (free_to / free_first_one / reset: done)
     RgSendOps<P> q;
     rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u);
     rg_send_serve<P, IX, false, WAVE && !SPEC>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);

@@ -389,9 +389,11 @@ RG_HD void rg_group_tick_send_a(RgGroup<P> &r, const A &a, IX g, u64 max_entries
     const RgState st = a.st();
     const RgIns ins = a.ins();
     // A reject of this group waits for the host's log (RG_OUT_HOST_HINT, rg_resolve_host_hints): its send_append belongs BEFORE
-    // the group's other sends of the tick, so the whole group's stage waits with it -- that call runs it. The stage below sees an
-    // empty result word: no Inflights effect, no work item; the real word goes to RG_COL_OUT as always.
-    const u32 sout = (r.out & RG_OUT_HOST_HINT) ? 0u : r.out;
+    // the group's other sends of the tick, so the group's send REQUESTS wait with it -- that call serves them. The stage below
+    // applies the tick's Inflights effects only (free_to, free_first_one, the window resets): no work item; the real word goes
+    // to RG_COL_OUT as always.
+    const u32 sout = r.out;
+    flags = (r.out & RG_OUT_HOST_HINT) ? flags | RG_SEND_EFFECTS_ONLY : flags;
 #if defined(__HIP_DEVICE_COMPILE__) && RG_TS_SPEC == 2
     if (win) {
         // the DMA the kernel issued before the tick is a pending LDS write on the VM counter

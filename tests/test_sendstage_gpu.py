@@ -152,6 +152,88 @@ def test_send_stage_waits_for_host_hints(rg, n_slots, cap, max_entries, form):
     eng.close()
 
 
+def test_unanswered_host_hints_refuse_the_next_step(rg):
+    """Device Inflights: until EVERY reject a tick left to the host (RG_OUT_HOST_HINT) has been answered, nothing that starts the
+    next step is accepted (RG_ERR_STATE, device state untouched) -- the group's send requests are served by
+    rg_resolve_host_hints alone, so a host that moved on would leave `next` and the windows behind the reference's. The
+    Inflights effects of the tick are applied by the stage either way; a group's bit falls with the LAST of its slots: answering
+    one slot of a two-slot group releases nothing, answering a slot twice changes nothing."""
+    from raft_rs_amd.engine import EngineError, ERR, COL
+    rng = np.random.default_rng(9911)
+    G, P, cap, TERM = 3000, 5, 4, 30
+    st = O.add_term_table(O.alloc_state(G, P))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, P, missing_progress_frac=0.03)
+    fuzz.random_state(rng, st, probe_frac=0.5, base=200)
+    fuzz.random_term_table(rng, st, TERM, min_runs=O.TERM_RUNS)
+    eng = rg.Engine(G, P, max_inflight=cap)
+    eng.load_state(st)
+    cl = O.Cluster(G)
+    cl.load_soa(st, term=TERM, max_inflight=cap)
+    cl.set_own_inflights(True)
+    msgs = O.alloc_msgs(G, P)
+    mb = rg.MsgBuffers(G, P, eng.stride)
+    gout = np.zeros(G, dtype=np.uint32)
+    seen = {"refused": 0, "partial_groups": 0, "settled": 0}
+    for t in range(6):
+        cl.store_soa(st)
+        fuzz.random_msgs(rng, st, msgs, valid_p=0.8, reject_p=0.6, rs_p=0.05, sent_p=0.0, heartbeat_p=0.1, logterm_max=TERM + t,
+                         elect_p=0.5, elect_term=TERM + 1 + t)
+        hosthints.spread_reject_hints(rng, st, msgs, TERM + 1 + t)
+        sendstage.prepare_msgs(msgs)
+        for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_logterm", "m_flags"):
+            getattr(mb, k)[...] = msgs[k]
+        if t % 2:
+            eng.tick_send(mb, 0)
+        else:
+            eng.tick(mb)
+            eng.send_appends(0)
+        cl.tick_soa(msgs, gout)
+        out0 = eng.read_column(COL.OUT)
+        hh = eng.read_column(COL.HOST_HINT)
+        hinted = np.nonzero(out0 & hosthints.OUT_HOST_HINT)[0]
+        if hinted.size:
+            before = eng.read_state()
+            meta0, ring0 = eng.read_inflights()
+            for call in (lambda: eng.tick(mb), lambda: eng.tick_send(mb, 0),
+                         lambda: eng.progress_events([(int(hinted[0]), 1, 1)]), lambda: eng.recompute()):
+                with pytest.raises(EngineError) as e:
+                    call()
+                assert e.value.code == ERR["STATE"] and "rg_resolve_host_hints" in str(e.value)
+                seen["refused"] += 1
+            assert not fuzz.diff_states(before, eng.read_state(), G, P) and np.array_equal(before["out"], eng.read_column(COL.OUT))
+            meta1, ring1 = eng.read_inflights()
+            assert np.array_equal(meta0, meta1) and np.array_equal(ring0, ring1)
+
+        def resolve(recs):
+            first, rest, have = [], [], set()
+            for r in recs:  # one slot of every group now, the others afterwards
+                (rest if r[0] in have else first).append(r)
+                have.add(r[0])
+            assert eng.resolve_host_hints(first).all()
+            if rest:
+                waiting = {r[0] for r in rest}
+                seen["partial_groups"] += len(waiting)
+                out1 = eng.read_column(COL.OUT)
+                for g in have:
+                    assert bool(out1[g] & hosthints.OUT_HOST_HINT) == (g in waiting), g
+                assert not eng.resolve_host_hints(first).any(), "answered slots do not wait any more"
+                with pytest.raises(EngineError) as e:
+                    eng.tick(mb)
+                assert e.value.code == ERR["STATE"]
+                assert {int(r["group"]) for r in eng.host_hints()} == waiting
+                assert eng.resolve_host_hints(rest).all()
+            return eng.read_column(COL.OUT)
+
+        merged, n = hosthints.settle(cl, msgs, out0, hh, resolve=resolve)
+        seen["settled"] += n
+        assert (merged == gout).all(), (t, np.nonzero(merged != gout)[0][:5])
+        items = sendstage.compare_items(eng.send_items(), cl.send_stage_soa(gout, 0))
+        apply_snapshots(rg, eng, cl, st, items)
+        check(rg, eng, cl, st, cap, f"tick {t}")
+    assert seen["refused"] >= 12 and seen["partial_groups"] > 5 and seen["settled"] > 50, seen
+    eng.close()
+
+
 def test_send_stage_after_sparse_ticks(rg):
     """rg_ingest -> rg_tick_ingested -> rg_send_appends: the stage walks the touched groups only."""
     from test_sparse_path_gpu import records_from_msgs

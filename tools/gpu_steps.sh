@@ -4,7 +4,7 @@ label=$1; shift
 cd "$GRAFT_REPO_ROOT" || exit 9
 export TMPDIR=/tmp
 O=gpurun_out/$label; mkdir -p "$O"
-sp() { echo "${1//,/ }"; }
+sp() { local x="${1//,/ }"; echo "${x//+/,}"; } # (commas separate words; a + stands for a literal comma inside one)
 for step in "$@"; do
   IFS=: read -r kind a b c <<< "$step"
   echo "=== $step" | tee -a "$O/steps.txt"

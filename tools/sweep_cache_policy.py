@@ -57,6 +57,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--slots", default="3,7")
     ap.add_argument("--mults", default="0.8,1.1,1.3,1.5,2.0,2.5,3.5,5.0,7.5,9.0")
+    ap.add_argument("--groups", default="", help="explicit engine sizes (groups) instead of --mults")
+    ap.add_argument("--policies", default="plain,stream_msgs,stream_all,resident")
     args = ap.parse_args()
     import torch
     import raft_rs_amd as rg
@@ -65,8 +67,10 @@ def main():
     print("# state = mult x 256 MiB; us per tick: median [min-max] of 3 x K ticks; * = what RG_CACHE_AUTO picks; bytes/eval = 9P+58(P-0.2)+37")
     for P in [int(x) for x in args.slots.split(",")]:
         per_group = 24 * P + 40
-        for mult in [float(x) for x in args.mults.split(",")]:
-            G = int(mult * mall / per_group) // 256 * 256
+        sizes = ([int(x) for x in args.groups.split(",")] if args.groups else
+                 [int(float(x) * mall / per_group) // 256 * 256 for x in args.mults.split(",")])
+        for G in sizes:
+            mult = G * per_group / mall
             steps = max(6, min(30, int(3e6 * 30 / G)))
             auto = rg.Engine(G, P)
             pick = auto.device_info()["cache_policy"]
@@ -74,6 +78,8 @@ def main():
             row = []
             for name, pol in (("plain", rg.CACHE.PLAIN), ("stream_msgs", rg.CACHE.STREAM_MSGS), ("stream_all", rg.CACHE.STREAM_ALL),
                               ("resident", rg.CACHE.RESIDENT)):
+                if name not in args.policies.split(","):
+                    continue
                 if name == "resident" and G * per_group <= 176 * 2**20 + 256 * per_group:
                     row.append(f"{name}: -")
                     continue
