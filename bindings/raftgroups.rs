@@ -63,6 +63,9 @@ pub const RG_SEND_HOST: u32 = 3;
 pub const RG_SEND_SKIP_BCAST_COMMIT: u32 = 0x1;
 pub const RG_SEND_BYTES: u32 = 0x2;
 pub const RG_COMM_ID_BYTES: u32 = 128;
+pub const RG_COMM_ALL_AUTO: u32 = 0;
+pub const RG_COMM_ALL_RCCL: u32 = 1;
+pub const RG_COMM_ALL_LOCAL: u32 = 2;
 pub const RG_PUBLISH_FULL: u32 = 0x1;
 pub const RG_WL_MAJORITY: u32 = 2;
 pub const RG_WL_JOINT: u32 = 3;
@@ -324,6 +327,14 @@ pub struct RgCommConfig {
 }
 
 #[repr(C)]
+pub struct RgCommAllConfig {
+    pub ring_ticks: u32,
+    pub overflow_slots: u32,
+    pub transport: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
 pub struct RgPublishStats {
     pub publications: u64,
     pub full_publications: u64,
@@ -442,6 +453,8 @@ extern "C" {
     pub fn rg_comm_unique_id(id: *mut u8) -> i32;
     pub fn rg_comm_init(h: *mut RgEngine, cfg: *const RgCommConfig) -> i32;
     pub fn rg_comm_destroy(h: *mut RgEngine) -> i32;
+    pub fn rg_comm_init_all(engines: *mut *const RgEngine, n: u32, cfg: *const RgCommAllConfig) -> i32;
+    pub fn rg_publish_commit_all(engines: *mut *const RgEngine, n: u32, flags: u32) -> i32;
     pub fn rg_publish_commit(h: *mut RgEngine, flags: u32) -> i32;
     pub fn rg_publish_sync(h: *mut RgEngine) -> i32;
     pub fn rg_published_commit_ptr(h: *mut RgEngine, stride: *mut u64) -> *const u64;

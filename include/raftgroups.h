@@ -19,7 +19,8 @@
  *  - plain C types only; all buffers are caller-owned; the engine keeps no host pointer
  *    after a call returns (async H2D copies are completed or staged before return);
  *  - every call returns RG_OK (0) or a negative rg_status; rg_last_error() has the text;
- *  - one caller thread per handle (mirrors "thread-unsafe" RawNode, src/raw_node.rs:284);
+ *  - one caller thread per handle at a time (mirrors "thread-unsafe" RawNode, src/raw_node.rs:284); different handles may be
+ *    driven by different threads of one process concurrently (see "several ranks in ONE process" below);
  *  - a group has up to 8 peer slots; slot s of a group is one Progress (src/tracker/progress.rs:8-56);
  *  - device state is struct-of-arrays: per-slot u64 columns are peer-major [P][stride]
  *    (stride = n_groups rounded up to 256), per-slot flag bytes are one u64 row per group
@@ -216,9 +217,9 @@ typedef struct {
  * columns (16 P + 8) are read once. Measured windows (profiles/r04_nt_state.txt, r04_resident.txt at 5 slots;
  * profiles/r05_cache_policy_sweep.txt at 3 and 7): */
 #define RG_CACHE_AUTO 0u        /* by footprint: PLAIN while state + one tick of messages fit the cache; STREAM_MSGS beyond;
-                                   RESIDENT where 1.3 x cache < state <= 2.5 x cache and no other engine lives on the device
-                                   at rg_create (the cache is one per device); STREAM_ALL where 1.5 x cache < state <= 7.5 x
-                                   cache; engines with device Inflights: PLAIN / STREAM_MSGS only */
+                                   RESIDENT where 1.25 x cache < state <= 2.5 x cache and no other engine lives on the device
+                                   at rg_create (the cache is one per device); else STREAM_ALL where state > 1.5 x cache and
+                                   the shard holds at most 13 M groups; engines with device Inflights: PLAIN / STREAM_MSGS */
 #define RG_CACHE_PLAIN 1u       /* every access allocates in the cache */
 #define RG_CACHE_STREAM_MSGS 2u /* the read-once message columns are streamed past it (non-temporal loads) */
 #define RG_CACHE_STREAM_ALL 3u  /* ... and the state columns, loads and stores: nothing of the launch is allocated */
@@ -767,6 +768,30 @@ typedef struct {
  * publication so every replica starts from the actual commit columns. */
 int rg_comm_init(rg_engine *h, const rg_comm_config *cfg);
 int rg_comm_destroy(rg_engine *h);
+/* Several ranks in ONE process (`rg_create(cfg{..., n_devices, device_ids[]})`; the reference's own embedding
+ * drives many RawNodes from one thread, src/raw_node.rs:284, examples/five_mem_node/main.rs:67-112). Two forms:
+ *  (1) one THREAD per engine: each thread creates its engine and calls rg_comm_init / rg_publish_commit on it like a rank of
+ *      its own process would (the library keeps no state across handles beyond a per-device engine count and the lazily
+ *      loaded RCCL binding, both behind locks; rg_last_error is per thread) -- RCCL's ordinary multi-threaded use;
+ *  (2) ONE thread for all of them: rg_comm_init_all makes engines[i] rank i of n, and every publication goes through
+ *      rg_publish_commit_all(engines, n, flags) -- the n ranks' exchanges are issued together (RCCL: inside one
+ *      ncclGroupStart / ncclGroupEnd, without which a single thread would block in rank 0's collective before rank 1's is
+ *      issued). rg_publish_sync / rg_published_commit / rg_publish_stats_get / rg_comm_destroy stay per engine. Transport:
+ *      RG_COMM_ALL_AUTO = RCCL when every engine has a device of its own (n > 1), else RG_COMM_ALL_LOCAL: device-to-device
+ *      copies between the engines' buffers (same process, so every rank's slice is addressable: peer copies over xGMI between
+ *      GPUs, plain copies inside one -- what several shards on ONE device use, which RCCL refuses). All engines hold the same
+ *      number of groups. rg_publish_commit on such an engine is refused (RG_ERR_STATE). */
+typedef struct {
+    uint32_t ring_ticks;     /* as rg_comm_config */
+    uint32_t overflow_slots; /* as rg_comm_config */
+    uint32_t transport;      /* RG_COMM_ALL_* */
+    uint32_t reserved;
+} rg_comm_all_config;
+#define RG_COMM_ALL_AUTO 0u
+#define RG_COMM_ALL_RCCL 1u
+#define RG_COMM_ALL_LOCAL 2u
+int rg_comm_init_all(rg_engine *const *engines, uint32_t n, const rg_comm_all_config *cfg /* NULL = defaults */);
+int rg_publish_commit_all(rg_engine *const *engines, uint32_t n, uint32_t flags);
 /* Collective, asynchronous: publish this rank's commit advances since its previous publication (call it after every
  * tick for per-tick visibility, or less often: the ticks accumulate). The exchange runs on a side stream and overlaps
  * the ticks that follow. RG_PUBLISH_FULL forces the 8 B/group snapshot on ALL ranks (pass it on all of them). */

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_progress_events(RgState st, u32 *ins_me
 __global__ __launch_bounds__(256) void k_resolve_apply(RgState st, u32 *ins_meta, const rg_resolved_hint *it, u64 n, u32 P, u8 *applied) {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const bool dec = rg_resolve_hint_at(
+    const u32 res = rg_resolve_hint_at(
         st, ins_meta, it, P, i,
         [&](u64 g, u32 s) { // (byte g of the column lives in the aligned word g / 4; the column is padded to a multiple of 256)
             u32 *w = reinterpret_cast<u32 *>(st.hhint) + (g >> 2);
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_resolve_apply(RgState st, u32 *ins_meta
             if (bits) atomicOr(&st.out[g], bits);
             if (clear) atomicAnd(&st.out[g], ~clear);
         });
-    applied[i] = dec ? 1 : 0;
+    applied[i] = (u8)res; // RG_RESOLVE_*
 }
 
 __global__ __launch_bounds__(256) void k_progress_event_dense(RgState st, u32 *ins_meta, const u8 *slot_plus1, u32 kind, u32 P) {
@@ -962,10 +962,14 @@ struct RgRccl {
     decltype(&ncclCommDestroy) CommDestroy;
     decltype(&ncclAllGather) AllGather;
     decltype(&ncclGetErrorString) GetErrorString;
+    decltype(&ncclGroupStart) GroupStart;
+    decltype(&ncclGroupEnd) GroupEnd;
 };
-static RgRccl g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static RgRccl g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static std::mutex g_rccl_mu; // (engines of one process may be driven by one thread each: the first loads, the others wait)
 
 static int rg_rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.lib) return RG_OK;
     static const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
@@ -977,7 +981,10 @@ static int rg_rccl_load() {
     g_rccl.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     g_rccl.AllGather = reinterpret_cast<decltype(&ncclAllGather)>(dlsym(lib, "ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString) {
+    g_rccl.GroupStart = reinterpret_cast<decltype(&ncclGroupStart)>(dlsym(lib, "ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(&ncclGroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         dlclose(lib);
         return rg_fail(RG_ERR_NO_DEVICE, "rg_comm: the RCCL library lacks an expected symbol");
     }
@@ -1008,6 +1015,8 @@ struct RgPub {
     bool done_pending[RG_PUB_SEND], chk_pending[2];
     u64 n_pub;                // publications so far
     u32 pending;              // ring slots gathered and not yet folded into the replica
+    bool in_process;          // one of several ranks of ONE process driven by one thread (rg_comm_init_all / rg_publish_commit_all)
+    hipEvent_t ev_read;       // ... in-process transport: this rank's side stream has read every rank's slice of the current publication
     bool local_lost;          // this rank's deltas no longer describe its commit column (restore / column load)
     bool lost_announced;      // ... and a slice carrying RG_PUB_LOST has gone out (the full snapshot follows)
     rg_publish_stats stats;
@@ -1152,20 +1161,24 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     //    (16 P + 8 B per group, read once) do not fit together (with the Inflights on the device a step also touches the
     //    window and work-item columns: 40 P B per group more);
     //  * STREAM_ALL when the state alone is more than 1.5 x the cache -- by the time a launch comes back to a line the cache
-    //    has turned over, so allocating there only costs. The window is measured (profiles/r04_nt_state.txt, 5 slots;
-    //    profiles/r05_cache_policy_sweep.txt, 3 and 7): it pays from 2.4 M x 5 (384 MB of state: 153 -> 148 us) through 8 M
-    //    (528 -> 483, fraction 0.68 -> 0.75) to 12 M (803 -> 778); below it a good part of the state still survives from
-    //    launch to launch (2 M: 106 -> 126), and from 16 M groups (2.5 GB of state) on the plain accesses are the faster ones
-    //    again (1034-1067 -> 1085-1135 us), so the regime has an upper end as well: 1.5 x cache < state <= 7.5 x cache;
+    //    has turned over, so allocating there only costs -- and the shard holds at most 13 M groups. Both ends are measured, at
+    //    3, 5 and 7 slots (profiles/r04_nt_state.txt; profiles/r05_cache_policy_sweep.txt): the lower one follows the BYTES of
+    //    state (1.3 x: streamed loses 1-5 %; 1.5 x: wins 6-9 % at every slot count; 8 M x 5: 528 -> 483 us, fraction 0.68 ->
+    //    0.75), the upper one the NUMBER of groups -- at 12 M groups everything streamed wins at 3, 5 and 7 slots alike (529 /
+    //    786 / 1046 us against 559 / 812 / 1068), at 14 M it loses or ties (705 / 1006 / 1275 against 664 / 975 / 1270), at 16 M
+    //    it loses 6-8 % -- although the state of those engines spans 1.3 to 3.2 GB (round 4 had put that end at 7.5 x the cache
+    //    in bytes, from 5 slots alone: right there, 12 % wrong at 3 slots);
     //  * RESIDENT (k_tick_split): a leading range of the groups keeps its state in the cache, the rest is streamed. Measured
-    //    (profiles/r04_resident.txt): with 176 MB of state resident 2.4 M x 5 runs in 134 us instead of 150 (all streamed; 155
-    //    plain) and 4 M x 5 in 227-233 instead of 246 -- but at 8 M x 5 it LOSES (491 -> 556 us): over a launch that long the
-    //    resident lines are gone before the next one comes back to them. At 2 M x 5 (1.2 x the cache) it equals the plain
-    //    kernel. So: 1.3 x cache < state <= 2.5 x cache. The cache is ONE per device: three size-class engines of config 5 at
+    //    (profiles/r04_resident.txt, r05_cache_policy_sweep.txt): with 176 MB of state resident 2.4 M x 5 runs in 134 us instead
+    //    of 150 (all streamed; 155 plain), 4 M x 5 in 227-233 instead of 246; at 3 / 7 slots it is the fastest policy from 1.3 x
+    //    (114 / 126 us against 125 / 128) through 2.5 x the cache (237 / 248 against 243 / 259) and loses beyond (3.5 x at 3
+    //    slots: 393 against 339; 8 M x 5: 491 -> 556) -- over a launch that long the resident lines are gone before the next one
+    //    comes back to them; below 1.25 x (1.1 x: 95 / 109 against 94 / 102) the plain accesses with streamed messages win.
+    //    So: 1.25 x cache < state <= 2.5 x cache. The cache is ONE per device: three size-class engines of config 5 at
     //    8 M groups, two of them with a resident range, took 893 us instead of 724 -- so AUTO grants the range only to an
     //    engine that is ALONE on its device when it is created (engines_on_device == 1 in rg_device_info); a later engine on the
-    //    same device gets STREAM_ALL by the rule above and the first one keeps what it was given. A host that knows better says
-    //    so: an explicit policy is honoured as given.
+    //    same device gets the streaming policy of its size and the first one keeps what it was given. A host that knows better
+    //    says so: an explicit policy is honoured as given.
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         h->dev.engines_on_device = (uint32_t)++g_live_on_device[cfg->device];
@@ -1179,8 +1192,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         u32 pol = cfg->cache_policy;
         if (pol == RG_CACHE_AUTO) {
             pol = with_msgs > mall ? RG_CACHE_STREAM_MSGS : RG_CACHE_PLAIN;
-            if (!cfg->max_inflight && state > 1.5 * mall && state <= 7.5 * mall) pol = RG_CACHE_STREAM_ALL;
-            if (!cfg->max_inflight && lane && state > 1.3 * mall && state <= 2.5 * mall && h->dev.engines_on_device == 1)
+            if (!cfg->max_inflight && state > 1.5 * mall && h->G <= 13000000ull) pol = RG_CACHE_STREAM_ALL;
+            if (!cfg->max_inflight && lane && state > 1.25 * mall && state <= 2.5 * mall && h->dev.engines_on_device == 1)
                 pol = RG_CACHE_RESIDENT;
         }
         if (cfg->max_inflight && pol > RG_CACHE_STREAM_MSGS) { // (k_tick_send / k_send_dense have no all-streamed form)
@@ -2695,14 +2708,16 @@ extern "C" int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items
     std::vector<u8> applied(n);
     RG_HIP(hipMemcpyAsync(applied.data(), d_applied, n, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
-    if (host_applied) memcpy(host_applied, applied.data(), n);
+    if (host_applied)
+        for (u64 i = 0; i < n; i++) host_applied[i] = applied[i] & RG_RESOLVE_APPLIED;
     h->host_res_valid = false; // (the host copy of a sparse tick's result words no longer matches RG_COL_OUT)
-    if (h->ins_arena && !h->send_ready) {
-        // the send stage of this tick has run already and skipped these groups (rg_group_send / rg_group_tick_send): run it
-        // now, over exactly them, with that stage's limit and flags, and append its work items to the compact list
-        // (send_ready still set: the stage is yet to come, rg_send_appends will find the completed result words)
-        std::vector<u64> groups(n);
-        for (u64 i = 0; i < n; i++) groups[i] = items[i].group;
+    std::vector<u64> groups; // the groups whose LAST waiting slot this call answered: their send requests are due now
+    for (u64 i = 0; i < n; i++)
+        if (applied[i] & RG_RESOLVE_RELEASED) groups.push_back(items[i].group);
+    if (h->ins_arena && !h->send_ready && !groups.empty()) {
+        // the send stage of this tick has run already and held these groups' requests back (rg_group_send / rg_group_tick_send):
+        // serve them now, over exactly these groups, with that stage's limit and flags, and append the work items to the compact
+        // list (send_ready still set: the stage is yet to come, rg_send_appends will find the completed result words)
         std::sort(groups.begin(), groups.end());
         groups.erase(std::unique(groups.begin(), groups.end()), groups.end());
         rc = rg_send_materialize(h); // (a dense stage's items: columns -> list, so that the list holds everything)
@@ -3715,17 +3730,28 @@ static inline double rg_now_us() {
     return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 
-static int rg_publish_impl(rg_engine *h, bool force_full) {
+// One publication of one engine in three phases, so that a single host thread can drive several engines of ONE process
+// through the same exchange (rg_publish_commit_all): `pre` of every engine (everything up to the exchange: the loss protocol's
+// check point, the snapshot of a full publication, the side stream ordered behind the tick that completed the slice), the
+// exchange of all of them together (RCCL: one ncclGroupStart / ncclAllGather x n / ncclGroupEnd -- the group is what keeps a
+// single thread from blocking in rank 0's collective while rank 1's has not been issued; the in-process transport:
+// device-to-device copies), `post` of every engine (the slice starts its next interval, rotation). rg_publish_commit is the
+// three phases of one engine back to back.
+struct RgPubStep {
+    bool full;
+    int b;
+    const void *send;
+    void *recv;
+    u64 bytes;
+    double t0, t1, t2;
+};
+
+static int rg_pub_pre(rg_engine *h, bool force_full, RgPubStep &s) {
     RgPub *p = h->pub;
     const u64 i = p->n_pub;
     const int b = (int)(i % RG_PUB_SEND);
-    const double t0 = rg_now_us();
-#ifdef RG_PUB_DEBUG_BUILD /* measurement builds only (python -m raft_rs_amd.build --exp pubdbg -DRG_PUB_DEBUG_BUILD=1): the default library reads no environment */
-    static const int dbg = getenv("RG_PUB_DEBUG") ? atoi(getenv("RG_PUB_DEBUG")) : 0; // measurement knobs (profiles/)
-#else
-    const int dbg = 0;
-#endif
-
+    s.b = b;
+    s.t0 = rg_now_us();
     // Loss protocol. Every `ring` publications is a CHECK POINT (the same publication numbers on every rank): all
     // buffered slices are folded into the replica first -- the update kernel raises d_lost for a slice that carries
     // RG_PUB_LOST or an overfull list -- and d_lost is copied to the host. The copy of the PREVIOUS check point
@@ -3756,29 +3782,44 @@ static int rg_publish_impl(rg_engine *h, bool force_full) {
         RG_HIP(hipMemcpyAsync(p->full_send, h->st.commit, h->G * 8, hipMemcpyDeviceToDevice, h->stream));
     RG_HIP(hipEventRecord(p->ev_tick[b], h->stream));
     RG_HIP(hipStreamWaitEvent(p->side, p->ev_tick[b], 0));
-    const double t1 = rg_now_us();
-    int rc;
+    s.full = full;
     if (full) {
         // the snapshot supersedes every buffered delta publication (and this interval's deltas)
         p->pending = 0;
-        rc = rg_pub_allgather(h, p->full_send, p->replica, p->lay.Gpad * 8);
-        if (rc) return rc;
+        s.send = p->full_send;
+        s.recv = p->replica;
+        s.bytes = p->lay.Gpad * 8;
+    } else {
+        if (p->pending == p->ring) { // (reads between check points can leave the ring out of step with them)
+            int rc = rg_pub_materialize(h);
+            if (rc) return rc;
+        }
+        s.send = p->send[b];
+        s.recv = p->ring_buf + (u64)p->pending * p->world * p->lay.bytes_per_rank;
+        s.bytes = p->lay.bytes_per_rank;
+    }
+    s.t1 = rg_now_us();
+    return RG_OK;
+}
+
+static int rg_pub_post(rg_engine *h, RgPubStep &s) {
+    RgPub *p = h->pub;
+    const int b = s.b;
+#ifdef RG_PUB_DEBUG_BUILD /* measurement builds only (python -m raft_rs_amd.build --exp pubdbg -DRG_PUB_DEBUG_BUILD=1): the default library reads no environment */
+    static const int dbg = getenv("RG_PUB_DEBUG") ? atoi(getenv("RG_PUB_DEBUG")) : 0; // measurement knobs (profiles/)
+#else
+    const int dbg = 0;
+#endif
+    if (s.full) {
         p->local_lost = false;
         p->lost_announced = false;
         p->stats.full_publications++;
         p->stats.bytes_per_rank_last = p->lay.Gpad * 8;
     } else {
-        if (p->pending == p->ring) { // (reads between check points can leave the ring out of step with them)
-            rc = rg_pub_materialize(h);
-            if (rc) return rc;
-        }
-        char *slot = p->ring_buf + (u64)p->pending * p->world * p->lay.bytes_per_rank;
-        rc = rg_pub_allgather(h, p->send[b], slot, p->lay.bytes_per_rank);
-        if (rc) return rc;
         p->pending++;
         p->stats.bytes_per_rank_last = p->lay.bytes_per_rank;
     }
-    const double t2 = rg_now_us();
+    s.t2 = rg_now_us();
     // this slice starts its next interval empty
     RG_HIP(hipMemsetAsync(p->send[b], 0, p->lay.bytes_per_rank, p->side));
     const double t3 = rg_now_us();
@@ -3795,9 +3836,80 @@ static int rg_publish_impl(rg_engine *h, bool force_full) {
     p->n_pub++;
     p->stats.publications++;
     const double t4 = rg_now_us();
-    p->stats.host_us_events += (t1 - t0) + (t4 - t3);
-    p->stats.host_us_allgather += t2 - t1;
-    p->stats.host_us_memset += t3 - t2;
+    p->stats.host_us_events += (s.t1 - s.t0) + (t4 - t3);
+    p->stats.host_us_allgather += s.t2 - s.t1;
+    p->stats.host_us_memset += t3 - s.t2;
+    return RG_OK;
+}
+
+static int rg_publish_impl(rg_engine *h, bool force_full) {
+    if (h->pub->in_process)
+        return rg_fail(RG_ERR_STATE, "rg_publish_commit: this engine is one of several ranks driven by ONE thread (rg_comm_init_all): "
+                                     "publish through rg_publish_commit_all");
+    RgPubStep s;
+    int rc = rg_pub_pre(h, force_full, s);
+    if (rc) return rc;
+    rc = rg_pub_allgather(h, s.send, s.recv, s.bytes);
+    if (rc) return rc;
+    return rg_pub_post(h, s);
+}
+
+// ---- several engines of ONE process, driven by ONE thread: every engine is a rank of the same publication ----
+// The exchange of all ranks in one go. RCCL: the n ncclAllGather calls inside one group (each on its engine's device and side
+// stream). In-process transport (RG_COMM_ALL_LOCAL; engines that share a device, or a host that does not want RCCL): rank i's
+// side stream copies every rank's slice into its gather buffer, device to device, behind the event that marks that slice
+// complete; afterwards every rank's side stream waits for the others' copies of ITS slice, so that the slice is not reset
+// (post) while somebody still reads it.
+static int rg_pub_gather_all(rg_engine *const *e, uint32_t n, RgPubStep *st) {
+    for (uint32_t i = 1; i < n; i++)
+        if (st[i].bytes != st[0].bytes || st[i].full != st[0].full)
+            return rg_fail(RG_ERR_STATE, "rg_publish_commit_all: the ranks disagree about the form of this publication "
+                                         "(engine %u: %s, engine 0: %s) -- they must be published together, always", i,
+                           st[i].full ? "full" : "delta", st[0].full ? "full" : "delta");
+    if (e[0]->pub->comm) {
+        ncclResult_t r = g_rccl.GroupStart();
+        for (uint32_t i = 0; i < n && r == ncclSuccess; i++) {
+            RG_HIP(hipSetDevice(e[i]->cfg.device));
+            r = g_rccl.AllGather(st[i].send, st[i].recv, (size_t)st[i].bytes, ncclUint8, e[i]->pub->comm, e[i]->pub->side);
+        }
+        const ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_publish_commit_all: grouped ncclAllGather failed: %s", rg_nccl_err(r));
+        return RG_OK;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        RgPub *p = e[i]->pub;
+        RG_HIP(hipSetDevice(e[i]->cfg.device));
+        for (uint32_t r = 0; r < n; r++) {
+            if (r != i) RG_HIP(hipStreamWaitEvent(p->side, e[r]->pub->ev_tick[st[r].b], 0));
+            RG_HIP(hipMemcpyAsync(reinterpret_cast<char *>(st[i].recv) + (u64)r * st[i].bytes, st[r].send, st[i].bytes,
+                                  hipMemcpyDeviceToDevice, p->side));
+        }
+        RG_HIP(hipEventRecord(p->ev_read, p->side));
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        RG_HIP(hipSetDevice(e[i]->cfg.device));
+        for (uint32_t r = 0; r < n; r++)
+            if (r != i) RG_HIP(hipStreamWaitEvent(e[i]->pub->side, e[r]->pub->ev_read, 0));
+    }
+    return RG_OK;
+}
+
+static int rg_publish_all_impl(rg_engine *const *e, uint32_t n, bool force_full) {
+    std::vector<RgPubStep> st(n);
+    for (uint32_t i = 0; i < n; i++) {
+        RG_HIP(hipSetDevice(e[i]->cfg.device));
+        int rc = rg_mailbox_quiesce(e[i]);
+        if (!rc) rc = rg_pub_pre(e[i], force_full, st[i]);
+        if (rc) return rc;
+    }
+    int rc = rg_pub_gather_all(e, n, st.data());
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+        RG_HIP(hipSetDevice(e[i]->cfg.device));
+        rc = rg_pub_post(e[i], st[i]);
+        if (rc) return rc;
+    }
     return RG_OK;
 }
 
@@ -3834,6 +3946,7 @@ extern "C" int rg_comm_destroy(rg_engine *h) {
     if (p->full_send) (void)hipFree(p->full_send);
     if (p->d_lost) (void)hipFree(p->d_lost);
     if (p->pin_lost) (void)hipHostFree(p->pin_lost);
+    if (p->ev_read) (void)hipEventDestroy(p->ev_read);
     if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
     h->pub = nullptr;
@@ -3841,25 +3954,20 @@ extern "C" int rg_comm_destroy(rg_engine *h) {
     return RG_OK;
 }
 
-extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
-    if (!h || !cfg) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: null argument");
-    if (h->pub) return rg_fail(RG_ERR_STATE, "rg_comm_init: already initialised (rg_comm_destroy first)");
-    if (cfg->world == 0 || cfg->rank >= cfg->world)
-        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: rank %u of %u", cfg->rank, cfg->world);
-    if (!cfg->transport && !cfg->unique_id)
-        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: the RCCL transport needs the unique id of rg_comm_unique_id");
-    if (cfg->ring_ticks > RG_PUB_MAX_RING)
-        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: ring_ticks %u, at most %d", cfg->ring_ticks, RG_PUB_MAX_RING);
-    RG_ENTER(h);
+// Everything of rg_comm_init but the communicator and the first publication: buffers, streams, events.
+// xdev: slices are read by OTHER devices (in-process transport across GPUs): the slice-complete events keep their system-scope fence.
+static int rg_comm_setup(rg_engine *h, u32 rank, u32 world, u32 ring_ticks, u32 overflow_slots, rg_allgather_fn transport,
+                         void *transport_user, bool in_process, bool xdev) {
     RgPub *p = new (std::nothrow) RgPub();
     if (!p) return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_comm_init: host allocation failed");
     memset(p, 0, sizeof(*p));
-    p->rank = cfg->rank;
-    p->world = cfg->world;
-    p->transport = cfg->transport;
-    p->transport_user = cfg->transport_user;
-    p->ring = cfg->ring_ticks ? cfg->ring_ticks : 32;
-    const u32 cap = cfg->overflow_slots ? cfg->overflow_slots : (u32)(h->G / 256 + 64);
+    p->rank = rank;
+    p->world = world;
+    p->transport = transport;
+    p->transport_user = transport_user;
+    p->in_process = in_process;
+    p->ring = ring_ticks ? ring_ticks : 32;
+    const u32 cap = overflow_slots ? overflow_slots : (u32)(h->G / 256 + 64);
     p->lay = rg_pub_layout(h->G, cap);
     h->pub = p;
 #define RG_PUB_TRY(expr)                                                                                       \
@@ -3875,11 +3983,12 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
     // ev_tick orders the tick kernel before the exchange's first kernel ON THIS DEVICE (ncclAllGather reads the slice
     // with a kernel of this device; a host transport synchronises the device itself), so the system-scope fence a
     // recorded event normally implies -- an L2 write-back worth ~2 us per tick -- is not needed
-    // (RG_PUB_DEBUG & 4 keeps it, for A/B measurements: profiles/r02_publish_overhead.txt)
+    // (RG_PUB_DEBUG & 4 keeps it, for A/B measurements: profiles/r02_publish_overhead.txt; so does the in-process
+    // transport between DIFFERENT devices, whose copies read the slice from the other GPU)
 #ifdef RG_PUB_DEBUG_BUILD
-    const unsigned evf = hipEventDisableTiming | ((getenv("RG_PUB_DEBUG") && (atoi(getenv("RG_PUB_DEBUG")) & 4)) ? 0 : hipEventDisableSystemFence);
+    const unsigned evf = hipEventDisableTiming | ((xdev || (getenv("RG_PUB_DEBUG") && (atoi(getenv("RG_PUB_DEBUG")) & 4))) ? 0 : hipEventDisableSystemFence);
 #else
-    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
+    const unsigned evf = hipEventDisableTiming | (xdev ? 0u : (unsigned)hipEventDisableSystemFence);
 #endif
     for (int k = 0; k < RG_PUB_SEND; k++) {
         RG_PUB_TRY(hipMalloc(&p->send[k], p->lay.bytes_per_rank));
@@ -3888,6 +3997,7 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
         RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
     }
     for (int k = 0; k < 2; k++) RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_chk[k], hipEventDisableTiming));
+    RG_PUB_TRY(hipEventCreateWithFlags(&p->ev_read, hipEventDisableTiming));
     RG_PUB_TRY(hipMalloc(&p->ring_buf, (size_t)p->ring * p->world * p->lay.bytes_per_rank));
     RG_PUB_TRY(hipMalloc(&p->replica, (size_t)p->world * p->lay.Gpad * 8));
     RG_PUB_TRY(hipMemsetAsync(p->replica, 0, (size_t)p->world * p->lay.Gpad * 8, h->stream));
@@ -3899,8 +4009,27 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
     memset(p->pin_lost, 0, 64);
     RG_PUB_TRY(hipStreamSynchronize(h->stream));
 #undef RG_PUB_TRY
+    h->dev.engine_bytes += RG_PUB_SEND * p->lay.bytes_per_rank + (u64)p->ring * p->world * p->lay.bytes_per_rank +
+                           (u64)p->world * p->lay.Gpad * 8 + p->lay.Gpad * 8;
+    rg_pub_target(h, 0);
+    return RG_OK;
+}
+
+extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
+    if (!h || !cfg) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: null argument");
+    if (h->pub) return rg_fail(RG_ERR_STATE, "rg_comm_init: already initialised (rg_comm_destroy first)");
+    if (cfg->world == 0 || cfg->rank >= cfg->world)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: rank %u of %u", cfg->rank, cfg->world);
+    if (!cfg->transport && !cfg->unique_id)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: the RCCL transport needs the unique id of rg_comm_unique_id");
+    if (cfg->ring_ticks > RG_PUB_MAX_RING)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: ring_ticks %u, at most %d", cfg->ring_ticks, RG_PUB_MAX_RING);
+    RG_ENTER(h);
+    int rc = rg_comm_setup(h, cfg->rank, cfg->world, cfg->ring_ticks, cfg->overflow_slots, cfg->transport, cfg->transport_user, false, false);
+    if (rc) return rc;
+    RgPub *p = h->pub;
     if (!cfg->transport) {
-        int rc = rg_rccl_load();
+        rc = rg_rccl_load();
         if (rc) {
             (void)rg_comm_destroy(h);
             return rc;
@@ -3915,16 +4044,93 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
                            rg_nccl_err(r));
         }
     }
-    h->dev.engine_bytes += RG_PUB_SEND * p->lay.bytes_per_rank + (u64)p->ring * p->world * p->lay.bytes_per_rank +
-                           (u64)p->world * p->lay.Gpad * 8 + p->lay.Gpad * 8;
-    rg_pub_target(h, 0);
     // every replica starts from the actual columns: one full publication (a collective: all ranks are in here)
-    int rc = rg_publish_impl(h, true);
+    rc = rg_publish_impl(h, true);
     if (rc) {
         (void)rg_comm_destroy(h);
         return rc;
     }
     return RG_OK;
+}
+
+static int rg_all_check(rg_engine *const *engines, uint32_t n, const char *who, bool need_pub) {
+    if (!engines || n == 0) return rg_fail(RG_ERR_INVALID_ARG, "%s: no engines", who);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!engines[i]) return rg_fail(RG_ERR_INVALID_ARG, "%s: engine %u is null", who, i);
+        for (uint32_t j = 0; j < i; j++)
+            if (engines[j] == engines[i]) return rg_fail(RG_ERR_INVALID_ARG, "%s: engine %u is listed twice", who, i);
+        if (engines[i]->G != engines[0]->G)
+            return rg_fail(RG_ERR_INVALID_ARG, "%s: engine %u holds %llu groups, engine 0 %llu (equal shards: the all-gather moves equal slices)",
+                           who, i, (unsigned long long)engines[i]->G, (unsigned long long)engines[0]->G);
+        if (need_pub && (!engines[i]->pub || !engines[i]->pub->in_process || engines[i]->pub->world != n || engines[i]->pub->rank != i))
+            return rg_fail(RG_ERR_STATE, "%s: engine %u is not rank %u of %u of an rg_comm_init_all communicator", who, i, i, n);
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_comm_init_all(rg_engine *const *engines, uint32_t n, const rg_comm_all_config *cfg) {
+    int rc = rg_all_check(engines, n, "rg_comm_init_all", false);
+    if (rc) return rc;
+    rg_comm_all_config c = {0, 0, RG_COMM_ALL_AUTO, 0};
+    if (cfg) c = *cfg;
+    if (c.transport > RG_COMM_ALL_LOCAL) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init_all: unknown transport %u", c.transport);
+    if (c.ring_ticks > RG_PUB_MAX_RING) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init_all: ring_ticks %u, at most %d", c.ring_ticks, RG_PUB_MAX_RING);
+    bool shared = false, xdev = false; // two engines on one device (RCCL refuses that) / engines on different devices
+    for (uint32_t i = 0; i < n; i++) {
+        if (engines[i]->pub) return rg_fail(RG_ERR_STATE, "rg_comm_init_all: engine %u already has a communicator (rg_comm_destroy first)", i);
+        for (uint32_t j = 0; j < i; j++) {
+            shared = shared || engines[j]->cfg.device == engines[i]->cfg.device;
+            xdev = xdev || engines[j]->cfg.device != engines[i]->cfg.device;
+        }
+    }
+    if (c.transport == RG_COMM_ALL_RCCL && shared)
+        return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init_all: RCCL needs one device per rank; two of the engines share one (RG_COMM_ALL_LOCAL)");
+    const bool rccl = c.transport == RG_COMM_ALL_RCCL || (c.transport == RG_COMM_ALL_AUTO && !shared && n > 1);
+    auto undo = [&](uint32_t upto) {
+        for (uint32_t i = 0; i < upto; i++) (void)rg_comm_destroy(engines[i]);
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        rg_engine *h = engines[i];
+        RG_HIP(hipSetDevice(h->cfg.device));
+        rc = rg_mailbox_quiesce(h);
+        if (!rc) rc = rg_comm_setup(h, i, n, c.ring_ticks, c.overflow_slots, nullptr, nullptr, true, !rccl && xdev);
+        if (rc) {
+            undo(i);
+            return rc;
+        }
+    }
+    if (rccl) {
+        rc = rg_rccl_load();
+        ncclUniqueId u;
+        ncclResult_t r = ncclSuccess;
+        if (!rc) r = g_rccl.GetUniqueId(&u);
+        if (!rc && r == ncclSuccess) {
+            // one thread, n ranks: the initialisations of all of them inside ONE group (outside it the first
+            // ncclCommInitRank would wait for ranks this very thread has not started yet)
+            r = g_rccl.GroupStart();
+            for (uint32_t i = 0; i < n && r == ncclSuccess; i++) {
+                if (hipSetDevice(engines[i]->cfg.device) != hipSuccess) r = ncclUnhandledCudaError;
+                else r = g_rccl.CommInitRank(&engines[i]->pub->comm, (int)n, u, (int)i);
+            }
+            const ncclResult_t r2 = g_rccl.GroupEnd();
+            if (r == ncclSuccess) r = r2;
+        }
+        if (rc || r != ncclSuccess) {
+            for (uint32_t i = 0; i < n; i++) engines[i]->pub->comm = nullptr; // (a failed group leaves no usable communicator)
+            undo(n);
+            return rc ? rc : rg_fail(RG_ERR_NO_DEVICE, "rg_comm_init_all: grouped ncclCommInitRank of %u ranks failed: %s", n, rg_nccl_err(r));
+        }
+    }
+    rc = rg_publish_all_impl(engines, n, true); // every replica starts from the actual columns
+    if (rc) undo(n);
+    return rc;
+}
+
+extern "C" int rg_publish_commit_all(rg_engine *const *engines, uint32_t n, uint32_t flags) {
+    if (flags & ~RG_PUBLISH_FULL) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit_all: unknown flags %#x", flags);
+    int rc = rg_all_check(engines, n, "rg_publish_commit_all", true);
+    if (rc) return rc;
+    return rg_publish_all_impl(engines, n, (flags & RG_PUBLISH_FULL) != 0);
 }
 
 extern "C" int rg_publish_commit(rg_engine *h, uint32_t flags) {

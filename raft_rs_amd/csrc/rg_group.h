@@ -566,15 +566,20 @@ RG_HD bool rg_apply_resolved_reject(u64 match, u64 &next, u64 &psnap, u32 &pf, u
 // a host that passes some of a group's rejects now and the rest later releases the stage with the last of them.
 // `take(g, s)`: atomically clear bit s of hhint[g] and return the byte as it was (records of one group may sit in different
 // lanes); `orw(g, bits, clear)`: out[g] = (out[g] | bits) & ~clear, atomically on the device.
+// Returns bit 0: maybe_decr_to applied (send_append is due); bit 1: the record answered a waiting slot; bit 2: it was the group's
+// last one -- RG_OUT_HOST_HINT fell, the group's held-back send requests can be served.
+#define RG_RESOLVE_APPLIED 1u
+#define RG_RESOLVE_TAKEN 2u
+#define RG_RESOLVE_RELEASED 4u
 template <typename TAKE, typename ORW>
-RG_HD bool rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolved_hint *it, u32 P, u64 i, TAKE &&take, ORW &&orw) {
+RG_HD u32 rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolved_hint *it, u32 P, u64 i, TAKE &&take, ORW &&orw) {
     const u64 g = it[i].group;
     const u32 s = it[i].slot;
-    if (g >= st.G || s >= P) return false;
-    if (!((RG_CFG_PRESENT(st.cfg[g]) >> s) & 1u)) return false;
-    if (!(st.out[g] & RG_OUT_HOST_HINT)) return false; // (the byte is only meaningful under the bit: raftgroups.h)
+    if (g >= st.G || s >= P) return 0u;
+    if (!((RG_CFG_PRESENT(st.cfg[g]) >> s) & 1u)) return 0u;
+    if (!(st.out[g] & RG_OUT_HOST_HINT)) return 0u; // (the byte is only meaningful under the bit: raftgroups.h)
     const u32 before = take(g, s);
-    if (!((before >> s) & 1u)) return false;
+    if (!((before >> s) & 1u)) return 0u;
     const u64 o = (u64)s * st.stride + g;
     u8 *pfb = reinterpret_cast<u8 *>(st.pflags) + g * 8 + s;
     u32 pf = *pfb;
@@ -595,7 +600,7 @@ RG_HD bool rg_resolve_hint_at(const RgState &st, u32 *ins_meta, const rg_resolve
     }
     const bool last = (before & ~(1u << s) & 0xffu) == 0;
     orw(g, dec ? 1u << (8 + s) : 0u, last ? (u32)RG_OUT_HOST_HINT : 0u);
-    return dec;
+    return (dec ? RG_RESOLVE_APPLIED : 0u) | RG_RESOLVE_TAKEN | (last ? RG_RESOLVE_RELEASED : 0u);
 }
 
 // RaftLog::maybe_commit (src/raft_log.rs:487-499) with term(mci)==cur_term restated as lo<=mci<=hi

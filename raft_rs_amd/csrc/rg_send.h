@@ -238,7 +238,7 @@ template <int P, typename IX> RG_HD void rg_send_prefetch(const RgState &st, con
 // SPEC or FUSED -- the group-level words the work set is decided from, which the caller requested with `out`).
 template <int P, typename IX, bool SPEC, bool FUSED, bool PRE = false, bool WAVE = false>
 RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u32 flags, RgSendOps<P> &q,
-                           RgGroup<P> *r, u32 nxv) {
+                           RgGroup<P> *r, u32 nxv, bool hold = false) {
     // everything indexed by the group alone is requested at once, before anything is decided: with the result word the
     // caller loaded that is ONE memory round trip ahead of the per-peer cells (it used to be three: out, cfg, the rest)
     if (FUSED) {
@@ -269,7 +269,8 @@ RG_HD void rg_send_request(const RgState &st, const RgIns &ins, IX g, u32 out, u
     // RG_SEND_EFFECTS_ONLY (engine-internal: a skipped stage being settled, a group that waits for its host hint): only the
     // Inflights effects below. (RG_SEND_REQUESTS_ONLY, rg_resolve_host_hints completing such a group: rg_group_send masks the
     // effect bits out of the result word it passes.)
-    q.serve = !(flags & RG_SEND_EFFECTS_ONLY);
+    // `hold` (per group, where `flags` is the launch's): this group's requests wait for rg_resolve_host_hints
+    q.serve = !(flags & RG_SEND_EFFECTS_ONLY) && !hold;
     q.bcast = q.serve && (out & RG_OUT_APPENDED) != 0;
     if (q.serve && (out & RG_OUT_CHANGED))
         q.bcast = q.bcast || !(flags & RG_SEND_SKIP_BCAST_COMMIT) || ((q.row0 >> (8 * self)) & RG_PF_PENDING_CONF);
@@ -520,10 +521,11 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
     // rg_resolve_host_hints runs (the deferred reject's send_append comes before the group's other sends of the tick); the
     // tick's Inflights EFFECTS -- free_to, free_first_one, the window resets -- are applied here and now, once, whatever the host
     // does next (round 4 dropped them with the requests: a host that moved on without resolving left the windows stale)
+    bool hold = false;
     if ((out & RG_OUT_HOST_HINT) && (flags & RG_SEND_REQUESTS_ONLY)) out = 0; // (still waiting for more answers; its effects are done)
-    else if (out & RG_OUT_HOST_HINT) flags |= RG_SEND_EFFECTS_ONLY;
+    else if (out & RG_OUT_HOST_HINT) hold = true;
     else if (flags & RG_SEND_REQUESTS_ONLY) out &= ~(0xff000000u | (u32)RG_OUT_BECAME_LEADER); // (free_to / free_first_one / reset: done)
     RgSendOps<P> q;
-    rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u);
+    rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u, hold);
     rg_send_serve<P, IX, false, WAVE && !SPEC>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);
 }

@@ -393,7 +393,7 @@ RG_HD void rg_group_tick_send_a(RgGroup<P> &r, const A &a, IX g, u64 max_entries
     // applies the tick's Inflights effects only (free_to, free_first_one, the window resets): no work item; the real word goes
     // to RG_COL_OUT as always.
     const u32 sout = r.out;
-    flags = (r.out & RG_OUT_HOST_HINT) ? flags | RG_SEND_EFFECTS_ONLY : flags;
+    const bool hold = (r.out & RG_OUT_HOST_HINT) != 0;
 #if defined(__HIP_DEVICE_COMPILE__) && RG_TS_SPEC == 2
     if (win) {
         // the DMA the kernel issued before the tick is a pending LDS write on the VM counter
@@ -412,9 +412,9 @@ RG_HD void rg_group_tick_send_a(RgGroup<P> &r, const A &a, IX g, u64 max_entries
     const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
 #if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
     rg_store_group<P, IX, 1, WAVE>(r, st, g);
-    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv);
+    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv, hold);
 #else
-    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv);
+    rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv, hold);
     rg_store_group<P, IX, 1, WAVE>(r, st, g);
 #endif
     rg_send_serve<P, IX, true, TSW>(st, ins, g, sout, max_entries, flags, q, it, &r, nxv);

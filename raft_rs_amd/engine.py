@@ -300,6 +300,8 @@ SYMBOLS = {
     "rg_comm_init": (_i, [_vp, C.POINTER(CommConfig)]),
     "rg_comm_destroy": (_i, [_vp]),
     "rg_publish_commit": (_i, [_vp, C.c_uint32]),
+    "rg_comm_init_all": (_i, [_vp, C.c_uint32, _vp]),
+    "rg_publish_commit_all": (_i, [_vp, C.c_uint32, C.c_uint32]),
     "rg_publish_sync": (_i, [_vp]),
     "rg_published_commit_ptr": (_vp, [_vp, C.POINTER(_u64)]),
     "rg_published_commit": (_i, [_vp, C.c_uint32, _u64, _u64, _vp]),
@@ -880,6 +882,30 @@ def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, 
                                 msgs.m_flags.ctypes.data)
     if rc:
         raise EngineError(rc, L.rg_last_error().decode())
+
+
+class CommAllConfig(C.Structure):
+    _fields_ = [("ring_ticks", C.c_uint32), ("overflow_slots", C.c_uint32), ("transport", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+COMM_ALL_AUTO, COMM_ALL_RCCL, COMM_ALL_LOCAL = 0, 1, 2
+
+
+def comm_init_all(engines, ring_ticks=0, overflow_slots=0, transport=COMM_ALL_AUTO):
+    """rg_comm_init_all: the engines of ONE process become ranks 0..n-1 of one publication, driven by one thread."""
+    L = engines[0].L
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    cfg = CommAllConfig(ring_ticks, overflow_slots, transport, 0)
+    engines[0]._check(L.rg_comm_init_all(arr, len(engines), C.byref(cfg)))
+    for i, e in enumerate(engines):
+        e.comm_rank, e.comm_world = i, len(engines)
+
+
+def publish_commit_all(engines, full=False):
+    """rg_publish_commit_all: one publication of every rank (the n exchanges issued together)."""
+    L = engines[0].L
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    engines[0]._check(L.rg_publish_commit_all(arr, len(engines), PUBLISH_FULL if full else 0))
 
 
 def comm_unique_id():

@@ -352,6 +352,6 @@ extern "C" int rg_host_check_resolve_hints(unsigned P, unsigned long G, unsigned
     for (u64 i = 0; i < n; i++)
         applied[i] = rg_resolve_hint_at(st, ins_meta, it, P, i,
                                         [&](u64 g, u32 s) { const u32 b = st.hhint[g]; st.hhint[g] = (u8)(b & ~(1u << s)); return b; },
-                                        [&](u64 g, u32 bits, u32 clear) { st.out[g] = (st.out[g] | bits) & ~clear; }) ? 1 : 0;
+                                        [&](u64 g, u32 bits, u32 clear) { st.out[g] = (st.out[g] | bits) & ~clear; }) & RG_RESOLVE_APPLIED;
     return 0;
 }

@@ -420,3 +420,145 @@ def test_bench_starts_its_own_ranks_with_strong_scaling_and_an_automatic_cadence
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-groups", "262145", "--steps", "2",
                           "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
     assert bad.returncode != 0 and "does not divide" in bad.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# several ranks in ONE process (one host process driving every shard, like the reference's embedding drives many
+# RawNodes from one thread): (1) one thread for all engines -- rg_comm_init_all / rg_publish_commit_all; (2) one thread per
+# engine -- rg_comm_init / rg_publish_commit as a rank of its own process would. Three engines share this box's one GPU, so the
+# exchange is the in-process device-to-device transport (1) or a transport callback between the threads (2); with a GPU per
+# engine the same calls go through RCCL (grouped in form 1).
+# ---------------------------------------------------------------------------------------------------------------
+def _unsharded_commit(rg, torch, world, n, n_slots, workload, ticks):
+    """The same global groups [0, world * n) in ONE engine: what every replica must end up holding."""
+    eng = rg.Engine(world * n, n_slots)
+    eng.workload_init(workload, first_group=0)
+    cols, flags = _device_msgs(torch, eng, n_slots)
+    per_tick = []
+    for t in range(ticks):
+        eng.workload_gen(workload, t, *[c.data_ptr() for c in cols], flags.data_ptr(), first_group=0)
+        eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        per_tick.append(eng.read_column(rg.COL.COMMIT).reshape(world, n).copy())
+    eng.close()
+    return per_tick
+
+
+@pytest.mark.parametrize("workload,n_slots", [(2, 5), (5, 7)])
+def test_three_engines_one_thread_publish_together(rg, workload, n_slots):
+    """rg_comm_init_all + rg_publish_commit_all: three shards of one process on one GPU, published after every tick by the one
+    thread that also ticks them; every replica equals all three commit columns after every publication, and the unsharded run."""
+    import torch
+    from raft_rs_amd import engine as E
+    world, n, ticks = 3, 20_224, 9
+    want = _unsharded_commit(rg, torch, world, n, n_slots, workload, ticks)
+    engs = [rg.Engine(n, n_slots) for _ in range(world)]
+    assert [e.device_info()["engines_on_device"] for e in engs] == [1, 2, 3]
+    for r, e in enumerate(engs):
+        e.workload_init(workload, first_group=r * n)
+    E.comm_init_all(engs, ring_ticks=4)
+    with pytest.raises(rg.EngineError) as ei:
+        engs[1].publish_commit()
+    assert ei.value.code == E.ERR["STATE"] and "rg_publish_commit_all" in str(ei.value)
+    bufs = [_device_msgs(torch, e, n_slots) for e in engs]
+    for t in range(ticks):
+        for r, (e, (cols, flags)) in enumerate(zip(engs, bufs)):
+            e.workload_gen(workload, t, *[c.data_ptr() for c in cols], flags.data_ptr(), first_group=r * n)
+            e.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+        E.publish_commit_all(engs, full=(t == 6))  # (a forced full snapshot in between: all ranks take the same form)
+        for e in engs:
+            rep = e.published_commit()
+            assert np.array_equal(rep, want[t]), (t, e.comm_rank)
+    for r, e in enumerate(engs):
+        assert np.array_equal(e.read_column(rg.COL.COMMIT), want[-1][r])
+        st = e.publish_stats()
+        assert st["publications"] == ticks + 1 and st["full_publications"] == 2 and st["bytes_per_rank_delta"] < 1.2 * n + 4096
+        e.comm_destroy()
+        e.close()
+
+
+def test_publish_all_refuses_what_is_not_one_communicator(rg):
+    from raft_rs_amd import engine as E
+    a, b, c = rg.Engine(1000, 3), rg.Engine(1000, 3), rg.Engine(1200, 3)
+    for e in (a, b, c):
+        e.workload_init(2)
+    with pytest.raises(rg.EngineError) as ei:  # unequal shards
+        E.comm_init_all([a, b, c])
+    assert ei.value.code == E.ERR["INVALID_ARG"]
+    with pytest.raises(rg.EngineError) as ei:  # RCCL cannot put two ranks on one device
+        E.comm_init_all([a, b], transport=E.COMM_ALL_RCCL)
+    assert ei.value.code == E.ERR["INVALID_ARG"] and "share" in str(ei.value)
+    with pytest.raises(rg.EngineError) as ei:  # never initialised
+        E.publish_commit_all([a, b])
+    assert ei.value.code == E.ERR["STATE"]
+    E.comm_init_all([a, b])
+    with pytest.raises(rg.EngineError) as ei:  # the ranks of a communicator are published together, in rank order
+        E.publish_commit_all([b, a])
+    assert ei.value.code == E.ERR["STATE"]
+    E.publish_commit_all([a, b])
+    assert np.array_equal(a.published_commit(1), b.read_column(rg.COL.COMMIT))
+    for e in (a, b, c):
+        e.close()
+
+
+def test_three_engines_one_thread_each(rg):
+    """Thread-per-engine: three threads of ONE process, each with its own engine on the shared GPU, each calling rg_comm_init /
+    rg_tick_device / rg_publish_commit on its own handle -- concurrently, like three ranks -- with a transport callback that
+    meets the other threads at a barrier (what RCCL's collective does between ranks). Nothing but the handles' own state and
+    the callback's meeting point is shared; every replica ends up equal to the unsharded run."""
+    import threading
+    import torch
+    world, n, n_slots, ticks = 3, 12_032, 5, 8
+    want = _unsharded_commit(rg, torch, world, n, n_slots, 2, ticks)
+    barrier = threading.Barrier(world)
+    sends, errors, out = [None] * world, [], [None] * world
+
+    class Dev:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                eng = rg.Engine(n, n_slots)
+                eng.set_stream(stream.cuda_stream)
+                eng.workload_init(2, first_group=rank * n)
+
+                def allgather(dev_send, dev_recv, nbytes, hip_stream):
+                    torch.cuda.synchronize()  # (a host transport: the slice is complete before it is handed over)
+                    sends[rank] = (dev_send, nbytes)
+                    barrier.wait()
+                    recv = torch.as_tensor(Dev(dev_recv, world * nbytes), device="cuda")
+                    for r in range(world):
+                        assert sends[r][1] == nbytes
+                        recv[r * nbytes:(r + 1) * nbytes].copy_(torch.as_tensor(Dev(sends[r][0], nbytes), device="cuda"))
+                    torch.cuda.synchronize()
+                    barrier.wait()  # nobody resets its slice while somebody still reads it
+                    return 0
+
+                eng.comm_init(rank, world, transport=allgather, ring_ticks=3)
+                cols, flags = _device_msgs(torch, eng, n_slots)
+                seen = []
+                for t in range(ticks):
+                    eng.workload_gen(2, t, *[c.data_ptr() for c in cols], flags.data_ptr(), first_group=rank * n)
+                    eng.tick_device(*[c.data_ptr() for c in cols], flags.data_ptr())
+                    eng.publish_commit()
+                    seen.append(eng.published_commit())
+                out[rank] = seen
+                barrier.wait()
+                eng.comm_destroy()
+                eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    for rank in range(world):
+        for t in range(ticks):
+            assert np.array_equal(out[rank][t], want[t]), (rank, t)
