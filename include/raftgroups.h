@@ -219,10 +219,13 @@ typedef struct {
 #define RG_CACHE_AUTO 0u        /* by footprint: PLAIN while state + one tick of messages fit the cache; STREAM_MSGS beyond;
                                    RESIDENT where 1.25 x cache < state <= 2.5 x cache and no other engine lives on the device
                                    at rg_create (the cache is one per device); else STREAM_ALL where state > 1.5 x cache and
-                                   the shard holds at most 13 M groups; engines with device Inflights: PLAIN / STREAM_MSGS */
+                                   the shard holds at most 13 M groups; engines with device Inflights: PLAIN / STREAM_MSGS
+                                   (STREAM_ALL on request, RESIDENT never) */
 #define RG_CACHE_PLAIN 1u       /* every access allocates in the cache */
 #define RG_CACHE_STREAM_MSGS 2u /* the read-once message columns are streamed past it (non-temporal loads) */
-#define RG_CACHE_STREAM_ALL 3u  /* ... and the state columns, loads and stores: nothing of the launch is allocated */
+#define RG_CACHE_STREAM_ALL 3u  /* ... and the state columns, loads and stores: nothing of the launch is allocated (with device
+                                   Inflights: meant for the one-launch form rg_tick_device_send; a separate rg_send_appends
+                                   re-reads what the tick has just streamed out) */
 #define RG_CACHE_RESIDENT 4u    /* STREAM_ALL except for a leading range of groups whose state stays resident (one launch,
                                    two bodies: k_tick_split); needs max_inflight = 0, no group commit, the lane variant --
                                    where those do not hold the launch falls back to STREAM_ALL and the report says so */

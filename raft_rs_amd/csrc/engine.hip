@@ -534,20 +534,62 @@ __global__ __launch_bounds__(256) void k_update_state(RgState st, RgIns ins, con
 // The dense stage: every group of the shard, one lane each, work items into the peer-major columns (RgSendCols).
 // A pure streaming kernel like the tick: 64-thread workgroups, no LDS, no atomics, no barrier.
 // IX = u32 when every cell lies within 4 GiB of its column's start (32-bit cell offsets, rg_common.h: rg_at).
+// The arguments are ONE struct and every phase -- the result word, the requests, the serve loop, the item stores -- reads the
+// column pointers it needs from the kernarg segment ITSELF (as k_tick_send's phases do, rg_tick_kernels.h: RgTsKernarg): taken
+// from the parameters all ~30 pointers are live from the first load to the last store, twice what the scalar registers hold
+// -- round 4's build moved them in and out of VGPR lanes with 138 spill slots.
+struct RgSendDenseArgs {
+    RgState st;
+    RgIns ins;
+    u64 max_entries;
+    u32 flags;
+    RgSendCols oc;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+struct RgSdKernarg {
+    typedef const __attribute__((address_space(4))) RgSendDenseArgs *KA;
+    RG_D static KA ptr() {
+        KA ka = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka)); // (opaque per call: a phase's scalar loads cannot be hoisted into an earlier phase)
+        return ka;
+    }
+};
+#endif
 template <int P, typename IX>
-__global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState st, RgIns ins, u64 max_entries, u32 flags, RgSendCols oc) {
+__global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgSendDenseArgs a_) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const u64 g64 = (u64)blockIdx.x * RG_BLOCK + threadIdx.x;
-    if (g64 >= st.G) return;
+    if (g64 >= a_.st.G) return;
     const IX g = (IX)g64;
+    const u32 flags = a_.flags;
     RgSendRegs<P> it;
     it.count = 0;
     it.snap = 0;
     it.hostm = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
-    const u32 out = rg_at(st.out, g);
-    rg_group_send<P, IX, RG_SEND_SPEC_LOADS != 0, RG_SEND_WAVE_LINES != 0>(st, ins, g, out, max_entries, flags, it); // (unconditional: its loads ride with `out`)
-    rg_store_send_items<P, IX>(it, oc, st.stride, g);
+    u32 out;
+    {
+        const RgState st = RgSdKernarg::ptr()->st;
+        out = rg_at(st.out, g);
+    }
+    const bool hold = rg_send_hold(out, flags);
+    RgSendOps<P> q;
+    constexpr bool SPEC = RG_SEND_SPEC_LOADS != 0, WAVE = RG_SEND_WAVE_LINES != 0;
+    {   // (unconditional: its loads ride with `out`)
+        const RgState st = RgSdKernarg::ptr()->st;
+        const RgIns ins = RgSdKernarg::ptr()->ins;
+        rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u, hold);
+    }
+    {
+        const RgState st = RgSdKernarg::ptr()->st;
+        const RgIns ins = RgSdKernarg::ptr()->ins;
+        rg_send_serve<P, IX, false, WAVE && !SPEC>(st, ins, g, out, RgSdKernarg::ptr()->max_entries, flags, q, it, nullptr, 0u);
+    }
+    const RgSendCols oc = RgSdKernarg::ptr()->oc;
+    const u64 stride = RgSdKernarg::ptr()->st.stride;
+    rg_store_send_items<P, IX>(it, oc, stride, g);
+#endif
 }
 #ifndef RG_SEND_IX32 /* the dense send stage's 32-bit cell index (rg_u32o measured: 125 -> 123 VGPRs, nothing else: profiles/r04_addressing.txt) */
 #define RG_SEND_IX32 u32
@@ -555,10 +597,16 @@ __global__ __launch_bounds__(RG_BLOCK, RG_SEND_WAVES) void k_send_dense(RgState 
 template <int P>
 static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, const RgState &st, const RgIns &ins, u64 max_entries,
                                  u32 flags, const RgSendCols &oc) {
+    RgSendDenseArgs a;
+    a.st = st;
+    a.ins = ins;
+    a.max_entries = max_entries;
+    a.flags = flags;
+    a.oc = oc;
     if (rg_ix32(st, P))
-        hipLaunchKernelGGL((k_send_dense<P, RG_SEND_IX32>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
+        hipLaunchKernelGGL((k_send_dense<P, RG_SEND_IX32>), grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, st, ins, max_entries, flags, oc);
+        hipLaunchKernelGGL((k_send_dense<P, u64>), grid, block, 0, stream, a);
 }
 
 // Compact list out of the columns, on request (rg_send_items / rg_send_items_ptr after a dense stage).
@@ -1196,10 +1244,10 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
             if (!cfg->max_inflight && lane && state > 1.25 * mall && state <= 2.5 * mall && h->dev.engines_on_device == 1)
                 pol = RG_CACHE_RESIDENT;
         }
-        if (cfg->max_inflight && pol > RG_CACHE_STREAM_MSGS) { // (k_tick_send / k_send_dense have no all-streamed form)
+        if (cfg->max_inflight && pol == RG_CACHE_RESIDENT) { // (k_tick_split has no send stage)
             rg_drop(h);
-            return rg_fail(RG_ERR_INVALID_ARG, "rg_create: cache_policy %u needs max_inflight = 0 (engines with device Inflights: "
-                                               "RG_CACHE_PLAIN or RG_CACHE_STREAM_MSGS)", pol);
+            return rg_fail(RG_ERR_INVALID_ARG, "rg_create: RG_CACHE_RESIDENT needs max_inflight = 0 (engines with device Inflights: "
+                                               "RG_CACHE_PLAIN, RG_CACHE_STREAM_MSGS or RG_CACHE_STREAM_ALL)");
         }
         h->nt_msgs = pol >= RG_CACHE_STREAM_MSGS;
         h->nt_all = pol >= RG_CACHE_STREAM_ALL;
@@ -1625,20 +1673,21 @@ static int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send = 
     int src = rg_settle_send(h);
     if (src) return src;
     if (send) {
+        const bool nts = h->nt_all && !h->any_group_commit && rg_ix32(h->st, h->P);
         switch (h->P) {
-        case 1: rg_launch_tick_send_t<1>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        case 2: rg_launch_tick_send_t<2>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        case 3: rg_launch_tick_send_t<3>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        case 4: rg_launch_tick_send_t<4>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        case 5: rg_launch_tick_send_t<5>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        case 6: rg_launch_tick_send_t<6>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        case 7: rg_launch_tick_send_t<7>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
-        default: rg_launch_tick_send_t<8>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols); break;
+        case 1: rg_launch_tick_send_t<1>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        case 2: rg_launch_tick_send_t<2>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        case 3: rg_launch_tick_send_t<3>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        case 4: rg_launch_tick_send_t<4>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        case 5: rg_launch_tick_send_t<5>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        case 6: rg_launch_tick_send_t<6>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        case 7: rg_launch_tick_send_t<7>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
+        default: rg_launch_tick_send_t<8>(h->stream, h->st, ms, h->any_group_commit, h->ins, send->max_entries, send->flags, h->send_cols, nts); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick + send stage launch failed: %s", hipGetErrorString(e));
         h->dev.last_tick_kernel = RG_KERNEL_TICK_SEND;
-        h->dev.last_tick_streaming = 1u; // (k_tick_send streams its message columns at any size)
+        h->dev.last_tick_streaming = nts ? 2u : 1u; // (k_tick_send streams its message columns at any size)
         h->tick_launches++;
         h->ticked = true;
         h->out_is_dense = true;

@@ -512,6 +512,15 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
     }
 }
 
+// What a stage of its own does with a group that waits -- or waited -- for its host hint: returns `hold` (serve no request now) and
+// adjusts the result word the stage sees.
+RG_HD bool rg_send_hold(u32 &out, u32 flags) {
+    if ((out & RG_OUT_HOST_HINT) && (flags & RG_SEND_REQUESTS_ONLY)) out = 0; // (still waiting for more answers; its effects are done)
+    else if (out & RG_OUT_HOST_HINT) return true;
+    else if (flags & RG_SEND_REQUESTS_ONLY) out &= ~(0xff000000u | (u32)RG_OUT_BECAME_LEADER); // (free_to / free_first_one / reset: done)
+    return false;
+}
+
 // The stage of one group in its own launch (k_send_dense, k_send_appends, the host twin of the tests).
 // WAVE: the lanes of a wave hold consecutive groups (k_send_dense): whole-line accesses, see rg_wave_any.
 template <int P, typename IX = u64, bool SPEC = false, bool WAVE = false>
@@ -521,10 +530,7 @@ RG_HD void rg_group_send(const RgState &st, const RgIns &ins, IX g, u32 out, u64
     // rg_resolve_host_hints runs (the deferred reject's send_append comes before the group's other sends of the tick); the
     // tick's Inflights EFFECTS -- free_to, free_first_one, the window resets -- are applied here and now, once, whatever the host
     // does next (round 4 dropped them with the requests: a host that moved on without resolving left the windows stale)
-    bool hold = false;
-    if ((out & RG_OUT_HOST_HINT) && (flags & RG_SEND_REQUESTS_ONLY)) out = 0; // (still waiting for more answers; its effects are done)
-    else if (out & RG_OUT_HOST_HINT) hold = true;
-    else if (flags & RG_SEND_REQUESTS_ONLY) out &= ~(0xff000000u | (u32)RG_OUT_BECAME_LEADER); // (free_to / free_first_one / reset: done)
+    const bool hold = rg_send_hold(out, flags);
     RgSendOps<P> q;
     rg_send_request<P, IX, SPEC, false, false, WAVE && !SPEC>(st, ins, g, out, flags, q, nullptr, 0u, hold);
     rg_send_serve<P, IX, false, WAVE && !SPEC>(st, ins, g, out, max_entries, flags, q, it, nullptr, 0u);

@@ -369,7 +369,7 @@ struct RgTsDirect {
     RG_HD RgMsgs ms() const { return m; }
     RG_HD RgIns ins() const { return i; }
 };
-template <int P, bool GC, typename IX, bool WAVE, typename A>
+template <int P, bool GC, typename IX, bool WAVE, typename A, bool NTS = false>
 RG_HD void rg_group_tick_send_a(RgGroup<P> &r, const A &a, IX g, u64 max_entries, u32 flags, RgSendRegs<P> &it,
                                 const RgSendWin<P> *win = nullptr, u32 lane = 0) {
     RgSendOps<P> q;
@@ -411,14 +411,14 @@ RG_HD void rg_group_tick_send_a(RgGroup<P> &r, const A &a, IX g, u64 max_entries
     // election rewrites all of them (rg_prefetch_rare / RgTick::set_next)
     const u32 nxv = r.evm | ((r.dirty >> 8) & 0xffu);
 #if RG_TS_ORDER == 1 /* experiment: the tick's stores first (their registers are free before the stage's operands arrive) */
-    rg_store_group<P, IX, 1, WAVE>(r, st, g);
+    rg_store_group<P, IX, 1, WAVE, NTS>(r, st, g);
     rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv, hold);
 #else
     rg_send_request<P, IX, false, true, PRE, TSW>(st, ins, g, sout, flags, q, &r, nxv, hold);
-    rg_store_group<P, IX, 1, WAVE>(r, st, g);
+    rg_store_group<P, IX, 1, WAVE, NTS>(r, st, g);
 #endif
     rg_send_serve<P, IX, true, TSW>(st, ins, g, sout, max_entries, flags, q, it, &r, nxv);
-    rg_store_group<P, IX, 2>(r, st, g);
+    rg_store_group<P, IX, 2, false, NTS>(r, st, g);
 }
 template <int P, bool GC, typename IX, bool WAVE = (RG_SEND_WAVE_LINES != 0)>
 RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, const RgIns &ins, IX g, u64 max_entries,
@@ -478,7 +478,10 @@ struct RgTsKernarg { // (never used on the host)
     RgIns ins() const { return RgIns(); }
 };
 #endif
-template <int P, bool GC, typename IX>
+// NTS: the tick's STATE columns streamed as well, loads and stores (rg_load_group / rg_store_group: the third memory regime) --
+// for an engine with device Inflights whose state is far beyond the Infinity Cache (rg_config.cache_policy =
+// RG_CACHE_STREAM_ALL; the window and work-item columns are streamed in every form).
+template <int P, bool GC, typename IX, bool NTS = false>
 __global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgTickSendArgs ka_) {
     const RgState &st = ka_.st; // (the prologue below; the phases go through RgTsKernarg)
     const RgIns &ins = ka_.ins;
@@ -520,13 +523,13 @@ __global__ __launch_bounds__(RG_BLOCK, RG_TS_WAVES) void k_tick_send(RgTickSendA
     {
         const RgState st1 = a.st();
         const RgMsgs ms1 = a.ms();
-        rg_load_group<P, RG_LANE_NX, IX, true>(r, st1, ms1, g); // (message columns streamed: an engine with device Inflights is past the cache at any size that matters)
+        rg_load_group<P, RG_LANE_NX, IX, true, NTS>(r, st1, ms1, g); // (message columns streamed: an engine with device Inflights is past the cache at any size that matters)
     }
     RgSendRegs<P> it;
 #if RG_TS_SPEC == 2
-    rg_group_tick_send_a<P, GC, IX, (RG_SEND_WAVE_LINES != 0)>(r, a, g, ka_.max_entries, ka_.flags, it, &win, lane);
+    rg_group_tick_send_a<P, GC, IX, (RG_SEND_WAVE_LINES != 0), RgTsKernarg, NTS>(r, a, g, ka_.max_entries, ka_.flags, it, &win, lane);
 #else
-    rg_group_tick_send_a<P, GC, IX, (RG_SEND_WAVE_LINES != 0)>(r, a, g, ka_.max_entries, ka_.flags, it);
+    rg_group_tick_send_a<P, GC, IX, (RG_SEND_WAVE_LINES != 0), RgTsKernarg, NTS>(r, a, g, ka_.max_entries, ka_.flags, it);
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const RgSendCols oc = RgTsKernarg::ptr()->oc;
@@ -1167,7 +1170,7 @@ void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &
 template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &st, const RgFused &fm, bool gc);
 template <int P>
 void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIns &ins, u64 max_entries,
-                           u32 flags, const RgSendCols &oc);
+                           u32 flags, const RgSendCols &oc, bool nts);
 template <int P>
 void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIngest &a, u64 *rh,
                              u64 *mflags_rw, const RgListOut &lo);
@@ -1281,7 +1284,7 @@ template <int P> void rg_launch_tick_fused_t(hipStream_t stream, const RgState &
 }
 template <int P>
 void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const RgIns &ins, u64 max_entries,
-                           u32 flags, const RgSendCols &oc) {
+                           u32 flags, const RgSendCols &oc, bool nts) {
     const dim3 grid(rg_grid_for(st.G, RG_BLOCK)), block(RG_BLOCK);
     const bool ix32 = rg_ix32(st, P); // 32-bit cell offsets (rg_launch_tick_t)
     RgTickSendArgs ta;
@@ -1295,7 +1298,8 @@ void rg_launch_tick_send_t(hipStream_t stream, const RgState &st, const RgMsgs &
         if (ix32) hipLaunchKernelGGL((k_tick_send<P, true, u32>), grid, block, 0, stream, ta);
         else hipLaunchKernelGGL((k_tick_send<P, true, u64>), grid, block, 0, stream, ta);
     } else {
-        if (ix32) hipLaunchKernelGGL((k_tick_send<P, false, u32>), grid, block, 0, stream, ta);
+        if (ix32 && nts) hipLaunchKernelGGL((k_tick_send<P, false, u32, true>), grid, block, 0, stream, ta); // (the one streamed instantiation)
+        else if (ix32) hipLaunchKernelGGL((k_tick_send<P, false, u32>), grid, block, 0, stream, ta);
         else hipLaunchKernelGGL((k_tick_send<P, false, u64>), grid, block, 0, stream, ta);
     }
 }
@@ -1305,7 +1309,7 @@ extern template void rg_launch_tick_classes_t<1>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<1>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<1>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<1>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1314,7 +1318,7 @@ extern template void rg_launch_tick_classes_t<2>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<2>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<2>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<2>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1323,7 +1327,7 @@ extern template void rg_launch_tick_classes_t<3>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<3>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<3>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<3>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1332,7 +1336,7 @@ extern template void rg_launch_tick_classes_t<4>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<4>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<4>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<4>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1341,7 +1345,7 @@ extern template void rg_launch_tick_classes_t<5>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<5>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<5>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<5>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1350,7 +1354,7 @@ extern template void rg_launch_tick_classes_t<6>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<6>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<6>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<6>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1359,7 +1363,7 @@ extern template void rg_launch_tick_classes_t<7>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<7>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<7>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<7>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);
@@ -1368,7 +1372,7 @@ extern template void rg_launch_tick_classes_t<8>(hipStream_t, const RgState &, c
 extern template void rg_launch_tick_split_t<8>(hipStream_t, const RgState &, const RgMsgs &, u64);
 extern template void rg_launch_tick_list_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const u64 *, const u32 *, u64, u64 *, const RgListOut &);
 extern template void rg_launch_tick_fused_t<8>(hipStream_t, const RgState &, const RgFused &, bool);
-extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &);
+extern template void rg_launch_tick_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32, const RgSendCols &, bool);
 extern template void rg_launch_flush_small_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &);
 extern template void rg_launch_flush_small_send_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *, const RgListOut &, const RgSmallSend &);
 extern template void rg_launch_mailbox_t<8>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u32 *, u64 *, u64 *, const RgListOut &, RgMbox *, u64, u64, const RgSmallSend &);

@@ -12,7 +12,7 @@ template void rg_launch_tick_list_t<RG_P>(hipStream_t, const RgState &, const Rg
                                           u64 *, const RgListOut &);
 template void rg_launch_tick_fused_t<RG_P>(hipStream_t, const RgState &, const RgFused &, bool);
 template void rg_launch_tick_send_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIns &, u64, u32,
-                                          const RgSendCols &);
+                                          const RgSendCols &, bool);
 template void rg_launch_flush_small_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *,
                                             const RgListOut &);
 template void rg_launch_flush_small_send_t<RG_P>(hipStream_t, const RgState &, const RgMsgs &, bool, const RgIngest &, u64 *, u64 *,

@@ -390,8 +390,8 @@ class Engine:
         cache_policy = d["cache_policy"] if cache_policy is None else cache_policy
         flags = d["flags"] if flags is None else flags
         cache_resident_groups = d["cache_resident_groups"] if cache_resident_groups is None else cache_resident_groups
-        if max_inflight and cache_policy > CACHE.STREAM_MSGS and from_default:
-            cache_policy = CACHE.STREAM_MSGS  # (a suite-wide default the send-stage engines cannot take: rg_create refuses it)
+        if max_inflight and cache_policy == CACHE.RESIDENT and from_default:
+            cache_policy = CACHE.STREAM_ALL  # (a suite-wide default the send-stage engines cannot take: rg_create refuses it)
         cfg = _Config(n_groups, n_slots, device, variant, max_inflight, cache_policy, flags, cache_resident_groups)
         self._check(self.L.rg_create(C.byref(cfg), C.byref(self.h)))
         self.n_groups, self.n_slots, self.device, self.max_inflight = n_groups, n_slots, device, max_inflight

@@ -92,6 +92,22 @@ def test_send_stage_matches_oracle(rg, n_slots, cap, max_entries, fused):
     eng.close()
 
 
+@pytest.mark.parametrize("n_slots,cap,max_entries", [(3, 2, 1), (5, 256, 0), (7, 4, 0)])
+def test_send_stage_with_everything_streamed(rg, n_slots, cap, max_entries):
+    """rg_config.cache_policy = RG_CACHE_STREAM_ALL on an engine with device Inflights: the one-launch form runs
+    k_tick_send<.., NTS = true> (the tick's state columns streamed, loads and stores), the two-launch form the streamed lane kernel
+    in front of k_send_dense -- same work items, columns and windows as ever."""
+    from raft_rs_amd import engine as E
+    with E.config_defaults(cache_policy=E.CACHE.STREAM_ALL):
+        eng = rg.Engine(64, n_slots, max_inflight=cap)
+        assert eng.device_info()["cache_policy"] == "stream_all"
+        eng.close()
+        test_send_stage_matches_oracle(rg, n_slots, cap, max_entries, True)
+        test_send_stage_matches_oracle(rg, n_slots, cap, max_entries, False)
+    with pytest.raises(rg.EngineError):
+        rg.Engine(64, n_slots, max_inflight=cap, cache_policy=E.CACHE.RESIDENT)
+
+
 @pytest.mark.parametrize("form", ["resolve_before_stage", "resolve_after_stage", "one_launch"])
 @pytest.mark.parametrize("n_slots,cap,max_entries", [(3, 2, 1), (5, 4, 0), (7, 3, 2)])
 def test_send_stage_waits_for_host_hints(rg, n_slots, cap, max_entries, form):
