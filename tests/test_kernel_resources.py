@@ -97,8 +97,10 @@ def test_tick_kernels_keep_their_register_budget():
     # round 4: the tick and its send stage in one launch at FOUR waves per SIMD (its phases read their column pointers from the
     # kernarg segment themselves: 145 -> 123 VGPRs), and the one-launch kernel for shards placed by size class at the plain
     # kernel's occupancy (its bodies do the same: the first form carried 1 566 spill-lane instructions)
-    send = next(v for k, v in rows.items() if "k_tick_sendILi5ELb0EjE" in k)
+    send = next(v for k, v in rows.items() if "k_tick_sendILi5ELb0EjLb0EE" in k)
     assert int(send["VGPRs"]) <= 128 and int(send["Occupancy [waves/SIMD]"]) >= 4 and int(send["ScratchSize [bytes/lane]"]) == 0, send
+    send_nt = next(v for k, v in rows.items() if "k_tick_sendILi5ELb0EjLb1EE" in k)  # round 5: the tick's state columns streamed as well
+    assert int(send_nt["VGPRs"]) <= 128 and int(send_nt["Occupancy [waves/SIMD]"]) >= 4 and int(send_nt["ScratchSize [bytes/lane]"]) == 0, send_nt
     cls = next(v for k, v in rows.items() if "k_tick_classesILi5EjLi0EE" in k)
     assert int(cls["VGPRs"]) <= 128 and int(cls["Occupancy [waves/SIMD]"]) >= 4 and int(cls["ScratchSize [bytes/lane]"]) == 0, cls
 
@@ -109,7 +111,7 @@ def test_occupancy_of_the_other_slot_counts():
         rows = resource_usage(p)
         lane = next(v for k, v in rows.items() if f"k_tick_laneILi{p}ELb0EjLi0EE" in k)
         assert int(lane["Occupancy [waves/SIMD]"]) >= waves and int(lane["ScratchSize [bytes/lane]"]) == 0, (p, lane)
-        for name in (f"k_tick_sendILi{p}ELb0EjE", f"k_tick_listILi{p}ELb0EjE"):  # no scratch at any slot count
+        for name in (f"k_tick_sendILi{p}ELb0EjLb0EE", f"k_tick_listILi{p}ELb0EjE"):  # no scratch at any slot count
             r = next(v for k, v in rows.items() if name in k)
             assert int(r["ScratchSize [bytes/lane]"]) == 0, (p, name, r)
     # config 5's one launch: the 7-slot body sets the allocation of every class -- three waves per SIMD, not two
@@ -135,6 +137,8 @@ def test_streamed_stores_are_streamed():
     assert cls.get("nt stores", 0) >= 16, cls
     split = one("k_tick_splitILi5EjE")            # both bodies in one kernel: the streamed one's stores, at the lane kernel's budget
     assert split.get("nt stores", 0) >= 16 and int(split["VGPRs"]) <= 128 and int(split["ScratchSize [bytes/lane]"]) == 0, split
-    send = one("k_tick_sendILi5ELb0EjE")          # the item columns (3 x 5) and the window columns (3 x 5, stored at two places);
+    send = one("k_tick_sendILi5ELb0EjLb0EE")      # the item columns (3 x 5) and the window columns (3 x 5, stored at two places);
     assert send.get("nt stores", 0) >= 45, send   # loads: the messages (11) and the window columns (15)
     assert send.get("nt loads", 0) >= 26, send
+    send_all = one("k_tick_sendILi5ELb0EjLb1EE")  # ... and the tick's own state columns, loads and stores (RG_CACHE_STREAM_ALL)
+    assert send_all.get("nt stores", 0) >= send.get("nt stores", 0) + 16 and send_all.get("nt loads", 0) >= send.get("nt loads", 0) + 15, (send, send_all)

@@ -7,6 +7,8 @@
 # A step is `name[:arg[:arg...]]` (tools/gpu_steps.sh has the bodies):
 #   tests:<pytest -k expr or ->:<files...>   pytest -m gpu over the given test files (default: all), tail to tests.txt
 #   bench:<args with , for spaces>           python bench.py <args> -> last JSON line appended to bench.jsonl
+#   headline:<tag>:<steps>                   rocprofv3 stats + FETCH_SIZE + WRITE_SIZE passes of the default configuration ->
+#                                            <tag>_rocprof_summary.{md,json}, <tag>_kernel_stats.csv (tools/summarize_prof.py)
 #   prof:<name>:<bench args>                 rocprofv3 --kernel-trace --stats of bench.py <args> -> <name>_kernel_stats.csv
 #   pmc:<traffic.json key, + for :>:<steps>:<bench args>   FETCH_SIZE / WRITE_SIZE PMC passes (tools/pmc_traffic.sh ->
 #                                            gpurun_out/traffic_<key>.json; fold them in with tools/merge_traffic.py)

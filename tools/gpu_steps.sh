@@ -26,6 +26,15 @@ except Exception as e: print('??', e)"
   prof)
     rm -rf /tmp/prof_$a; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$a -o $a --output-format csv -- python "$GRAFT_REPO_ROOT/bench.py" $(sp "$b") > "$GRAFT_REPO_ROOT/$O/prof_$a.log" 2>&1 )
     f=$(find /tmp/prof_$a -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/${a}_kernel_stats.csv" && head -6 "$O/${a}_kernel_stats.csv" | cut -c1-200 ;;
+  headline) # headline:<tag>:<steps> -- the rocprofv3 stats + FETCH_SIZE + WRITE_SIZE passes of the default configuration, condensed
+    CMD="python $GRAFT_REPO_ROOT/bench.py --steps ${b:-50} --warmup 5 --repeats 1 --no-cpu-baseline --no-extras"
+    P=/tmp/headline_$a; rm -rf $P; mkdir -p $P
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -o s -- $CMD > "$GRAFT_REPO_ROOT/$O/headline_bench.json" 2> "$GRAFT_REPO_ROOT/$O/headline_stats.err"
+      timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/fetch -o f -- $CMD > /dev/null 2> "$GRAFT_REPO_ROOT/$O/headline_fetch.err"
+      timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/write -o w -- $CMD > /dev/null 2> "$GRAFT_REPO_ROOT/$O/headline_write.err" )
+    python tools/summarize_prof.py --tag "$a" --stats $P/stats --fetch $P/fetch --write $P/write --last "${b:-50}" --out "$O" \
+      --note "python bench.py --steps ${b:-50} --warmup 5 --repeats 1 --no-cpu-baseline --no-extras (1 M groups x 5 peers, config 2), csrc $(python -c 'import bench; print(bench.csrc_sha16())')" > /dev/null
+    f=$(find $P/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/${a}_kernel_stats.csv" && head -4 "$O/${a}_kernel_stats.csv" | cut -c1-160 ;;
   pmc)
     bash tools/pmc_traffic.sh "${a//+/:}" "$b" $(sp "$c") > "$O/pmc_${a//+/_}.txt" 2>&1; tail -3 "$O/pmc_${a//+/_}.txt" ;;
   sweep) # sweep:<libs, + between them>:<name>:<bench args, commas for spaces>  -> sweep.txt (tools/sweep_libs.py)

@@ -10,13 +10,13 @@ O=$R/gpurun_out/traffic_$TAG
 rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $R/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-extras $*"
+CMD="python $R/bench.py --steps $STEPS --warmup 3 --repeats 1 --no-cpu-baseline --no-extras $*"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/f -o f -- $CMD > /dev/null 2> $O/f.err
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- $CMD > /dev/null 2> $O/w.err
 python - "$O" "$KEY" "$STEPS" "$*" <<'PY' > $R/gpurun_out/traffic_$TAG.json
 import csv, glob, sys, collections, json, re
 O, key, steps, args = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-res = {"key": key, "command": f"bench.py --steps {steps} --warmup 3 --no-cpu-baseline --no-extras {args}", "kernels": {}}
+res = {"key": key, "command": f"bench.py --steps {steps} --warmup 3 --repeats 1 --no-cpu-baseline --no-extras {args}", "kernels": {}}
 for sub, name in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
     rows = collections.defaultdict(dict)
     for f in glob.glob(f"{O}/{sub}/**/*counter_collection.csv", recursive=True):
