@@ -715,7 +715,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
         print(json.dumps(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
                                     one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
-                                    sorted_classes=args.sorted)),
+                                    sorted_classes=args.sorted, repeats=max(1, args.repeats))),
               flush=True)
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the

@@ -21,7 +21,10 @@ for k, v in d["other_configs"].items():
     show(k, v)
     if "send_stage" in v:
         s = v["send_stage"]
-        print("    send stage: tick %.1f us stage %.1f us frac %.3f bytes/group %.0f" % (s["us_per_tick_median"], s["us_per_stage_median"], s["roofline"]["frac"], s["roofline"]["bytes_per_group"]))
+        if "us_per_tick_median" in s:
+            print("    send stage: tick %.1f us stage %.1f us frac %.3f bytes/group %.0f" % (s["us_per_tick_median"], s["us_per_stage_median"], s["roofline"]["frac"], s["roofline"]["bytes_per_group"]))
+        else:
+            print("    tick + send stage, one launch: %.1f us frac %.3f bytes/group %.0f" % (s["us_per_step_median"], s["roofline"]["frac"], s["roofline"]["bytes_per_group"]))
 print(d["small_batch_latency"])
 c = d["cpu_baseline"]
 print({k: c[k] for k in ("value", "cores", "value_1core", "soa_value", "soa_value_1core", "soa_cores")})
