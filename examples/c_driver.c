@@ -209,6 +209,34 @@ int main(void) {
                (unsigned long long)ps.bytes_per_rank_full);
         CHECK(rg_comm_destroy(h));
     }
+    /* ---- one process, ONE thread, several engines (raftgroups.h: "several ranks in ONE process"): two more shards of
+     *      the same shape become ranks 0 and 1 of one publication; both live on this box's one device, so the exchange is
+     *      the in-process transport (with a device each it is RCCL inside one ncclGroupStart / ncclGroupEnd) ---- */
+    if (ok) {
+        rg_engine *e2[2] = {NULL, NULL};
+        rg_workload w = {0x5EED5EEDull, RG_WL_MAJORITY, 0};
+        uint64_t own[2][G], seen[G];
+        uint32_t o2[G];
+        rg_device_info di;
+        for (int r = 0; r < 2; r++) {
+            CHECK(rg_create(&cfg, &e2[r]));
+            CHECK(rg_workload_init(e2[r], &w, (uint64_t)r * G));
+        }
+        CHECK(rg_get_device_info(e2[1], &di));
+        ok = ok && di.engines_on_device == 3; /* h and the two shards: counted per DEVICE, at rg_create */
+        CHECK(rg_comm_init_all(e2, 2, NULL)); /* NULL = defaults; AUTO picks the in-process transport for a shared device */
+        ok = ok && rg_publish_commit(e2[0], 0) == RG_ERR_STATE; /* such ranks are published together */
+        for (int r = 0; r < 2; r++) CHECK(rg_recompute(e2[r])); /* (any commit-changing call accumulates into the slice) */
+        CHECK(rg_publish_commit_all(e2, 2, 0));
+        for (int r = 0; r < 2; r++) CHECK(rg_results(e2[r], own[r], o2));
+        for (int reader = 0; reader < 2; reader++)
+            for (int r = 0; r < 2; r++) {
+                CHECK(rg_published_commit(e2[reader], (uint32_t)r, 0, G, seen));
+                for (int g = 0; g < G; g++) ok = ok && seen[g] == own[r][g];
+            }
+        printf("two engines, one thread: rank 1's first commit index %llu seen by rank 0\n", (unsigned long long)seen[0]);
+        for (int r = 0; r < 2; r++) rg_destroy(e2[r]);
+    }
     rg_device_info info;
     CHECK(rg_get_device_info(h, &info));
     printf("device %s, %u CUs, wave%u, engine holds %llu bytes\n", info.arch, info.compute_units, info.wavefront,

@@ -28,6 +28,9 @@ def main():
             continue
         key, note = d["key"], ""
         kernels = d["kernels"]
+        if key.startswith("recompute:"):  # (`--side recompute` runs three ticks of the stream first: only the recompute launches count)
+            kernels = {k: v for k, v in kernels.items() if k.startswith("k_recompute")}
+            note = "; k_recompute launches only"
         if key.endswith(":fused-send"):  # the recording pass of the bench runs the two-launch kernels as well: only the timed ones
             kernels = {k: v for k, v in kernels.items() if k.startswith("k_tick_send")}
             note = "; the k_tick_send launches of the timed replay only"
