@@ -449,7 +449,8 @@ template <int P> struct RgGroup {
     static constexpr int HN = RG_HINT_REGS(P);
     u64 hint[HN];
     u32 hsel;
-    u64 pc_self;        // early stores (RgTick's ES): the leader's own committed_index once pc[] has gone to memory
+    u64 pc_self;        // early stores / late loads (RgTick's ES): the leader's own committed_index while pc[] is not in registers
+    u64 mc_self_v;      // late loads: m_commit of the leader's own slot (RG_MF_APPEND: the new last_index), fetched with the rare batch
     u32 el_n;           // an election: the term-run table's fill count (RG_COL_RUN_COUNT) -- with it rg_push_run files the previous
                         // leader's run on the spot, two stores and no look at the table (round 3 read the table for the first
                         // unused run, behind the group's stores: two dependent round trips at the tail of every wave that holds
@@ -654,10 +655,13 @@ RG_HD u32 rg_count_runs(const RgState &st, u64 g) {
 // rollover (BASELINE config 5) practically every wave needed a dozen of them, one after the other.
 // Every destination is written once, before its load is issued, and not touched again until the tick reads it: a
 // later write (even under a disjoint exec mask) would make the compiler wait for the load first.
-template <int P, typename IX> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
+struct RgNoEarlyStores; // (the tick's store / load policy, below: ES)
+template <int P, typename IX, typename ES = RgNoEarlyStores> RG_HD void rg_prefetch_rare(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
     const u32 cfg = r.cfg;
     const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
     const bool elect = rg_has_election(r.mf, cfg, P);
+    // (ES::late_pc: the own slot's committed_index and Message.commit travel with this batch; a no-op otherwise)
+    ES::template load_self<P, IX>(r, st, ms, g, self, self < (u32)P && ((present >> self) & 1u) && ((r.mf >> (8 * self)) & 0xffULL) != 0);
     r.el_old = 0;
     r.el_n = 0;
     if (elect) {
@@ -745,13 +749,24 @@ template <int P, typename IX> RG_HD u64 rg_hint_of(const RgGroup<P> &r, const Rg
 // ballots as in rg_store_group), `next` behind each slot -- and only the leader's own committed_index (raft.rs:896-900 raises
 // it to the new commit index at the very end) travels on, in ONE register pair (RgGroup::pc_self), to be stored with the group. Same cells, same values, same
 // number of stores; what changes is when they are issued and that 4 P - 2 registers are free when the quorum is evaluated.
+// ES::late_pc -- late loads (round 5, second attempt at the 7-slot body's registers; rg_tick_kernels.h: RgLatePc). The peak of
+// the allocation is the load phase: six u64 operands per slot in flight at once. Two of them, `committed_index` and
+// Message.commit, are needed by nothing but each other (update_committed) -- except on the leader's own slot (the new last_index
+// of RG_MF_APPEND; the election's and the commit phase's `prs[self].update_committed`). With ES::late_pc those two cells of the
+// own slot ride with the rare-path prefetch batch (pc_self, mc_self_v), the 2 P column loads are issued only when the slots
+// have been walked -- `next`, the hints and the election operands are dead by then -- and land while the quorum is evaluated;
+// update_committed runs behind the commit phase. Same loads, same stores, same values; 4 P registers less at the peak.
 struct RgNoEarlyStores {
     static constexpr bool on = false;
+    static constexpr bool late_pc = false;
+    template <int P, typename IX> RG_HD static void load_self(RgGroup<P> &, const RgState &, const RgMsgs &, IX, u32, bool) {}
+    template <int P, typename IX> RG_HD static void load_pc_mc(RgGroup<P> &, const RgState &, const RgMsgs &, IX) {}
     template <int P, typename IX> RG_HD static void store_pc(RgGroup<P> &, const RgState &, IX, u32) {}
     template <int S, int P, typename IX> RG_HD static void store_next(RgGroup<P> &, const RgState &, IX) {}
 };
 template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEarlyStores> struct RgTick {
-    static_assert(!ES::on || !FUSED, "early stores: single-tick kernels only");
+    static_assert(!(ES::on || ES::late_pc) || !FUSED, "early stores / late loads: single-tick kernels only");
+    static_assert(!(ES::on && ES::late_pc), "early stores and late loads exclude each other");
     static constexpr bool LAZY_NX = NXM == RG_NX_LAZY;
     static constexpr bool PREF = NXM == RG_NX_PREFETCH;
     RgGroup<P> &r;
@@ -865,7 +880,12 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
             if ((u32)i == self) {
                 // assert_eq!(last_index, self.raft_log.persisted) (raft.rs:1170): matched IS the persisted index
                 if (r.mt[i] != old_hi) out |= RG_OUT_FAULT;
-                if (r.pc[i] != r.commit) {
+                if constexpr (ES::late_pc) { // (pc[] is not here yet: the own cell came with the rare batch)
+                    if (r.pc_self != r.commit) {
+                        r.pc_self = r.commit;
+                        r.dirty |= 1u << (16 + i);
+                    }
+                } else if (r.pc[i] != r.commit) {
                     r.pc[i] = r.commit;
                     r.dirty |= 1u << (16 + i);
                 }
@@ -1088,7 +1108,7 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
     }
 
     template <int S> RG_HD void self_committed() { // prs[self].update_committed(committed), raft.rs:896-900
-        if constexpr (ES::on) { // (the followers' cells are in memory already; rg_store_group<.., EARLY> writes pc_self)
+        if constexpr (ES::on || ES::late_pc) { // (pc[] is in memory already / not loaded yet: the own cell travels in pc_self)
             if ((u32)S == self && ((present >> S) & 1u) && r.pc_self < r.commit) {
                 r.pc_self = r.commit;
                 r.dirty |= 1u << (16 + S);
@@ -1182,7 +1202,45 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
         }
     }
 
+    // ES::late_pc: update_committed behind the commit phase, on the columns that have just arrived
+    template <int S> RG_HD void peer_committed_late() {
+        if ((u32)S == self) { // (the own cell: what the election / the commit phase made of it)
+            if ((present >> S) & 1u) r.pc[S] = r.pc_self;
+            return;
+        }
+        const u32 f = (u32)(r.mf >> (8 * S)) & 0xffu;
+        if (!((present >> S) & 1u) || !(f & (RG_MF_VALID | RG_MF_HEARTBEAT))) return;
+        if (r.mc[S] > r.pc[S]) {
+            r.pc[S] = r.mc[S];
+            r.dirty |= 1u << (16 + S);
+        }
+    }
+
     template <int... S> RG_HD void run(rg_seq<S...> seq) {
+        if constexpr (ES::late_pc) {
+            mc_self = r.mc_self_v;
+            (slot<S>(), ...);
+            // (the group index the late loads use is made to DEPEND on what the slots produced: left alone, the scheduler hoists
+            // the 2 P loads to the top of the kernel -- where they would be in flight with everything else again: 174 VGPRs)
+#ifndef RG_LATE_PC_AFTER_COMMIT /* 1 = the two columns are requested behind the commit phase (lowest register pressure, one exposed
+                                   round trip: 112 VGPRs at 7 slots); 0 = behind the slots, in flight across the quorum evaluation
+                                   (138 VGPRs: no fourth wave, measured no gain) */
+#define RG_LATE_PC_AFTER_COMMIT 1
+#endif
+            IX gl = g;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (!RG_LATE_PC_AFTER_COMMIT) asm volatile("" : "+v"(gl) : "v"(acc), "v"(out), "v"(r.dirty));
+#endif
+            if (!RG_LATE_PC_AFTER_COMMIT) ES::template load_pc_mc<P, IX>(r, st, ms, gl); // (2 P loads in flight across the quorum evaluation)
+            commit_phase(seq);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (RG_LATE_PC_AFTER_COMMIT) asm volatile("" : "+v"(gl) : "v"(out), "v"(r.dirty), "v"((u32)r.commit));
+#endif
+            if (RG_LATE_PC_AFTER_COMMIT) ES::template load_pc_mc<P, IX>(r, st, ms, gl);
+            (peer_committed_late<S>(), ...);
+            r.out = out;
+            return;
+        }
         mc_self = 0;
         (peer_committed<S>(), ...);
         if constexpr (ES::on) {

@@ -101,7 +101,7 @@ template <bool NTM = (RG_OPT_NT_MSG != 0), typename T> RG_HD T rg_ld_stream(cons
 // state alone is far beyond the Infinity Cache: nothing a launch touches is touched again before the cache has turned over,
 // so nothing should be allocated there. Only together do the two halves pay (8 M x 5, one box: loads alone 525 -> 616 us,
 // stores alone 534, both 485: profiles/r04_nt_state.txt).
-template <int P, int NXM, typename IX, bool NTM = (RG_OPT_NT_MSG != 0), bool NTS = false>
+template <int P, int NXM, typename IX, bool NTM = (RG_OPT_NT_MSG != 0), bool NTS = false, typename ES = RgNoEarlyStores>
 RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
     constexpr bool LOAD_NX = NXM == RG_NX_LOADED;
     r.mf = rg_ld_stream<NTM>(&rg_at(ms.mflags, g));
@@ -116,11 +116,12 @@ RG_HD void rg_load_group(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX 
         const IX o = (IX)p * (IX)st.stride + g;
         r.mt[p] = rg_ld_stream<NTS>(&rg_at(st.match, o));
         if (LOAD_NX) r.nx[p] = rg_at(st.next, o);
-        r.pc[p] = rg_ld_stream<NTS>(&rg_at(st.prc, o));
+        if (!ES::late_pc) r.pc[p] = rg_ld_stream<NTS>(&rg_at(st.prc, o));
         r.mi[p] = rg_ld_stream<NTM>(&rg_at(ms.mi, o));
-        r.mc[p] = rg_ld_stream<NTM>(&rg_at(ms.mc, o));
+        if (!ES::late_pc) r.mc[p] = rg_ld_stream<NTM>(&rg_at(ms.mc, o)); // (late loads: RgTick::run requests the two columns itself)
     }
-    if (NXM == RG_NX_PREFETCH) rg_prefetch_rare<P, IX>(r, st, ms, g);
+    static_assert(!ES::late_pc || NXM == RG_NX_PREFETCH, "late loads ride with the rare-path prefetch batch");
+    if (NXM == RG_NX_PREFETCH) rg_prefetch_rare<P, IX, ES>(r, st, ms, g);
 }
 
 // WHICH: bit 0 = everything but `next` and the flag row, bit 1 = those two (k_tick_send stores them behind its send
@@ -206,8 +207,50 @@ template <bool NTS> struct RgEarlyStores {
         r.dirty &= ~(1u << (8 + S));
     }
 };
-template <int P, bool NTS> struct RgLaneStores {
-    typedef typename std::conditional<(P >= RG_EARLY_ST_FROM), RgEarlyStores<NTS>, RgNoEarlyStores>::type type;
+// RgTick's late loads (rg_group.h: ES::late_pc): committed_index and Message.commit of the followers requested behind the slots,
+// the own slot's two cells with the rare-path batch. NTM / NTS: the launch's streaming choice for message / state columns.
+// MEASURED (round 5, profiles/r05_c5_occupancy.txt, second table): requested BEHIND the commit phase, with opaque 32-bit offsets,
+// the 7-slot body needs 112 VGPRs (162 before) -- four waves per SIMD without scratch, without a dependent fetch in the rare paths
+// and without mid-tick stores -- at the price of one exposed round trip at the end of every wave. Where the state sits in the
+// Infinity Cache that round trip is short: config 5 in one launch 84.8 -> 80.8 us (0.52 -> 0.55 on that box), 1 M x 8 87.9 -> 84.9;
+// where it comes from HBM it is not: 8 M x 7 all-streamed 639 -> 668 us. A steady 7-slot shard gains nothing (74.6 -> 75.5).
+// So: the bodies of k_tick_classes with RG_LATE_PC_FROM slots or more, in the cached regimes (NTS = false) -- the launch whose
+// occupancy the 7-slot body sets for every class. RG_LATE_PC_LANE_FROM: the same for the plain lane kernel (experiment, 99 = never).
+#ifndef RG_LATE_PC_FROM
+#define RG_LATE_PC_FROM 7
+#endif
+#ifndef RG_LATE_PC_LANE_FROM
+#define RG_LATE_PC_LANE_FROM 99
+#endif
+template <bool NTM, bool NTS> struct RgLatePc : RgNoEarlyStores {
+    static constexpr bool late_pc = true;
+    template <int P, typename IX> RG_HD static void load_self(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g, u32 self, bool has_event) {
+        r.pc_self = 0;
+        r.mc_self_v = 0;
+        if (self < (u32)P) {
+            const IX o = (IX)self * (IX)st.stride + g;
+            r.pc_self = rg_ld_stream<NTS>(&rg_at(st.prc, o));
+            if (has_event) r.mc_self_v = rg_ld_stream<NTM>(&rg_at(ms.mc, o));
+        }
+    }
+    template <int P, typename IX> RG_HD static void load_pc_mc(RgGroup<P> &r, const RgState &st, const RgMsgs &ms, IX g) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const IX o = (IX)p * (IX)st.stride + g;
+            r.pc[p] = rg_ld_stream<NTS>(&rg_at(st.prc, o));
+            r.mc[p] = rg_ld_stream<NTM>(&rg_at(ms.mc, o));
+        }
+    }
+};
+template <int P, bool NTS, bool NTM = true, bool CLS = false> struct RgLaneStores {
+    static constexpr bool late = !NTS && P >= (CLS ? RG_LATE_PC_FROM : RG_LATE_PC_LANE_FROM);
+    typedef typename std::conditional<late, RgLatePc<NTM, NTS>,
+                                      typename std::conditional<(P >= RG_EARLY_ST_FROM), RgEarlyStores<NTS>, RgNoEarlyStores>::type>::type type;
+};
+// The cell index of a body of k_tick_classes: opaque offsets where the body loads late (they are what keeps the address pairs of
+// the cells still to be stored out of the registers while the two late columns are in flight: 146 VGPRs with plain u32, 112 with)
+template <int Q, int NTM> struct RgClassIx {
+    typedef typename std::conditional<RgLaneStores<Q, NTM == 2, true, true>::late, rg_u32o, typename RgLaneIx<Q>::type>::type type;
 };
 
 template <int P, typename F> RG_D void rg_cpt_fields(RgGroup<P> &r, u64 &g64, u64 &cfg_adv, F &&f);
@@ -223,7 +266,8 @@ template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_LANE_BOUNDS(P)
     asm volatile("" ::"v"((u32)(uintptr_t)&occ_pad[threadIdx.x]));
 #endif
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2>(r, st, ms, g);
+    typedef typename RgLaneStores<P, NTM == 2, NTM != 0 || (RG_OPT_NT_MSG != 0)>::type ES;
+    rg_load_group<P, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2, ES>(r, st, ms, g);
 #if defined(RG_LANE_FENCE) && defined(__HIP_DEVICE_COMPILE__) /* experiment: keep the compiler from interleaving the tick with the loads */
 #if RG_LANE_FENCE == 1
     asm volatile("" ::: "memory");
@@ -238,7 +282,6 @@ template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_LANE_BOUNDS(P)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #endif
-    typedef typename RgLaneStores<P, NTM == 2>::type ES;
     rg_group_tick<P, GC, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
     rg_store_group<P, IX, 3, true, NTM == 2, ES::on>(r, st, g);
 }
@@ -287,7 +330,7 @@ struct RgClassArgs {
 // whichever body runs; what does not fit the scalar registers there is spilled to VGPR lanes for good and read back at every
 // use -- 1 500 v_readlane / v_writelane in the code, ~250 executed per wave, in bodies (3 and 5 slots) that compiled on their
 // own spill nothing. A scalar load that hits the constant cache costs the VALU nothing.
-template <int Q, typename IX, int NTM> RG_D void rg_lane_body(IX g) {
+template <int Q, typename IX, int NTM, bool CLS = false> RG_D void rg_lane_body(IX g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) RgClassArgs *KArgs;
     KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -295,8 +338,8 @@ template <int Q, typename IX, int NTM> RG_D void rg_lane_body(IX g) {
     const RgState st = ka->st;
     const RgMsgs ms = ka->ms;
     RgGroup<Q> r;
-    rg_load_group<Q, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2>(r, st, ms, g);
-    typedef typename RgLaneStores<Q, NTM == 2>::type ES;
+    typedef typename RgLaneStores<Q, NTM == 2, NTM != 0 || (RG_OPT_NT_MSG != 0), CLS>::type ES;
+    rg_load_group<Q, RG_LANE_NX, IX, NTM != 0 || (RG_OPT_NT_MSG != 0), NTM == 2, ES>(r, st, ms, g);
     rg_group_tick<Q, false, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
     rg_store_group<Q, IX, 3, true, NTM == 2, ES::on>(r, st, g);
 #endif
@@ -306,11 +349,11 @@ template <int P, typename IX, int NTM> __global__ RG_LANE_BOUNDS(P) void k_tick_
     const u32 blk = e & 0x0fffffffu, np = e >> 28;
     const u64 g64 = (u64)blk * RG_BLOCK + threadIdx.x;
     if (g64 >= a.st.G) return;
-    // (each body with the index type of its own slot count: RgLaneIx)
-    if (P > 3 && np <= 3) rg_lane_body<3, typename RgLaneIx<3>::type, NTM>((typename RgLaneIx<3>::type)g64);
-    else if (P > 5 && np <= 5) rg_lane_body<5, typename RgLaneIx<5>::type, NTM>((typename RgLaneIx<5>::type)g64);
-    else if (P > 7 && np <= 7) rg_lane_body<7, typename RgLaneIx<7>::type, NTM>((typename RgLaneIx<7>::type)g64);
-    else rg_lane_body<P, IX, NTM>((IX)g64);
+    // (each body with the index type and the load policy of its own slot count: RgClassIx, RgLaneStores<.., CLS = true>)
+    if (P > 3 && np <= 3) rg_lane_body<3, typename RgClassIx<3, NTM>::type, NTM, true>((typename RgClassIx<3, NTM>::type)g64);
+    else if (P > 5 && np <= 5) rg_lane_body<5, typename RgClassIx<5, NTM>::type, NTM, true>((typename RgClassIx<5, NTM>::type)g64);
+    else if (P > 7 && np <= 7) rg_lane_body<7, typename RgClassIx<7, NTM>::type, NTM, true>((typename RgClassIx<7, NTM>::type)g64);
+    else rg_lane_body<P, typename RgClassIx<P, NTM>::type, NTM, true>((typename RgClassIx<P, NTM>::type)g64);
 }
 
 // The lane kernel over an engine whose state is PARTLY RESIDENT in the Infinity Cache (round 4). Beyond the cache a launch

@@ -46,10 +46,12 @@ static RgMsgs make_msgs(const void *const *p) {
 }
 
 #include <vector>
-template <int P, typename IX> static void host_one(const RgState &st, const RgMsgs &ms, bool gc, IX g) {
+template <int P, typename IX, bool CLS = false> static void host_one(const RgState &st, const RgMsgs &ms, bool gc, IX g) {
     RgGroup<P> r;
-    rg_load_group<P, RG_LANE_NX, IX>(r, st, ms, g);
-    typedef typename RgLaneStores<P, false>::type ES; // (the lane kernels' own choice: early stores from 7 slots on)
+    // (the kernels' own choice of store / load policy for this slot count: CLS = as a body of k_tick_classes -- late loads of
+    // committed_index / Message.commit from 7 slots on)
+    typedef typename RgLaneStores<P, false, false, CLS>::type ES;
+    rg_load_group<P, RG_LANE_NX, IX, false, false, ES>(r, st, ms, g);
     if (gc) rg_group_tick<P, true, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
     else rg_group_tick<P, false, RG_LANE_NX, false, IX, ES>(r, st, ms, g);
     rg_store_group<P, IX, 3, false, false, ES::on>(r, st, g);
@@ -70,8 +72,10 @@ template <int P> static void host_tick(const RgState &st, const RgMsgs &ms_in, b
     // so both instantiations are diffed against the oracle)
     const bool fits32 = rg_fits_u32_offsets(P, st.stride);
     for (u64 g = g0; g < g1; g++) {
-        if (fits32 && !(g & 1)) host_one<P, u32>(st, ms, gc, (u32)g);
-        else host_one<P, u64>(st, ms, gc, g);
+        // ... and every other pair of groups as a body of k_tick_classes would run them (no group commit there)
+        const bool cls = !gc && (g & 2);
+        if (fits32 && !(g & 1)) cls ? host_one<P, u32, true>(st, ms, gc, (u32)g) : host_one<P, u32>(st, ms, gc, (u32)g);
+        else cls ? host_one<P, u64, true>(st, ms, gc, g) : host_one<P, u64>(st, ms, gc, g);
     }
 }
 

@@ -114,9 +114,12 @@ def test_occupancy_of_the_other_slot_counts():
         for name in (f"k_tick_sendILi{p}ELb0EjLb0EE", f"k_tick_listILi{p}ELb0EjE"):  # no scratch at any slot count
             r = next(v for k, v in rows.items() if name in k)
             assert int(r["ScratchSize [bytes/lane]"]) == 0, (p, name, r)
-    # config 5's one launch: the 7-slot body sets the allocation of every class -- three waves per SIMD, not two
-    cls7 = next(v for k, v in resource_usage(7).items() if "k_tick_classesILi7EjLi0EE" in k)
-    assert int(cls7["VGPRs"]) <= 168 and int(cls7["Occupancy [waves/SIMD]"]) >= 3 and int(cls7["ScratchSize [bytes/lane]"]) == 0, cls7
+    # config 5's one launch: the 7-slot body sets the allocation of every class. Round 5: it loads committed_index / Message.commit
+    # behind the commit phase (RgLatePc, opaque offsets) in the cached regimes -- FOUR waves per SIMD, no scratch; the all-streamed
+    # instantiation keeps the plain body (three waves)
+    for ntm, waves, vgprs in ((0, 4, 128), (1, 4, 128), (2, 3, 168)):
+        cls7 = next(v for k, v in resource_usage(7).items() if f"k_tick_classesILi7EjLi{ntm}EE" in k)
+        assert int(cls7["VGPRs"]) <= vgprs and int(cls7["Occupancy [waves/SIMD]"]) >= waves and int(cls7["ScratchSize [bytes/lane]"]) == 0, (ntm, cls7)
 
 
 def test_streamed_stores_are_streamed():
