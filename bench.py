@@ -284,11 +284,27 @@ def workload_label(workload, n_groups, n_slots, one_engine=False, sorted_classes
     return f"{n_groups} groups x {n_slots} slots, workload {workload}"
 
 
+class _DevU32:
+    """A device range of u32 as something torch.as_tensor accepts (CUDA array interface)."""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
 def send_stage_bytes(rg, eng, n_items, with_work=False):
     """The send stage's own algorithmic bytes for the LAST tick: per group out 4 + cfg 4 +
     last_index 8 + first_index 8 + flag row 8 r + 8 w = 40; per peer in the work set (a send request, an Inflights effect,
     or a broadcast) window meta 4 r + 4 w, oldest / newest inflight 16 r + 16 w, next 8 r + 8 w, pending snapshot request
-    8 r, matched 8 r = 72; work items as peer-major columns: 4 B per (slot, group) cell + 16 B per item."""
+    8 r, matched 8 r = 72; work items as peer-major columns: 4 B per (slot, group) cell + 8 B per item (prev_index) + 8 B per
+    item whose last_index is not the window's new newest inflight (round 5: those that are do not store it a second time --
+    bit 31 of the n / kind word, counted here from the column itself)."""
+    import torch
+    in_tail = 0
+    try:
+        _, _, pn = eng.send_columns()
+        nk = torch.as_tensor(_DevU32(pn, eng.n_slots * eng.stride), device="cuda")
+        in_tail = int((nk < 0).sum().item())  # (bit 31 of a u32 read as i32)
+    except Exception:  # noqa: BLE001 -- a sparse stage has no columns: every item carries both indices
+        pass
     _, out = eng.results()
     cfg = eng.read_column(rg.COL.CFG)
     present, self_slot = (cfg >> 24) & 0xff, (cfg >> 16) & 7
@@ -296,7 +312,7 @@ def send_stage_bytes(rg, eng, n_items, with_work=False):
     work = ((out >> 8) | (out >> 16) | (out >> 24)) & 0xff
     work = np.where(bcast, work | present, work) & present & ~(1 << self_slot)
     n_work = int(sum(((work >> p) & 1).sum() for p in range(8)))
-    b = 40 * eng.n_groups + 72 * n_work + 4 * eng.n_slots * eng.n_groups + 16 * n_items
+    b = 40 * eng.n_groups + 72 * n_work + 4 * eng.n_slots * eng.n_groups + 16 * n_items - 8 * in_tail
     return (b, n_work) if with_work else b
 
 

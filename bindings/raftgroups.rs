@@ -62,6 +62,7 @@ pub const RG_SEND_SNAPSHOT: u32 = 2;
 pub const RG_SEND_HOST: u32 = 3;
 pub const RG_SEND_SKIP_BCAST_COMMIT: u32 = 0x1;
 pub const RG_SEND_BYTES: u32 = 0x2;
+pub const RG_SEND_LAST_IS_TAIL: u32 = 0x80000000;
 pub const RG_COMM_ID_BYTES: u32 = 128;
 pub const RG_COMM_ALL_AUTO: u32 = 0;
 pub const RG_COMM_ALL_RCCL: u32 = 1;
@@ -438,6 +439,7 @@ extern "C" {
     pub fn rg_send_items(h: *mut RgEngine, host_items: *mut RgSendItem, cap: u64, n: *mut u64) -> i32;
     pub fn rg_send_items_ptr(h: *mut RgEngine) -> *const RgSendItem;
     pub fn rg_send_columns(h: *mut RgEngine, dev_prev_index: *mut *const u64, dev_last_index: *mut *const u64, dev_n_kind: *mut *const u32) -> i32;
+    pub fn rg_send_tail_column(h: *mut RgEngine, dev_newest_inflight: *mut *const u64) -> i32;
     pub fn rg_inflights_bytes(h: *const RgEngine, ring: i32) -> u64;
     pub fn rg_read_inflights(h: *mut RgEngine, host_meta: *mut u32, host_ring: *mut u64) -> i32;
     pub fn rg_load_inflights(h: *mut RgEngine, host_meta: *const u32, host_ring: *const u64) -> i32;

@@ -682,6 +682,13 @@ const rg_send_item *rg_send_items_ptr(rg_engine *h);
  * few touched groups (the sparse path) produce the compact list directly and leave these columns alone. */
 int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, const uint64_t **dev_last_index,
                     const uint32_t **dev_n_kind);
+/* Bit 31 of an n / kind word (RG_SEND_LAST_IS_TAIL; the kind is bits 16-30): the item's last_index was NOT written to its cell
+ * of dev_last_index, because the stage had just stored the same value elsewhere -- it is the peer's NEWEST INFLIGHT (every
+ * MsgAppend that carries entries to a Replicate peer ends in Progress::update_state(last) -> ins.add(last), progress.rs:231-243:
+ * the steady case, 8 B less per item). A consumer of the columns reads it from the window's tail column, same layout
+ * (u64 [P][stride]): rg_send_tail_column. The compact list (rg_send_items) always carries last_index itself. */
+#define RG_SEND_LAST_IS_TAIL 0x80000000u
+int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inflight);
 /* Inflights in/out (parity, checkpoints): meta u32 [P][stride] = start | count << 16; ring u64 [G][P][cap]. */
 uint64_t rg_inflights_bytes(const rg_engine *h, int ring);
 int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring); /* either may be NULL */

@@ -93,14 +93,19 @@ RG_HD u64 rg_limit_size(const u32 *row, u32 mask, u64 next, u64 avail, u64 max) 
 // consumer (a message builder) reads them in place; the compact rg_send_item list is materialised on request.
 struct RgSendCols {
     u64 *prev, *last; // [P][stride] Message.index of the first message / index of the last entry sent (valid where n != 0)
-    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-31); 0 = nothing to send to this peer
+    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-30); 0 = nothing to send to this peer;
+                      // bit 31 (RG_SEND_LAST_IS_TAIL): the `last` cell was NOT written -- the index of the last entry sent is the
+                      // peer's newest inflight, the window's tail column (RgIns::tail), which the stage has just stored anyway
 };
+#define RG_SEND_NK_LAST_IS_TAIL 0x80000000u
 
 template <int P> struct RgSendRegs {
     u64 prev[P], last[P];
     u32 n[P];   // messages per slot, 0 = nothing to send
     u32 snap;   // bit s: slot s needs a snapshot instead (RG_SEND_SNAPSHOT)
     u32 hostm;  // bit s: slot s is the host's to serve (RG_SEND_HOST: entry sizes outside the device's window)
+    u32 tailm;  // bit s: the item's last_index IS the window's new newest inflight (a Replicate peer that was sent entries:
+                // Progress::update_state -> ins.add(last)) -- the item COLUMNS then leave the `last` cell alone (RG_SEND_LAST_IS_TAIL)
     u32 count;  // items of this group
 };
 template <int P> RG_HD void rg_send_regs_clear(RgSendRegs<P> &it) {
@@ -112,6 +117,7 @@ template <int P> RG_HD void rg_send_regs_clear(RgSendRegs<P> &it) {
     }
     it.snap = 0;
     it.hostm = 0;
+    it.tailm = 0;
     it.count = 0;
 }
 // The work item of slot s as the `n_msgs | kind << 16` word of the item columns (0 = nothing for this peer)
@@ -326,6 +332,7 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                          RgSendRegs<P> &it, RgGroup<P> *r, u32 nxv) {
     it.snap = 0;
     it.hostm = 0;
+    it.tailm = 0;
     it.count = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
@@ -403,6 +410,7 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                 }
                 n = snd ? 1u : 0u;
                 const bool addw = took && repl; // Progress::update_state(last) (progress.rs:231-243): optimistic_update + ins.add(last)
+                it.tailm |= addw ? 1u << s : 0u;
                 if (addw && count >= 2) {       // Inflights::add: the previous newest becomes a middle entry
                     u32 pos = start + count - 1;
                     if (pos >= ins.cap) pos -= ins.cap;
@@ -451,6 +459,7 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                                     if (state == RG_STATE_REPLICATE) {
                                         next += take; // optimistic_update
                                         rg_ins_add(ins, base, start, count, head, tail, next - 1);
+                                        it.tailm |= 1u << s; // (it.last[s] == tail from here on: every later message adds its own last)
                                     } else {
                                         pb |= RG_PF_PAUSED;
                                     }
@@ -470,6 +479,7 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                     }
                 }
             }
+            if (snap || host) it.tailm &= ~(1u << s); // (the item carries the snapshot index / the leader's last_index instead)
             if (snap) {
                 it.snap |= 1u << s;
                 it.prev[s] = next - 1;

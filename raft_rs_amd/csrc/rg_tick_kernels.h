@@ -471,23 +471,31 @@ RG_HD void rg_group_tick_send(RgGroup<P> &r, const RgState &st, const RgMsgs &ms
 }
 
 // The work items of a dense stage into their peer-major columns (k_send_dense, k_tick_send).
+// Round 5: an item whose last_index IS the window's new newest inflight (every MsgAppend with entries to a Replicate peer: the
+// steady case) does not store it a second time -- bit 31 of the n / kind word says so and the consumer reads the window's tail
+// column, which the stage has just written (8 B less per item; the compact list rg_send_items materialises is unchanged).
+#ifndef RG_SEND_DROP_LAST /* 0 = every item stores its `last` cell (rounds 1-4; A/B builds) */
+#define RG_SEND_DROP_LAST 1
+#endif
 template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P> &it, const RgSendCols &oc, u64 stride, IX g) {
 #pragma unroll
     for (int s = 0; s < P; s++) {
         const IX o = (IX)s * (IX)stride + g;
-        const u32 nk = rg_send_nk<P>(it, s);
+        const u32 nk0 = rg_send_nk<P>(it, s);
+        const bool in_tail = RG_SEND_DROP_LAST && nk0 != 0 && ((it.tailm >> s) & 1u);
+        const u32 nk = nk0 | (in_tail ? RG_SEND_NK_LAST_IS_TAIL : 0u);
         rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.n, o), nk); // every cell, every stage: 0 = nothing for this peer
         // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
-        // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched
+        // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched; and the `last`
+        // column of a slot is written (by every lane) only if some lane's item needs it there
 #if defined(__HIP_DEVICE_COMPILE__)
         const bool any = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0) != 0 : nk != 0;
+        const bool any_last = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0 && !in_tail) != 0 : (nk != 0 && !in_tail);
 #else
-        const bool any = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
+        const bool any = true, any_last = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
 #endif
-        if (any) {
-            rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0);
-            rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.last, o), nk ? it.last[s] : (u64)0);
-        }
+        if (any) rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0);
+        if (any && any_last) rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.last, o), nk ? it.last[s] : (u64)0);
     }
 }
 

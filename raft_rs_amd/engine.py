@@ -273,6 +273,7 @@ SYMBOLS = {
     "rg_send_items": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "rg_send_items_ptr": (_vp, [_vp]),
     "rg_send_columns": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "rg_send_tail_column": (_i, [_vp, C.POINTER(_vp)]),
     "rg_inflights_bytes": (_u64, [_vp, _i]),
     "rg_read_inflights": (_i, [_vp, _vp, _vp]),
     "rg_load_inflights": (_i, [_vp, _vp, _vp]),
@@ -662,6 +663,13 @@ class Engine:
         self._check(self.L.rg_send_columns(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def send_tail_column(self):
+        """Device pointer of the windows' newest-inflight column (u64 [P][stride]): where an item whose n / kind word has bit 31
+        (SEND_LAST_IS_TAIL) keeps its last_index."""
+        a = _vp()
+        self._check(self.L.rg_send_tail_column(self.h, C.byref(a)))
+        return a.value
+
     def read_inflights(self):
         """(meta u32 [P][stride] = start | count << 16, ring u64 [G][P][cap])."""
         meta = np.empty((self.n_slots, self.stride), dtype=np.uint32)
@@ -889,6 +897,7 @@ class CommAllConfig(C.Structure):
 
 
 COMM_ALL_AUTO, COMM_ALL_RCCL, COMM_ALL_LOCAL = 0, 1, 2
+SEND_LAST_IS_TAIL = 0x80000000
 
 
 def comm_init_all(engines, ring_ticks=0, overflow_slots=0, transport=COMM_ALL_AUTO):

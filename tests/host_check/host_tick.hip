@@ -205,6 +205,9 @@ static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, u32 
                 r.kind = (uint16_t)(nk >> 16);
                 items[k] = r;
             }
+            // the premise of RG_SEND_NK_LAST_IS_TAIL (the item columns leave `last` unwritten): where the stage says so, the
+            // window's tail column -- just stored -- holds the item's last_index
+            if (((it.tailm >> s) & 1u) && ins.tail[(u64)s * st.stride + g] != it.last[s]) return -2;
             k++;
         }
     }
@@ -263,6 +266,7 @@ static long host_tick_send(const RgState &st, const RgMsgs &ms_in, const RgIns &
                 r.kind = (uint16_t)(nk >> 16);
                 items[k] = r;
             }
+            if (((it.tailm >> s) & 1u) && ins.tail[(u64)s * st.stride + g] != it.last[s]) return -2; // (as in host_send)
             k++;
         }
     }
