@@ -645,10 +645,11 @@ __global__ __launch_bounds__(256) void k_send_compact(RgSendCols oc, const u64 *
         rg_send_item r;
         r.group = g;
         r.prev_index = oc.prev[o];
-        r.last_index = (nk & RG_SEND_NK_LAST_IS_TAIL) ? tail[o] : oc.last[o]; // (the window's newest inflight: rg_store_send_items)
+        // (the window's newest inflight / the item's own prev_index: rg_store_send_items)
+        r.last_index = (nk & RG_SEND_NK_LAST_IS_TAIL) ? tail[o] : (nk & RG_SEND_NK_LAST_IS_PREV) ? r.prev_index : oc.last[o];
         r.slot = s;
         r.n_msgs = (uint16_t)(nk & 0xffffu);
-        r.kind = (uint16_t)((nk >> 16) & 0x7fffu);
+        r.kind = (uint16_t)((nk >> 16) & 0x3fffu);
         items[k++] = r;
     }
 }
@@ -2592,7 +2593,7 @@ extern "C" int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inf
     *dev_newest_inflight = h->ins.tail;
     return RG_OK;
 }
-static_assert(RG_SEND_LAST_IS_TAIL == RG_SEND_NK_LAST_IS_TAIL, "the header's bit is the kernels'");
+static_assert(RG_SEND_LAST_IS_TAIL == RG_SEND_NK_LAST_IS_TAIL && RG_SEND_LAST_IS_PREV == RG_SEND_NK_LAST_IS_PREV, "the header's bits are the kernels'");
 
 extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
     if (!h || !h->ins_arena) return 0;

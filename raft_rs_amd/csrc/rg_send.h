@@ -93,11 +93,13 @@ RG_HD u64 rg_limit_size(const u32 *row, u32 mask, u64 next, u64 avail, u64 max) 
 // consumer (a message builder) reads them in place; the compact rg_send_item list is materialised on request.
 struct RgSendCols {
     u64 *prev, *last; // [P][stride] Message.index of the first message / index of the last entry sent (valid where n != 0)
-    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-30); 0 = nothing to send to this peer;
+    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-29); 0 = nothing to send to this peer;
                       // bit 31 (RG_SEND_LAST_IS_TAIL): the `last` cell was NOT written -- the index of the last entry sent is the
-                      // peer's newest inflight, the window's tail column (RgIns::tail), which the stage has just stored anyway
+                      // peer's newest inflight, the window's tail column (RgIns::tail), which the stage has just stored anyway;
+                      // bit 30 (RG_SEND_LAST_IS_PREV): not written either -- an empty MsgAppend: last_index == prev_index
 };
 #define RG_SEND_NK_LAST_IS_TAIL 0x80000000u
+#define RG_SEND_NK_LAST_IS_PREV 0x40000000u
 
 template <int P> struct RgSendRegs {
     u64 prev[P], last[P];

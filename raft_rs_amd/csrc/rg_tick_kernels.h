@@ -483,14 +483,18 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
         const IX o = (IX)s * (IX)stride + g;
         const u32 nk0 = rg_send_nk<P>(it, s);
         const bool in_tail = RG_SEND_DROP_LAST && nk0 != 0 && ((it.tailm >> s) & 1u);
-        const u32 nk = nk0 | (in_tail ? RG_SEND_NK_LAST_IS_TAIL : 0u);
+        // (an empty MsgAppend -- send_append to a peer that has everything, raft.rs:773-819 with no entries left -- carries
+        // last_index == prev_index: the second most common item of a steady stream, and as long as ONE lane of a wave needs its
+        // `last` cell the whole line is written)
+        const bool is_prev = RG_SEND_DROP_LAST && nk0 != 0 && !in_tail && (nk0 >> 16) == RG_SEND_APPEND && it.last[s] == it.prev[s];
+        const u32 nk = nk0 | (in_tail ? RG_SEND_NK_LAST_IS_TAIL : 0u) | (is_prev ? RG_SEND_NK_LAST_IS_PREV : 0u);
         rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.n, o), nk); // every cell, every stage: 0 = nothing for this peer
         // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
         // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched; and the `last`
         // column of a slot is written (by every lane) only if some lane's item needs it there
 #if defined(__HIP_DEVICE_COMPILE__)
         const bool any = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0) != 0 : nk != 0;
-        const bool any_last = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0 && !in_tail) != 0 : (nk != 0 && !in_tail);
+        const bool any_last = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0 && !in_tail && !is_prev) != 0 : (nk != 0 && !in_tail && !is_prev);
 #else
         const bool any = true, any_last = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
 #endif

@@ -613,10 +613,13 @@ def test_dense_stage_work_item_columns_equal_the_compact_list(rg):
         assert len(items) == int((nk[:, :G] != 0).sum()) and len(items) > 3 * G
         g, s = items["group"].astype(np.int64), items["slot"].astype(np.int64)
         # an item whose last_index is the window's new newest inflight does not store it twice (bit 31 of the n / kind word)
-        in_tail = (nk[s, g] >> 31).astype(bool)
-        assert in_tail.sum() > 0.9 * len(items), (int(in_tail.sum()), len(items))  # the steady stream: entries to Replicate peers
-        assert (prev[s, g] == items["prev_index"]).all() and (np.where(in_tail, tail[s, g], last[s, g]) == items["last_index"]).all()
-        assert ((nk[s, g] & 0xffff) == items["n_msgs"]).all() and (((nk[s, g] >> 16) & 0x7fff) == items["kind"]).all()
+        # (bit 31 of the n / kind word; an empty MsgAppend's last_index is its prev_index: bit 30)
+        in_tail, is_prev = (nk[s, g] >> 31).astype(bool), ((nk[s, g] >> 30) & 1).astype(bool)
+        assert not (in_tail & is_prev).any()
+        assert in_tail.sum() > 0.8 * len(items) and (in_tail | is_prev).sum() > 0.97 * len(items), (int(in_tail.sum()), int(is_prev.sum()), len(items))
+        want_last = np.where(in_tail, tail[s, g], np.where(is_prev, prev[s, g], last[s, g]))
+        assert (prev[s, g] == items["prev_index"]).all() and (want_last == items["last_index"]).all()
+        assert ((nk[s, g] & 0xffff) == items["n_msgs"]).all() and (((nk[s, g] >> 16) & 0x3fff) == items["kind"]).all()
         assert len(set(zip(g.tolist(), s.tolist()))) == len(items)
     from raft_rs_amd.engine import EngineError, ERR
     rec = np.zeros(1, dtype=rg.engine.WIRE_DTYPE)
