@@ -294,16 +294,15 @@ def send_stage_bytes(rg, eng, n_items, with_work=False):
     """The send stage's own algorithmic bytes for the LAST tick: per group out 4 + cfg 4 +
     last_index 8 + first_index 8 + flag row 8 r + 8 w = 40; per peer in the work set (a send request, an Inflights effect,
     or a broadcast) window meta 4 r + 4 w, oldest / newest inflight 16 r + 16 w, next 8 r + 8 w, pending snapshot request
-    8 r, matched 8 r = 72; work items as peer-major columns: 4 B per (slot, group) cell + 8 B per item whose prev_index is not
-    the peer's `matched` + 8 B per item whose last_index is neither the window's new newest inflight nor its own prev_index
-    (round 5: such values are not stored a second time -- bits 31 / 30 / 29 of the n / kind word, counted here from the column)."""
+    8 r, matched 8 r = 72; work items as peer-major columns: 4 B per (slot, group) cell + 8 B per item (prev_index) + 8 B per
+    item whose last_index is neither the window's new newest inflight nor its own prev_index (round 5: those do not store it a
+    second time -- bits 31 / 30 of the n / kind word, counted here from the column itself)."""
     import torch
     in_tail = 0
     try:
         _, _, pn = eng.send_columns()
         nk = torch.as_tensor(_DevU32(pn, eng.n_slots * eng.stride), device="cuda")
-        # (bits 31 / 30 of a u32 read as i32: last_index is the window's tail / the item's prev_index; bit 29: prev_index is `matched`)
-        in_tail = int(((nk < 0) | ((nk >> 30) & 1).bool()).sum().item()) + int(((nk >> 29) & 1).sum().item())
+        in_tail = int(((nk < 0) | ((nk >> 30) & 1).bool()).sum().item())  # (bits 31 / 30 of a u32 read as i32: last_index is the window's tail / the item's prev_index)
     except Exception:  # noqa: BLE001 -- a sparse stage has no columns: every item carries both indices
         pass
     _, out = eng.results()

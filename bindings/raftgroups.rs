@@ -64,7 +64,6 @@ pub const RG_SEND_SKIP_BCAST_COMMIT: u32 = 0x1;
 pub const RG_SEND_BYTES: u32 = 0x2;
 pub const RG_SEND_LAST_IS_TAIL: u32 = 0x80000000;
 pub const RG_SEND_LAST_IS_PREV: u32 = 0x40000000;
-pub const RG_SEND_PREV_IS_MATCH: u32 = 0x20000000;
 pub const RG_COMM_ID_BYTES: u32 = 128;
 pub const RG_COMM_ALL_AUTO: u32 = 0;
 pub const RG_COMM_ALL_RCCL: u32 = 1;

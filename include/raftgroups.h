@@ -682,19 +682,16 @@ const rg_send_item *rg_send_items_ptr(rg_engine *h);
  * few touched groups (the sparse path) produce the compact list directly and leave these columns alone. */
 int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, const uint64_t **dev_last_index,
                     const uint32_t **dev_n_kind);
-/* Bits 31 / 30 / 29 of an n / kind word (the kind is bits 16-28): the item's last_index (prev_index) was NOT written to its cell
- * of dev_last_index (dev_prev_index), because the value is at hand elsewhere:
+/* Bits 31 / 30 of an n / kind word (the kind is bits 16-29): the item's last_index was NOT written to its cell of
+ * dev_last_index, because the value is at hand elsewhere:
  *   RG_SEND_LAST_IS_TAIL  it is the peer's NEWEST INFLIGHT, which the stage has just stored (every MsgAppend that carries entries
  *                         to a Replicate peer ends in Progress::update_state(last) -> ins.add(last), progress.rs:231-243: the
  *                         steady case) -- read it from the window's tail column, same layout (u64 [P][stride]): rg_send_tail_column;
- *   RG_SEND_LAST_IS_PREV  an empty MsgAppend (send_append to a peer that already has every entry): last_index == prev_index;
- *   RG_SEND_PREV_IS_MATCH prev_index is the peer's Progress.matched -- a peer that has acknowledged everything it was sent
- *                         (next_idx == matched + 1) -- read it from RG_COL_MATCH (rg_column_ptr).
- * A wave of the stage writes a line of dev_last_index / dev_prev_index only when one of its 64 groups has an item that needs the
- * cell (8 B less per item and column otherwise). The compact list (rg_send_items) always carries both indices itself. */
+ *   RG_SEND_LAST_IS_PREV  an empty MsgAppend (send_append to a peer that already has every entry): last_index == prev_index.
+ * A wave of the stage writes a line of dev_last_index only when one of its 64 groups has an item of neither kind (8 B less per
+ * item otherwise). The compact list (rg_send_items) always carries last_index itself. */
 #define RG_SEND_LAST_IS_TAIL 0x80000000u
 #define RG_SEND_LAST_IS_PREV 0x40000000u
-#define RG_SEND_PREV_IS_MATCH 0x20000000u
 int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inflight);
 /* Inflights in/out (parity, checkpoints): meta u32 [P][stride] = start | count << 16; ring u64 [G][P][cap]. */
 uint64_t rg_inflights_bytes(const rg_engine *h, int ring);

@@ -610,7 +610,7 @@ static void rg_launch_send_dense(hipStream_t stream, dim3 grid, dim3 block, cons
 }
 
 // Compact list out of the columns, on request (rg_send_items / rg_send_items_ptr after a dense stage).
-__global__ __launch_bounds__(256) void k_send_compact(RgSendCols oc, const u64 *tail, const u64 *match, u64 G, u64 stride, u32 P, rg_send_item *items, u32 *counter) {
+__global__ __launch_bounds__(256) void k_send_compact(RgSendCols oc, const u64 *tail, u64 G, u64 stride, u32 P, rg_send_item *items, u32 *counter) {
     __shared__ u32 wave_tot[4];
     __shared__ u32 block_base;
     const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -644,12 +644,12 @@ __global__ __launch_bounds__(256) void k_send_compact(RgSendCols oc, const u64 *
         if (!nk) continue;
         rg_send_item r;
         r.group = g;
-        r.prev_index = (nk & RG_SEND_NK_PREV_IS_MATCH) ? match[o] : oc.prev[o];
+        r.prev_index = oc.prev[o];
         // (the window's newest inflight / the item's own prev_index: rg_store_send_items)
         r.last_index = (nk & RG_SEND_NK_LAST_IS_TAIL) ? tail[o] : (nk & RG_SEND_NK_LAST_IS_PREV) ? r.prev_index : oc.last[o];
         r.slot = s;
         r.n_msgs = (uint16_t)(nk & 0xffffu);
-        r.kind = (uint16_t)((nk >> 16) & 0x1fffu);
+        r.kind = (uint16_t)((nk >> 16) & 0x3fffu);
         items[k++] = r;
     }
 }
@@ -2519,7 +2519,7 @@ extern "C" int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_
 static int rg_send_materialize(rg_engine *h) {
     if (!h->send_cols_fresh) return RG_OK;
     RG_HIP(hipMemsetAsync(h->send_counter, 0, 4, h->stream));
-    hipLaunchKernelGGL(k_send_compact, dim3(rg_grid(h->G, 256)), dim3(256), 0, h->stream, h->send_cols, (const u64 *)h->ins.tail, (const u64 *)h->st.match, h->G, h->stride, h->P,
+    hipLaunchKernelGGL(k_send_compact, dim3(rg_grid(h->G, 256)), dim3(256), 0, h->stream, h->send_cols, (const u64 *)h->ins.tail, h->G, h->stride, h->P,
                        h->send_items, h->send_counter);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_send_items: compaction launch failed: %s", hipGetErrorString(e));
@@ -2593,8 +2593,7 @@ extern "C" int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inf
     *dev_newest_inflight = h->ins.tail;
     return RG_OK;
 }
-static_assert(RG_SEND_LAST_IS_TAIL == RG_SEND_NK_LAST_IS_TAIL && RG_SEND_LAST_IS_PREV == RG_SEND_NK_LAST_IS_PREV &&
-                  RG_SEND_PREV_IS_MATCH == RG_SEND_NK_PREV_IS_MATCH, "the header's bits are the kernels'");
+static_assert(RG_SEND_LAST_IS_TAIL == RG_SEND_NK_LAST_IS_TAIL && RG_SEND_LAST_IS_PREV == RG_SEND_NK_LAST_IS_PREV, "the header's bits are the kernels'");
 
 extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
     if (!h || !h->ins_arena) return 0;

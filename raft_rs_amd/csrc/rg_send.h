@@ -93,22 +93,19 @@ RG_HD u64 rg_limit_size(const u32 *row, u32 mask, u64 next, u64 avail, u64 max) 
 // consumer (a message builder) reads them in place; the compact rg_send_item list is materialised on request.
 struct RgSendCols {
     u64 *prev, *last; // [P][stride] Message.index of the first message / index of the last entry sent (valid where n != 0)
-    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-28); 0 = nothing to send to this peer;
-                      // bit 29 (RG_SEND_PREV_IS_MATCH): the `prev` cell was NOT written -- prev_index is the peer's `matched` (RG_COL_MATCH);
+    u32 *n;           // [P][stride] n_msgs (bits 0-15) | kind RG_SEND_* (bits 16-29); 0 = nothing to send to this peer;
                       // bit 31 (RG_SEND_LAST_IS_TAIL): the `last` cell was NOT written -- the index of the last entry sent is the
                       // peer's newest inflight, the window's tail column (RgIns::tail), which the stage has just stored anyway;
                       // bit 30 (RG_SEND_LAST_IS_PREV): not written either -- an empty MsgAppend: last_index == prev_index
 };
 #define RG_SEND_NK_LAST_IS_TAIL 0x80000000u
 #define RG_SEND_NK_LAST_IS_PREV 0x40000000u
-#define RG_SEND_NK_PREV_IS_MATCH 0x20000000u
 
 template <int P> struct RgSendRegs {
     u64 prev[P], last[P];
     u32 n[P];   // messages per slot, 0 = nothing to send
     u32 snap;   // bit s: slot s needs a snapshot instead (RG_SEND_SNAPSHOT)
     u32 hostm;  // bit s: slot s is the host's to serve (RG_SEND_HOST: entry sizes outside the device's window)
-    u32 prevm;  // bit s: the item's prev_index IS the peer's `matched` (RG_SEND_PREV_IS_MATCH: the `prev` cell is left alone too)
     u32 tailm;  // bit s: the item's last_index IS the window's new newest inflight (a Replicate peer that was sent entries:
                 // Progress::update_state -> ins.add(last)) -- the item COLUMNS then leave the `last` cell alone (RG_SEND_LAST_IS_TAIL)
     u32 count;  // items of this group
@@ -123,7 +120,6 @@ template <int P> RG_HD void rg_send_regs_clear(RgSendRegs<P> &it) {
     it.snap = 0;
     it.hostm = 0;
     it.tailm = 0;
-    it.prevm = 0;
     it.count = 0;
 }
 // The work item of slot s as the `n_msgs | kind << 16` word of the item columns (0 = nothing for this peer)
@@ -339,7 +335,6 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
     it.snap = 0;
     it.hostm = 0;
     it.tailm = 0;
-    it.prevm = 0;
     it.count = 0;
 #pragma unroll
     for (int s = 0; s < P; s++) it.n[s] = 0;
@@ -499,13 +494,6 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
             }
             it.n[s] = n;
             if (n || snap || host) it.count++;
-            {   // RG_SEND_PREV_IS_MATCH: the item's prev_index is the peer's `matched` (a peer that has acknowledged everything it
-                // was sent: next == matched + 1) -- known here whenever `matched` is at hand: always in the one-launch form (the
-                // tick's register), after an accepted ack otherwise (it was fetched for free_to)
-                const bool have_m = FUSED || (((fr_bits & sm_bits) >> s) & 1u);
-                const u64 m = FUSED ? r->mt[s] : q.match_v[s];
-                if (have_m && (n || snap || host) && it.prev[s] == m) it.prevm |= 1u << s;
-            }
             if (FUSED) { // the group's `next` cells are stored once, by the caller (whole lines: every cell the stage looked at)
                 r->nx[s] = next;
                 r->dirty |= 1u << (8 + s);

@@ -487,10 +487,7 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
         // last_index == prev_index: the second most common item of a steady stream, and as long as ONE lane of a wave needs its
         // `last` cell the whole line is written)
         const bool is_prev = RG_SEND_DROP_LAST && nk0 != 0 && !in_tail && (nk0 >> 16) == RG_SEND_APPEND && it.last[s] == it.prev[s];
-        // (... and prev_index itself is the peer's `matched` wherever the peer had acknowledged everything it was sent)
-        const bool is_match = RG_SEND_DROP_LAST && nk0 != 0 && ((it.prevm >> s) & 1u);
-        const u32 nk = nk0 | (in_tail ? RG_SEND_NK_LAST_IS_TAIL : 0u) | (is_prev ? RG_SEND_NK_LAST_IS_PREV : 0u) |
-                       (is_match ? RG_SEND_NK_PREV_IS_MATCH : 0u);
+        const u32 nk = nk0 | (in_tail ? RG_SEND_NK_LAST_IS_TAIL : 0u) | (is_prev ? RG_SEND_NK_LAST_IS_PREV : 0u);
         rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.n, o), nk); // every cell, every stage: 0 = nothing for this peer
         // whole lines where the wave stores at all: a slot some lane of the wave has an item for is written by every lane
         // (zeros where there is none); a slot nobody sends to -- the leaders' own, mostly -- is not touched; and the `last`
@@ -498,11 +495,10 @@ template <int P, typename IX> RG_HD void rg_store_send_items(const RgSendRegs<P>
 #if defined(__HIP_DEVICE_COMPILE__)
         const bool any = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0) != 0 : nk != 0;
         const bool any_last = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0 && !in_tail && !is_prev) != 0 : (nk != 0 && !in_tail && !is_prev);
-        const bool any_prev = RG_SEND_WHOLE_LINES ? __builtin_amdgcn_ballot_w64(nk != 0 && !is_match) != 0 : (nk != 0 && !is_match);
 #else
-        const bool any = true, any_last = true, any_prev = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
+        const bool any = true, any_last = true; // (the host twin writes every cell: zeros where the device leaves a line alone)
 #endif
-        if (any && any_prev) rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0);
+        if (any) rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.prev, o), nk ? it.prev[s] : (u64)0);
         if (any && any_last) rg_st<(RG_SEND_NT_ITEMS != 0)>(rg_at(oc.last, o), nk ? it.last[s] : (u64)0);
     }
 }

@@ -897,7 +897,7 @@ class CommAllConfig(C.Structure):
 
 
 COMM_ALL_AUTO, COMM_ALL_RCCL, COMM_ALL_LOCAL = 0, 1, 2
-SEND_LAST_IS_TAIL, SEND_LAST_IS_PREV, SEND_PREV_IS_MATCH = 0x80000000, 0x40000000, 0x20000000
+SEND_LAST_IS_TAIL, SEND_LAST_IS_PREV = 0x80000000, 0x40000000
 
 
 def comm_init_all(engines, ring_ticks=0, overflow_slots=0, transport=COMM_ALL_AUTO):

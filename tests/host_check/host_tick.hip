@@ -208,7 +208,6 @@ static long host_send(const RgState &st, const RgIns &ins, u64 max_entries, u32 
             // the premise of RG_SEND_NK_LAST_IS_TAIL (the item columns leave `last` unwritten): where the stage says so, the
             // window's tail column -- just stored -- holds the item's last_index
             if (((it.tailm >> s) & 1u) && ins.tail[(u64)s * st.stride + g] != it.last[s]) return -2;
-            if (((it.prevm >> s) & 1u) && st.match[(u64)s * st.stride + g] != it.prev[s]) return -3; // (RG_SEND_NK_PREV_IS_MATCH)
             k++;
         }
     }
@@ -268,7 +267,6 @@ static long host_tick_send(const RgState &st, const RgMsgs &ms_in, const RgIns &
                 items[k] = r;
             }
             if (((it.tailm >> s) & 1u) && ins.tail[(u64)s * st.stride + g] != it.last[s]) return -2; // (as in host_send)
-            if (((it.prevm >> s) & 1u) && st.match[(u64)s * st.stride + g] != it.prev[s]) return -3;
             k++;
         }
     }
