@@ -462,6 +462,87 @@ static void test_bcast_beat() {
     }
 }
 
+// harness/tests/integration_cases/test_raft.rs:5573-5839 test_fast_log_rejection, leader side, three of its rows: the follower's
+// rejection carries (reject_hint, log_term) and the leader turns it into the next probe through find_conflict_by_term
+// (raft_log.rs:209-235, raft.rs:1657-1660). This host loads no term-run table, so the device cannot answer the walk below the
+// leader's own term: the tick hands the reject back (RG_OUT_HOST_HINT) and ready(Storage &) answers from the host's log -- with
+// the Inflights on the device too, where the group's sends wait for that answer. ready() without a Storage must refuse such a
+// batch loudly instead of reporting it half-applied.
+static void test_fast_log_rejection() {
+    struct Row {
+        std::vector<std::pair<u64, u64>> leader_log; // (term, index)
+        u64 reject_hint_term, reject_hint_index, next_append_term, next_append_index;
+    };
+    const Row rows[] = {
+        {{{1, 1}, {2, 2}, {2, 3}, {4, 4}, {4, 5}, {4, 6}, {4, 7}}, 3, 7, 2, 3},
+        {{{1, 1}, {2, 2}, {2, 3}, {3, 4}, {4, 5}, {4, 6}, {4, 7}, {5, 8}}, 3, 8, 3, 4},
+        {{{1, 1}, {1, 2}, {1, 3}, {4, 4}, {5, 5}}, 4, 4, 4, 4},
+    };
+    for (unsigned inflights : {0u, 4u}) {
+        int i = 0;
+        for (const Row &row : rows) {
+            Config c;
+            c.n_groups = 1;
+            c.max_peers = 3;
+            c.max_inflight_msgs = inflights;
+            MultiRaft ld(c);
+            LogFixture st;
+            for (const auto &e : row.leader_log) st.append(0, e.first);
+            const u64 last = row.leader_log.size();
+            st.append(0, 1); // become_candidate from term 0 -> term 1; become_leader's noop at last + 1 (raft.rs:1163-1194)
+            GroupSpec s;
+            s.id = 1;
+            s.term = 1;
+            s.voters = {1, 2, 3};
+            s.first_index_of_term = last + 1;
+            s.last_index = last + 1;
+            s.committed = 0;
+            s.next_idx = last + 1;
+            s.follower_state = ProgressState::Probe;
+            ld.init_group(0, s);
+            ld.bootstrap();
+            Progress p = ld.progress(0, 2);
+            p.paused = true; // the probe MsgAppend(index = next - 1 = last) went out
+            ld.set_progress(0, 2, p);
+            Message m;
+            m.msg_type = MessageType::MsgAppendResponse;
+            m.from = 2, m.to = 1, m.term = 1, m.index = last;
+            m.reject = true, m.reject_hint = row.reject_hint_index, m.log_term = row.reject_hint_term;
+            ld.step(0, m);
+            bool refused = false;
+            if (i == 0 && inflights == 0) { // (once: the batch is consumed by the flush, so this engine is done afterwards)
+                try {
+                    ld.ready();
+                } catch (const Error &e) {
+                    refused = e.kind == ErrorKind::State;
+                }
+                EXPECT(refused, "ready() without a Storage reports a batch that needs the host's log");
+                i++;
+                continue;
+            }
+            const std::vector<LightReady> rd = ld.ready(st);
+            EXPECT(rd.size() == 1, "one group saw traffic");
+            bool sa = false;
+            for (u64 id : rd[0].send_append) sa = sa || id == 2;
+            EXPECT(sa || inflights, "send_append(2) after the rejection (row %d)", i);
+            const u64 next = ld.progress(0, 2).next_idx;
+            EXPECT(next - 1 == row.next_append_index || (inflights && next - 1 >= row.next_append_index),
+                   "row %d (inflights %u): next append index %llu, want %llu", i, inflights, (unsigned long long)(next - 1),
+                   (unsigned long long)row.next_append_index);
+            if (!inflights) {
+                EXPECT(st.term(0, next - 1) == row.next_append_term, "row %d: next append term", i);
+            } else {
+                // the device made the send decision as well: the probe that follows the rejection starts at next_append_index
+                bool found = false;
+                for (const SendItem &it : rd[0].messages)
+                    if (it.to == 2) found = it.prev_index == row.next_append_index;
+                EXPECT(found, "row %d: a MsgAppend to 2 with index = %llu", i, (unsigned long long)row.next_append_index);
+            }
+            i++;
+        }
+    }
+}
+
 int main() {
     try {
         Config probe;
@@ -482,6 +563,7 @@ int main() {
     test_recv_msg_unreachable();
     test_snapshot_failure_and_succeed();
     test_bcast_beat();
+    test_fast_log_rejection();
     std::printf("CPP_REFERENCE_TESTS_OK\n");
     return 0;
 }

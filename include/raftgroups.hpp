@@ -206,6 +206,33 @@ class Storage {
     virtual Snapshot snapshot(u64 group, u64 request_index) = 0;
 };
 
+// RaftLog::term (src/raft_log.rs:122-140) over a Storage: 0 outside [first_index - 1, last_index]; *ok = false where the
+// storage cannot say (the reference's Err: compacted / unavailable)
+inline u64 log_term(Storage &st, u64 group, u64 idx, bool *ok) {
+    *ok = true;
+    const u64 dummy = st.first_index(group) - 1;
+    if (idx < dummy || idx > st.last_index(group)) return 0;
+    try {
+        return st.term(group, idx);
+    } catch (const StorageError &) {
+        *ok = false;
+        return 0;
+    }
+}
+// RaftLog::find_conflict_by_term (src/raft_log.rs:209-235): the largest index <= `index` whose term is <= `term` -- the hint a
+// leader derives from a rejection that carries the follower's log_term (src/raft.rs:1657-1660). The device answers it from its
+// bounded term-run table; MultiRaft::ready(Storage &) answers with this walk where that table no longer reaches (RG_OUT_HOST_HINT).
+inline u64 find_conflict_by_term(Storage &st, u64 group, u64 index, u64 term) {
+    u64 conflict_index = index;
+    if (index > st.last_index(group)) return index; // "index is out of range": returned as is (:214-223)
+    for (;;) {
+        bool ok;
+        const u64 t = log_term(st, group, conflict_index, &ok);
+        if (!ok || t <= term) return conflict_index;
+        conflict_index -= 1;
+    }
+}
+
 enum class SnapshotStatus { Finish, Failure }; // src/raw_node.rs:47-54
 
 // ---- tracker::ProgressState / Progress ----
@@ -463,6 +490,8 @@ class MultiRaft {
             r.request_snapshot = m.request_snapshot;
             r.ins_full = ins_full ? 1 : 0;
             check(rg_step(h_, group, &r));
+            // (a rejection that carries log_term may come back as RG_OUT_HOST_HINT: ready(Storage &) needs it again)
+            if (m.reject && m.log_term) rejects_.push_back(PendingReject{group, m.from, m.index, m.reject_hint, m.log_term});
             return;
         }
         case MessageType::MsgHeartbeatResponse:
@@ -552,7 +581,17 @@ class MultiRaft {
     }
 
     // ---- RawNode::ready for every group with queued traffic: ONE launch for all of them ----
-    std::vector<LightReady> ready() {
+    // ready(): throws Error{State} if a rejection of the batch needs the host's log (RG_OUT_HOST_HINT: the group's log has seen more
+    // term changes since its last snapshot than the device's table holds) -- use ready(Storage &), which answers from the Storage
+    // (find_conflict_by_term) through rg_resolve_host_hints before it reports the batch.
+    std::vector<LightReady> ready() { return ready_impl(nullptr); }
+    std::vector<LightReady> ready(Storage &st) { return ready_impl(&st); }
+
+  private:
+    struct PendingReject {
+        u64 group, from, index, reject_hint, log_term;
+    };
+    std::vector<LightReady> ready_impl(Storage *st) {
         need_boot();
         const bool dev_ins = cfg_.max_inflight_msgs != 0;
         if (dev_ins)
@@ -565,6 +604,44 @@ class MultiRaft {
         std::vector<u64> groups(n), commit(n);
         std::vector<std::uint32_t> out(n);
         if (n) check(rg_ingested_results(h_, groups.data(), commit.data(), out.data(), n, &n));
+        // RG_OUT_HOST_HINT: maybe_decr_to of these rejections waits for find_conflict_by_term on the HOST's log
+        // (src/raft.rs:1657-1660, src/raft_log.rs:209-235); with the Inflights on the device so do the groups' sends
+        bool hinted = false;
+        for (u64 i = 0; i < n; i++) hinted = hinted || (out[i] & RG_OUT_HOST_HINT);
+        if (hinted) {
+            if (!st)
+                throw Error(ErrorKind::State, RG_ERR_STATE,
+                            "a rejection of this batch needs the host's log (RG_OUT_HOST_HINT): call ready(Storage &)");
+            u64 nh = 0;
+            check(rg_host_hints(h_, nullptr, 0, &nh));
+            std::vector<rg_host_hint> hh(nh);
+            if (nh) check(rg_host_hints(h_, hh.data(), nh, &nh));
+            std::vector<rg_resolved_hint> res;
+            for (const rg_host_hint &x : hh)
+                for (unsigned s = 0; s < cfg_.max_peers; s++) {
+                    if (!((x.slot_mask >> s) & 1u)) continue;
+                    const u64 from = ids_[x.group * 8 + s];
+                    const PendingReject *pr = nullptr;
+                    for (const PendingReject &c : rejects_)
+                        if (c.group == x.group && c.from == from) pr = &c;
+                    if (!pr) throw Error(ErrorKind::State, RG_ERR_STATE, "RG_OUT_HOST_HINT for a rejection this host did not step");
+                    rg_resolved_hint r;
+                    std::memset(&r, 0, sizeof r);
+                    r.group = x.group, r.slot = s, r.index = pr->index;
+                    r.hint = find_conflict_by_term(*st, x.group, pr->reject_hint, pr->log_term);
+                    res.push_back(r);
+                }
+            if (!res.empty()) check(rg_resolve_host_hints(h_, res.data(), res.size(), nullptr));
+            // the completed result words of those groups (the compact results above are not rewritten)
+            std::vector<u64> hg;
+            for (const rg_host_hint &x : hh) hg.push_back(x.group);
+            std::vector<rg_group_status> gs(hg.size());
+            if (!hg.empty()) check(rg_read_groups(h_, hg.data(), hg.size(), gs.data()));
+            for (u64 i = 0; i < n; i++)
+                for (std::size_t k = 0; k < hg.size(); k++)
+                    if (groups[i] == hg[k]) out[i] = gs[k].out;
+        }
+        rejects_.clear();
         std::vector<LightReady> rd(n);
         for (u64 i = 0; i < n; i++) {
             LightReady &r = rd[i];
@@ -604,6 +681,7 @@ class MultiRaft {
         return rd;
     }
 
+  public:
     // ---- Ready.messages for one group of ready(): the send decisions as the reference's Messages, built out of the host's
     // Storage (build_messages); a snapshot that was actually fetched is followed by Progress::become_snapshot on the
     // device (progress.rs:117-121), as prepare_send_snapshot does (raft.rs:699-711) ----
@@ -723,6 +801,7 @@ class MultiRaft {
     rg_engine *h_ = nullptr;
     u64 stride_ = 0;
     bool booted_ = false;
+    std::vector<PendingReject> rejects_; // rejections with log_term stepped since the last ready()
     std::vector<u64> match_, next_, prc_, commit_, lo_, hi_, term_, ids_, cum_;
     std::vector<std::uint8_t> pflags_;
     std::vector<std::uint32_t> cfgw_;
