@@ -489,10 +489,13 @@ static void test_fast_log_rejection() {
             LogFixture st;
             for (const auto &e : row.leader_log) st.append(0, e.first);
             const u64 last = row.leader_log.size();
-            st.append(0, 1); // become_candidate from term 0 -> term 1; become_leader's noop at last + 1 (raft.rs:1163-1194)
+            // become_leader's noop at last + 1 (raft.rs:1163-1194). (The reference's fixture campaigns from term 0, i.e. leads at
+            // term 1 over entries of terms up to 5; a log's terms never decrease, so this host leads at term 6 -- the walk and its
+            // answer do not depend on the leader's term.)
+            st.append(0, 6);
             GroupSpec s;
             s.id = 1;
-            s.term = 1;
+            s.term = 6;
             s.voters = {1, 2, 3};
             s.first_index_of_term = last + 1;
             s.last_index = last + 1;
@@ -506,7 +509,7 @@ static void test_fast_log_rejection() {
             ld.set_progress(0, 2, p);
             Message m;
             m.msg_type = MessageType::MsgAppendResponse;
-            m.from = 2, m.to = 1, m.term = 1, m.index = last;
+            m.from = 2, m.to = 1, m.term = 6, m.index = last;
             m.reject = true, m.reject_hint = row.reject_hint_index, m.log_term = row.reject_hint_term;
             ld.step(0, m);
             bool refused = false;
