@@ -8,7 +8,10 @@ MESSAGES MultiRaft::messages builds out of a Storage, and examples/cpp_message_b
 limit_size, build_messages, Message::write_to_bytes against test_storage_entries, test_slice and a restated send loop), which
 needs no device and runs in the CPU suite. Also restated for the GPU run: test_recv_msg_unreachable (test_raft.rs:2913-2933),
 test_snapshot_failure / test_snapshot_succeed (test_raft_snap.rs:68-109) through MultiRaft::report_unreachable / report_snapshot,
-test_bcast_beat (test_raft.rs:2680-2752) through MultiRaft::bcast_heartbeat."""
+test_bcast_beat (test_raft.rs:2680-2752) through MultiRaft::bcast_heartbeat. Round 5: three rows of test_fast_log_rejection
+(test_raft.rs:5573-5839) through MultiRaft::ready(Storage &) -- the rejection's find_conflict_by_term answered from the HOST's log
+where the device hands it back (RG_OUT_HOST_HINT), with the Inflights on the host and on the device; ready() without a Storage
+refuses such a batch."""
 import os
 import subprocess
 
