@@ -320,7 +320,7 @@ SIDE_REPEATS = 3  # timed regions per side measurement (median reported, min / m
 
 
 def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
-               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS):
+               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS, cfg_flags=0):
     """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
     headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
     synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
@@ -349,7 +349,7 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt = Part()
         pt.n, pt.slots, pt.first = n, slots, first
         pt.fixed = slots if (workload == 5 and not one_engine) else 0
-        pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights)
+        pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights, flags=cfg_flags)
         pt.eng.set_stream(main_stream.cuda_stream)
         pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=sorted_classes)
         first += n
@@ -659,6 +659,8 @@ def main():
     ap.add_argument("--fuse", type=int, default=1,
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
+    ap.add_argument("--cfg-flags", type=lambda s: int(s, 0), default=0,
+                    help="rg_config.flags of the measured engines (RG_CFGF_*: 0x8 = class-placed ticks as one kernel with inline elections)")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
     ap.add_argument("--sorted", action="store_true",
                     help="config 5: ONE engine with the groups placed by replica-set size class (one launch per tick, k_tick_classes)")
@@ -761,7 +763,7 @@ def main():
         pt = Part()
         pt.n, pt.slots, pt.first = n, slots, first
         pt.fixed = slots if (args.workload == 5 and not args.one_engine) else 0
-        pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant, max_inflight=args.inflights)
+        pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant, max_inflight=args.inflights, flags=args.cfg_flags)
         pt.eng.set_stream(stream.cuda_stream)
         pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=args.sorted)
         pt.eng.checkpoint()
