@@ -483,7 +483,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
             extra["elections_per_group"] = round(census["elections"] / denom, 5)
         if inflights and fused_send:
             pt = parts[0]
-            step_us = sorted(a.elapsed_time(b) for a, b, _ in per_launch)[len(per_launch) // 2] * 1e3
+            step_all = sorted(a.elapsed_time(b) * 1e3 for a, b, _ in per_launch)
+            step_us = step_all[len(step_all) // 2]
             items = len(pt.eng.send_items())
             sb, n_work = send_stage_bytes(rg, pt.eng, items, with_work=True)
             # what one launch for both removes from the two models' sum: the stage no longer reads the result word, cfg,
@@ -497,13 +498,15 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                 "roofline": {"bound": "hbm", "regime": regime_of(hot), "achieved": fg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fg / HBM_PEAK_GBS, "kernel": "k_tick_send", "algorithmic_bytes_per_launch": fb,
                              "bytes_per_group": fb / n_groups, "avg_launch_us": step_us, "traffic": None,
+                             "avg_launch_us_min": step_all[0], "avg_launch_us_max": step_all[-1],  # (single launches: the windows fill as the replay goes on)
                              "note": "tick + send stage in ONE launch: the tick's SURVEY 8(d) bytes plus the stage's own byte model "
                                      "(DESIGN.md section 3) minus what the shared registers save (32 B per group, 24 B per peer in "
                                      "the work set), counted on the last tick"}}
         elif inflights:
             pt = parts[0]
             tick_us = sorted(a.elapsed_time(b) for a, b, _ in per_launch)[len(per_launch) // 2] * 1e3
-            stage_us = sorted(b.elapsed_time(c) for _, b, c in per_launch)[len(per_launch) // 2] * 1e3
+            stage_all = sorted(b.elapsed_time(c) * 1e3 for _, b, c in per_launch)
+            stage_us = stage_all[len(stage_all) // 2]
             items = len(pt.eng.send_items())
             sb = send_stage_bytes(rg, pt.eng, items)
             sg = sb / (stage_us * 1e-6) / 1e9
@@ -513,6 +516,7 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                 "roofline": {"bound": "hbm", "regime": regime_of(hot), "achieved": sg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": sg / HBM_PEAK_GBS, "kernel": "k_send_dense", "algorithmic_bytes_per_launch": sb,
                              "bytes_per_group": sb / n_groups, "avg_launch_us": stage_us, "traffic": None,
+                             "avg_launch_us_min": stage_all[0], "avg_launch_us_max": stage_all[-1],  # (single launches: the windows fill as the replay goes on)
                              "note": "the stage's OWN byte model (DESIGN.md section 3), counted on the last tick; SURVEY 8(d) "
                                      "counts no bytes for the send path"}}
     for pt in parts:
@@ -575,6 +579,11 @@ def by_config_summary(result):
         if "frac" in e:
             e["step_us"] = round(obj["us_per_step"], 2)
             e["frac_by_tick_bytes"] = round(obj["roofline"]["frac"], 4)
+            # PMC bytes of one STEP (tick + stage; in the one-launch form that is the k_tick_send launch itself)
+            st = obj["roofline"].get("traffic")
+            e["step_traffic"] = None if st is None else int(st)
+            if name == "send_one_launch":
+                e["traffic"], e["traffic_stale"] = e["step_traffic"], obj["roofline"].get("traffic_stale")
         out[name] = e
     return out
 
@@ -595,6 +604,8 @@ def flat_config_keys(by_config):
         for k in ("step_us", "frac_by_tick_bytes"):
             if k in e:
                 flat[f"{k}_{name}"] = e[k]
+        if e.get("step_traffic") is not None:
+            flat[f"step_traffic_mb_{name}"] = round(e["step_traffic"] / 1e6, 2)
     return flat
 
 
