@@ -702,6 +702,21 @@ def main():
         # launcher (WORLD_SIZE set) nothing of this runs.
         raise SystemExit(self_launch(args.gpus))
 
+    # fd 1 belongs to the JSON line alone: gloo ("[Gloo] Rank 3 is connected to 7 peer ranks...") and RCCL (its version banner)
+    # write progress lines to stdout from every rank. From here on whatever anybody prints goes to stderr; emit() writes the line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch
     import torch.distributed as dist
     import raft_rs_amd as rg
@@ -742,10 +757,9 @@ def main():
     T = W + K
     if args.side:
         torch.cuda.set_stream(torch.cuda.Stream())
-        print(json.dumps(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
-                                    one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
-                                    sorted_classes=args.sorted, repeats=max(1, args.repeats))),
-              flush=True)
+        emit(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
+                        one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
+                        sorted_classes=args.sorted, repeats=max(1, args.repeats), cfg_flags=args.cfg_flags))
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
     # other streams of the process, which serialises the publication's side stream with the ticks
@@ -1181,14 +1195,8 @@ def main():
         result["cpu_baseline"] = None
     if distributed:
         dist.destroy_process_group()
-    # RCCL prints its version banner through C stdio; drain it so the JSON is the LAST line of stdout
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:  # noqa: BLE001
-        pass
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)  # (the ONLY thing this process writes to its stdout)
 
 
 if __name__ == "__main__":

@@ -382,6 +382,8 @@ def test_bench_line_of_eight_ranks_sharing_the_gpu(rg):
            "--steps", "6", "--warmup", "2", "--publish-every", "1"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    # ONE line on stdout: what gloo and RCCL print while eight ranks connect goes to stderr (bench.py keeps fd 1 for the JSON)
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 8 and line["steps"] == 6 and line["scaling"] == "weak" and line["unit"] == "group-evals/s"
     assert line["value"] == pytest.approx(8 * 131072 * 6 / (line["ms_per_step"] * 6 / 1e3), rel=1e-6)
@@ -406,6 +408,7 @@ def test_bench_starts_its_own_ranks_with_strong_scaling_and_an_automatic_cadence
            "--publish-every", "auto", "--no-publish-compare"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["groups_per_gpu"] == 131072
     assert line["value"] == pytest.approx(262144 * 6 / (line["ms_per_step"] * 6 / 1e3), rel=1e-6)
