@@ -112,3 +112,45 @@ def test_algorithmic_bytes_is_the_survey_formula():
     # summed over a tick: G groups with S slots, A messages, R rejects in total
     assert bench.algorithmic_bytes(1000, 5000, 4800, 10) == 9 * 5000 + 58 * 4800 + 8 * 10 + 37 * 1000
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_committed_bench_line_keeps_the_contract_a_reader_needs():
+    """The line `python bench.py` printed on the final kernels (profiles/r05_bench_n1.json): the contract's keys; every
+    configuration as SCALAR keys of `roofline` from which its fraction can be recomputed (frac = MB / us / 8 TB/s); no string in
+    `roofline` longer than 120 characters; the PMC traffic taken on the build that ran; and bench.py's own flattening of the
+    line's sub-objects gives the keys the line carries."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = json.load(open(os.path.join(root, "profiles", "r05_bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "u64" and d["data"] == "synthetic"
+    assert d["repeats"] >= 5 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    G = d["config"]["groups_per_gpu"]
+    assert abs(d["value"] - G / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic_stale"] is False and r["csrc_sha16"] in r["traffic_source"]
+    for k, v in r.items():
+        assert not isinstance(v, str) or len(v) <= 120, (k, len(v))
+    names = [k[5:] for k in r if k.startswith("frac_") and not k.startswith("frac_by_")]
+    assert {"c2_headline", "c2_hbm_8M", "c2_resident_2_4M", "c3_joint", "c4_shard", "c5_one_launch", "c5_one_launch_hbm_8M",
+            "c5_size_class", "c5_interleaved", "recompute", "recompute_hbm_8M", "send_two_launch", "send_one_launch"} <= set(names)
+    for n in names:
+        f, us, mb = r[f"frac_{n}"], r[f"us_{n}"], r[f"mb_{n}"]
+        assert isinstance(f, float) and 0 < f < 1, (n, f)
+        assert abs(f - mb * 1e6 / (us * 1e-6) / 8e12) < 2e-3, (n, f, mb, us)  # (the keys are rounded: 4 / 2 / 2 digits)
+        assert not r.get(f"traffic_stale_{n}"), n
+        if r.get(f"us_min_{n}") is not None:
+            assert r[f"us_min_{n}"] <= us <= r[f"us_max_{n}"], n
+    cp = d["cpu_baseline"]
+    assert cp["kind"] == "port" and cp["cores"] >= 1 and cp["value"] > 0 and cp["unit"] == d["unit"] and cp["sample"]
+    flat = bench.flat_config_keys(bench.by_config_summary(d))
+    assert {k: v for k, v in r.items() if k in flat} == flat
