@@ -29,5 +29,5 @@ def test_header_is_c99_and_driver_links(tmp_path, rg):
 @pytest.mark.gpu
 def test_c_driver_runs_on_gpu(tmp_path, rg):
     exe = build_driver(tmp_path, rg)
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)  # (the first communicator of a torch-less process maps librccl.so.1: 573 MB, minutes on a box whose page cache is cold)
     assert r.returncode == 0 and "C_DRIVER_OK" in r.stdout, r.stdout
