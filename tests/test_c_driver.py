@@ -29,5 +29,10 @@ def test_header_is_c99_and_driver_links(tmp_path, rg):
 @pytest.mark.gpu
 def test_c_driver_runs_on_gpu(tmp_path, rg):
     exe = build_driver(tmp_path, rg)
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)  # (the first communicator of a torch-less process maps librccl.so.1: 573 MB, minutes on a box whose page cache is cold)
+    # (line-buffered, so that a run that does not come back shows how far it got)
+    try:
+        r = subprocess.run(["stdbuf", "-oL", "-eL", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    except subprocess.TimeoutExpired as e:
+        out = e.output.decode(errors="replace") if isinstance(e.output, bytes) else (e.output or "")
+        pytest.fail("examples/c_driver did not finish in 600 s; its output so far:\n" + out[-3000:])
     assert r.returncode == 0 and "C_DRIVER_OK" in r.stdout, r.stdout
