@@ -11,13 +11,19 @@ for i in $(seq 1 $N); do
   pid=$!
   while kill -0 $pid 2>/dev/null && [ $(( $(date +%s) - s )) -lt $T ]; do sleep 1; done
   if kill -0 $pid 2>/dev/null; then
-    echo "run $i: still running after $T s; output so far:"; tail -30 /tmp/c_driver_loop.out | cut -c1-220
+    echo "run $i: still running after $T s; output so far:"; tail -5 /tmp/c_driver_loop.out | cut -c1-220
     cpid=$(pgrep -P $pid | head -1); [ -z "$cpid" ] && cpid=$pid
-    if command -v rocgdb > /dev/null; then
-      echo "---- threads (rocgdb):"; timeout 60 rocgdb -p $cpid -batch -ex "thread apply all bt 12" 2>&1 | grep -v "^\[New\|^warning\|^Reading\|^Loaded" | tail -60 | cut -c1-200
-    fi
-    kill -9 $cpid $pid 2>/dev/null
-    break
+    # what is it doing? (ptrace is not permitted on the box: /proc instead) -- twice, 10 s apart, then wait for it up to 10 min in all
+    for k in 1 2; do
+      echo "---- /proc/$cpid: $(grep State /proc/$cpid/status | tr -s '\t ' ' ') wchan=$(cat /proc/$cpid/wchan 2>/dev/null) rccl maps=$(grep -c rccl /proc/$cpid/maps)"
+      grep -E "rchar|read_bytes" /proc/$cpid/io | tr '\n' ' '; echo
+      for t in /proc/$cpid/task/*; do echo "  thread $(basename $t): $(cat $t/comm) $(grep State $t/status | tr -s '\t ' ' ') wchan=$(cat $t/wchan 2>/dev/null)"; done | head -12
+      sleep 10
+    done
+    while kill -0 $pid 2>/dev/null && [ $(( $(date +%s) - s )) -lt 600 ]; do sleep 2; done
+    if kill -0 $pid 2>/dev/null; then echo "run $i: NOT back after 600 s"; kill -9 $cpid $pid 2>/dev/null; break; fi
+    wait $pid; echo "run $i: came back with rc $? after $(( $(date +%s) - s )) s"; tail -12 /tmp/c_driver_loop.out | cut -c1-200
+    continue
   fi
   wait $pid; rc=$?
   echo "run $i: rc $rc in $(( $(date +%s) - s )) s"
