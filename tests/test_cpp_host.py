@@ -41,12 +41,12 @@ def test_cpp_host_side_builds_and_fails_loudly_without_a_gpu(tmp_path, rg):
 def test_message_builder_on_the_host(tmp_path, rg):
     """From send items to the reference's Messages and their bytes: pure host code around the engine (no device)."""
     exe = build(tmp_path, rg, "cpp_message_builder")
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "CPP_MESSAGE_BUILDER_OK" in r.stdout, r.stdout
 
 
 @pytest.mark.gpu
 def test_reference_tests_through_the_cpp_host_side(tmp_path, rg):
     exe = build(tmp_path, rg)
-    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "CPP_REFERENCE_TESTS_OK" in r.stdout, r.stdout
