@@ -671,7 +671,7 @@ def main():
                     help="temporal fusion: process this many consecutive ticks per launch (1..8, default 1)")
     ap.add_argument("--split", type=int, default=1, help="sub-shards per rank, each on its own HIP stream")
     ap.add_argument("--cfg-flags", type=lambda s: int(s, 0), default=0,
-                    help="rg_config.flags of the measured engines (RG_CFGF_*: 0x8 = class-placed ticks as one kernel with inline elections)")
+                    help="rg_config.flags of the measured engines (RG_CFGF_*: 0x1 = no size classes, 0x2 = class blocks in block order, 0x4 = 64-bit cell offsets)")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
     ap.add_argument("--sorted", action="store_true",
                     help="config 5: ONE engine with the groups placed by replica-set size class (one launch per tick, k_tick_classes)")
