@@ -82,9 +82,8 @@ def cpu_baseline(n_groups, n_slots, workload, sample_ticks, seed, threads):
     soa = soa_cpu_line(n_groups, n_slots, workload, seed, threads)
     out = {"value": evals[threads] / elapsed[threads] if elapsed[threads] else None, "unit": "group-evals/s",
            "cores": threads, "kind": "port",
-           "sample": f"{n_groups} groups x {n_slots} peers, {sample_ticks} ticks of the same stream "
-                     f"(alternating 1-thread / {threads}-thread ticks), C oracle oracle/raft_oracle.c "
-                     f"(message-at-a-time, per-group hash map like the reference)",
+           "sample": f"{n_groups} groups x {n_slots} peers, {sample_ticks} ticks of the same stream, alternating 1 / {threads} "
+                     f"threads; C port oracle/raft_oracle.c",
            "value_1core": evals[1] / elapsed[1] if elapsed[1] else None,
            "host_cores": os.cpu_count()}
     out.update(soa)
@@ -568,6 +567,8 @@ def by_config_summary(result):
                       ("c4_shard", oc.get("configs[3] one rank's shard")), ("c5_one_launch", oc.get("configs[4] one launch, class-sorted")),
                       ("c5_size_class", oc.get("configs[4] size-class engines")), ("c5_interleaved", oc.get("configs[4] one 7-slot engine")),
                       ("c5_one_launch_hbm_8M", oc.get("configs[4] one launch, class-sorted, 8M groups")),
+                      ("c5_placed", oc.get("configs[4] interleaved, after rg_permute_groups")),
+                      ("c2_group_commit", oc.get("configs[1] group commit")),
                       ("recompute", result.get("recompute_only")), ("recompute_hbm_8M", result.get("recompute_only_out_of_cache"))):
         if obj is not None:
             out[name] = entry(obj)
@@ -591,6 +592,8 @@ def by_config_summary(result):
 def flat_config_keys(by_config):
     flat = {}
     for name, e in by_config.items():
+        if name == "c2_headline":
+            continue  # (roofline's own frac / avg_launch_us / algorithmic_bytes_per_launch / traffic)
         if "frac" not in e:
             flat[f"frac_{name}"] = None
             continue
@@ -607,6 +610,114 @@ def flat_config_keys(by_config):
         if e.get("step_traffic") is not None:
             flat[f"step_traffic_mb_{name}"] = round(e["step_traffic"] / 1e6, 2)
     return flat
+
+
+LINE_LIMIT = 6000  # bytes of the ONE line on stdout: the driver's record keeps an ~8 KB tail of stdout and parses the line from it
+FULL_RESULT = os.path.join("gpurun_out", "bench_full.json")  # every nested sub-object of the run (relative to the repo root)
+
+# what each flat `<prefix>_<cfg>` key of `roofline` means; frac = mb / us / 8 TB/s can be recomputed from the line alone
+_FLAT_PREFIXES = ("frac_", "us_", "mb_", "traffic_mb_", "step_us_", "frac_by_tick_bytes_", "step_traffic_mb_", "traffic_stale_")
+
+
+def _short(v, digits=6, text=160):
+    """A scalar as the line carries it: floats to `digits` significant digits, strings cut at `text` characters."""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, str):
+        return v if len(v) <= text else v[:text - 3] + "..."
+    return None
+
+
+def _scalars(obj, text=160, skip=()):
+    return {k: _short(v, text=text) for k, v in (obj or {}).items()
+            if k not in skip and (v is None or isinstance(v, (bool, int, float, str)))}
+
+
+def compact_line(result):
+    """The ONE line stdout carries, from the complete (nested) result of a run: the contract's top-level keys, `config` and
+    `roofline` and `cpu_baseline` as objects of SCALARS (every side configuration as frac_/us_/mb_/traffic_mb_<cfg> keys of
+    `roofline`), nothing nested below them, at most LINE_LIMIT bytes. Everything else the run measured (other_configs,
+    out_of_cache, between_regimes, recompute_only*, small_batch_latency, by_config, fused_model, the publication statistics)
+    goes to FULL_RESULT and to stderr -- the name of that file is the line's `full` key."""
+    line = _scalars(result, skip=("full",))
+    line["full"] = FULL_RESULT
+    cfg_in = result.get("config") or {}
+    cfg = _scalars(cfg_in, text=220)
+    cfg["engines"] = "+".join(f"{e['groups']}x{e['slots']}" for e in cfg_in.get("engines", [])) or None
+    dev = cfg_in.get("device") or {}
+    for k in ("arch", "compute_units", "cache_policy", "last_tick_kernel", "last_tick_streaming", "resident_groups"):
+        if k in dev:
+            cfg[k] = _short(dev[k])
+    pub = cfg_in.get("publication") or {}
+    for k, v in _scalars(pub).items():
+        cfg[f"pub_{k}"] = v
+    auto = cfg_in.get("publish_every_auto") or {}
+    for k in ("tick_us", "exchange_us"):
+        if k in auto:
+            cfg[f"publish_auto_{k}"] = auto[k]
+    pc = cfg_in.get("publication_compare") or {}
+    if pc:
+        cfg["pub_compare_mode"], cfg["pub_compare_ms_per_step"], cfg["pub_compare_value"] = \
+            _short(pc.get("mode"), text=60), _short(pc.get("ms_per_step")), _short(pc.get("value"))
+    line["config"] = cfg
+    roof_in = result.get("roofline") or {}
+    roof = _scalars(roof_in, text=120)
+    fm = roof_in.get("fused_model") or {}
+    if fm:
+        roof["fused_ticks_per_launch"], roof["fused_per_tick_model_bytes"] = fm.get("ticks_per_launch"), _short(fm.get("per_tick_model_bytes"))
+    line["roofline"] = roof
+    cb = result.get("cpu_baseline")
+    if cb is None or "error" in cb:
+        line["cpu_baseline"] = cb if cb is None else _scalars(cb, text=200)
+    else:
+        out = _scalars(cb, text=150, skip=("soa_note",))
+        for k, v in _scalars(cb.get("config1") or {}, text=80, skip=("note", "unit", "kind")).items():
+            out[f"config1_{k}"] = v
+        line["cpu_baseline"] = out
+    if result.get("send_stage"):
+        line["send_stage"] = _scalars(result["send_stage"])
+    lat = result.get("small_batch_latency")
+    if lat and "error" not in lat:
+        line["latency_us"] = {k: v for k, v in _scalars(lat).items() if isinstance(v, (int, float))}
+
+    def size():
+        return len(json.dumps(line, separators=(",", ":"))) + 1
+
+    # Should the line ever outgrow the limit, what goes first is what FULL_RESULT holds anyway -- never a contract key, never
+    # frac_/us_/mb_ of a configuration.
+    droppers = [lambda: line.pop("latency_us", None),
+                lambda: [roof.pop(k) for k in list(roof) if k.startswith(("us_min_", "us_max_"))],
+                lambda: [roof.pop(k, None) for k in ("regime_note", "traffic_source", "note")],
+                lambda: [line["cpu_baseline"].pop(k, None) for k in ("sample", "config1_workload")] if line.get("cpu_baseline") else None,
+                lambda: [cfg.pop(k) for k in list(cfg) if k.startswith(("pub_", "publish_auto_")) and k not in ("pub_compare_value",)],
+                lambda: [roof.pop(k) for k in list(roof) if k.startswith(("traffic_mb_", "step_traffic_mb_", "traffic_stale_"))]]
+    for drop in droppers:
+        if size() <= LINE_LIMIT:
+            break
+        drop()
+    if size() > LINE_LIMIT:
+        raise SystemExit(f"bench.py: the JSON line is {size()} bytes (limit {LINE_LIMIT})")
+    return line
+
+
+def line_text(result):
+    return json.dumps(compact_line(result), separators=(",", ":")) + "\n"
+
+
+def write_full(result):
+    """The complete nested result: gpurun_out/bench_full.json under the repo root, and stderr."""
+    text = json.dumps(result)
+    try:
+        path = os.path.join(ROOT, FULL_RESULT)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {FULL_RESULT}: {e}\n")
+    sys.stderr.write("bench.py full result: " + text + "\n")
+    sys.stderr.flush()
 
 
 def self_launch(n):
@@ -674,7 +785,10 @@ def main():
                     help="rg_config.flags of the measured engines (RG_CFGF_*: 0x1 = no size classes, 0x2 = class blocks in block order, 0x4 = 64-bit cell offsets)")
     ap.add_argument("--one-engine", action="store_true", help="config 5: keep all sizes interleaved in one engine")
     ap.add_argument("--sorted", action="store_true",
-                    help="config 5: ONE engine with the groups placed by replica-set size class (one launch per tick, k_tick_classes)")
+                    help="config 5: ONE 7-slot engine with the groups placed by replica-set size class (one launch per tick, "
+                         "k_tick_classes) -- what --workload 5 runs unless --one-engine / --size-class-engines says otherwise")
+    ap.add_argument("--size-class-engines", action="store_true",
+                    help="config 5: one engine per replica-set size (three launches per tick on three streams)")
     ap.add_argument("--inflights", type=int, default=0,
                     help="N > 0: keep the Inflights (cap N) on the device and run the send stage (rg_send_appends: "
                          "maybe_send_append decisions, SURVEY 8f row 3) after every tick, inside the timed region; the "
@@ -693,8 +807,12 @@ def main():
     ap.add_argument("--cpu-sample-groups", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-ticks", type=int, default=16)
     args = ap.parse_args()
+    if args.workload == 5 and not (args.one_engine or args.size_class_engines):
+        args.sorted = True  # config 5's layout of record: placed by size class, ONE launch per tick
     if args.sorted:
         args.one_engine = True
+    if args.workload == 5:
+        args.slots = max(args.slots, 7)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # The plain command line (`python bench.py --gpus 8 ...`, what works at N = 1) starts its own ranks: one process
@@ -708,14 +826,21 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    def emit(obj):
+    def emit(obj, whole=False):
+        """The headline result goes out as compact_line (<= LINE_LIMIT bytes; the nested rest to FULL_RESULT and stderr);
+        `whole`: a --side object, printed as it is (what the profiling tools parse)."""
         sys.stdout.flush()
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:  # noqa: BLE001
             pass
-        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+        if whole:
+            os.write(json_fd, (json.dumps(obj) + "\n").encode())
+            return
+        text = line_text(obj)  # (raises before anything is written if the line could not be made to fit)
+        write_full(obj)
+        os.write(json_fd, text.encode())
 
     import torch
     import torch.distributed as dist
@@ -759,7 +884,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
         emit(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
                         one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
-                        sorted_classes=args.sorted, repeats=max(1, args.repeats), cfg_flags=args.cfg_flags))
+                        sorted_classes=args.sorted, repeats=max(1, args.repeats), cfg_flags=args.cfg_flags), whole=True)
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
     # other streams of the process, which serialises the publication's side stream with the ticks
@@ -1176,7 +1301,8 @@ def main():
                          ("configs[1] + send stage, one launch", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256,
                                                                       fused_send=True))):
             if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") \
-                    and kw.get("variant", 0) == args.variant and kw.get("one_engine", False) == args.one_engine:
+                    and kw.get("variant", 0) == args.variant and kw.get("sorted_classes", False) == args.sorted \
+                    and (kw.get("one_engine", False) or kw.get("sorted_classes", False)) == args.one_engine:
                 continue  # that is the headline itself
             oc[name] = guarded(run_config, rg, torch, seed=args.seed, **{"warmup": 5, "steps": 30, **kw})
             torch.cuda.empty_cache()

@@ -154,3 +154,4 @@ def test_committed_bench_line_keeps_the_contract_a_reader_needs():
     assert cp["kind"] == "port" and cp["cores"] >= 1 and cp["value"] > 0 and cp["unit"] == d["unit"] and cp["sample"]
     flat = bench.flat_config_keys(bench.by_config_summary(d))
     assert {k: v for k, v in r.items() if k in flat} == flat
+    assert not any(k.endswith("_c2_headline") for k in flat)  # (from round 6 on the headline is `roofline`'s own keys only)

@@ -10,7 +10,11 @@ tail -3 $O/bench_default.err
 python - "$O" <<'PY'
 import json, sys
 O = sys.argv[1]
-d = json.loads(open(O + "/bench_default.json").read().strip().splitlines()[-1])
+raw = open(O + "/bench_default.json").read()
+line = json.loads(raw.strip().splitlines()[-1])
+print("stdout: %d line(s), %d bytes; roofline.frac %.4f; cpu_baseline %s" % (raw.count("\n"), len(raw), line["roofline"]["frac"], (line.get("cpu_baseline") or {}).get("value")))
+d = json.load(open("gpurun_out/bench_full.json"))  # the nested result (the line itself carries scalars only)
+import shutil; shutil.copy("gpurun_out/bench_full.json", O + "/bench_full.json")
 def show(name, o):
     r = o["roofline"]
     print("%-34s %8.2f G/s %8.1f us  frac %.3f  %s  traffic %s" % (name, o["value"] / 1e9, o.get("us_per_step", d["ms_per_step"] * 1e3), r["frac"], r["regime"], r.get("traffic")))

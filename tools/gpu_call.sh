@@ -3,7 +3,7 @@
 # script per call under profiles/calls/, most of them differing in two lines).
 #
 # Runs locally: it sends the steps to a fresh MI355X box through gpurun, appends the invocation and its exit code to
-# profiles/calls/r05_invocations.log, and leaves whatever the steps wrote under gpurun_out/<label>/ on this side.
+# profiles/calls/r06_invocations.log, and leaves whatever the steps wrote under gpurun_out/<label>/ on this side.
 # A step is `name[:arg[:arg...]]` (tools/gpu_steps.sh has the bodies):
 #   tests:<pytest -k expr or ->:<files...>   pytest -m gpu over the given test files (default: all), tail to tests.txt
 #   bench:<args with , for spaces>           python bench.py <args> -> last JSON line appended to bench.jsonl
@@ -23,5 +23,5 @@ cmd="bash tools/gpu_steps.sh $label $steps"
 start=$(date -u +%Y-%m-%dT%H:%M:%SZ)
 /usr/local/graft/bin/gpurun --timeout "$to" -- "$cmd"
 rc=$?
-echo "$start head=$(git rev-parse --short HEAD)$(git diff --quiet || echo +dirty) rc=$rc timeout=$to label=$label steps: $steps" >> profiles/calls/r05_invocations.log
+echo "$start head=$(git rev-parse --short HEAD)$(git diff --quiet || echo +dirty) rc=$rc timeout=$to label=$label steps: $steps" >> profiles/calls/r06_invocations.log
 exit $rc
