@@ -5,6 +5,7 @@
 use std::os::raw::{c_char, c_void};
 
 pub const RG_MAX_SLOTS: u32 = 8;
+pub const RG_ABI_VERSION: u32 = 6;
 pub const RG_PF_STATE_MASK: u32 = 0x03;
 pub const RG_STATE_PROBE: u32 = 0;
 pub const RG_STATE_REPLICATE: u32 = 1;
@@ -65,6 +66,10 @@ pub const RG_SEND_BYTES: u32 = 0x2;
 pub const RG_SEND_LAST_IS_TAIL: u32 = 0x80000000;
 pub const RG_SEND_LAST_IS_PREV: u32 = 0x40000000;
 pub const RG_COMM_ID_BYTES: u32 = 128;
+pub const RG_TRANSPORT_NONE: u32 = 0;
+pub const RG_TRANSPORT_RCCL: u32 = 1;
+pub const RG_TRANSPORT_CALLBACK: u32 = 2;
+pub const RG_TRANSPORT_LOCAL: u32 = 3;
 pub const RG_COMM_ALL_AUTO: u32 = 0;
 pub const RG_COMM_ALL_RCCL: u32 = 1;
 pub const RG_COMM_ALL_LOCAL: u32 = 2;
@@ -85,6 +90,7 @@ pub const RG_ERR_SLOT_BUSY: i32 = -6;
 pub const RG_ERR_HIGHER_TERM: i32 = -7;
 pub const RG_ERR_STATE: i32 = -8;
 pub const RG_ERR_NOT_ON_PATH: i32 = -9;
+pub const RG_ERR_HOST_HINT: i32 = -10;
 
 // rg_column
 pub const RG_COL_MATCH: i32 = 0;
@@ -329,6 +335,16 @@ pub struct RgCommConfig {
 }
 
 #[repr(C)]
+pub struct RgCommInfo {
+    pub rank: u32,
+    pub world: u32,
+    pub transport: u32,
+    pub in_process: u32,
+    pub rccl_ranks: u32,
+    pub rccl_rank: u32,
+}
+
+#[repr(C)]
 pub struct RgCommAllConfig {
     pub ring_ticks: u32,
     pub overflow_slots: u32,
@@ -379,6 +395,7 @@ pub struct RgHostState {
 
 extern "C" {
     pub fn rg_version() -> *const c_char;
+    pub fn rg_abi_version() -> u32;
     pub fn rg_last_error() -> *const c_char;
     pub fn rg_device_count() -> i32;
     pub fn rg_create(cfg: *const RgConfig, out: *mut *mut RgEngine) -> i32;
@@ -402,6 +419,7 @@ extern "C" {
     pub fn rg_tick(h: *mut RgEngine, host_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device(h: *mut RgEngine, dev_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device_fused(h: *mut RgEngine, dev_msgs: *const RgMsgs, n_ticks: u32, dev_out_t: *mut u32, dev_commit_t: *mut u64) -> i32;
+    pub fn rg_fused_ticks_done(h: *const RgEngine, n: *mut u32) -> i32;
     pub fn rg_recompute(h: *mut RgEngine) -> i32;
     pub fn rg_maximal_committed_index(h: *mut RgEngine, host_mci: *mut u64, host_used_gc: *mut u8) -> i32;
     pub fn rg_heartbeat_commits(h: *mut RgEngine, dev_hb_commit: *mut u64, host_hb_commit: *mut u64) -> i32;
@@ -456,8 +474,10 @@ extern "C" {
     pub fn rg_comm_unique_id(id: *mut u8) -> i32;
     pub fn rg_comm_init(h: *mut RgEngine, cfg: *const RgCommConfig) -> i32;
     pub fn rg_comm_destroy(h: *mut RgEngine) -> i32;
-    pub fn rg_comm_init_all(engines: *mut *const RgEngine, n: u32, cfg: *const RgCommAllConfig) -> i32;
-    pub fn rg_publish_commit_all(engines: *mut *const RgEngine, n: u32, flags: u32) -> i32;
+    pub fn rg_comm_warmup() -> i32;
+    pub fn rg_comm_info_get(h: *mut RgEngine, out: *mut RgCommInfo) -> i32;
+    pub fn rg_comm_init_all(engines: *const *mut RgEngine, n: u32, cfg: *const RgCommAllConfig) -> i32;
+    pub fn rg_publish_commit_all(engines: *const *mut RgEngine, n: u32, flags: u32) -> i32;
     pub fn rg_publish_commit(h: *mut RgEngine, flags: u32) -> i32;
     pub fn rg_publish_sync(h: *mut RgEngine) -> i32;
     pub fn rg_published_commit_ptr(h: *mut RgEngine, stride: *mut u64) -> *const u64;

@@ -37,6 +37,11 @@ extern "C" {
 #endif
 
 #define RG_MAX_SLOTS 8
+/* The ABI is SOURCE-compatible across versions, not binary-compatible: rg_config and rg_device_info grow in place (zero-initialised
+ * new members keep the old meaning), so a caller is compiled against the header of the library it loads. RG_ABI_VERSION is bumped
+ * whenever a struct layout, an enum value or a signature changes; rg_abi_version() returns what the library was built with --
+ * compare the two at start-up (raftgroups.hpp and the Python / Rust bindings do). */
+#define RG_ABI_VERSION 6u
 
 /* ---- status codes; the negative values mirror src/errors.rs:6-50 where one applies ---- */
 typedef enum {
@@ -49,8 +54,10 @@ typedef enum {
     RG_ERR_SLOT_BUSY = -6,       /* a second message for the same (group, peer) before rg_tick */
     RG_ERR_HIGHER_TERM = -7,     /* m.term > term: the host must step down (src/raft.rs:1284-1348) */
     RG_ERR_STATE = -8,           /* call sequence error (e.g. results before any tick) */
-    RG_ERR_NOT_ON_PATH = -9      /* rg_step_bytes: a well-formed message of a type this path does not handle (MsgAppend,
+    RG_ERR_NOT_ON_PATH = -9,     /* rg_step_bytes: a well-formed message of a type this path does not handle (MsgAppend,
                                     votes, ...): the host's own Raft::step takes it */
+    RG_ERR_HOST_HINT = -10       /* rg_tick_device_fused: a tick of the call raised RG_OUT_HOST_HINT; the call stopped BEHIND that
+                                    tick (state, RG_COL_OUT and RG_COL_HOST_HINT are that tick's; rg_fused_ticks_done) */
 } rg_status;
 
 /* ---- Progress flag byte (one per slot; src/tracker/progress.rs:8-56, src/tracker/state.rs:22-29) ---- */
@@ -254,6 +261,7 @@ typedef struct {
 
 /* ---- lifecycle ---- */
 const char *rg_version(void);
+uint32_t rg_abi_version(void); /* RG_ABI_VERSION of the build */
 const char *rg_last_error(void);
 int rg_device_count(void);
 int rg_create(const rg_config *cfg, rg_engine **out);
@@ -403,15 +411,24 @@ int rg_tick_device(rg_engine *h, const rg_msgs *dev_msgs);
  * BEFORE that tick, so the library runs it as a single-tick launch (behind its pre-pass) between the fused launches of the
  * ticks around it -- same results, same arrays. With commit publication active (rg_comm_init) the call's total advance of
  * every group lands in its publication byte, exactly as n_ticks single launches without a publication in between would
- * leave it. A log-term tick that raises RG_OUT_HOST_HINT reports it in its row of dev_out_t ONLY (RG_COL_OUT / RG_COL_HOST_HINT
- * hold the last tick's): the later ticks of the call run with that reject unapplied, exactly as if the host had stepped them
- * before answering -- a host whose term-run tables may be non-contiguous does not fuse log-term ticks.
+ * leave it.
+ * Exact or loud: a log-term tick that raises RG_OUT_HOST_HINT (a reject whose find_conflict_by_term needs terms the bounded
+ * term-run table no longer holds) ENDS the call -- the reference applies that reject before anything later
+ * (src/raft_log.rs:209-235 -> src/raft.rs:1657-1660), so the ticks behind it are not run. The call returns RG_ERR_HOST_HINT;
+ * rg_fused_ticks_done reports how many ticks were applied (the hinted tick included: everything of it that does not depend on
+ * the hint is in place, as after a single rg_tick_device), their rows of dev_out_t / dev_commit_t are written, and RG_COL_OUT /
+ * RG_COL_HOST_HINT are the hinted tick's, so rg_host_hints / rg_resolve_host_hints (or re-stepping the reject) work as after a
+ * single tick; the host then submits the remaining ticks again. A hinted LAST tick of the call returns RG_OK (nothing was run
+ * behind it; the host sees the bit in RG_COL_OUT as usual). What it costs: behind every log-term tick of the call the host waits
+ * for that tick's pre-pass (not for the tick); only a pre-pass that deferred something waits for the tick and counts.
  * Not available with device Inflights (rg_send_appends has to follow every tick).
  * Asynchronous. Use it to
  * work off a backlog of queued ticks or to replay a log of ticks; a single tick has no fusion to exploit. */
 #define RG_MAX_FUSE 8
 int rg_tick_device_fused(rg_engine *h, const rg_msgs *dev_msgs, uint32_t n_ticks, uint32_t *dev_out_t,
                          uint64_t *dev_commit_t);
+/* Ticks the last rg_tick_device_fused applied: n_ticks after RG_OK, fewer after RG_ERR_HOST_HINT (or a launch failure). */
+int rg_fused_ticks_done(const rg_engine *h, uint32_t *n);
 /* Raft::maybe_commit() for every group with no messages (post_conf_change src/raft.rs:2630,
  * enable_group_commit :513-518, assign_commit_groups :531-544). Asynchronous. */
 int rg_recompute(rg_engine *h);
@@ -689,7 +706,9 @@ int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, const uint64_
  *                         steady case) -- read it from the window's tail column, same layout (u64 [P][stride]): rg_send_tail_column;
  *   RG_SEND_LAST_IS_PREV  an empty MsgAppend (send_append to a peer that already has every entry): last_index == prev_index.
  * A wave of the stage writes a line of dev_last_index only when one of its 64 groups has an item of neither kind (8 B less per
- * item otherwise). The compact list (rg_send_items) always carries last_index itself. */
+ * item otherwise). The compact list (rg_send_items) always carries last_index itself. The tail column is LIVE state: a consumer
+ * of the columns reads it before the next call that moves a window (a tick's stage, rg_update_state, rg_load_inflights,
+ * rg_restore -- those three make the compact list from the columns first, so rg_send_items stays right across them). */
 #define RG_SEND_LAST_IS_TAIL 0x80000000u
 #define RG_SEND_LAST_IS_PREV 0x40000000u
 int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inflight);
@@ -782,6 +801,24 @@ typedef struct {
  * publication so every replica starts from the actual commit columns. */
 int rg_comm_init(rg_engine *h, const rg_comm_config *cfg);
 int rg_comm_destroy(rg_engine *h);
+/* RCCL's first use in a process is slow: the library is ~0.5 GB to map (seconds, up to minutes on a cold machine) and the
+ * first communicator sets up its transports. rg_comm_warmup loads it and creates and destroys a ONE-rank communicator on the
+ * calling thread's current device -- call it at start-up, before any step a timeout bounds. Not a collective. */
+int rg_comm_warmup(void);
+/* What the engine's publication runs over -- and, for RCCL, what the COMMUNICATOR reports about itself (ncclCommCount /
+ * ncclCommUserRank), as opposed to what the engine was told: a multi-GPU run proves its rank count with this. */
+typedef struct {
+    uint32_t rank, world;  /* as given to rg_comm_init / rg_comm_init_all (0 / 0 without a communicator) */
+    uint32_t transport;    /* RG_TRANSPORT_* */
+    uint32_t in_process;   /* 1 = one of several ranks driven by one thread (rg_comm_init_all) */
+    uint32_t rccl_ranks;   /* ncclCommCount of the engine's communicator (0 unless RG_TRANSPORT_RCCL) */
+    uint32_t rccl_rank;    /* ncclCommUserRank */
+} rg_comm_info;
+#define RG_TRANSPORT_NONE 0u     /* no communicator: a single engine */
+#define RG_TRANSPORT_RCCL 1u     /* ncclAllGather */
+#define RG_TRANSPORT_CALLBACK 2u /* the host's rg_allgather_fn */
+#define RG_TRANSPORT_LOCAL 3u    /* device-to-device copies between engines of one process (RG_COMM_ALL_LOCAL) */
+int rg_comm_info_get(rg_engine *h, rg_comm_info *out);
 /* Several ranks in ONE process (`rg_create(cfg{..., n_devices, device_ids[]})`; the reference's own embedding
  * drives many RawNodes from one thread, src/raw_node.rs:284, examples/five_mem_node/main.rs:67-112). Two forms:
  *  (1) one THREAD per engine: each thread creates its engine and calls rg_comm_init / rg_publish_commit on it like a rank of

@@ -49,6 +49,7 @@ enum class ErrorKind {
     NotOnPath,        // step(bytes): a well-formed message of a type this path does not handle
     InvalidArgument,
     State,            // call sequence error
+    HostHint,         // a fused launch stopped behind a tick that left a reject to the host (RG_ERR_HOST_HINT)
     NoDevice,         // no gfx950 device / HIP error (no CPU fallback)
     OutOfMemory,
 };
@@ -68,6 +69,7 @@ inline void check(int rc) {
     case RG_ERR_SLOT_BUSY: k = ErrorKind::SlotBusy; break;
     case RG_ERR_NOT_ON_PATH: k = ErrorKind::NotOnPath; break;
     case RG_ERR_STATE: k = ErrorKind::State; break;
+    case RG_ERR_HOST_HINT: k = ErrorKind::HostHint; break;
     case RG_ERR_NO_DEVICE: k = ErrorKind::NoDevice; break;
     case RG_ERR_OUT_OF_MEMORY: k = ErrorKind::OutOfMemory; break;
     default: break;
@@ -372,6 +374,8 @@ struct Config { // the subset of raft::Config (src/config.rs) the path depends o
 class MultiRaft {
   public:
     explicit MultiRaft(const Config &c) : cfg_(c) {
+        if (rg_abi_version() != RG_ABI_VERSION) // (the ABI is source-compatible only: this header's struct layouts must be the library's)
+            throw Error(ErrorKind::State, RG_ERR_STATE, "libraftgroups was built with another RG_ABI_VERSION than this header");
         rg_config rc;
         std::memset(&rc, 0, sizeof rc);
         rc.n_groups = c.n_groups;

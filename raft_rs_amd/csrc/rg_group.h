@@ -333,7 +333,7 @@ RG_HD bool rg_election_valid(const RgState &st, const RgMsgs &ms, u64 g, u32 sel
 // which this pre-pass decides from the state the tick will see (an election of the same tick puts every peer in Probe
 // with next = last_index + 1 first; nothing else before a slot's message changes its state or, outside Replicate, its
 // next_idx). The tick leaves exactly those rejects alone and raises RG_OUT_HOST_HINT (RgTick::slot).
-RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u64 *rh) {
+RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_slots, u64 *rh, u32 *raised = nullptr) {
     const u64 mf = ms.mflags[g];
     const u32 cfg = st.cfg[g];
     const u32 self = RG_CFG_SELF(cfg), present = RG_CFG_PRESENT(cfg);
@@ -398,6 +398,15 @@ RG_HD void rg_resolve_hints(const RgState &st, const RgMsgs &ms, u64 g, u32 n_sl
         }
     }
     st.hhint[g] = (u8)defer;
+    // `raised` (optional): one word per launch that says "some reject of this tick was left to the host" -- what lets the engine
+    // skip the check for unanswered hints (and its synchronisation) after every log-term tick that raised none
+    if (defer && raised) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(raised, 1u);
+#else
+        *raised |= 1u;
+#endif
+    }
 }
 
 // Does this tick carry RG_MF_BECOME_LEADER for the group (the REJECT bit of the leader's OWN slot)?

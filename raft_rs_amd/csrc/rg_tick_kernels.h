@@ -1,6 +1,6 @@
 // rg_tick_kernels.h -- the tick kernels (one lane per raft group; LDS-staged variant) and their
 // launcher. Instantiated once per slot count in tick_inst.hip (-DRG_P=n) so the eight
-// specialisations compile in parallel; engine.hip only sees the extern template declarations.
+// specialisations compile in parallel; the ABI units (abi_*.hip) only see the extern template declarations.
 #pragma once
 
 #include "rg_group.h"
@@ -293,7 +293,7 @@ template <int P, bool GC, typename IX, int NTM = 0> __global__ RG_LANE_BOUNDS(P)
 // some group that has the peer, so every line travels (config 5 in one 7-slot engine: 533 MB of HBM traffic for 354 MB of
 // algorithmic bytes, profiles/traffic.json). Where the host places groups of one size in contiguous ranges, whole blocks of 64
 // groups use only the first Q < P slots -- the engine derives that from the cfg words by itself (rg_refresh_classes in
-// engine.hip: per block the highest slot any cfg word of the block names, one byte per block in device memory; a wave reads
+// abi_tick.hip (rg_refresh_classes): per block the highest slot any cfg word of the block names, one byte per block in device memory; a wave reads
 // its byte with ONE scalar load before its first vector load. A table of ranges in the kernel arguments was tried first: its
 // 17 SGPRs, live at the top of the kernel together with every column pointer, pushed 16 of those pointers into spill lanes
 // for good -- 1 566 v_readlane / v_writelane in the code, ~250 executed per wave -- and it capped the layout at 8 ranges,

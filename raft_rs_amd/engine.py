@@ -57,7 +57,7 @@ class OUT:
 
 
 ERR = {"NOT_ON_PATH": -9, "INVALID_ARG": -1, "NO_DEVICE": -2, "OUT_OF_MEMORY": -3, "STEP_LOCAL_MSG": -4,
-       "STEP_PEER_NOT_FOUND": -5, "SLOT_BUSY": -6, "HIGHER_TERM": -7, "STATE": -8}
+       "STEP_PEER_NOT_FOUND": -5, "SLOT_BUSY": -6, "HIGHER_TERM": -7, "STATE": -8, "HOST_HINT": -10}
 
 WL_MAJORITY, WL_JOINT, WL_MIXED = 2, 3, 5
 VARIANT_DEFAULT, VARIANT_LANE, VARIANT_LDS, VARIANT_COOP, VARIANT_LDS_DMA, VARIANT_COMPACT = 0, 1, 2, 3, 4, 5
@@ -204,6 +204,13 @@ class PublishStats(C.Structure):
                 ("host_us_events", C.c_double), ("host_us_allgather", C.c_double), ("host_us_memset", C.c_double)]
 
 
+ABI_VERSION = 6  # RG_ABI_VERSION of include/raftgroups.h these ctypes layouts mirror (tests/test_abi.py compares)
+class CommInfo(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("transport", C.c_uint32), ("in_process", C.c_uint32),
+                ("rccl_ranks", C.c_uint32), ("rccl_rank", C.c_uint32)]
+
+
+TRANSPORT_NAMES = {0: "none", 1: "rccl", 2: "callback", 3: "local"}
 COMM_ID_BYTES = 128
 PUBLISH_FULL = 1
 
@@ -223,6 +230,7 @@ assert SEND_ITEM_DTYPE.itemsize == 32
 _vp, _u64, _i = C.c_void_p, C.c_uint64, C.c_int
 SYMBOLS = {
     "rg_version": (C.c_char_p, []),
+    "rg_abi_version": (C.c_uint32, []),
     "rg_last_error": (C.c_char_p, []),
     "rg_device_count": (_i, []),
     "rg_create": (_i, [C.POINTER(_Config), C.POINTER(_vp)]),
@@ -243,6 +251,7 @@ SYMBOLS = {
     "rg_tick": (_i, [_vp, C.POINTER(_Msgs)]),
     "rg_tick_device": (_i, [_vp, C.POINTER(_Msgs)]),
     "rg_tick_device_fused": (_i, [_vp, C.POINTER(_Msgs), C.c_uint32, _vp, _vp]),
+    "rg_fused_ticks_done": (_i, [_vp, C.POINTER(C.c_uint32)]),
     "rg_recompute": (_i, [_vp]),
     "rg_maximal_committed_index": (_i, [_vp, _vp, _vp]),
     "rg_results": (_i, [_vp, _vp, _vp]),
@@ -300,6 +309,8 @@ SYMBOLS = {
     "rg_comm_unique_id": (_i, [_vp]),
     "rg_comm_init": (_i, [_vp, C.POINTER(CommConfig)]),
     "rg_comm_destroy": (_i, [_vp]),
+    "rg_comm_warmup": (_i, []),
+    "rg_comm_info_get": (_i, [_vp, C.POINTER(CommInfo)]),
     "rg_publish_commit": (_i, [_vp, C.c_uint32]),
     "rg_comm_init_all": (_i, [_vp, C.c_uint32, _vp]),
     "rg_publish_commit_all": (_i, [_vp, C.c_uint32, C.c_uint32]),
@@ -338,6 +349,9 @@ def load_library():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if L.rg_abi_version() != ABI_VERSION:  # (the ABI is source-compatible only: struct layouts follow the header)
+        raise ImportError(f"{LIB_PATH} was built with RG_ABI_VERSION {L.rg_abi_version()}, these bindings are written "
+                          f"against {ABI_VERSION}: rebuild with `python -m raft_rs_amd.build --force`")
     _lib = L
     return L
 
@@ -559,11 +573,21 @@ class Engine:
 
     def tick_device_fused(self, ticks, dev_out_t, dev_commit_t=None):
         """ticks: list (1..8) of (m_index, m_commit, m_hint, m_rs, m_flags) DEVICE pointers in tick order;
-        dev_out_t: device u32 [T][G]; dev_commit_t: optional device u64 [T][G]. Asynchronous."""
+        dev_out_t: device u32 [T][G]; dev_commit_t: optional device u64 [T][G]. Asynchronous. Returns the number of ticks
+        applied: len(ticks), or fewer when a log-term tick raised RG_OUT_HOST_HINT and the call stopped behind it
+        (RG_ERR_HOST_HINT; answer the hints, then submit the rest)."""
         arr = (_Msgs * len(ticks))()
         for i, t in enumerate(ticks):
             arr[i] = _Msgs(*([_ptr(x) for x in t] + [None] * (6 - len(t))))
-        self._check(self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t)))
+        rc = self.L.rg_tick_device_fused(self.h, arr, len(ticks), _ptr(dev_out_t), _ptr(dev_commit_t))
+        if rc != ERR["HOST_HINT"]:
+            self._check(rc)
+        return self.fused_ticks_done()
+
+    def fused_ticks_done(self):
+        n = C.c_uint32(0)
+        self._check(self.L.rg_fused_ticks_done(self.h, C.byref(n)))
+        return int(n.value)
 
     # ---- send stage (device Inflights + maybe_send_append decisions) ------------------------------
     def send_appends(self, max_entries_per_msg=0, skip_bcast_commit=False, max_bytes=None):
@@ -827,6 +851,14 @@ class Engine:
     def comm_destroy(self):
         self._check(self.L.rg_comm_destroy(self.h))
 
+    def comm_info(self):
+        """rg_comm_info_get: rank / world as given, the transport, and -- over RCCL -- the communicator's own ncclCommCount /
+        ncclCommUserRank (what proves how many ranks an exchange really spans)."""
+        ci = CommInfo()
+        self._check(self.L.rg_comm_info_get(self.h, C.byref(ci)))
+        return {"rank": ci.rank, "world": ci.world, "transport": TRANSPORT_NAMES.get(ci.transport, str(ci.transport)),
+                "in_process": bool(ci.in_process), "rccl_ranks": ci.rccl_ranks, "rccl_rank": ci.rccl_rank}
+
     def publish_commit(self, full=False):
         self._check(self.L.rg_publish_commit(self.h, PUBLISH_FULL if full else 0))
 
@@ -915,6 +947,14 @@ def publish_commit_all(engines, full=False):
     L = engines[0].L
     arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
     engines[0]._check(L.rg_publish_commit_all(arr, len(engines), PUBLISH_FULL if full else 0))
+
+
+def comm_warmup():
+    """rg_comm_warmup: load RCCL and run a one-rank communicator through its life on the current device (start-up cost, paid early)."""
+    L = load_library()
+    rc = L.rg_comm_warmup()
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())
 
 
 def comm_unique_id():

@@ -42,6 +42,18 @@ def test_library_exports_every_declared_symbol(rg):
     assert not unbound, f"python binding lacks {unbound}"
 
 
+def test_abi_version_is_the_headers_everywhere(rg):
+    """The ABI is source-compatible only (rg_config / rg_device_info grow in place): the header's RG_ABI_VERSION, what the built
+    library reports, the Python binding's layouts and the generated Rust constant name the same version."""
+    from raft_rs_amd import engine as E
+    v = header_defines()["RG_ABI_VERSION"]
+    lib = ctypes.CDLL(rg.LIB_PATH)
+    lib.rg_abi_version.restype = ctypes.c_uint32
+    assert lib.rg_abi_version() == v == E.ABI_VERSION
+    rs = open(os.path.join(os.path.dirname(HEADER), "..", "bindings", "raftgroups.rs")).read()
+    assert re.search(r"pub const RG_ABI_VERSION: u32 = %d;" % v, rs)
+
+
 def test_oracle_adapter_uses_the_header_bit_layouts():
     d = header_defines()
     osrc = open(os.path.join(ROOT, "oracle", "raft_oracle.c")).read()

@@ -34,24 +34,22 @@ def camel(name):
 
 def rust_type(ctype, typedefs):
     """ctype: e.g. 'const uint64_t *', 'rg_engine **', 'void *'."""
-    t = ctype.strip()
-    stars = t.count("*")
-    t = t.replace("*", " ").strip()
-    const = bool(re.search(r"\bconst\b", t))
-    base = re.sub(r"\bconst\b|\bstruct\b", " ", t).strip()
+    # `base q0 * q1 * q2 ...`: q0 qualifies the pointee of the innermost pointer, q_k (k >= 1) the k-th pointer itself -- i.e.
+    # the pointee of the (k+1)-th. `rg_engine *const *engines` is a pointer to CONST pointers to mutable engines:
+    # *const *mut RgEngine (round 5's generator had the two levels swapped).
+    parts = ctype.strip().split("*")
+    stars = len(parts) - 1
+    consts = [bool(re.search(r"\bconst\b", q)) for q in parts]
+    base = re.sub(r"\bconst\b|\bstruct\b", " ", parts[0]).strip()
     if base in SCALARS:
         r = SCALARS[base]
     elif base in typedefs:
         r = typedefs[base]
     else:
         raise ValueError(f"unknown C type {ctype!r}")
-    if stars == 0:
-        return r
-    # only the innermost level of a `const T **` is const; the outer pointers are *mut
-    out = ("*const " if const else "*mut ") + r
-    for _ in range(stars - 1):
-        out = "*mut " + out
-    return out
+    for k in range(stars):
+        r = ("*const " if consts[k] else "*mut ") + r
+    return r
 
 
 def ident(name):
