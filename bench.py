@@ -319,7 +319,7 @@ SIDE_REPEATS = 3  # timed regions per side measurement (median reported, min / m
 
 
 def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
-               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS, cfg_flags=0):
+               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS, cfg_flags=0, group_commit=False):
     """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
     headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
     synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
@@ -350,7 +350,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt.fixed = slots if (workload == 5 and not one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights, flags=cfg_flags)
         pt.eng.set_stream(main_stream.cuda_stream)
-        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=sorted_classes)
+        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=sorted_classes,
+                             group_commit=group_commit)
         first += n
         parts.append(pt)
     classes = parts[0].eng.size_classes() if sorted_classes else None
@@ -395,11 +396,13 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         for t in range(T):
             for pt in parts:
                 pt.eng.workload_gen(workload, t, *ptrs(pt, t), seed=seed, first_group=pt.first, fixed_peers=pt.fixed,
-                                    sorted_classes=sorted_classes)
+                                    sorted_classes=sorted_classes, group_commit=group_commit)
                 if inflights:
                     pt.flags[t] &= 0xE7  # no RG_MF_SENT / RG_MF_INS_FULL: the device owns the send path
                 s = pt.eng.msg_stats(pt.flags[t].data_ptr())
                 alg[t] += algorithmic_bytes(pt.n, s["slots"], s["valid"], s["rejects"])
+                if group_commit:  # ... plus Progress.commit_group_id of every peer, read once per group (8 P): SURVEY 8(d)'s
+                    alg[t] += 8 * s["slots"]  # formula is the plain quorum's and counts no gid column
                 if t >= warmup:
                     for k in census:
                         census[k] += s[k]
@@ -475,7 +478,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         kernel = {2: "k_tick_lds", 4: "k_tick_lds", 5: "k_tick_compact"}.get(variant, "k_tick_classes" if sorted_classes else "k_tick_lane")
         unit = "group-evals/s"
         key = (f"{workload}:{n_groups}:{n_slots}" + (":sorted" if sorted_classes else ":one-engine" if (workload == 5 and one_engine) else "") +
-               (f":v{variant}" if variant else "") + (":inflights" if inflights else "") + (":fused-send" if (inflights and fused_send) else ""))
+               (f":v{variant}" if variant else "") + (":inflights" if inflights else "") + (":fused-send" if (inflights and fused_send) else "") +
+               (":gc" if group_commit else ""))
         denom = float(n_groups * steps)
         extra = {"acks_per_group": round(census["valid"] / denom, 3), "rejects_per_group": round(census["rejects"] / denom, 5)}
         if workload == 5:
@@ -528,6 +532,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         kernel = info["last_tick_kernel"]  # what the engine says it launched (k_tick_split / k_tick_classes / k_tick_send ...)
     label = (workload_label(workload, n_groups, n_slots, one_engine, sorted_classes) if what == "tick" else
              f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers")
+    if group_commit:
+        label += " + group commit in every group, three commit groups over the peers (majority.rs:99-123)"
     if inflights:
         label += (f" + Inflights (cap {inflights}) on the device and the send stage after every tick, " +
                   ("tick and stage as ONE launch (rg_tick_device_send)" if fused_send else "as a launch of its own (rg_send_appends)"))
@@ -798,6 +804,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the recompute_only and out_of_cache sub-measurements (N=1 only; they run after the "
                          "timed region and do not touch `value`)")
+    ap.add_argument("--group-commit", action="store_true",
+                    help="--side tick: ProgressTracker.group_commit on in every group, three commit groups over the peers (RG_WL_GROUP_COMMIT)")
     ap.add_argument("--side", default=None, choices=["recompute", "tick"],
                     help="profiling hook: run ONLY one sub-measurement (run_config) of --groups x --slots, workload "
                          "--workload, and print its object -- what the PMC passes behind profiles/traffic.json wrap")
@@ -884,7 +892,8 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream())
         emit(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
                         one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
-                        sorted_classes=args.sorted, repeats=max(1, args.repeats), cfg_flags=args.cfg_flags), whole=True)
+                        sorted_classes=args.sorted, repeats=max(1, args.repeats), cfg_flags=args.cfg_flags,
+                        group_commit=args.group_commit), whole=True)
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
     # other streams of the process, which serialises the publication's side stream with the ticks
@@ -976,6 +985,15 @@ def main():
     transport_note = None
     if distributed:
         from raft_rs_amd import engine as E_
+        if not share_gpu:
+            # RCCL's first use in a process maps ~0.5 GB and sets up its transports (seconds, minutes on a cold box): paid here,
+            # before anything timed or bounded by a timeout -- a one-rank communicator created and destroyed (rg_comm_warmup)
+            t_w = time.perf_counter()
+            try:
+                E_.comm_warmup()
+                sys.stderr.write(f"bench.py rank {rank}: rg_comm_warmup {time.perf_counter() - t_w:.2f} s\n")
+            except rg.EngineError as e:
+                sys.stderr.write(f"bench.py rank {rank}: rg_comm_warmup failed: {e}\n")
         for pt in parts:
             if share_gpu:  # RCCL refuses two ranks on one device: gloo moves the slices (test hook)
                 pt.eng.comm_init(rank, world, transport=gloo_allgather)
@@ -1145,6 +1163,18 @@ def main():
                 if not np.array_equal(rep[r], cols_all[r].numpy().view(np.uint64)):
                     raise SystemExit(f"rank {rank}: published commit indices of rank {r} differ from its commit column")
     pub_stats = parts[0].eng.publish_stats() if distributed else None
+    comm_census = None
+    if distributed:
+        # what the exchange REALLY spanned: the communicator's own ncclCommCount / ncclCommUserRank of every rank (not what the
+        # launcher said), gathered over the control plane -- a line that says "8 ranks over RCCL" has eight distinct RCCL ranks
+        # of an 8-rank communicator behind it
+        ci = parts[0].eng.comm_info()
+        infos = [None] * world
+        dist.all_gather_object(infos, ci)
+        comm_census = {"transport": ci["transport"], "rccl_ranks": ci["rccl_ranks"], "rccl_rank": ci["rccl_rank"],
+                       "rccl_ranks_min": min(i["rccl_ranks"] for i in infos), "rccl_ranks_max": max(i["rccl_ranks"] for i in infos),
+                       "rccl_distinct_ranks": len({i["rccl_rank"] for i in infos if i["transport"] == "rccl"}),
+                       "rccl_engines": sum(1 for i in infos if i["transport"] == "rccl")}
     pub_compare = None
     if distributed:
         if not args.no_publish_compare:
@@ -1244,6 +1274,7 @@ def main():
                        f"{'gloo transport callback (shared-GPU test hook)' if share_gpu else (transport_note or 'ncclAllGather (RCCL)')} of "
                        f"{pub_stats['bytes_per_rank_delta']} B/rank delta slices (full column: {pub_stats['bytes_per_rank_full']} B)"
                        if distributed else ""),
+                   **(comm_census or {}),
                    **({"publication": pub_stats,
                        "publication_mode": "raw 8 B/group column every tick (RG_PUBLISH_FULL)" if args.publish_raw else "delta slices (~1 B/group)",
                        "publication_compare": pub_compare, "publish_every": E,
@@ -1291,6 +1322,7 @@ def main():
         oc = {}
         c5v = args.c5_variant
         for name, kw in (("configs[2] joint", dict(n_groups=1_000_000, n_slots=5, workload=3)),
+                         ("configs[1] group commit", dict(n_groups=1_000_000, n_slots=5, workload=2, group_commit=True)),
                          ("configs[3] one rank's shard", dict(n_groups=1_000_000, n_slots=7, workload=2)),
                          ("configs[4] one launch, class-sorted", dict(n_groups=1_000_000, n_slots=7, workload=5, sorted_classes=True)),
                          ("configs[4] one launch, class-sorted, 8M groups", dict(n_groups=8_000_000, n_slots=7, workload=5, sorted_classes=True,
@@ -1300,7 +1332,7 @@ def main():
                          ("configs[1] + send stage", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256)),
                          ("configs[1] + send stage, one launch", dict(n_groups=1_000_000, n_slots=5, workload=2, inflights=256,
                                                                       fused_send=True))):
-            if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") \
+            if (kw["workload"], kw["n_groups"], kw["n_slots"]) == (args.workload, G, P) and not kw.get("inflights") and not kw.get("group_commit") \
                     and kw.get("variant", 0) == args.variant and kw.get("sorted_classes", False) == args.sorted \
                     and (kw.get("one_engine", False) or kw.get("sorted_classes", False)) == args.one_engine:
                 continue  # that is the headline itself

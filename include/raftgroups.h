@@ -886,6 +886,9 @@ typedef struct {
 #define RG_WL_JOINT 3u    /* config 3: incoming {0,1,2} && outgoing {1,2,3}, slot 4.. learners */
 #define RG_WL_MIXED 5u    /* config 5: P in {3,5,7} by group, 10% groups in post-election probe/reject */
 #define RG_WL_PLACE_SORTED 0x10u /* rg_workload.reserved flag, see there */
+#define RG_WL_GROUP_COMMIT 0x20u /* rg_workload.reserved flag: ProgressTracker.group_commit on in every group (RG_CFG_GROUP_COMMIT)
+                                    and every peer in one of three commit groups (Progress.commit_group_id 1..3, by hash): each
+                                    commit evaluation of the stream is the group-commit form (src/quorum/majority.rs:99-123) */
 /* Initialise all engine state for the workload (device-side generator). */
 int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t first_group_global);
 /* Generate tick `tick`'s messages from the CURRENT device state into device message columns. */

@@ -46,7 +46,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
     if (!h || !w) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: bad argument");
     if (w->workload != RG_WL_MAJORITY && w->workload != RG_WL_JOINT && w->workload != RG_WL_MIXED)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: unknown workload %u", w->workload);
-    if ((w->reserved & 0xfu) > 8 || (w->reserved & ~0x1fu))
+    if ((w->reserved & 0xfu) > 8 || (w->reserved & ~0x3fu))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_init: fixed replica-set size %u / flags %#x", w->reserved & 0xfu, w->reserved & ~0xfu);
     RG_ENTER(h);
     hipLaunchKernelGGL(k_wl_init, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, (u64)w->seed,
@@ -56,6 +56,7 @@ extern "C" int rg_workload_init(rg_engine *h, const rg_workload *w, uint64_t fir
     if (h->pub) h->pub->local_lost = true;
     h->host_cfg_valid = false;
     h->cls_stale = true;
+    h->any_group_commit = (w->reserved & RG_WL_GROUP_COMMIT) != 0; // (every cfg word of the shard was just written)
     return RG_OK;
 }
 

@@ -205,9 +205,12 @@ RG_HD u64 rg_majority_ci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 M, bo
 }
 
 // ProgressTracker::maximal_committed_index with group commit on (tracker.rs:294-298, joint.rs:47-51).
-// (not inlined: it is called after every accepted ack and only the rare group-commit kernels carry it)
+// Inlined, and every kernel has ONE call site of it (the tick's commit phase walks its evaluations in a loop around that one
+// site: RgTick::commit_phase_gc): through round 5 this was a __noinline__ function taking the match and gid arrays by
+// reference, which put both arrays -- and with them the group's whole register image -- into 400-512 B of scratch per lane
+// in every group-commit kernel.
 template <int P>
-__host__ __device__ __noinline__ u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
+RG_HD u64 rg_mci_group(const u64 (&v)[P], const u64 (&gid)[P], u32 incoming, u32 outgoing, bool &used) {
     bool fi, fo;
     const u64 a = rg_majority_ci_group<P>(v, gid, incoming, fi);
     const u64 b = rg_majority_ci_group<P>(v, gid, outgoing, fo);
@@ -925,16 +928,9 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
         out |= RG_OUT_BECAME_LEADER | RG_OUT_APPENDED; // the caller follows with bcast_append (raft.rs:2190-2191)
     }
 
-    // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v`.
+    // ProgressTracker::maximal_committed_index (tracker.rs:294-298) over the matches `v` (groups with group commit on go
+    // through commit_phase_gc instead).
     RG_HD u64 mci_of(const RgQuorum<P> &qm, const u64 (&v)[P]) {
-        if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
-            u64 gidv[P];
-#pragma unroll
-            for (int i = 0; i < P; i++)
-                gidv[i] = ((present >> i) & 1u) ? rg_at(st.gid, (IX)i * (IX)st.stride + g) : 0ULL;
-            bool used;
-            return rg_mci_group<P>(v, gidv, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg), used);
-        }
         return qm.mci(v, RG_CFG_INCOMING(r.cfg), RG_CFG_OUTGOING(r.cfg));
     }
 
@@ -1141,13 +1137,8 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
             r.mt[S] = r.mi[S];
             r.mi[S] = old;
         }
-        u64 mci;
-        if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
-            mci = mci_of(qm, r.mt);
-        } else {
-            run.template raise<S>(r.mt, r.mi[S]); // (the matched index this ack replaced)
-            mci = run.mci();
-        }
+        run.template raise<S>(r.mt, r.mi[S]); // (the matched index this ack replaced)
+        const u64 mci = run.mci();
         // last_index as it was when this message was processed: the leader's APPEND lands at its own slot
         const u64 hi_then = (u32)S < self ? last0 : r.hi;
         if (rg_log_maybe_commit(mci, commit, r.lo, hi_then)) out |= RG_OUT_CHANGED;
@@ -1167,9 +1158,62 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
     // acks beyond last_index), else an exact replay of the sequence (from the old matches
     // maybe_update parked in r.mi). Both paths are bit-identical to the message-at-a-time
     // reference for ANY state and input.
-    template <int... S> RG_HD void commit_phase(rg_seq<S...>) {
+    // The same decisions for a group with ProgressTracker.group_commit on (GC kernels only; tracker.rs:294-298 ->
+    // majority.rs:99-123): the evaluation on the final matches, then -- under the same conditions as below -- the exact replay.
+    // Every evaluation is the LITERAL group-commit algorithm (rg_mci_group) on the matches of that moment; there is no running
+    // form of it. All of them go through ONE inlined call site: step -1 is the evaluation on the final matches, steps 0 .. P-1
+    // the replay, in a loop that is not unrolled -- the slot a step swaps back is picked by compile-time-indexed predicated
+    // swaps, so nothing is ever indexed dynamically and nothing leaves the registers (no scratch).
+    template <int... S> RG_HD void commit_phase_gc(rg_seq<S...>, u64 commit0) {
+        u64 gidv[P];
+#pragma unroll
+        for (int i = 0; i < P; i++)
+            gidv[i] = ((present >> i) & 1u) ? rg_at(st.gid, (IX)i * (IX)st.stride + g) : 0ULL;
+        const u32 inc = RG_CFG_INCOMING(r.cfg), outg = RG_CFG_OUTGOING(r.cfg);
+        const u32 last_acc = 31u - (u32)__builtin_clz(acc);
+        const u64 hi_last = last_acc < self ? last0 : r.hi;
+        bool replay = false;
+        u64 commit = commit0;
+#pragma unroll 1
+        for (int step = -1; step < P; step++) {
+            if (step >= 0) {
+                if (!((acc >> step) & 1u)) continue;
+                (((S == step) ? (void)rg_swap64(r.mt[S], r.mi[S]) : (void)0), ...); // this ack lands: its new match back in
+            }
+            bool used;
+            const u64 mci = rg_mci_group<P>(r.mt, gidv, inc, outg, used);
+            if (step < 0) {
+                if (mci <= hi_last) { // (as in commit_phase: the evaluation at the last accepted ack decides)
+                    u64 c = r.commit;
+                    const bool changed = rg_log_maybe_commit(mci, c, r.lo, hi_last);
+                    replay = changed && acc_oldp != 0;
+                    if (!replay) {
+                        r.commit = c;
+                        if (changed) out |= RG_OUT_CHANGED;
+                        else out |= acc_oldp << 8;
+                        break;
+                    }
+                } else {
+                    replay = true;
+                }
+                ((((acc >> S) & 1u) ? (void)rg_swap64(r.mt[S], r.mi[S]) : (void)0), ...); // the old matches in, the acked ones parked
+            } else {
+                const u64 hi_then = (u32)step < self ? last0 : r.hi;
+                if (rg_log_maybe_commit(mci, commit, r.lo, hi_then)) out |= RG_OUT_CHANGED;
+                else if ((acc_oldp >> step) & 1u) out |= 1u << (8 + step); // raft.rs:1749-1751
+            }
+        }
+        if (replay) r.commit = commit;
+    }
+
+    template <int... S> RG_HD void commit_phase(rg_seq<S...> seq) {
         if (acc == 0) return;
         const u64 commit0 = r.commit;
+        if (GC && (r.cfg & RG_CFG_GROUP_COMMIT)) {
+            commit_phase_gc(seq, commit0);
+            commit_tail(seq, commit0);
+            return;
+        }
         RgQuorum<P> qm;
         bool replay;
         {
@@ -1204,6 +1248,9 @@ template <int P, bool GC, int NXM, bool FUSED, typename IX, typename ES = RgNoEa
             (replay_slot<S>(qm, run, commit), ...);
             r.commit = commit;
         }
+        commit_tail(seq, commit0);
+    }
+    template <int... S> RG_HD void commit_tail(rg_seq<S...>, u64 commit0) {
         if (r.commit != commit0) {
             r.dirty |= RG_DIRTY_COMMIT;
             (self_committed<S>(), ...);

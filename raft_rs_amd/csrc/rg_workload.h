@@ -68,6 +68,11 @@ RG_HD RgWlGroup rg_wl_group(u64 seed, u32 workload_word, u32 n_slots, u64 gg) {
 // host's choice; contiguous classes are what lets ONE launch skip the peer slots a class does not have
 // (k_tick_classes). Returns the offset of local group g's global id from the shard's first id.
 #define RG_WL_SORTED_BIT 0x1000u
+// RG_WL_GC_BIT (bit 13 of the workload word; rg_workload.reserved bit 5, RG_WL_GROUP_COMMIT): the same stream with
+// ProgressTracker.group_commit on in every group (Raft::enable_group_commit, src/raft.rs:513-518) and every peer assigned to
+// one of three commit groups (assign_commit_groups, :531-544: ids 1..3 by hash -- availability zones; some replica sets end
+// up in two, a few in one), so that every commit evaluation is the group-commit form of majority.rs:99-123.
+#define RG_WL_GC_BIT 0x2000u
 RG_HD u64 rg_wl_place(u32 workload_word, u64 g, u64 G) {
     if (!(workload_word & RG_WL_SORTED_BIT)) return g;
     const u64 n0 = (G + 2) / 3, n1 = (G + 1) / 3;
@@ -139,7 +144,7 @@ RG_HD void rg_wl_init_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64
         next[o] = n;
         psnap[o] = 0;
         prs[o] = 0;
-        gid[o] = 0;
+        gid[o] = ((workload & RG_WL_GC_BIT) && p < w.n_peers) ? 1 + rg_hash(seed, 0, gg, 8 + p) % 3 : 0;
         pflags[g * 8 + p] = f;
     }
     for (u32 p = n_slots; p < 8; p++) pflags[g * 8 + p] = 0;
@@ -154,7 +159,7 @@ RG_HD void rg_wl_init_group(u64 seed, u32 workload, u32 n_slots, u64 stride, u64
     commit[g] = c;
     lo[g] = tlo;
     hi[g] = last;
-    cfg[g] = RG_CFG_MAKE(w.incoming, w.outgoing, 0, 0, 0, w.present);
+    cfg[g] = RG_CFG_MAKE(w.incoming, w.outgoing, 0, (workload & RG_WL_GC_BIT) != 0, 0, w.present);
 }
 
 // Messages of tick `tick` for group g, generated from the group's CURRENT state.

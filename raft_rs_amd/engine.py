@@ -883,13 +883,13 @@ class Engine:
         return {k: getattr(st, k) for k, _ in PublishStats._fields_}
 
     # ---- synthetic stream --------------------------------------------------------------------
-    def workload_init(self, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False):
-        w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
+    def workload_init(self, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False, group_commit=False):
+        w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0) | (WL_GROUP_COMMIT if group_commit else 0))
         self._check(self.L.rg_workload_init(self.h, C.byref(w), first_group))
 
     def workload_gen(self, workload, tick, m_index, m_commit, m_hint, m_rs, m_flags, seed=0x5EED5EED, first_group=0,
-                     fixed_peers=0, sorted_classes=False):
-        w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
+                     fixed_peers=0, sorted_classes=False, group_commit=False):
+        w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0) | (WL_GROUP_COMMIT if group_commit else 0))
         self._check(self.L.rg_workload_gen(self.h, C.byref(w), first_group, tick, _ptr(m_index), _ptr(m_commit),
                                            _ptr(m_hint), _ptr(m_rs), _ptr(m_flags)))
 
@@ -899,23 +899,24 @@ def _host_state_struct(st):
                       *[st[k].ctypes.data for k in COL.NAMES[:11]])
 
 
+WL_GROUP_COMMIT = 0x20  # rg_workload.reserved flag: group commit on, three commit groups (RG_WL_GROUP_COMMIT)
 WL_PLACE_SORTED = 0x10  # rg_workload.reserved flag: the groups of a shard placed by replica-set size class (RG_WL_PLACE_SORTED)
 
 
-def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False):
+def workload_init_host(st, workload, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False, group_commit=False):
     """Host twin of Engine.workload_init over numpy columns (no GPU)."""
     L = load_library()
-    w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
+    w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0) | (WL_GROUP_COMMIT if group_commit else 0))
     s = _host_state_struct(st)
     rc = L.rg_workload_init_host(C.byref(w), first_group, C.byref(s))
     if rc:
         raise EngineError(rc, L.rg_last_error().decode())
 
 
-def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False):
+def workload_gen_host(st, msgs, workload, tick, seed=0x5EED5EED, first_group=0, fixed_peers=0, sorted_classes=False, group_commit=False):
     """Host twin of Engine.workload_gen: messages of `tick` from the numpy state columns."""
     L = load_library()
-    w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0))
+    w = _Workload(seed, workload, fixed_peers | (WL_PLACE_SORTED if sorted_classes else 0) | (WL_GROUP_COMMIT if group_commit else 0))
     s = _host_state_struct(st)
     rc = L.rg_workload_gen_host(C.byref(w), first_group, tick, C.byref(s), msgs.m_index.ctypes.data,
                                 msgs.m_commit.ctypes.data, msgs.m_hint.ctypes.data, msgs.m_rs.ctypes.data,

@@ -23,11 +23,11 @@ TERM = 5  # RG_WL_TERM0 of the generator
 MSG_KEYS = ("m_index", "m_commit", "m_hint", "m_rs")
 
 
-def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_peers=0, variant=0, placed=False):
+def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_peers=0, variant=0, placed=False, group_commit=False):
     import torch
     threads = os.cpu_count() or 8
     eng = rg.Engine(n_groups, n_slots, variant=variant)
-    eng.workload_init(workload, first_group=first_group, fixed_peers=fixed_peers, sorted_classes=placed)
+    eng.workload_init(workload, first_group=first_group, fixed_peers=fixed_peers, sorted_classes=placed, group_commit=group_commit)
     if placed:  # three ranges, one launch per tick (k_tick_classes)
         assert [q for _, _, q in eng.size_classes()] == [3, 5, 7]
     st = eng.read_state()
@@ -40,7 +40,7 @@ def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_
     seen = {"changed": 0, "rejects": 0, "elections": 0, "valid": 0}
     for t in range(ticks):
         eng.workload_gen(workload, t, *[d.data_ptr() for d in dev], dflags.data_ptr(), first_group=first_group,
-                         fixed_peers=fixed_peers, sorted_classes=placed)
+                         fixed_peers=fixed_peers, sorted_classes=placed, group_commit=group_commit)
         eng.sync()
         for k, d in zip(MSG_KEYS, dev):
             msgs[k] = np.ascontiguousarray(d.cpu().numpy().view(np.uint64))
@@ -76,6 +76,25 @@ def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_
 def test_one_million_groups_match_the_oracle(rg, workload, n_slots, name):
     seen = _run_full_size(rg, workload, 1_000_000, n_slots, ticks=4)
     assert seen["changed"] > 2_500_000 and seen["valid"] > 4 * 1_000_000 * (n_slots - 1) * 0.9, (name, seen)
+
+
+@pytest.mark.parametrize("workload,n_slots,name", [(2, 5, "config 2"), (3, 5, "config 3"), (2, 7, "config 4 shard")])
+def test_one_million_groups_with_group_commit_match_the_oracle(rg, workload, n_slots, name):
+    """The same streams with ProgressTracker.group_commit on in every group and three commit groups over the peers
+    (RG_WL_GROUP_COMMIT; Raft::enable_group_commit + assign_commit_groups, src/raft.rs:513-544): every commit evaluation of
+    every group is the group-commit form (src/quorum/majority.rs:99-123; joint: min of the two, AND of the flags,
+    joint.rs:47-51) -- 1 M groups, every column and result word against the oracle. The kernels are the GC = true
+    instantiations (no scratch since round 6: tests/test_kernel_resources.py)."""
+    import raft_rs_amd as R
+    eng = R.Engine(1000, n_slots)
+    eng.workload_init(workload, group_commit=True)
+    st = eng.read_state()
+    eng.close()
+    used = st["cfg"][:1000]
+    assert ((used >> 19) & 1).all() and set(np.unique(st["gid"][:n_slots if workload == 2 else 4, :1000])) <= {1, 2, 3}
+    seen = _run_full_size(rg, workload, 1_000_000, n_slots, ticks=4, group_commit=True)
+    # (a commit now waits for the slowest commit group: fewer groups move per tick than under the plain quorum, most still do)
+    assert seen["changed"] > 1_000_000 and seen["valid"] > 4 * 1_000_000 * (n_slots - 1) * 0.9, (name, seen)
 
 
 def test_config5_one_engine_matches_the_oracle(rg):

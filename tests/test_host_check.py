@@ -206,12 +206,16 @@ def test_device_arithmetic_near_the_top_of_the_index_range(host_tick):
     assert (st["commit"] >= 2 ** 62).mean() > 0.5
 
 
+@pytest.mark.parametrize("gc", [False, True])
 @pytest.mark.parametrize("workload,n_slots", [(2, 5), (3, 5), (5, 7)])
-def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slots):
+def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slots, gc):
+    """(gc: the same streams with group commit on in every group and three commit groups over the peers, RG_WL_GROUP_COMMIT --
+    what the bench's group-commit figure and tests/test_full_size_gpu.py run at 1 M groups)"""
     from raft_rs_amd import engine as E
     G = 4000
     st = O.alloc_state(G, n_slots)
-    E.workload_init_host(st, workload)
+    E.workload_init_host(st, workload, group_commit=gc)
+    assert bool((st["cfg"] >> 19 & 1).all()) == gc and bool(st["gid"].any()) == gc
     cl = O.Cluster(G)
     cl.load_soa(st, term=6)
     eng_st = copy_state(st)
@@ -219,8 +223,8 @@ def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slo
     gout = np.zeros(G, dtype=np.uint32)
     out = np.zeros(G, dtype=np.uint32)
     for t in range(6):
-        E.workload_gen_host(st, mb, workload, t)
-        host_tick(eng_st, mb.as_dict(), out, False)
+        E.workload_gen_host(st, mb, workload, t, group_commit=gc)
+        host_tick(eng_st, mb.as_dict(), out, gc)
         cl.tick_soa(mb.as_dict(), gout)
         cl.store_soa(st)
         assert not fuzz.diff_states(st, eng_st, G, n_slots)

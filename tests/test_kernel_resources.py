@@ -122,6 +122,22 @@ def test_occupancy_of_the_other_slot_counts():
         assert int(cls7["VGPRs"]) <= vgprs and int(cls7["Occupancy [waves/SIMD]"]) >= waves and int(cls7["ScratchSize [bytes/lane]"]) == 0, (ntm, cls7)
 
 
+def test_group_commit_kernels_carry_no_scratch():
+    """Round 6: every GC = true instantiation (the kernels an engine launches once some group has ProgressTracker.group_commit
+    on) keeps the group in registers -- through round 5 the literal group-commit evaluation was a __noinline__ function taking
+    the match and gid arrays by reference, which put 400-512 B per lane into scratch in all of them. The dense 5-slot kernel
+    (what the bench's group-commit figure runs) holds three waves per SIMD."""
+    for p in (5, 7):
+        rows = resource_usage(p)
+        gc = {k: v for k, v in rows.items() if re.search(r"k_tick_(lane|list|send|compact)ILi%dELb1E" % p, k) or
+              re.search(r"k_tick_fusedILi%dELb1E" % p, k)}
+        assert len(gc) >= 6, sorted(gc)
+        for k, v in gc.items():
+            assert int(v["ScratchSize [bytes/lane]"]) == 0, (k, v)
+    lane = next(v for k, v in resource_usage(5).items() if "k_tick_laneILi5ELb1EjLi0EE" in k)
+    assert int(lane["VGPRs"]) <= 160 and int(lane["Occupancy [waves/SIMD]"]) >= 3, lane
+
+
 def test_streamed_stores_are_streamed():
     """The non-temporal bit of the stores the design streams is IN the ISA. Round 4 found it was not: rg_st took the choice as
     a run-time bool that was constant at every call site, and after inlining LLVM merged the two stores of the if/else into

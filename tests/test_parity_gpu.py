@@ -482,6 +482,84 @@ def test_fused_call_with_log_term_ticks_and_elections(rg, n_slots):
     eng.close()
 
 
+@pytest.mark.parametrize("n_slots", [3, 7])
+def test_fused_call_stops_behind_a_tick_that_leaves_a_reject_to_the_host(rg, n_slots):
+    """Exact or loud inside fused launches: histories that grow to 12+ runs (a full term-run table plus elections in every
+    tick), eight log-term ticks submitted as ONE rg_tick_device_fused call. The reference applies a reject before anything later
+    (raft_log.rs:209-235 -> raft.rs:1657-1660), so the call must END behind the first tick that leaves one to the host
+    (RG_ERR_HOST_HINT, rg_fused_ticks_done), with RG_COL_OUT / RG_COL_HOST_HINT that tick's; the host answers
+    (rg_resolve_host_hints against the oracle's complete log) and submits the rest. Every tick's result word and commit index
+    and the final state must be what the unfused sequence -- the oracle, tick by tick -- produces."""
+    import torch
+    import hosthints
+    from raft_rs_amd.engine import COL
+    rng = np.random.default_rng(9900 + n_slots)
+    G, TERM, T = 3000, 30, 8
+    st = O.add_term_table(O.alloc_state(G, n_slots))
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.03)
+    fuzz.random_state(rng, st, probe_frac=0.5, base=200)
+    fuzz.random_term_table(rng, st, TERM, min_runs=O.TERM_RUNS)
+    eng = rg.Engine(G, n_slots)
+    eng.load_state(st)
+    ahead, host = O.Cluster(G), O.Cluster(G)  # the oracle twice: one runs ahead to write the stream, one follows the engine
+    ahead.load_soa(st, term=TERM)
+    host.load_soa(st, term=TERM)
+    gout = np.zeros(G, dtype=np.uint32)
+    ticks, dev, want_out, want_commit = [], [], [], []
+    for t in range(T):
+        ahead.store_soa(st)
+        msgs = O.alloc_msgs(G, n_slots)
+        fuzz.random_msgs(rng, st, msgs, valid_p=0.8, reject_p=0.6, rs_p=0.05, sent_p=0.2, heartbeat_p=0.05, logterm_max=TERM + t,
+                         elect_p=0.5, elect_term=TERM + 1 + t)
+        hosthints.spread_reject_hints(rng, st, msgs, TERM + 1 + t)
+        ahead.tick_soa(msgs, gout)
+        ahead.store_soa(st)
+        ticks.append(msgs)
+        want_out.append(gout.copy())
+        want_commit.append(st["commit"].copy())
+        dev.append([torch.from_numpy(np.ascontiguousarray(msgs[k]).view(np.uint8 if k == "m_flags" else np.int64).copy()).cuda()
+                    for k in ("m_index", "m_commit", "m_hint", "m_rs", "m_flags", "m_logterm")])
+    assert max(len(hosthints.log_runs(ahead, g)[0]) for g in range(0, G, 37)) >= 12
+    out_t = torch.zeros((T, G), dtype=torch.int32, device="cuda")
+    commit_t = torch.zeros((T, G), dtype=torch.int64, device="cuda")
+    pos, calls, early_stops, settled = 0, 0, 0, 0
+    hgout = np.zeros(G, dtype=np.uint32)
+    while pos < T:
+        n = eng.tick_device_fused([[c.data_ptr() for c in tick] for tick in dev[pos:]], out_t[pos:].data_ptr(), commit_t[pos:].data_ptr())
+        calls += 1
+        assert 1 <= n <= T - pos and eng.fused_ticks_done() == n
+        eng.sync()
+        rows = out_t[pos:pos + n].cpu().numpy().view(np.uint32)
+        # only the LAST applied tick of a call may carry the bit -- and must, if the call ended early
+        assert not (rows[:-1] & hosthints.OUT_HOST_HINT).any()
+        if pos + n < T:
+            early_stops += 1
+            assert (rows[-1] & hosthints.OUT_HOST_HINT).any()
+        for k in range(n):
+            host.tick_soa(ticks[pos + k], hgout)
+        last = pos + n - 1
+        out = eng.read_column(COL.OUT)
+        assert (out == rows[-1]).all()  # RG_COL_OUT is the hinted (= last applied) tick's, not a later one's
+        hh = eng.read_column(COL.HOST_HINT)
+
+        def resolve(recs):
+            assert eng.resolve_host_hints(recs).all()
+            return eng.read_column(COL.OUT)
+
+        merged, k = hosthints.settle(host, ticks[last], out, hh, resolve=resolve)
+        settled += k
+        for t in range(pos, last):
+            assert (rows[t - pos] == want_out[t]).all(), t
+        assert (merged == want_out[last]).all(), (last, np.nonzero(merged != want_out[last])[0][:5])
+        ct = commit_t[pos:pos + n].cpu().numpy().view(np.uint64)
+        for t in range(pos, pos + n):
+            assert (ct[t - pos] == want_commit[t]).all(), t
+        pos += n
+    assert early_stops >= 2 and settled >= 20, (calls, early_stops, settled)
+    assert_same(eng, host, st, want_out[-1], f"fused call stopped by host hints P={n_slots}")
+    eng.close()
+
+
 @pytest.mark.parametrize("n_slots", [3, 8])
 def test_garbage_events_on_gpu(rg, n_slots):
     rng = np.random.default_rng(4321 + n_slots)
@@ -560,7 +638,9 @@ def test_bench_two_ranks_sharing_the_gpu(rg, tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0
-    assert d["config"]["groups_per_gpu"] == 60000 and "published every 4 tick(s)" in d["config"]["sharding"] and d["config"]["publication"]["publications"] > 0
+    assert d["config"]["groups_per_gpu"] == 60000 and "published every 4 tick(s)" in d["config"]["sharding"] and d["config"]["pub_publications"] > 0
+    assert d["config"]["transport"] == "callback" and d["config"]["rccl_engines"] == 0  # (two ranks on one GPU: gloo moves the slices, and the line says so)
+    assert len(line) <= 6000
 
 
 def test_device_info_is_queried_not_assumed(rg):

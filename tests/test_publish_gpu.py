@@ -24,6 +24,17 @@ def _device_msgs(torch, eng, n_slots):
     return cols, flags
 
 
+def test_comm_warmup_and_the_census_of_an_engine_without_a_communicator(rg):
+    """rg_comm_warmup loads RCCL and runs a one-rank communicator through its life (a host calls it at start-up, before any step
+    a timeout bounds); an engine without a communicator reports transport "none" and no RCCL ranks."""
+    from raft_rs_amd import engine as E
+    E.comm_warmup()
+    E.comm_warmup()  # (idempotent: the second call finds the library mapped)
+    eng = rg.Engine(1000, 3)
+    assert eng.comm_info() == {"rank": 0, "world": 0, "transport": "none", "in_process": False, "rccl_ranks": 0, "rccl_rank": 0}
+    eng.close()
+
+
 @pytest.mark.parametrize("workload,n_slots", [(2, 5), (5, 7)])
 def test_rccl_world1_replica_follows_every_tick(rg, workload, n_slots):
     """ncclAllGather at world size 1: after every tick the replica equals the commit column; the slice is ~1 B/group."""
@@ -44,6 +55,9 @@ def test_rccl_world1_replica_follows_every_tick(rg, workload, n_slots):
     st = eng.publish_stats()
     assert st["publications"] == 12 and st["full_publications"] == 1
     assert st["bytes_per_rank_delta"] < 1.1 * G + 4096 and st["bytes_per_rank_full"] >= 8 * G
+    # what the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what the engine was told
+    ci = eng.comm_info()
+    assert ci == {"rank": 0, "world": 1, "transport": "rccl", "in_process": False, "rccl_ranks": 1, "rccl_rank": 0}
     ptr, stride = eng.published_commit_ptr()
     assert ptr and stride >= G
     eng.comm_destroy()
@@ -387,12 +401,19 @@ def test_bench_line_of_eight_ranks_sharing_the_gpu(rg):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 8 and line["steps"] == 6 and line["scaling"] == "weak" and line["unit"] == "group-evals/s"
     assert line["value"] == pytest.approx(8 * 131072 * 6 / (line["ms_per_step"] * 6 / 1e3), rel=1e-6)
+    assert len(r.stdout.encode()) <= 6000  # (what the driver's record keeps of a run's stdout holds the whole line)
     cfg = line["config"]
     assert "configs[3]" in cfg["workload"] and "sharded over 8 GPUs" in cfg["workload"] and cfg["peer_slots"] == 7
-    pub = cfg["publication"]
-    assert pub["publications"] >= 6 + 2 and pub["bytes_per_rank_delta"] < 1.1 * 131072 + 4096 <= pub["bytes_per_rank_full"]
-    assert cfg["publication_mode"].startswith("delta") and cfg["publication_compare"]["mode"].startswith("raw")
-    assert cfg["publication_compare"]["bytes_per_rank_per_publication"] == pub["bytes_per_rank_full"]
+    assert not any(isinstance(v, (dict, list)) for v in cfg.values())  # scalars only; the nested statistics are in `full`
+    assert cfg["pub_publications"] >= 6 + 2 and cfg["pub_bytes_per_rank_delta"] < 1.1 * 131072 + 4096 <= cfg["pub_bytes_per_rank_full"]
+    assert cfg["publication_mode"].startswith("delta") and cfg["pub_compare_mode"].startswith("raw") and cfg["pub_compare_value"] > 0
+    # the census of the exchange: eight ranks sharing ONE GPU cannot be RCCL ranks (RCCL refuses two ranks on a device) and the
+    # line says so -- on an 8-GPU node the same keys read transport "rccl", rccl_ranks 8, rccl_distinct_ranks 8
+    assert cfg["transport"] == "callback" and cfg["rccl_ranks"] == 0 and cfg["rccl_engines"] == 0 and cfg["rccl_distinct_ranks"] == 0
+    full = json.load(open(os.path.join(ROOT, line["full"])))
+    pub = full["config"]["publication"]
+    assert pub["publications"] == cfg["pub_publications"]
+    assert full["config"]["publication_compare"]["bytes_per_rank_per_publication"] == pub["bytes_per_rank_full"]
     assert line["roofline"]["regime"] in ("infinity-cache", "hbm") and line["cpu_baseline"] is None
 
 
@@ -412,13 +433,14 @@ def test_bench_starts_its_own_ranks_with_strong_scaling_and_an_automatic_cadence
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["groups_per_gpu"] == 131072
     assert line["value"] == pytest.approx(262144 * 6 / (line["ms_per_step"] * 6 / 1e3), rel=1e-6)
-    auto = line["config"]["publish_every_auto"]
-    assert 1 <= auto["publish_every"] <= 32 and auto["publish_every"] == line["config"]["publish_every"]
-    assert auto["tick_us"] > 0 and auto["exchange_us"] > 0
+    cfg = line["config"]
+    E_, tick_us, exchange_us = cfg["publish_every"], cfg["publish_auto_tick_us"], cfg["publish_auto_exchange_us"]
+    assert 1 <= E_ <= 32 and tick_us > 0 and exchange_us > 0
     # (through the host transport an exchange is far slower than a tick: the rule must have picked a cadence above 1)
-    assert abs(auto["publish_every"] - min(32, int(np.ceil(auto["exchange_us"] / auto["tick_us"])))) <= 1  # (the note rounds to 0.01 us)
-    pub = line["config"]["publication"]
-    assert pub["publications"] >= 1 + 6 // auto["publish_every"]
+    assert abs(E_ - min(32, int(np.ceil(exchange_us / tick_us)))) <= 1  # (the note rounds to 0.01 us)
+    assert cfg["pub_publications"] >= 1 + 6 // E_
+    full = json.load(open(os.path.join(ROOT, line["full"])))
+    assert full["config"]["publish_every_auto"]["publish_every"] == E_
     # an uneven split is refused, loudly
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-groups", "262145", "--steps", "2",
                           "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
@@ -459,6 +481,8 @@ def test_three_engines_one_thread_publish_together(rg, workload, n_slots):
     for r, e in enumerate(engs):
         e.workload_init(workload, first_group=r * n)
     E.comm_init_all(engs, ring_ticks=4)
+    assert [e.comm_info() for e in engs] == [{"rank": r, "world": 3, "transport": "local", "in_process": True, "rccl_ranks": 0,
+                                              "rccl_rank": 0} for r in range(3)]
     with pytest.raises(rg.EngineError) as ei:
         engs[1].publish_commit()
     assert ei.value.code == E.ERR["STATE"] and "rg_publish_commit_all" in str(ei.value)
