@@ -213,8 +213,9 @@ def test_device_arithmetic_on_host_runs_the_workloads(host_tick, workload, n_slo
     what the bench's group-commit figure and tests/test_full_size_gpu.py run at 1 M groups)"""
     from raft_rs_amd import engine as E
     G = 4000
-    st = O.alloc_state(G, n_slots)
+    st = O.add_term_table(O.alloc_state(G, n_slots))  # (its own term columns: config 5's elections write them)
     E.workload_init_host(st, workload, group_commit=gc)
+    st["cur_term"][:] = 6
     assert bool((st["cfg"] >> 19 & 1).all()) == gc and bool(st["gid"].any()) == gc
     cl = O.Cluster(G)
     cl.load_soa(st, term=6)
