@@ -636,8 +636,8 @@ def _short(v, digits=6, text=160):
     return None
 
 
-def _scalars(obj, text=160, skip=()):
-    return {k: _short(v, text=text) for k, v in (obj or {}).items()
+def _scalars(obj, text=160, skip=(), digits=6):
+    return {k: _short(v, digits=digits, text=text) for k, v in (obj or {}).items()
             if k not in skip and (v is None or isinstance(v, (bool, int, float, str)))}
 
 
@@ -647,7 +647,7 @@ def compact_line(result):
     `roofline`), nothing nested below them, at most LINE_LIMIT bytes. Everything else the run measured (other_configs,
     out_of_cache, between_regimes, recompute_only*, small_batch_latency, by_config, fused_model, the publication statistics)
     goes to FULL_RESULT and to stderr -- the name of that file is the line's `full` key."""
-    line = _scalars(result, skip=("full",))
+    line = _scalars(result, skip=("full",), digits=12)  # (value / ms_per_step: the contract's own numbers keep their digits)
     line["full"] = FULL_RESULT
     cfg_in = result.get("config") or {}
     cfg = _scalars(cfg_in, text=220)

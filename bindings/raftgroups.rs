@@ -78,6 +78,7 @@ pub const RG_WL_MAJORITY: u32 = 2;
 pub const RG_WL_JOINT: u32 = 3;
 pub const RG_WL_MIXED: u32 = 5;
 pub const RG_WL_PLACE_SORTED: u32 = 0x10;
+pub const RG_WL_GROUP_COMMIT: u32 = 0x20;
 
 // rg_status
 pub const RG_OK: i32 = 0;
@@ -416,6 +417,8 @@ extern "C" {
     pub fn rg_progress_events(h: *mut RgEngine, events: *const RgProgressEvent, n: u64) -> i32;
     pub fn rg_progress_event_dense(h: *mut RgEngine, kind: u32, host_slot_plus1: *const u8) -> i32;
     pub fn rg_size_classes(h: *mut RgEngine, out: *mut RgSizeClass, cap: u32, n: *mut u32) -> i32;
+    pub fn rg_plan_placement(cfg_words: *const u32, n_groups: u64, n_slots: u32, perm: *mut u64, classes: *mut RgSizeClass, cap: u32, n_classes: *mut u32) -> i32;
+    pub fn rg_permute_groups(h: *mut RgEngine, host_perm: *const u64) -> i32;
     pub fn rg_tick(h: *mut RgEngine, host_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device(h: *mut RgEngine, dev_msgs: *const RgMsgs) -> i32;
     pub fn rg_tick_device_fused(h: *mut RgEngine, dev_msgs: *const RgMsgs, n_ticks: u32, dev_out_t: *mut u32, dev_commit_t: *mut u64) -> i32;

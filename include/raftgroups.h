@@ -394,6 +394,32 @@ typedef struct {
 } rg_size_class;
 int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, uint32_t *n);
 
+/* ---- placement: getting a shard INTO that layout ----
+ * Membership is the host's to change at any time (ProgressTracker::apply_conf, src/tracker.rs:380-397 over the voter sets of
+ * src/tracker.rs:37-92), and groups arrive in whatever order the host learns of them: a shard whose replica-set sizes are
+ * interleaved runs the plain kernel and moves the cells of absent peers with everything else (config 5 interleaved: 1.47 x the
+ * algorithmic bytes, 0.41 of the roofline against 0.55 placed). Two calls fix the layout:
+ *   rg_plan_placement   pure host arithmetic (no engine, no device): from the groups' cfg words, the permutation that places
+ *                       them by size class -- the bodies k_tick_classes has: 3, 5, 7 slots below n_slots, and n_slots --
+ *                       ascending, STABLE inside a class; perm[i] = the current position of the group that goes to position i.
+ *                       `classes` (capacity `cap`, may be NULL with cap = 0) receives the ranges the engine will derive from
+ *                       the permuted column, *n_classes their number (may exceed cap); a block of 64 groups that straddles a
+ *                       boundary belongs to the larger class.
+ *   rg_permute_groups   the device gather: EVERY column of the engine follows the permutation -- Progress cells, flag rows,
+ *                       log ranges, term-run tables, result words and host-hint bytes, the Inflights windows and rings, the
+ *                       entry-size windows -- and so do the host mirror's peer-id / term tables. Afterwards group i of every call
+ *                       is the group that was at host_perm[i]; the next dense tick derives the size classes of the new layout.
+ *                       Control path (synchronises; needs the state's size in free device memory once more while it runs).
+ *                       Before the call: flush queued steps (RG_ERR_SLOT_BUSY), tick ingested records (RG_ERR_STATE), answer
+ *                       host hints, and fetch the last stage's work items (their `group` fields name the old positions).
+ *                       A checkpoint taken earlier is dropped (it images the old placement); with commit publication active
+ *                       the rank's slice is marked lost, so the next check point publishes a full snapshot (as rg_restore).
+ * Re-placing pays when conf changes have accumulated: a group that grew past its range's class costs only its own block of
+ * 64 the shortcut (see above), so a host re-plans when rg_size_classes shows the ranges fraying, not per change. */
+int rg_plan_placement(const uint32_t *cfg_words, uint64_t n_groups, uint32_t n_slots, uint64_t *perm, rg_size_class *classes,
+                      uint32_t cap, uint32_t *n_classes);
+int rg_permute_groups(rg_engine *h, const uint64_t *host_perm);
+
 /* ---- the hot path ---- */
 /* One tick: for every group, apply its <=1 message per slot in slot order exactly as
  * handle_append_response would (commit re-evaluated after every accepted ack), update state in

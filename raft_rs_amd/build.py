@@ -4,7 +4,7 @@
 
 hipcc cross-compiles without a GPU. The tick kernels are instantiated once per slot count
 (csrc/tick_inst.hip, -DRG_P=1..8) and compiled in parallel with the ABI units (csrc/abi_*.hip: state / tick /
-send / mirror / wire / publish, along the sections of include/raftgroups.h), then linked. Everything is built with
+send / mirror / wire / publish / placement, along the sections of include/raftgroups.h), then linked. Everything is built with
 -fvisibility=hidden: the exported symbols are exactly the entry points the public header declares.
 The .so is git-ignored but travels with gpurun snapshots.
 """
@@ -18,10 +18,10 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libraftgroups.so")
-UNITS = ["abi_state.hip", "abi_tick.hip", "abi_send.hip", "abi_mirror.hip", "abi_wire.hip", "abi_publish.hip"]
+UNITS = ["abi_state.hip", "abi_tick.hip", "abi_send.hip", "abi_mirror.hip", "abi_wire.hip", "abi_publish.hip", "abi_placement.hip"]
 DEPS = UNITS + ["tick_inst.hip", "rg_engine.h", "rg_common.h", "rg_group.h", "rg_send.h", "rg_wire.h", "rg_workload.h", "rg_tick_kernels.h",
                 "rg_publish.h", "rg_kernels_quorum.h", "rg_kernels_sparse.h", "rg_kernels_send.h", "rg_kernels_state.h",
-                "rg_kernels_workload.h", "rg_kernels_publish.h", os.path.join("..", "..", "include", "raftgroups.h")]
+                "rg_kernels_workload.h", "rg_kernels_publish.h", "rg_kernels_placement.h", os.path.join("..", "..", "include", "raftgroups.h")]
 ARCH = "gfx950"
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
           "-Wno-pass-failed"]

@@ -258,6 +258,8 @@ SYMBOLS = {
     "rg_heartbeat_commits": (_i, [_vp, _vp, _vp]),
     "rg_step_heartbeat_response": (_i, [_vp, _u64, _u64, _u64, _u64, C.c_uint8]),
     "rg_result_counts": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rg_plan_placement": (_i, [_vp, _u64, C.c_uint32, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rg_permute_groups": (_i, [_vp, _vp]),
     "rg_size_classes": (_i, [_vp, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rg_host_hints": (_i, [_vp, C.c_void_p, _u64, C.POINTER(_u64)]),
     "rg_resolve_host_hints": (_i, [_vp, C.c_void_p, _u64, C.c_void_p]),
@@ -756,6 +758,19 @@ class Engine:
             self._check(self.L.rg_size_classes(self.h, out.ctypes.data, len(out), C.byref(n)))
         return [(int(r["first_group"]), int(r["n_groups"]), int(r["n_slots"])) for r in out[:n.value]]
 
+    def permute_groups(self, perm):
+        """rg_permute_groups: group i becomes the group that was at perm[i] -- every column, the Inflights, the mirror's tables."""
+        perm = np.ascontiguousarray(perm, dtype=np.uint64)
+        assert perm.shape == (self.n_groups,)
+        self._check(self.L.rg_permute_groups(self.h, perm.ctypes.data))
+
+    def place_by_size_class(self):
+        """Plan from the engine's own cfg column (rg_plan_placement) and permute: a shard loaded with its replica-set sizes
+        interleaved becomes the layout the one-launch class kernel runs. Returns (perm, the planned ranges)."""
+        perm, classes = plan_placement(self.read_column(COL.CFG), self.n_slots)
+        self.permute_groups(perm)
+        return perm, classes
+
     def host_hints(self):
         """Groups whose last tick raised RG_OUT_HOST_HINT -> HOST_HINT_DTYPE array (group, slot_mask)."""
         n = _u64(0)
@@ -948,6 +963,21 @@ def publish_commit_all(engines, full=False):
     L = engines[0].L
     arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
     engines[0]._check(L.rg_publish_commit_all(arr, len(engines), PUBLISH_FULL if full else 0))
+
+
+def plan_placement(cfg_words, n_slots):
+    """rg_plan_placement (pure host arithmetic): -> (perm u64[G] with perm[i] = current position of the group that goes to
+    position i, [(first_group, n_groups, n_slots)] = the ranges the engine will derive from the permuted column)."""
+    L = load_library()
+    cfg = np.ascontiguousarray(cfg_words, dtype=np.uint32)
+    perm = np.zeros(len(cfg), dtype=np.uint64)
+    dt = np.dtype([("first_group", "<u8"), ("n_groups", "<u8"), ("n_slots", "<u4"), ("reserved", "<u4")])
+    out = np.zeros(16, dtype=dt)
+    n = C.c_uint32(0)
+    rc = L.rg_plan_placement(cfg.ctypes.data, len(cfg), n_slots, perm.ctypes.data, out.ctypes.data, len(out), C.byref(n))
+    if rc:
+        raise EngineError(rc, L.rg_last_error().decode())
+    return perm, [(int(r["first_group"]), int(r["n_groups"]), int(r["n_slots"])) for r in out[:min(n.value, len(out))]]
 
 
 def comm_warmup():
