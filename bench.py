@@ -319,7 +319,8 @@ SIDE_REPEATS = 3  # timed regions per side measurement (median reported, min / m
 
 
 def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what="tick", variant=0, one_engine=False,
-               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS, cfg_flags=0, group_commit=False):
+               inflights=0, fused_send=False, sorted_classes=False, repeats=SIDE_REPEATS, cfg_flags=0, group_commit=False,
+               place_after_load=False):
     """A complete, self-contained measurement of one configuration on one GPU, for the bench line's sub-objects (the
     headline has its own region in main(), with the multi-GPU plumbing): engines are created, the W+K ticks of the
     synthetic stream are generated on the device from the evolving state and recorded, the state is restored from a
@@ -350,8 +351,14 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt.fixed = slots if (workload == 5 and not one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights, flags=cfg_flags)
         pt.eng.set_stream(main_stream.cuda_stream)
-        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=sorted_classes,
-                             group_commit=group_commit)
+        pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed,
+                             sorted_classes=sorted_classes and not place_after_load, group_commit=group_commit)
+        if place_after_load:
+            # the shard arrives with its sizes interleaved (id order) and is re-placed on the device: rg_plan_placement from its
+            # own cfg column, rg_permute_groups -- after which it IS the class-placed shard (same groups at the same positions)
+            t_p = time.perf_counter()
+            pt.eng.place_by_size_class()
+            pt.place_ms = (time.perf_counter() - t_p) * 1e3
         first += n
         parts.append(pt)
     classes = parts[0].eng.size_classes() if sorted_classes else None
@@ -534,6 +541,9 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
              f"rg_recompute (Raft::maybe_commit, no messages) over {n_groups} groups x {n_slots} peers")
     if group_commit:
         label += " + group commit in every group, three commit groups over the peers (majority.rs:99-123)"
+    if place_after_load:
+        label = label.replace("placed by size class", "LOADED INTERLEAVED, then placed by size class on the device (rg_plan_placement + rg_permute_groups)")
+        extra["placement_ms"] = round(parts[0].place_ms, 2)
     if inflights:
         label += (f" + Inflights (cap {inflights}) on the device and the send stage after every tick, " +
                   ("tick and stage as ONE launch (rg_tick_device_send)" if fused_send else "as a launch of its own (rg_send_appends)"))
@@ -793,6 +803,8 @@ def main():
     ap.add_argument("--sorted", action="store_true",
                     help="config 5: ONE 7-slot engine with the groups placed by replica-set size class (one launch per tick, "
                          "k_tick_classes) -- what --workload 5 runs unless --one-engine / --size-class-engines says otherwise")
+    ap.add_argument("--c5-sizes", default=None,
+                    help="--workload 5 --size-class-engines: the engines as slots:groups,... instead of 3 / 5 / 7 x G/3 (experiment)")
     ap.add_argument("--size-class-engines", action="store_true",
                     help="config 5: one engine per replica-set size (three launches per tick on three streams)")
     ap.add_argument("--inflights", type=int, default=0,
@@ -804,6 +816,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the recompute_only and out_of_cache sub-measurements (N=1 only; they run after the "
                          "timed region and do not touch `value`)")
+    ap.add_argument("--place-after-load", action="store_true",
+                    help="--side tick --workload 5 --sorted: load the shard interleaved, then rg_plan_placement + rg_permute_groups")
     ap.add_argument("--group-commit", action="store_true",
                     help="--side tick: ProgressTracker.group_commit on in every group, three commit groups over the peers (RG_WL_GROUP_COMMIT)")
     ap.add_argument("--side", default=None, choices=["recompute", "tick"],
@@ -893,7 +907,7 @@ def main():
         emit(run_config(rg, torch, G, P, args.workload, W, K, args.seed, what=args.side, variant=args.variant,
                         one_engine=args.one_engine, inflights=args.inflights, fused_send=args.fused_send,
                         sorted_classes=args.sorted, repeats=max(1, args.repeats), cfg_flags=args.cfg_flags,
-                        group_commit=args.group_commit), whole=True)
+                        group_commit=args.group_commit, place_after_load=args.place_after_load), whole=True)
         return
     # An explicit (non-default) stream for the engines: on the legacy NULL stream every launch orders itself against the
     # other streams of the process, which serialises the publication's side stream with the ticks
@@ -907,6 +921,8 @@ def main():
     # --one-engine keeps the mixed population interleaved in one P-slot engine for comparison.
     if args.workload == 5 and not args.one_engine:
         sizes = [(3, G // 3), (5, G // 3), (7, G - 2 * (G // 3))]
+        if args.c5_sizes:  # experiment: other replica-set sizes per engine, "slots:groups,..." (profiles/r06_c5_lane_pair.txt)
+            sizes = [tuple(int(x) for x in part.split(":")) for part in args.c5_sizes.split(",")]
     else:
         sizes = [(P, G)]
     if args.split > 1:
@@ -1325,6 +1341,8 @@ def main():
                          ("configs[1] group commit", dict(n_groups=1_000_000, n_slots=5, workload=2, group_commit=True)),
                          ("configs[3] one rank's shard", dict(n_groups=1_000_000, n_slots=7, workload=2)),
                          ("configs[4] one launch, class-sorted", dict(n_groups=1_000_000, n_slots=7, workload=5, sorted_classes=True)),
+                         ("configs[4] interleaved, after rg_permute_groups", dict(n_groups=1_000_000, n_slots=7, workload=5, sorted_classes=True,
+                                                                                  place_after_load=True)),
                          ("configs[4] one launch, class-sorted, 8M groups", dict(n_groups=8_000_000, n_slots=7, workload=5, sorted_classes=True,
                                                                                  warmup=3, steps=10)),
                          ("configs[4] size-class engines", dict(n_groups=1_000_000, n_slots=7, workload=5, variant=c5v)),

@@ -23,11 +23,16 @@ TERM = 5  # RG_WL_TERM0 of the generator
 MSG_KEYS = ("m_index", "m_commit", "m_hint", "m_rs")
 
 
-def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_peers=0, variant=0, placed=False, group_commit=False):
+def _run_full_size(rg, workload, n_groups, n_slots, ticks, first_group=0, fixed_peers=0, variant=0, placed=False, group_commit=False,
+                   place_after_load=False):
     import torch
     threads = os.cpu_count() or 8
     eng = rg.Engine(n_groups, n_slots, variant=variant)
-    eng.workload_init(workload, first_group=first_group, fixed_peers=fixed_peers, sorted_classes=placed, group_commit=group_commit)
+    eng.workload_init(workload, first_group=first_group, fixed_peers=fixed_peers, sorted_classes=placed and not place_after_load,
+                      group_commit=group_commit)
+    if place_after_load:  # loaded in id order (sizes interleaved), then re-placed on the device: rg_plan_placement + rg_permute_groups
+        assert placed and eng.size_classes() == []
+        eng.place_by_size_class()
     if placed:  # three ranges, one launch per tick (k_tick_classes)
         assert [q for _, _, q in eng.size_classes()] == [3, 5, 7]
     st = eng.read_state()
@@ -108,6 +113,15 @@ def test_config5_placed_by_size_class_one_launch_matches_the_oracle(rg):
     one launch per tick whose blocks run the tick instantiated for 3, 5 or 7 slots (k_tick_classes): every group, every
     column, five ticks of the rollover stream."""
     seen = _run_full_size(rg, 5, 1_000_000, 7, ticks=5, placed=True)
+    assert seen["elections"] > 5 * 1_000_000 / 32 * 0.9 and seen["rejects"] > 300_000, seen
+
+
+def test_config5_loaded_interleaved_then_placed_matches_the_oracle(rg):
+    """What a real host does: the 1 M groups arrive in id order (sizes interleaved), rg_plan_placement + rg_permute_groups
+    re-place them by size class on the device, and from then on the shard runs the one-launch class kernel -- every group, every
+    column, five ticks of the rollover stream against the oracle (whose state is the engine's after the permutation: the gather
+    itself is checked column by column in tests/test_placement_gpu.py)."""
+    seen = _run_full_size(rg, 5, 1_000_000, 7, ticks=5, placed=True, place_after_load=True)
     assert seen["elections"] > 5 * 1_000_000 / 32 * 0.9 and seen["rejects"] > 300_000, seen
 
 
