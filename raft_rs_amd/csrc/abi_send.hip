@@ -300,14 +300,24 @@ extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *ho
     }
     if (meta) RG_HIP(hipMemcpyAsync(meta, h->ins.meta, cells * 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
-    if (host_ring)
+    // to the outside every window is a ring: start < cap, the entries oldest first from there. A compact window (rg_send.h:
+    // up to four entries held as distances in the columns, start == RG_INS_COMPACT) is written out at start = 0.
+    if (meta)
         for (u32 p = 0; p < h->P; p++)
             for (u64 g = 0; g < h->G; g++) {
-                const u32 m = meta[(u64)p * h->stride + g], start = m & 0xffffu, count = m >> 16;
-                if (!count) continue;
+                const u64 o = (u64)p * h->stride + g;
+                const u32 m = meta[o], start = m & 0xffffu, count = m >> 16;
+                if (start == RG_INS_COMPACT) meta[o] = count << 16;
+                if (!count || !host_ring) continue;
                 u64 *cell = host_ring + (g * h->P + p) * h->ins.cap;
-                cell[start] = head[(u64)p * h->stride + g];
-                cell[(start + count - 1) % h->ins.cap] = tail[(u64)p * h->stride + g];
+                if (start == RG_INS_COMPACT) {
+                    u64 e[4];
+                    rg_ins_compact_entries(head[o], tail[o], e);
+                    for (u32 i = 0; i < count && i < 4; i++) cell[i] = e[count - 1 - i];
+                } else {
+                    cell[start] = head[o];
+                    cell[(start + count - 1) % h->ins.cap] = tail[o];
+                }
             }
     return RG_OK;
 }
@@ -317,6 +327,7 @@ extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const 
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_load_inflights: engine created with max_inflight = 0");
     const u64 cells = (u64)h->P * h->stride;
     std::vector<u64> head(cells, 0), tail(cells, 0);
+    std::vector<u32> meta_in(host_meta, host_meta + cells); // (windows that fit the columns are loaded compact: rg_send.h)
     for (u32 p = 0; p < h->P; p++)
         for (u64 g = 0; g < h->G; g++) { // start < cap, count <= cap for every cell
             const u64 o = (u64)p * h->stride + g;
@@ -332,13 +343,26 @@ extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const 
                     return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: group %llu slot %u: inflights must be strictly "
                                                        "increasing, oldest first", (unsigned long long)g, p);
             tail[o] = cell[(start + count - 1) % h->ins.cap];
+            if (count <= RG_INS_COMPACT_MAX) { // up to four entries whose distances fit 21 bits: the columns hold them all
+                u64 hd = 0;
+                bool fits = true;
+                for (u32 i = 1; i < count; i++) { // d_i = e[i - 1] - e[i], newest first
+                    const u64 d = cell[(start + count - i) % h->ins.cap] - cell[(start + count - 1 - i) % h->ins.cap];
+                    fits = fits && d <= RG_INS_DMASK;
+                    hd |= (d & RG_INS_DMASK) << (RG_INS_DBITS * (i - 1));
+                }
+                if (fits) {
+                    head[o] = hd;
+                    meta_in[o] = RG_INS_COMPACT | (count << 16);
+                }
+            }
         }
     RG_ENTER(h);
     {   // (the loaded windows replace the tail column RG_SEND_LAST_IS_TAIL items of the last dense stage point at)
         const int mrc = rg_send_materialize(h);
         if (mrc) return mrc;
     }
-    RG_HIP(hipMemcpyAsync(h->ins.meta, host_meta, cells * 4, hipMemcpyHostToDevice, h->stream));
+    RG_HIP(hipMemcpyAsync(h->ins.meta, meta_in.data(), cells * 4, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.head, head.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.tail, tail.data(), cells * 8, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync(h->ins.ring, host_ring, rg_inflights_bytes(h, 1), hipMemcpyHostToDevice, h->stream));

@@ -26,15 +26,21 @@
 #endif
 
 struct RgIns {
-    u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31)
-    u64 *head; // [P][stride]: the OLDEST inflight, Inflights.buffer[start]
+    u32 *meta; // [P][stride]: Inflights.start (bits 0-15) | Inflights.count (bits 16-31); start == RG_INS_COMPACT: a COMPACT window
+    u64 *head; // [P][stride]: ring mode: the OLDEST inflight, Inflights.buffer[start]; compact mode: the window's deltas (below)
     u64 *tail; // [P][stride]: the NEWEST inflight, Inflights.buffer[start + count - 1]
-               // These two peer-major columns (coalesced across a wave) are the authoritative copies of those two
-               // entries; the ring's own words for them may be stale. Entries are the last indices of consecutive
-               // MsgAppends, strictly increasing, so a window of <= 2 messages lives entirely in the columns (87 % of
-               // the windows of the bench stream), `to >= tail` frees a whole window unread, and the ring is only
-               // touched for the MIDDLE entries of windows of three and more.
-    u64 *ring; // [(g * P + slot) * cap + i]: Inflights.buffer of that Progress, contiguous per cell
+               // These peer-major columns (coalesced across a wave) are the authoritative copies of those entries; the ring's
+               // own words for them may be stale. Entries are the last indices of consecutive MsgAppends, strictly increasing.
+               // COMPACT windows (round 6): up to RG_INS_COMPACT_MAX = 4 entries whose distances fit 21 bits live ENTIRELY in
+               // the columns -- newest first t0 = tail, t1 = t0 - d1, t2 = t1 - d2, t3 = t2 - d3, with d1 | d2 << 21 | d3 << 42
+               // in the `head` cell -- and never touch the ring. Every window starts compact (the first add of an empty one)
+               // and becomes a ring window when a fifth message or a distance of 2 M entries arrives; a ring window that a
+               // free leaves with at most two entries becomes compact again. Through round 5 only windows of <= 2 messages
+               // stayed out of the ring: the third message cost a scattered 8-byte store (a 64-byte line of HBM traffic each,
+               // ~70 MB per step at 1 M x 5) and a partial free of a deeper window walked the ring with dependent loads, lane
+               // by lane -- with the ring accesses knocked out the one-launch step ran 28 % faster (profiles/r06_send_windows.txt).
+    u64 *ring; // [(g * P + slot) * cap + i]: Inflights.buffer of that Progress, contiguous per cell; ring windows only, and of
+               // those only the MIDDLE entries (positions start + 1 .. start + count - 2)
     u32 cap;   // Inflights::cap()
     // Byte-accurate Config::max_size_per_msg (rg_log_sizes_enable; nullptr = off): per group a ring of the cumulative
     // Entry::compute_size() of its last `esz_w` log entries, esz[g * esz_w + (index & (esz_w - 1))] = bytes of all
@@ -129,10 +135,62 @@ template <int P> RG_HD u32 rg_send_nk(const RgSendRegs<P> &it, int s) {
     return it.n[s] ? (it.n[s] | (RG_SEND_APPEND << 16)) : 0u;
 }
 
-// Inflights::free_to (inflights.rs:84-110) over (head, middle entries in the ring, tail).
+#define RG_INS_COMPACT 0xffffu      /* Inflights.start of a compact window (cap <= 65535: never a ring position) */
+#ifndef RG_INS_COMPACT_MAX
+#define RG_INS_COMPACT_MAX 4u      /* entries a compact window holds (2 = what rounds 1-5 kept out of the ring: the A/B build) */
+#endif
+#define RG_INS_DBITS 21
+#define RG_INS_DMASK ((1ULL << RG_INS_DBITS) - 1ULL)
+
+// The entries of a compact window, newest first (e[0] = tail); entries beyond `count` are meaningless
+RG_HD void rg_ins_compact_entries(u64 hd, u64 tail, u64 (&e)[4]) {
+    e[0] = tail;
+    e[1] = e[0] - (hd & RG_INS_DMASK);
+    e[2] = e[1] - ((hd >> RG_INS_DBITS) & RG_INS_DMASK);
+    e[3] = e[2] - ((hd >> (2 * RG_INS_DBITS)) & RG_INS_DMASK);
+}
+// ... with only the newest `keep` of them left: the distances behind the survivors are dropped (canonical form)
+RG_HD u64 rg_ins_compact_keep(u64 hd, u32 keep) {
+    return keep >= 4u ? hd : keep == 3u ? (hd & ((1ULL << (2 * RG_INS_DBITS)) - 1ULL)) : keep == 2u ? (hd & RG_INS_DMASK) : 0ULL;
+}
+// The OLDEST inflight of a window (Inflights.buffer[start])
+RG_HD u64 rg_ins_oldest(u32 start, u32 count, u64 hd, u64 tail) {
+    if (start != RG_INS_COMPACT) return hd;
+    u64 e[4];
+    rg_ins_compact_entries(hd, tail, e);
+    return count >= 4u ? e[3] : count == 3u ? e[2] : count == 2u ? e[1] : e[0];
+}
+// A ring window that holds at most two entries goes back to the columns (no ring word is read for it)
+RG_HD void rg_ins_ring_to_compact(u32 &start, u32 count, u64 &hd, u64 tail) {
+    if (count <= 1u) {
+        start = RG_INS_COMPACT;
+        hd = 0;
+    } else if (count == 2u && tail - hd <= RG_INS_DMASK) {
+        start = RG_INS_COMPACT;
+        hd = tail - hd;
+    }
+}
+
+// Inflights::free_to (inflights.rs:84-110). `hd`: the window's `head` cell (ring mode: the oldest entry; compact: the deltas).
 // Written as arithmetic on predicates (the stage is instruction-bound: every `if` of lane-varying code is a saveexec /
-// branch / restore sequence): only a partial free of a window of MORE than two messages walks the ring.
-RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &head, u64 tail, u64 to) {
+// branch / restore sequence): a compact window is decided from its registers alone; of the ring windows only a partial free
+// of MORE than two messages walks the ring.
+RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &hd, u64 tail, u64 to) {
+    if (start == RG_INS_COMPACT) {
+        u64 e[4];
+        rg_ins_compact_entries(hd, tail, e);
+        // entries ascend from e[count - 1] to e[0]: everything from the NEWEST entry <= `to` down is freed -- what stays is
+        // the entries newer than it, i.e. its index
+        u32 keep = count;
+        keep = (count > 3u && to >= e[3]) ? 3u : keep;
+        keep = (count > 2u && to >= e[2]) ? 2u : keep;
+        keep = (count > 1u && to >= e[1]) ? 1u : keep;
+        keep = (count > 0u && to >= e[0]) ? 0u : keep;
+        hd = rg_ins_compact_keep(hd, keep);
+        count = keep;
+        return;
+    }
+    u64 head = hd;
     const bool hit = count != 0 && to >= head; // (else: out of the left side of the window)
     const bool all = hit && to >= tail;        // everything in the window is <= tail <= to
     if (hit && !all && count > 2) {
@@ -153,22 +211,62 @@ RG_HD void rg_ins_free_to(const RgIns &ins, u64 base, u32 &start, u32 &count, u6
         head = nh;
         count -= i;
         start = idx;
-        return;
+    } else {
+        // nothing freed, everything freed, or the older of exactly two: no ring word is involved
+        const bool one = hit && !all;
+        const u32 adv = all ? count : (one ? 1u : 0u);
+        start += adv;
+        if (start >= ins.cap) start -= ins.cap;
+        count -= adv;
+        head = one ? tail : head;
     }
-    // nothing freed, everything freed, or the older of exactly two: no ring word is involved
-    const bool one = hit && !all;
-    const u32 adv = all ? count : (one ? 1u : 0u);
-    start += adv;
-    if (start >= ins.cap) start -= ins.cap;
-    count -= adv;
-    head = one ? tail : head;
+    hd = head;
+    if (count <= 2u) rg_ins_ring_to_compact(start, count, hd, tail);
 }
 
-// Inflights::add (inflights.rs:65-81): the previous newest becomes a middle entry (only then does it need a ring word)
-RG_HD void rg_ins_add(const RgIns &ins, u64 base, u32 start, u32 &count, u64 &head, u64 &tail, u64 v) {
+// Inflights::free_first_one (inflights.rs:114-117): free_to(the oldest entry); the caller has checked count != 0
+RG_HD void rg_ins_free_first(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &hd, u64 tail) {
+    if (start == RG_INS_COMPACT) {
+        count -= 1u;
+        hd = rg_ins_compact_keep(hd, count);
+        return;
+    }
+    rg_ins_free_to(ins, base, start, count, hd, tail, hd);
+}
+
+// Inflights::add (inflights.rs:65-81). An empty window starts compact; a compact window that cannot take the entry -- it
+// holds RG_INS_COMPACT_MAX already, or the entry lies 2 M indices or more beyond the newest -- moves to the ring first: its
+// middle entries are written to positions 1 .. count - 2 (start = 0; the oldest and the newest stay in the columns, as for
+// every ring window). Ring mode: the previous newest becomes a middle entry (only then does it need a ring word).
+RG_HD void rg_ins_add(const RgIns &ins, u64 base, u32 &start, u32 &count, u64 &hd, u64 &tail, u64 v) {
     if (count == 0) {
-        head = v;
-    } else if (count >= 2) {
+        start = RG_INS_COMPACT;
+        hd = 0;
+        tail = v;
+        count = 1;
+        return;
+    }
+    if (start == RG_INS_COMPACT) {
+        const u64 d = v - tail;
+        if (count < RG_INS_COMPACT_MAX && d <= RG_INS_DMASK) {
+            hd = ((hd << RG_INS_DBITS) & ((1ULL << (3 * RG_INS_DBITS)) - 1ULL)) | d;
+            tail = v;
+            count++;
+            return;
+        }
+        u64 e[4];
+        rg_ins_compact_entries(hd, tail, e);
+        if (!(RG_SEND_EXP & 2)) { // (entries newest first; ring position i holds the (i + 1)-th oldest)
+            if (count == 3u) ins.ring[base + 1] = e[1];
+            if (count == 4u) {
+                ins.ring[base + 1] = e[2];
+                ins.ring[base + 2] = e[1];
+            }
+        }
+        hd = count >= 4u ? e[3] : count == 3u ? e[2] : count == 2u ? e[1] : e[0];
+        start = 0;
+    }
+    if (count >= 2) {
         u32 pos = start + count - 1;
         if (pos >= ins.cap) pos -= ins.cap;
         if (!(RG_SEND_EXP & 2)) ins.ring[base + pos] = tail;
@@ -377,7 +475,7 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
         } else if ((fr_bits >> s) & 1u) {
             const u64 matched = FUSED ? r->mt[s] : q.match_v[s];
             if ((sm_bits >> s) & 1u) rg_ins_free_to(ins, base, start, count, head, tail, matched); // accepted ack: m.index == matched
-            else if (count) rg_ins_free_to(ins, base, start, count, head, tail, head);             // free_first_one (:114-117)
+            else if (count) rg_ins_free_first(ins, base, start, count, head, tail);                // free_first_one (:114-117)
         }
 
         // ---- send_append(to) then `while maybe_send_append(to, false)` ----
@@ -413,14 +511,18 @@ RG_HD void rg_send_serve(const RgState &st, const RgIns &ins, IX g, u32 out, u64
                 n = snd ? 1u : 0u;
                 const bool addw = took && repl; // Progress::update_state(last) (progress.rs:231-243): optimistic_update + ins.add(last)
                 it.tailm |= addw ? 1u << s : 0u;
-                if (addw && count >= 2) {       // Inflights::add: the previous newest becomes a middle entry
-                    u32 pos = start + count - 1;
-                    if (pos >= ins.cap) pos -= ins.cap;
-                    if (!(RG_SEND_EXP & 2)) ins.ring[base + pos] = tail;
+                // Inflights::add. The common window is compact with room to spare: one shift and one or, no memory access;
+                // everything else (a fifth message, a distance beyond 21 bits, a ring window) takes rg_ins_add's general road
+                const bool fast = addw && ((count == 0) | ((start == RG_INS_COMPACT) & (count < RG_INS_COMPACT_MAX) & (last - tail <= RG_INS_DMASK)));
+                if (addw && !fast) {
+                    rg_ins_add(ins, base, start, count, head, tail, last);
+                } else {
+                    const u64 shifted = ((head << RG_INS_DBITS) & ((1ULL << (3 * RG_INS_DBITS)) - 1ULL)) | (last - tail);
+                    head = fast ? (count == 0 ? 0ULL : shifted) : head;
+                    start = fast ? RG_INS_COMPACT : start;
+                    tail = fast ? last : tail;
+                    count += fast ? 1u : 0u;
                 }
-                head = (addw && count == 0) ? last : head;
-                tail = addw ? last : tail;
-                count += addw ? 1u : 0u;
                 next = addw ? last + 1 : next;
                 pb |= (took && probe) ? RG_PF_PAUSED : 0u;
             } else {

@@ -363,3 +363,42 @@ extern "C" int rg_host_check_resolve_hints(unsigned P, unsigned long G, unsigned
                                         [&](u64 g, u32 bits, u32 clear) { st.out[g] = (st.out[g] | bits) & ~clear; }) & RG_RESOLVE_APPLIED;
     return 0;
 }
+
+// One Inflights window driven op by op (tests/test_host_check.py::test_window_arithmetic_equals_a_plain_queue): op 0 = add(v),
+// 1 = free_to(v), 2 = free_first_one. After every op the window's logical contents (oldest first) are written to
+// contents[k][0..count) and counts[k]; modes[k] = 1 while the window is compact. The ring is the caller's (cap words).
+extern "C" int rg_host_check_window_ops(unsigned cap, unsigned long n_ops, const unsigned *ops, const u64 *vals, u64 *ring,
+                                        u64 *contents, unsigned *counts, unsigned *modes) {
+    RgIns ins;
+    ins.meta = nullptr; ins.head = nullptr; ins.tail = nullptr; ins.ring = ring; ins.cap = cap;
+    ins.esz = nullptr; ins.esz_w = 0;
+    u32 start = 0, count = 0;
+    u64 hd = 0, tail = 0;
+    for (unsigned long k = 0; k < n_ops; k++) {
+        if (ops[k] == 0) {
+            if (count == cap) return -1; // (the caller never adds to a full window: Inflights::add panics)
+            rg_ins_add(ins, 0, start, count, hd, tail, vals[k]);
+        } else if (ops[k] == 1) {
+            rg_ins_free_to(ins, 0, start, count, hd, tail, vals[k]);
+        } else if (count) {
+            rg_ins_free_first(ins, 0, start, count, hd, tail);
+        }
+        counts[k] = count;
+        modes[k] = start == RG_INS_COMPACT ? 1u : 0u;
+        u64 *row = contents + k * cap;
+        if (start == RG_INS_COMPACT) {
+            if (count > RG_INS_COMPACT_MAX) return -2;
+            u64 e[4];
+            rg_ins_compact_entries(hd, tail, e);
+            for (u32 i = 0; i < count; i++) row[i] = e[count - 1 - i];
+            if (count && rg_ins_oldest(start, count, hd, tail) != row[0]) return -3;
+        } else {
+            for (u32 i = 0; i < count; i++) row[i] = ring[(start + i) % cap];
+            if (count) {
+                row[0] = hd;
+                row[count - 1] = tail;
+            }
+        }
+    }
+    return 0;
+}

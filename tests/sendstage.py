@@ -51,10 +51,41 @@ def prepare_msgs(msgs):
     msgs["m_flags"][...] &= np.uint8(~(fuzz.MF_INS_FULL | fuzz.MF_SENT) & 0xff)
 
 
+INS_COMPACT, INS_DBITS, INS_DMASK = 0xffff, 21, (1 << 21) - 1  # rg_send.h: RG_INS_COMPACT, RG_INS_DBITS, RG_INS_DMASK
+
+
 def ring_contents(meta, ring, g, p, cap):
     m = int(meta[p, g])
     start, count = m & 0xffff, m >> 16
+    if start == INS_COMPACT:  # the engine-internal form of a window of <= 4 entries (patch_ring has written them out at 0)
+        start = 0
     return [int(ring[g, p, (start + i) % cap]) for i in range(count)]
+
+
+def compact_entries(hd, tail, count):
+    """The entries of a compact window, OLDEST first: newest first they are tail, tail - d1, tail - d1 - d2, ... with the
+    distances d1 | d2 << 21 | d3 << 42 in the window's `head` cell (rg_send.h)."""
+    e, out = int(tail), []
+    for i in range(count):
+        out.append(e & ((1 << 64) - 1))
+        e -= (int(hd) >> (INS_DBITS * i)) & INS_DMASK
+    return out[::-1]
+
+
+def patch_ring(meta, head, tail, ring, cap, G, P):
+    """What rg_read_inflights does with the engine-internal columns (host_check twins work on them directly): the oldest
+    and the newest entry of a ring window live in the head / tail columns, a compact window lives there entirely -- write
+    them into the ring so that ring_contents sees every window whole."""
+    for p in range(P):
+        m = meta[p, :G]
+        live = np.nonzero(m >> 16)[0]
+        start, count = (m[live] & 0xffff).astype(np.int64), (m[live] >> 16).astype(np.int64)
+        rw = start != INS_COMPACT
+        ring[live[rw], p, start[rw]] = head[p, live[rw]]
+        ring[live[rw], p, (start[rw] + count[rw] - 1) % cap] = tail[p, live[rw]]
+        for g, c in zip(live[~rw].tolist(), count[~rw].tolist()):
+            assert 1 <= c <= 4 and c <= cap, (g, p, c)
+            ring[g, p, :c] = compact_entries(head[p, g], tail[p, g], c)
 
 
 def compare_rings(cl, meta, ring, st, cap):
@@ -137,14 +168,27 @@ def host_update_state(st, meta, head, tail, ring, cap, g, p, lasts):
         if count == cap:
             break
         st["next"][p, g] = last + 1
-        if count == 0:
-            head[p, g] = last
-        elif count >= 2:
-            ring[g, p, (start + count - 1) % cap] = tail[p, g]
+        last = int(last)
+        if count == 0:  # an empty window starts compact
+            start, head[p, g] = INS_COMPACT, 0
+        elif start == INS_COMPACT and count < 4 and last - int(tail[p, g]) <= INS_DMASK:
+            head[p, g] = ((int(head[p, g]) << INS_DBITS) & ((1 << 63) - 1)) | (last - int(tail[p, g]))
+        else:
+            if start == INS_COMPACT:  # a fifth message / a distance beyond 21 bits: the window moves to the ring (start 0)
+                e = compact_entries(head[p, g], tail[p, g], count)
+                for i in range(1, count - 1):
+                    ring[g, p, i] = e[i]
+                start, head[p, g] = 0, e[0]
+            if count >= 2:
+                ring[g, p, (start + count - 1) % cap] = tail[p, g]
         tail[p, g] = last
         count += 1
     meta[p, g] = start | (count << 16)
     st["pflags"][g, p] = (int(st["pflags"][g, p]) & ~PF_INS_FULL) | (PF_INS_FULL if count == cap else 0)
-    if count:  # the logical view rg_read_inflights gives: oldest / newest entry from the head / tail columns
-        ring[g, p, start] = head[p, g]
-        ring[g, p, (start + count - 1) % cap] = tail[p, g]
+    # the logical view rg_read_inflights gives
+    if count:
+        if start == INS_COMPACT:
+            ring[g, p, :count] = compact_entries(head[p, g], tail[p, g], count)
+        else:
+            ring[g, p, start] = head[p, g]
+            ring[g, p, (start + count - 1) % cap] = tail[p, g]

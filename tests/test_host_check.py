@@ -537,14 +537,7 @@ def host_send():
                tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items),
                None if esz is None else esz.ctypes.data, 0 if esz is None else esz.shape[1])
         assert 0 <= n <= len(items)
-        # what rg_read_inflights does: the oldest and the newest entry of a window live in the head / tail columns
-        G, P = st["n_groups"], st["n_slots"]
-        for p in range(P):
-            m = meta[p, :G]
-            live = np.nonzero(m >> 16)[0]
-            start, count = (m[live] & 0xffff).astype(np.int64), (m[live] >> 16).astype(np.int64)
-            ring[live, p, start] = head[p, live]
-            ring[live, p, (start + count - 1) % cap] = tail[p, live]
+        sendstage.patch_ring(meta, head, tail, ring, cap, st["n_groups"], st["n_slots"])  # (what rg_read_inflights does)
         return items[:n]
     return send
 
@@ -566,13 +559,7 @@ def host_tick_send():
                head.ctypes.data, tail.ctypes.data, ring.ctypes.data, cap, max_entries, flags, items.ctypes.data, len(items),
                None if esz is None else esz.ctypes.data, 0 if esz is None else esz.shape[1])
         assert 0 <= n <= len(items)
-        G, P = st["n_groups"], st["n_slots"]
-        for p in range(P):
-            m = meta[p, :G]
-            live = np.nonzero(m >> 16)[0]
-            start, count = (m[live] & 0xffff).astype(np.int64), (m[live] >> 16).astype(np.int64)
-            ring[live, p, start] = head[p, live]
-            ring[live, p, (start + count - 1) % cap] = tail[p, live]
+        sendstage.patch_ring(meta, head, tail, ring, cap, st["n_groups"], st["n_slots"])
         return items[:n]
     return tick_send
 
@@ -929,3 +916,57 @@ def test_tick_for_fewer_slots_is_the_full_tick_where_no_higher_slot_is_named(hos
         assert (out_full == out_few).all(), (t, np.nonzero(out_full != out_few)[0][:5])
         for k in ("run_first", "run_term", "cur_term"):
             assert (full[k] == few[k]).all(), (t, k)
+
+
+@pytest.mark.parametrize("cap,spread", [(1, 3), (2, 5), (3, 1 << 22), (5, 9), (5, 1 << 23), (8, 40), (256, 7), (256, 1 << 21), (64, 1 << 62)])
+def test_window_arithmetic_equals_a_plain_queue(cap, spread):
+    """Inflights (src/tracker/inflights.rs:42-125) as the engine holds it since round 6 -- windows of up to four entries whose
+    distances fit 21 bits live entirely in two column cells (compact), deeper or wider ones in the ring, and they move between
+    the two forms -- against a plain Python list: add / free_to / free_first_one in random order, every intermediate state
+    compared. `spread` sets the distance between consecutive entries: small ones stay compact, 2^21 and more force the ring."""
+    if build_lib() is None:
+        pytest.skip("hipcc not available")
+    fn = C.CDLL(LIB).rg_host_check_window_ops
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint, C.c_ulong] + [C.c_void_p] * 6
+    rng = np.random.default_rng(cap * 31 + (spread % 1000))
+    n = 6000
+    ops = np.zeros(n, dtype=np.uint32)
+    vals = np.zeros(n, dtype=np.uint64)
+    model, want, last = [], [], 1000
+    for k in range(n):
+        r = rng.random()
+        if r < 0.5 and len(model) < cap and last < (1 << 64) - 8:  # (at the top of the index range only frees are left)
+            step = (1 + int(rng.random() * spread)) if rng.random() < 0.8 else int(rng.integers(1, 4))
+            last = min(last + step, (1 << 64) - 4)
+            if model and last <= model[-1]:
+                last = model[-1] + 1
+            ops[k], vals[k] = 0, last
+            model.append(last)
+        elif r < 0.85:
+            # free_to anywhere: below the window, on an entry, between entries, beyond the newest
+            lo = (model[0] - 2) if model else last
+            hi = (model[-1] + 2) if model else last + 2
+            pick = int(model[int(rng.integers(0, len(model)))]) if (model and rng.random() < 0.5) else (max(lo, 0) + int(rng.random() * (hi - max(lo, 0) + 1)))
+            pick = min(pick, (1 << 64) - 1)
+            ops[k], vals[k] = 1, pick
+            model = [e for e in model if e > pick]
+        else:
+            ops[k] = 2
+            model = model[1:]
+        want.append(list(model))
+    ring = np.zeros(cap, dtype=np.uint64)
+    contents = np.zeros((n, cap), dtype=np.uint64)
+    counts = np.zeros(n, dtype=np.uint32)
+    modes = np.zeros(n, dtype=np.uint32)
+    rc = fn(cap, n, ops.ctypes.data, vals.ctypes.data, ring.ctypes.data, contents.ctypes.data, counts.ctypes.data, modes.ctypes.data)
+    assert rc == 0, rc
+    for k in range(n):
+        assert counts[k] == len(want[k]) and contents[k, :counts[k]].tolist() == want[k], (k, int(ops[k]), int(vals[k]), want[k], contents[k, :counts[k]].tolist())
+    deep = max(len(w) for w in want)
+    if spread < (1 << 21):
+        assert modes[counts <= min(4, cap)].mean() > 0.5  # small windows of near entries live in the columns
+    if cap > 4 and spread < (1 << 60):  # (steps of 2^62 run out of index range after four entries)
+        assert deep > 4 and (modes == 0).any() and (modes[1:][(modes[:-1] == 0)] == 1).any()  # ... deeper ones in the ring, and back
+    if spread >= (1 << 22) and cap >= 3:
+        assert (modes[counts >= 2] == 0).any()  # a distance beyond 21 bits forces the ring
