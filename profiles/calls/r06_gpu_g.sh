@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06_g; O=gpurun_out/r06_g
+timeout 1500 python -m pytest tests/test_sendstage_gpu.py tests/test_placement_gpu.py tests/test_api_sequences_gpu.py tests/test_scenarios.py -m gpu -x -q 2>&1 | tail -15 | cut -c1-300 > $O/tests.txt; tail -3 $O/tests.txt
+timeout 900 python -m pytest tests/test_full_size_gpu.py -m gpu -x -q -k "send_stage" 2>&1 | tail -5 | cut -c1-300 > $O/tests_full.txt; tail -2 $O/tests_full.txt
+for i in 1 2; do
+python tools/sweep_libs.py --libs cw2,default --configs "send1:--inflights 256 --fused-send|send2:--inflights 256" 2>&1 | tee -a $O/sweep_windows2.txt
+done
+bash tools/pmc_traffic.sh 2:1000000:5:inflights:fused-send 20 --inflights 256 --fused-send > $O/pmc_fused.txt 2>&1; tail -12 $O/pmc_fused.txt
+bash tools/pmc_traffic.sh 2:1000000:5:inflights 20 --inflights 256 > $O/pmc_two.txt 2>&1; tail -4 $O/pmc_two.txt
