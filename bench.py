@@ -515,6 +515,7 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         elif inflights:
             pt = parts[0]
             tick_us = sorted(a.elapsed_time(b) for a, b, _ in per_launch)[len(per_launch) // 2] * 1e3
+            stage_in_order = [round(b.elapsed_time(c) * 1e3, 1) for _, b, c in per_launch]  # (the last region's launches, in replay order)
             stage_all = sorted(b.elapsed_time(c) * 1e3 for _, b, c in per_launch)
             stage_us = stage_all[len(stage_all) // 2]
             items = len(pt.eng.send_items())
@@ -523,6 +524,9 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
             extra["send_stage"] = {
                 "max_inflight": inflights, "max_entries_per_msg": 0, "work_items_last_tick": int(items),
                 "us_per_tick_median": tick_us, "us_per_stage_median": stage_us,
+                # every stage launch of the last region, in order: the spread of k_send_dense (round 5: "bimodal, 57-108 us") is
+                # the REPLAY -- each region starts from restored, nearly empty windows and the work per launch grows as they fill
+                "us_per_stage_in_replay_order": stage_in_order,
                 "roofline": {"bound": "hbm", "regime": regime_of(hot), "achieved": sg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": sg / HBM_PEAK_GBS, "kernel": "k_send_dense", "algorithmic_bytes_per_launch": sb,
                              "bytes_per_group": sb / n_groups, "avg_launch_us": stage_us, "traffic": None,
