@@ -525,7 +525,8 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
                 "max_inflight": inflights, "max_entries_per_msg": 0, "work_items_last_tick": int(items),
                 "us_per_tick_median": tick_us, "us_per_stage_median": stage_us,
                 # every stage launch of the last region, in order: the spread of k_send_dense (round 5: "bimodal, 57-108 us") is
-                # the REPLAY -- each region starts from restored, nearly empty windows and the work per launch grows as they fill
+                # the REPLAY -- each region starts from the restored windows and the time per launch falls monotonically as they
+                # settle into the stream's steady state (r06: 86 -> 69 us over 30 launches), not two modes of the hardware
                 "us_per_stage_in_replay_order": stage_in_order,
                 "roofline": {"bound": "hbm", "regime": regime_of(hot), "achieved": sg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": sg / HBM_PEAK_GBS, "kernel": "k_send_dense", "algorithmic_bytes_per_launch": sb,
