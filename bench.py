@@ -222,7 +222,14 @@ def small_batch_latency(rg, torch, n_groups, n_slots, seed):
     return out
 
 
-MALL_BYTES = 256 << 20  # Infinity Cache (MALL) of MI355X, /opt/skills/guides/MI355X_MICROARCH.md
+MALL_BYTES = 256 << 20  # Infinity Cache (MALL) of MI355X, /opt/skills/guides/MI355X_MICROARCH.md; replaced by what the engine asked the device (set_mall_bytes)
+
+
+def set_mall_bytes(n):
+    """The Infinity Cache size the engine asked the device for (rg_device_info.infinity_cache_bytes) replaces the MI355X constant."""
+    global MALL_BYTES
+    if n:
+        MALL_BYTES = int(n)
 
 
 def regime_of(hot_bytes):
@@ -351,6 +358,7 @@ def run_config(rg, torch, n_groups, n_slots, workload, warmup, steps, seed, what
         pt.fixed = slots if (workload == 5 and not one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=torch.cuda.current_device(), variant=variant, max_inflight=inflights, flags=cfg_flags)
         pt.eng.set_stream(main_stream.cuda_stream)
+        set_mall_bytes(pt.eng.device_info().get("infinity_cache_bytes"))
         pt.eng.workload_init(workload, seed=seed, first_group=first, fixed_peers=pt.fixed,
                              sorted_classes=sorted_classes and not place_after_load, group_commit=group_commit)
         if place_after_load:
@@ -668,7 +676,7 @@ def compact_line(result):
     cfg = _scalars(cfg_in, text=220)
     cfg["engines"] = "+".join(f"{e['groups']}x{e['slots']}" for e in cfg_in.get("engines", [])) or None
     dev = cfg_in.get("device") or {}
-    for k in ("arch", "compute_units", "cache_policy", "last_tick_kernel", "last_tick_streaming", "resident_groups"):
+    for k in ("arch", "compute_units", "cache_policy", "last_tick_kernel", "last_tick_streaming", "resident_groups", "infinity_cache_bytes"):
         if k in dev:
             cfg[k] = _short(dev[k])
     pub = cfg_in.get("publication") or {}
@@ -945,6 +953,7 @@ def main():
         pt.fixed = slots if (args.workload == 5 and not args.one_engine) else 0
         pt.eng = rg.Engine(n, slots, device=local_rank, variant=args.variant, max_inflight=args.inflights, flags=args.cfg_flags)
         pt.eng.set_stream(stream.cuda_stream)
+        set_mall_bytes(pt.eng.device_info().get("infinity_cache_bytes"))
         pt.eng.workload_init(args.workload, seed=args.seed, first_group=first, fixed_peers=pt.fixed, sorted_classes=args.sorted)
         pt.eng.checkpoint()
         pt.cols = [torch.empty((T, slots, pt.eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]

@@ -154,6 +154,9 @@ pub struct RgDeviceInfo {
     pub resident_groups: u64,
     pub last_tick_kernel: u32,
     pub last_tick_streaming: u32,
+    pub infinity_cache_bytes: u64,
+    pub infinity_cache_queried: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]

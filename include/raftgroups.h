@@ -286,6 +286,13 @@ typedef struct {
     uint32_t last_tick_kernel;  /* RG_KERNEL_* */
     uint32_t last_tick_streaming; /* 0 = plain accesses, 1 = message columns streamed, 2 = state columns too
                                      (RG_KERNEL_SPLIT: 2 beyond the resident range, 1 inside) */
+    /* the cache the policy is sized against: the device's memory-side (level-3) cache as the HSA runtime enumerates it
+     * (hsa_agent_iterate_caches; the agent matched to the HIP device by PCI address) -- 256 MiB on MI355X. The policy's windows
+     * (1.25 x / 1.5 x / 2.5 x this size, the 13 M-group bound, 11/16 of it for a resident range) are MEASURED on MI355X
+     * (profiles/r04_nt_state.txt, r04_resident.txt, r05_cache_policy_sweep.txt) and scale with the size the device reports. */
+    uint64_t infinity_cache_bytes;
+    uint32_t infinity_cache_queried; /* 1 = asked of the device; 0 = the query failed and the MI355X constant stands in */
+    uint32_t reserved;
 } rg_device_info;
 #define RG_KERNEL_NONE 0u
 #define RG_KERNEL_LANE 1u      /* k_tick_lane: one lane per group */

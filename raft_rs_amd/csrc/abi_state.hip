@@ -52,6 +52,68 @@ void rg_drop(rg_engine *h) {
     delete h;
 }
 
+// The size of the device's Infinity Cache (the memory-side "L3" / MALL: 256 MiB on MI355X), ASKED of the device instead of
+// assumed: HIP's device properties stop at the L2, the HSA runtime underneath enumerates every cache of an agent
+// (hsa_agent_iterate_caches: level 3 is the one). The runtime is in the process already (HIP sits on it); it is bound at run
+// time like RCCL, and the agent is matched to the HIP device by its PCI address. 0 = could not be asked (the caller falls back to
+// the MI355X constant and says so in rg_device_info.infinity_cache_queried).
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+namespace {
+struct RgHsaQuery {
+    decltype(&hsa_agent_get_info) agent_get_info;
+    decltype(&hsa_agent_iterate_caches) iterate_caches;
+    decltype(&hsa_cache_get_info) cache_get_info;
+    uint32_t want_bdf, want_domain;
+    uint64_t l3_bytes;
+};
+hsa_status_t rg_hsa_cache_cb(hsa_cache_t cache, void *data) {
+    RgHsaQuery *q = static_cast<RgHsaQuery *>(data);
+    uint8_t level = 0;
+    uint32_t size = 0;
+    if (q->cache_get_info(cache, HSA_CACHE_INFO_LEVEL, &level) == HSA_STATUS_SUCCESS &&
+        q->cache_get_info(cache, HSA_CACHE_INFO_SIZE, &size) == HSA_STATUS_SUCCESS && level == 3) {
+        // (ROCr hands on what the kernel driver's topology reports, and that is KiB -- 262 144 for MI355X's 256 MiB, as rocminfo
+        //  prints it -- although the HSA specification says bytes: anything below 1 Mi is taken as KiB)
+        const uint64_t bytes = size < (1u << 20) ? (uint64_t)size << 10 : (uint64_t)size;
+        if (bytes > q->l3_bytes) q->l3_bytes = bytes;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+hsa_status_t rg_hsa_agent_cb(hsa_agent_t agent, void *data) {
+    RgHsaQuery *q = static_cast<RgHsaQuery *>(data);
+    hsa_device_type_t type;
+    if (q->agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, domain = 0;
+    if (q->agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    (void)q->agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+    if ((bdf & 0xffffu) != q->want_bdf || domain != q->want_domain) return HSA_STATUS_SUCCESS;
+    (void)q->iterate_caches(agent, rg_hsa_cache_cb, q);
+    return HSA_STATUS_INFO_BREAK;
+}
+} // namespace
+static uint64_t rg_query_infinity_cache(const hipDeviceProp_t &prop) {
+    void *lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD); // (the instance HIP runs on)
+    if (!lib) lib = dlopen("libhsa-runtime64.so.1", RTLD_NOW);
+    if (!lib) return 0;
+    auto init = reinterpret_cast<decltype(&hsa_init)>(dlsym(lib, "hsa_init"));
+    auto shut = reinterpret_cast<decltype(&hsa_shut_down)>(dlsym(lib, "hsa_shut_down"));
+    auto iter = reinterpret_cast<decltype(&hsa_iterate_agents)>(dlsym(lib, "hsa_iterate_agents"));
+    RgHsaQuery q;
+    q.agent_get_info = reinterpret_cast<decltype(&hsa_agent_get_info)>(dlsym(lib, "hsa_agent_get_info"));
+    q.iterate_caches = reinterpret_cast<decltype(&hsa_agent_iterate_caches)>(dlsym(lib, "hsa_agent_iterate_caches"));
+    q.cache_get_info = reinterpret_cast<decltype(&hsa_cache_get_info)>(dlsym(lib, "hsa_cache_get_info"));
+    q.want_bdf = ((uint32_t)prop.pciBusID << 8) | ((uint32_t)prop.pciDeviceID << 3);
+    q.want_domain = (uint32_t)prop.pciDomainID;
+    q.l3_bytes = 0;
+    if (init && shut && iter && q.agent_get_info && q.iterate_caches && q.cache_get_info && init() == HSA_STATUS_SUCCESS) {
+        (void)iter(rg_hsa_agent_cb, &q);
+        (void)shut(); // (reference-counted: HIP's own use of the runtime is untouched)
+    }
+    return q.l3_bytes;
+}
+
 extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (!cfg || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: null argument");
     if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
@@ -83,6 +145,9 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     h->dev.lds_per_workgroup = prop.sharedMemPerBlock;
     h->dev.hbm_bytes = prop.totalGlobalMem;
     h->dev.l2_bytes = (uint64_t)prop.l2CacheSize;
+    h->dev.infinity_cache_bytes = rg_query_infinity_cache(prop);
+    h->dev.infinity_cache_queried = h->dev.infinity_cache_bytes ? 1u : 0u;
+    if (!h->dev.infinity_cache_bytes) h->dev.infinity_cache_bytes = 256ull << 20; // (MI355X; rg_device_info says that it was not asked)
     h->cfg = *cfg;
     h->G = cfg->n_groups;
     h->P = cfg->n_slots;
@@ -179,7 +244,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         h->counted_live = true;
     }
     {
-        const double mall = 256.0 * 1024.0 * 1024.0;
+        const double mall = (double)h->dev.infinity_cache_bytes; // (asked of the device: rg_query_infinity_cache)
         const double per_group = (double)(24u * h->P + 40u), state = (double)h->G * per_group;
         const double with_msgs = (double)h->G * (double)(40u * h->P + 48u + (cfg->max_inflight ? 40u * h->P : 0u));
         const bool lane = cfg->variant == RG_VARIANT_DEFAULT || cfg->variant == RG_VARIANT_LANE || cfg->variant == RG_VARIANT_COOP;
@@ -199,7 +264,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
         h->nt_all = pol >= RG_CACHE_STREAM_ALL;
         h->nt_resident = 0;
         if (pol == RG_CACHE_RESIDENT) {
-            const u64 groups = cfg->cache_resident_groups ? cfg->cache_resident_groups : (u64)(176.0 * 1024.0 * 1024.0 / per_group);
+            const u64 groups = cfg->cache_resident_groups ? cfg->cache_resident_groups : (u64)(0.6875 * mall / per_group) /* 176 of 256 MiB */;
             h->nt_resident = rg_min(groups, h->G) / RG_BLOCK;
             if (h->nt_resident == 0) pol = RG_CACHE_STREAM_ALL; // (less than one workgroup: nothing to keep)
         }

@@ -107,7 +107,8 @@ class DeviceInfo(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("wavefront", C.c_uint32),
                 ("lds_per_workgroup", C.c_uint64), ("hbm_bytes", C.c_uint64), ("l2_bytes", C.c_uint64),
                 ("engine_bytes", C.c_uint64), ("cache_policy", C.c_uint32), ("engines_on_device", C.c_uint32),
-                ("resident_groups", C.c_uint64), ("last_tick_kernel", C.c_uint32), ("last_tick_streaming", C.c_uint32)]
+                ("resident_groups", C.c_uint64), ("last_tick_kernel", C.c_uint32), ("last_tick_streaming", C.c_uint32),
+                ("infinity_cache_bytes", C.c_uint64), ("infinity_cache_queried", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 import contextlib
@@ -445,7 +446,8 @@ class Engine:
                 "lds_per_workgroup": d.lds_per_workgroup, "hbm_bytes": d.hbm_bytes, "l2_bytes": d.l2_bytes,
                 "engine_bytes": d.engine_bytes, "cache_policy": CACHE.NAMES[d.cache_policy],
                 "engines_on_device": d.engines_on_device, "resident_groups": d.resident_groups,
-                "last_tick_kernel": KERNEL.NAMES[d.last_tick_kernel], "last_tick_streaming": d.last_tick_streaming}
+                "last_tick_kernel": KERNEL.NAMES[d.last_tick_kernel], "last_tick_streaming": d.last_tick_streaming,
+                "infinity_cache_bytes": d.infinity_cache_bytes, "infinity_cache_queried": bool(d.infinity_cache_queried)}
 
     def column_shape_dtype(self, col):
         if col in COL.PER_SLOT:

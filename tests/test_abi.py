@@ -98,7 +98,7 @@ def test_library_reads_no_environment(rg):
     for name in (b"RG_NT_", b"RG_NO_CLASSES", b"RG_CLASS_ORDER", b"RG_FORCE_IX64", b"RG_PUB_DEBUG"):
         assert name not in blob, name
     from raft_rs_amd import engine as E
-    assert C.sizeof(E._Config) == 40 and C.sizeof(E.DeviceInfo) == 96
+    assert C.sizeof(E._Config) == 40 and C.sizeof(E.DeviceInfo) == 112
 
 
 def test_product_package_never_touches_the_oracle():

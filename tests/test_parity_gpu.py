@@ -647,6 +647,8 @@ def test_device_info_is_queried_not_assumed(rg):
     eng = rg.Engine(1000, 5)
     info = eng.device_info()
     assert info["arch"] == "gfx950" and info["wavefront"] == 64
+    # the cache the regime policy is sized against is ASKED of the device (HSA's cache enumeration, level 3), not a constant
+    assert info["infinity_cache_queried"] and info["infinity_cache_bytes"] == 256 << 20, info
     assert info["compute_units"] >= 64 and info["lds_per_workgroup"] >= 64 * 1024 and info["hbm_bytes"] > (100 << 30)
     cols = sum(eng.L.rg_column_bytes(eng.h, c) for c in range(17))
     assert cols <= info["engine_bytes"] <= cols + (64 << 10) + 4 * 5 * eng.stride * 8
