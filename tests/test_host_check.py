@@ -147,17 +147,20 @@ def test_device_arithmetic_on_host_matches_oracle(host_tick, n_slots, gc):
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5])
 
 
+@pytest.mark.parametrize("gc", [False, True])
 @pytest.mark.parametrize("n_slots", [3, 5, 7, 8])
-def test_acks_from_paused_peers_against_the_sequential_reference(host_tick, n_slots):
+def test_acks_from_paused_peers_against_the_sequential_reference(host_tick, n_slots, gc):
     """RgTick::paused_acks decides `else if old_paused { send_append }` (raft.rs:1749-1751) from two quorum evaluations
     per paused ack instead of replaying the sequence: streams where HALF the accepted acks come from paused peers (full
     windows, paused probes), joint and majority configurations, small values so that ties and commits at every position
-    of the sequence occur, some malformed acks (the replay fallback)."""
-    rng = np.random.default_rng(9100 + n_slots)
+    of the sequence occur, some malformed acks (the replay fallback).
+    gc (round 6): the same with group commit on in EVERY group and random commit groups -- the replay of
+    RgTick::commit_phase_gc, whose every step is the literal group-commit evaluation through one inlined call site."""
+    rng = np.random.default_rng(9100 + n_slots + (50 if gc else 0))
     G = 4000
     st = O.alloc_state(G, n_slots)
-    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.02)
-    fuzz.random_state(rng, st, small_values=True)
+    st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.02, group_commit_frac=1.0 if gc else 0.0)
+    fuzz.random_state(rng, st, small_values=True, with_gids=gc)
     cl = O.Cluster(G)
     cl.load_soa(st, term=6)
     eng_st = copy_state(st)
@@ -171,7 +174,7 @@ def test_acks_from_paused_peers_against_the_sequential_reference(host_tick, n_sl
         f = msgs["m_flags"]
         accept = ((f & 3) == 1)  # VALID, not REJECT
         f[...] = np.where(accept & (rng.random(f.shape) < 0.5), f | fuzz.MF_INS_FULL, f)
-        host_tick(eng_st, msgs, out, False)
+        host_tick(eng_st, msgs, out, gc)
         cl.tick_soa(msgs, gout)
         cl.store_soa(st)
         diffs = fuzz.diff_states(st, eng_st, G, n_slots)
@@ -179,7 +182,7 @@ def test_acks_from_paused_peers_against_the_sequential_reference(host_tick, n_sl
         assert (out == gout).all(), (t, np.nonzero(out != gout)[0][:5], [hex(x) for x in out[out != gout][:5]],
                                      [hex(x) for x in gout[out != gout][:5]])
         n_paused_changed += int((((gout & 1) != 0) & (((gout >> 8) & 0xff) != 0)).sum())
-    assert n_paused_changed > 500, n_paused_changed  # commits AND owed send_appends in the same tick: the decided case
+    assert n_paused_changed > (100 if gc else 500), n_paused_changed  # commits AND owed send_appends in the same tick: the decided case
 
 
 def test_device_arithmetic_near_the_top_of_the_index_range(host_tick):
