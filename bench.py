@@ -1237,6 +1237,8 @@ def main():
                            "ms_per_step": float(w2.item()) * 1e3 / K, "value": world * G * K / float(w2.item()),
                            "bytes_per_rank_per_publication": st2["bytes_per_rank_full"] if other else st2["bytes_per_rank_delta"]}
 
+    if args.c5_sizes:
+        G = sum(n for _, n in sizes)  # (experiment: the engines' own group counts)
     evals = world * G * K  # (strong scaling: world * G = --total-groups)
     value = evals / wall
     timed_bytes = float(np.mean(alg_bytes[W:]))

@@ -47,7 +47,15 @@ int rg_require_hints_resolved(rg_engine *h, const char *who) {
 // The find_conflict_by_term pre-pass of a dense tick whose messages carry a log-term column (k_resolve_hints over every group),
 // with the probe described at rg_engine::d_hint_raised around it. `probe`: engines with device Inflights (the only ones whose
 // next step depends on the answer) and the fused driver (which stops at a tick that raised a hint).
-static int rg_hint_prepass(rg_engine *h, RgMsgs &ms, bool probe) {
+// `probed` (out): the probe was armed. It is not while the stream is being CAPTURED into a hipGraph (tests/test_graph_capture_gpu.py:
+// a captured launch sequence is replayed without the host, which could neither wait for the event nor read the word): such a tick
+// falls back to what round 5 did -- the counting check at the next entry point / no stop inside a fused call.
+static int rg_hint_prepass(rg_engine *h, RgMsgs &ms, bool probe, bool *probed = nullptr) {
+    if (probe) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) probe = false;
+    }
+    if (probed) *probed = probe;
     if (probe) {
         if (!h->pin_hint_raised) {
             RG_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->pin_hint_raised), 64, hipHostMallocDefault));
@@ -282,13 +290,16 @@ static int rg_tick_device_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *
     ms.mlt = m->m_logterm ? (const u64 *)m->m_logterm : h->zero_col;
     ms.mflags = (const u64 *)m->m_flags;
     ms.mhr = ms.mh;
+    bool probed = false;
     if (m->m_logterm) { // this tick may carry log terms: resolve the flagged hints first
-        const int prc = rg_hint_prepass(h, ms, h->ins_arena != nullptr);
+        const int prc = rg_hint_prepass(h, ms, h->ins_arena != nullptr, &probed);
         if (prc) return prc;
     }
     const int trc = rg_tick_impl(h, ms, send);
-    if (trc == RG_OK && m->m_logterm && h->ins_arena) // (rg_require_hints_resolved: this tick CAN have raised RG_OUT_HOST_HINT;
-        h->hint_check_due = h->hint_probe_pending = true; //  whether it did is in the probe's word, read at the next entry point)
+    if (trc == RG_OK && m->m_logterm && h->ins_arena) { // (rg_require_hints_resolved: this tick CAN have raised RG_OUT_HOST_HINT;
+        h->hint_check_due = true;                       //  whether it did is in the probe's word, read at the next entry point)
+        h->hint_probe_pending = probed;
+    }
     return trc;
 }
 
@@ -371,7 +382,8 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
             ms.mlt = (const u64 *)m[e].m_logterm;
             ms.mflags = (const u64 *)m[e].m_flags;
             ms.mhr = ms.mh;
-            int rc = rg_hint_prepass(h, ms, true);
+            bool probed = false;
+            int rc = rg_hint_prepass(h, ms, true, &probed);
             if (rc) return rc;
             rc = rg_tick_impl(h, ms);
             if (rc) return rc;
@@ -384,8 +396,8 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
             // before anything later (raft_log.rs:209-235 -> raft.rs:1657-1660), so the call STOPS behind the tick -- the later
             // ticks are the host's to submit again once rg_resolve_host_hints (or the re-stepped reject) has answered. The
             // pre-pass's word says "none" without waiting for the tick; only a raised word costs the count and its wait.
-            RG_HIP(hipEventSynchronize(h->ev_hint));
-            if (e < n_ticks && *(volatile u32 *)h->pin_hint_raised != 0) {
+            if (probed) RG_HIP(hipEventSynchronize(h->ev_hint));
+            if (probed && e < n_ticks && *(volatile u32 *)h->pin_hint_raised != 0) {
                 RG_HIP(hipMemsetAsync(h->d_counts, 0, 32, h->stream));
                 const unsigned grid = rg_grid(h->G, RG_BLOCK) < 2048 ? rg_grid(h->G, RG_BLOCK) : 2048;
                 hipLaunchKernelGGL(k_count_out, dim3(grid), dim3(RG_BLOCK), 0, h->stream, (const u32 *)h->st.out, h->G, h->d_counts);
@@ -441,6 +453,7 @@ int rg_tick_host_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     int rc = rg_ensure_msg_arena(h);
     if (rc) return rc;
     const size_t colb = (size_t)h->P * h->stride * 8;
+    bool probed = false;
     RG_HIP(hipMemcpyAsync((void *)h->staged.mi, m->m_index, colb, hipMemcpyHostToDevice, h->stream));
     RG_HIP(hipMemcpyAsync((void *)h->staged.mc, m->m_commit, colb, hipMemcpyHostToDevice, h->stream));
     RgMsgs ms = h->staged;
@@ -453,12 +466,15 @@ int rg_tick_host_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     else ms.mlt = h->zero_col;
     RG_HIP(hipMemcpyAsync((void *)h->staged.mflags, m->m_flags, h->G * 8, hipMemcpyHostToDevice, h->stream));
     if (m->m_logterm) { // pre-pass (after ALL message columns are on the device): find_conflict_by_term
-        rc = rg_hint_prepass(h, ms, h->ins_arena != nullptr);
+        rc = rg_hint_prepass(h, ms, h->ins_arena != nullptr, &probed);
         if (rc) return rc;
     }
     rc = rg_tick_impl(h, ms, send);
     if (rc) return rc;
-    if (m->m_logterm && h->ins_arena) h->hint_check_due = h->hint_probe_pending = true;
+    if (m->m_logterm && h->ins_arena) {
+        h->hint_check_due = true;
+        h->hint_probe_pending = probed;
+    }
     // the engine-owned message columns must read "no events" outside a tick (sparse-path invariant)
     RG_HIP(hipMemsetAsync((void *)h->staged.mflags, 0, h->stride * 8, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream)); // caller-owned host buffers may be reused after return

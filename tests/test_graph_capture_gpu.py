@@ -25,3 +25,12 @@ def test_class_placed_ticks_captured_into_a_hipgraph_replay_identically():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_graph.py"), "30000", "12", "classes"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_fused_calls_with_log_term_ticks_captured_into_a_hipgraph_replay_identically():
+    """rg_tick_device_fused whose ticks carry a log-term column, under capture: the call's question to the pre-pass ("did you leave
+    a reject to the host?", round 6) is a host wait in eager mode and must not be asked of a stream that is being captured."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_graph.py"), "20000", "16", "fused-logterm"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stdout

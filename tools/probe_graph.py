@@ -17,6 +17,7 @@ import raft_rs_amd as rg  # noqa: E402
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 PLACED = len(sys.argv) > 3 and sys.argv[3] == "classes"
+FUSED_LT = len(sys.argv) > 3 and sys.argv[3] == "fused-logterm"  # rg_tick_device_fused, four ticks per call, every other tick with a log-term column
 P, WL = (7, 5) if PLACED else (5, 2)
 side = torch.cuda.Stream()
 eng = rg.Engine(G, P)
@@ -39,7 +40,18 @@ ref = eng.results()
 ref_state = eng.read_state()
 
 
+logterm = torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda")  # (no reject of this stream carries a log term: the column only has to be there)
+out_t = torch.zeros((4, G), dtype=torch.int32, device="cuda")
+
+
 def eager():
+    if FUSED_LT:
+        # a log-term tick inside a fused call runs as a single launch behind its pre-pass, and since round 6 the call asks that
+        # pre-pass whether it left a reject to the host -- a host wait that must NOT happen while the stream is being captured
+        for t0 in range(0, K, 4):
+            ticks = [ptrs(t) + ([logterm.data_ptr()] if t % 2 else []) for t in range(t0, min(t0 + 4, K))]
+            assert eng.tick_device_fused(ticks, out_t.data_ptr()) == len(ticks)
+        return
     for t in range(K):
         eng.tick_device(*ptrs(t))
 
