@@ -5,7 +5,7 @@
 use std::os::raw::{c_char, c_void};
 
 pub const RG_MAX_SLOTS: u32 = 8;
-pub const RG_ABI_VERSION: u32 = 6;
+pub const RG_ABI_VERSION: u32 = 7;
 pub const RG_PF_STATE_MASK: u32 = 0x03;
 pub const RG_STATE_PROBE: u32 = 0;
 pub const RG_STATE_REPLICATE: u32 = 1;
@@ -156,7 +156,7 @@ pub struct RgDeviceInfo {
     pub last_tick_streaming: u32,
     pub infinity_cache_bytes: u64,
     pub infinity_cache_queried: u32,
-    pub reserved: u32,
+    pub last_tick_offset_bits: u32,
 }
 
 #[repr(C)]

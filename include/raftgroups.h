@@ -41,7 +41,7 @@ extern "C" {
  * new members keep the old meaning), so a caller is compiled against the header of the library it loads. RG_ABI_VERSION is bumped
  * whenever a struct layout, an enum value or a signature changes; rg_abi_version() returns what the library was built with --
  * compare the two at start-up (raftgroups.hpp and the Python / Rust bindings do). */
-#define RG_ABI_VERSION 6u
+#define RG_ABI_VERSION 7u
 
 /* ---- status codes; the negative values mirror src/errors.rs:6-50 where one applies ---- */
 typedef enum {
@@ -292,7 +292,10 @@ typedef struct {
      * (profiles/r04_nt_state.txt, r04_resident.txt, r05_cache_policy_sweep.txt) and scale with the size the device reports. */
     uint64_t infinity_cache_bytes;
     uint32_t infinity_cache_queried; /* 1 = asked of the device; 0 = the query failed and the MI355X constant stands in */
-    uint32_t reserved;
+    /* the cell-offset width of that last launch: 32 while every cell of a column lies within 4 GiB of the column's start
+     * (max(n_slots, RG_TERM_RUNS) x stride x 8 < 4 GiB: up to 67 108 608 groups), 64 beyond that or under RG_CFGF_IX64; 0 before
+     * the first tick */
+    uint32_t last_tick_offset_bits;
 } rg_device_info;
 #define RG_KERNEL_NONE 0u
 #define RG_KERNEL_LANE 1u      /* k_tick_lane: one lane per group */

@@ -147,6 +147,7 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick + send stage launch failed: %s", hipGetErrorString(e));
         h->dev.last_tick_kernel = RG_KERNEL_TICK_SEND;
+        h->dev.last_tick_offset_bits = rg_ix32(h->st, h->P) ? 32u : 64u;
         h->dev.last_tick_streaming = nts ? 2u : 1u; // (k_tick_send streams its message columns at any size)
         h->tick_launches++;
         h->ticked = true;
@@ -191,6 +192,7 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
             hipError_t ce = hipGetLastError();
             if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));
             h->dev.last_tick_kernel = RG_KERNEL_CLASSES;
+            h->dev.last_tick_offset_bits = 32u; // (the class bodies exist for 32-bit offsets only: the condition above)
             h->dev.last_tick_streaming = h->nt_all ? 2u : h->nt_msgs ? 1u : 0u;
             h->tick_launches++;
             h->ticked = true;
@@ -229,6 +231,8 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
     h->dev.last_tick_kernel = kernel;
+    h->dev.last_tick_offset_bits = rg_ix32(h->st, h->P) ? 32u : 64u;
+    if (kernel == RG_KERNEL_LDS) h->dev.last_tick_offset_bits = 64u; // (the LDS-staged comparison kernels index with 64 bits at any size)
     // (the group-commit instantiation and the LDS / compact variants have no streaming twins: rg_launch_tick_gc)
     h->dev.last_tick_streaming = kernel == RG_KERNEL_SPLIT ? 2u : (kernel == RG_KERNEL_LANE && !h->any_group_commit) ? (h->nt_all ? 2u : h->nt_msgs ? 1u : 0u) : 0u;
     h->tick_launches++;

@@ -108,7 +108,7 @@ class DeviceInfo(C.Structure):
                 ("lds_per_workgroup", C.c_uint64), ("hbm_bytes", C.c_uint64), ("l2_bytes", C.c_uint64),
                 ("engine_bytes", C.c_uint64), ("cache_policy", C.c_uint32), ("engines_on_device", C.c_uint32),
                 ("resident_groups", C.c_uint64), ("last_tick_kernel", C.c_uint32), ("last_tick_streaming", C.c_uint32),
-                ("infinity_cache_bytes", C.c_uint64), ("infinity_cache_queried", C.c_uint32), ("reserved", C.c_uint32)]
+                ("infinity_cache_bytes", C.c_uint64), ("infinity_cache_queried", C.c_uint32), ("last_tick_offset_bits", C.c_uint32)]
 
 
 import contextlib
@@ -205,7 +205,7 @@ class PublishStats(C.Structure):
                 ("host_us_events", C.c_double), ("host_us_allgather", C.c_double), ("host_us_memset", C.c_double)]
 
 
-ABI_VERSION = 6  # RG_ABI_VERSION of include/raftgroups.h these ctypes layouts mirror (tests/test_abi.py compares)
+ABI_VERSION = 7  # RG_ABI_VERSION of include/raftgroups.h these ctypes layouts mirror (tests/test_abi.py compares)
 class CommInfo(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("transport", C.c_uint32), ("in_process", C.c_uint32),
                 ("rccl_ranks", C.c_uint32), ("rccl_rank", C.c_uint32)]
@@ -447,7 +447,8 @@ class Engine:
                 "engine_bytes": d.engine_bytes, "cache_policy": CACHE.NAMES[d.cache_policy],
                 "engines_on_device": d.engines_on_device, "resident_groups": d.resident_groups,
                 "last_tick_kernel": KERNEL.NAMES[d.last_tick_kernel], "last_tick_streaming": d.last_tick_streaming,
-                "infinity_cache_bytes": d.infinity_cache_bytes, "infinity_cache_queried": bool(d.infinity_cache_queried)}
+                "infinity_cache_bytes": d.infinity_cache_bytes, "infinity_cache_queried": bool(d.infinity_cache_queried),
+                "last_tick_offset_bits": d.last_tick_offset_bits}
 
     def column_shape_dtype(self, col):
         if col in COL.PER_SLOT:

@@ -310,6 +310,91 @@ def test_config5_eight_million_groups_class_placed_match_the_oracle(rg):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# maximum sizes: the two engines either side of the 4 GiB column boundary -- the LAST shard whose kernels address their cells
+# with 32-bit offsets (67 108 608 groups: slot / run 7 of the last group sits 2 KiB below 4 GiB) and the FIRST one that takes
+# the 64-bit-offset instantiations by its size alone (67 108 864 groups; every other test reaches those kernels through
+# RG_CFGF_IX64 on small engines). 35 GB of engine + 11 GB of messages on the device, so nothing of that size crosses to the
+# host: the compared sub-ranges are REPLICAS kept on the host -- the generator's host twin lays out the groups [a, a + n) of
+# the shard and produces their messages tick by tick from the replica's own state (the generator is a function of the global
+# group id and the group's state: tests/test_workload_host.py, test_device_generator_equals_host_generator), the oracle steps
+# them, and the device's groups are read back through rg_read_groups.
+# ---------------------------------------------------------------------------------------------------------------
+def _status_as_state(rows, n, n_slots):
+    got = O.alloc_state(n, n_slots)
+    for k in ("match", "next", "pr_commit", "pend_snap", "pend_rs"):
+        got[k][:, :n] = rows[k][:, :n_slots].T
+    got["pflags"][:] = rows["pflags"]
+    got["commit"][:] = rows["commit"]
+    got["term_lo"][:] = rows["term_lo"]
+    got["term_hi"][:] = rows["last_index"]
+    got["cfg"][:] = rows["cfg"]
+    return got
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_shards_either_side_of_the_four_gib_column_boundary_match_the_oracle(rg, bits):
+    import torch
+    from raft_rs_amd import engine as E
+    P, TICKS, N = 5, 3, 128 * 1024
+    rows = max(P, E.TERM_RUNS)
+    last32 = (0xFFFFFFFF // (8 * rows)) // 256 * 256  # the largest stride whose farthest cell is below 4 GiB
+    G = last32 if bits == 32 else last32 + 256
+    assert (rows * G * 8 <= 0xFFFFFFFF) == (bits == 32)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip(f"needs ~50 GB of device memory, {free >> 30} GiB free")
+    threads = os.cpu_count() or 8
+    eng = rg.Engine(G, P)
+    assert eng.stride == G and eng.device_info()["engine_bytes"] > 30 * 2**30
+    eng.workload_init(2)
+    # the head, a range in the middle (slot 4's cells there lie either side of byte offset 2 GiB + ...: a sign-extended 32-bit
+    # offset would land elsewhere), two near the end -- not block-aligned -- and the tail: the largest offsets the kernels form
+    mid = (G // 2 // 256) * 256 + 77
+    ranges = [(0, N), (mid, N), (G - 3 * N - 131, N), (G - N, N)]
+    reps = []
+    for a, n in ranges:
+        sub = O.alloc_state(n, P)
+        E.workload_init_host(sub, 2, first_group=a)
+        cl = O.Cluster(n)
+        cl.load_soa(sub, term=TERM)
+        reps.append((a, n, sub, cl, rg.MsgBuffers(n, P, sub["stride"]), np.zeros(n, dtype=np.uint32)))
+        got = _status_as_state(eng.read_groups(np.arange(a, a + n, dtype=np.uint64)), n, P)
+        assert not fuzz.diff_states(sub, got, n, P, keys=[k for k in fuzz.STATE_KEYS if k != "gid"]), ("initial state", a)
+    dev = [torch.zeros((P, eng.stride), dtype=torch.int64, device="cuda") for _ in range(4)]
+    dflags = torch.zeros((G, 8), dtype=torch.uint8, device="cuda")
+    changed = 0
+    for t in range(TICKS):
+        eng.workload_gen(2, t, *[d.data_ptr() for d in dev], dflags.data_ptr())
+        eng.tick_device(*[d.data_ptr() for d in dev], dflags.data_ptr())
+        eng.sync()
+        info = eng.device_info()
+        assert info["last_tick_kernel"] == "k_tick_lane" and info["last_tick_offset_bits"] == bits, info
+        for a, n, sub, cl, host, gout in reps:
+            E.workload_gen_host(sub, host, 2, t, first_group=a)
+            # (the device's message cells of this range are what the host twin wrote: the first and the last slot's rows)
+            for p in (0, P - 1):
+                assert np.array_equal(dev[0][p, a:a + n].cpu().numpy().view(np.uint64), host.m_index[p, :n]), (t, a, p)
+            m = host.as_dict()
+            del m["m_logterm"]
+            cl.tick_soa_mt(m, gout, threads)
+            cl.store_soa(sub)
+            rows_ = eng.read_groups(np.arange(a, a + n, dtype=np.uint64))
+            diffs = fuzz.diff_states(sub, _status_as_state(rows_, n, P), n, P, keys=[k for k in fuzz.STATE_KEYS if k != "gid"])
+            assert not diffs, f"{G} x {P} ({bits}-bit offsets) groups [{a}, {a + n}) tick {t}: " + "; ".join(diffs[:8])
+            bad = np.nonzero(rows_["out"] != gout)[0]
+            assert bad.size == 0, (t, a, bad[:5], [hex(x) for x in rows_["out"][bad[:5]]], [hex(x) for x in gout[bad[:5]]])
+            assert not (gout & 2).any()
+            changed += int((gout & 1).sum())
+    # ... and nothing faulted anywhere in the 67 M groups (counted on the device: rg_result_counts)
+    n_changed, n_fault = eng.result_counts()
+    assert n_fault == 0 and n_changed > 0.6 * G, (n_changed, n_fault)
+    eng.close()
+    del dev, dflags
+    torch.cuda.empty_cache()
+    assert changed > 0.6 * TICKS * len(ranges) * N, changed
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # the send stage at the size bench.py measures it: 1 M x 5, Inflights of capacity 256 on the device, both forms
 # ---------------------------------------------------------------------------------------------------------------
 def _items_by_key(items, a, n):
