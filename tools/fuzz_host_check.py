@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Long-running seeded fuzz of the kernels' arithmetic (rg_group.h compiled for the host: tests/host_check) against the oracle --
+the body of tests/test_host_check.py::test_device_arithmetic_on_host_matches_oracle with FRESH seeds, for as long as asked:
+
+    python tools/fuzz_host_check.py [--seconds 600] [--seed0 N]
+
+P = 1..8, joint configurations, group commit on / off, slots without a Progress, small and full-range index values, malformed
+events on some ticks. CPU only (not part of the suite: minutes). Prints one line per 50 rounds and the totals; exits 1 on the
+first mismatch with the seed that reproduces it."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import fuzz  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import test_host_check as H  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=600)
+    ap.add_argument("--seed0", type=int, default=int(time.time()))
+    args = ap.parse_args()
+    tick = H.host_tick.__wrapped__() if hasattr(H.host_tick, "__wrapped__") else None
+    if tick is None:
+        raise SystemExit("cannot reach the host_tick fixture body")
+    t0, rounds, group_ticks = time.time(), 0, 0
+    seed = args.seed0
+    while time.time() - t0 < args.seconds:
+        seed += 1
+        rng = np.random.default_rng(seed)
+        P = int(rng.integers(1, 9))
+        gc = bool(rng.integers(0, 2))
+        G = int(rng.integers(200, 6000))
+        small = bool(rng.integers(0, 4))  # (one round in four with full-range values)
+        st = O.alloc_state(G, P)
+        st["cfg"][:] = fuzz.random_cfg(rng, G, P, missing_progress_frac=float(rng.choice([0.0, 0.05, 0.3])),
+                                       group_commit_frac=0.5 if gc else 0.0)
+        fuzz.random_state(rng, st, small_values=small, with_gids=gc)
+        cl = O.Cluster(G)
+        cl.load_soa(st, term=6)
+        eng = H.copy_state(st)
+        msgs = O.alloc_msgs(G, P)
+        gout = np.zeros(G, dtype=np.uint32)
+        out = np.zeros(G, dtype=np.uint32)
+        T = int(rng.integers(3, 9))
+        for t in range(T):
+            cl.store_soa(st)
+            fuzz.random_msgs(rng, st, msgs, malformed_p=0.03 if rng.integers(0, 3) == 0 else 0.0)
+            tick(eng, msgs, out, gc)
+            cl.tick_soa(msgs, gout)
+            cl.store_soa(st)
+            diffs = fuzz.diff_states(st, eng, G, P)
+            if diffs or not (out == gout).all():
+                print(f"MISMATCH seed {seed} P {P} gc {gc} G {G} small {small} tick {t}: {diffs[:6]} "
+                      f"out {np.nonzero(out != gout)[0][:5]}", flush=True)
+                sys.exit(1)
+            group_ticks += G
+        rounds += 1
+        if rounds % 50 == 0:
+            print(f"{rounds} rounds, {group_ticks} group-ticks, {time.time() - t0:.0f} s, last seed {seed}", flush=True)
+    print(f"clean: {rounds} rounds, {group_ticks} group-ticks, seeds {args.seed0 + 1}..{seed}")
+
+
+if __name__ == "__main__":
+    main()
