@@ -588,6 +588,19 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, host_tick_send,
     """fused: the tick and its stage as ONE pass over the group's registers (rg_group_tick_send, k_tick_send's lane code)."""
     rng = np.random.default_rng(9100 + 17 * n_slots + cap + max_entries)
     G, ticks = (300, 60) if cap == 5 else (1500, 10)  # cap 5: a long run, the ring positions wrap many times
+    seen = send_stage_round(rng, host_tick, host_send, host_tick_send, fused, n_slots, cap, max_entries, G, ticks)
+    if n_slots > 1:
+        assert seen["items"] > 100, seen
+        assert seen["snap"] > 0, seen
+        if cap <= 4:
+            assert seen["full"] > 0, seen
+        if max_entries in (1, 2) and cap > 1:
+            assert seen["multi"] > 0, seen
+
+
+def send_stage_round(rng, host_tick, host_send, host_tick_send, fused, n_slots, cap, max_entries, G, ticks):
+    """One seeded run of tick + send stage on the host twins against the oracle with its own Inflights (the body of the test
+    above; tools/fuzz_host_check.py --send calls it with fresh seeds). Returns what the run exercised."""
     st = O.add_term_table(O.alloc_state(G, n_slots))
     st["cfg"][:] = fuzz.random_cfg(rng, G, n_slots, missing_progress_frac=0.05)
     fuzz.random_state(rng, st, small_values=True)
@@ -642,13 +655,7 @@ def test_send_stage_on_host_matches_oracle(host_tick, host_send, host_tick_send,
         seen["multi"] += sum(1 for v in got.values() if v[3] > 1)
         seen["snap"] += sum(1 for v in got.values() if v[0] == O.SEND_SNAPSHOT)
         seen["full"] += int(((st["pflags"][:, :n_slots] & 0x10) != 0).sum())
-    if n_slots > 1:
-        assert seen["items"] > 100, seen
-        assert seen["snap"] > 0, seen
-        if cap <= 4:
-            assert seen["full"] > 0, seen
-        if max_entries in (1, 2) and cap > 1:
-            assert seen["multi"] > 0, seen
+    return seen
 
 
 @pytest.mark.parametrize("n_slots,cap,window,max_bytes", [(3, 4, 8, 900), (5, 256, 64, 1500), (5, 3, 16, 0), (7, 8, 32, 2**32 + 5),
