@@ -106,7 +106,8 @@ def local_messages(rg, eng, cl, rng, G, P, mirror_ok=True):
     return form
 
 
-@pytest.mark.parametrize("seed,P", [(1, 3), (2, 5), (3, 7)])
+# (RG_SOAK_SEEDS=n adds n more seeded cases here as well, P = 1..8 by the seed: an ad hoc soak, see below)
+@pytest.mark.parametrize("seed,P", [(1, 3), (2, 5), (3, 7)] + [(200 + i, 1 + i % 8) for i in range(int(os.environ.get("RG_SOAK_SEEDS", "0")))])
 def test_random_api_sequences_match_the_oracle(rg, seed, P):
     rng = np.random.default_rng(4200 + seed)
     G = 1500
