@@ -43,7 +43,10 @@ extern "C" {
  * compare the two at start-up (raftgroups.hpp and the Python / Rust bindings do). */
 #define RG_ABI_VERSION 7u
 
-/* ---- status codes; the negative values mirror src/errors.rs:6-50 where one applies ---- */
+/* ---- status codes; the negative values mirror src/errors.rs:6-50 where one applies ----
+ * Every entry point that returns int returns one of these and leaves the text in rg_last_error() (per thread). Nothing unwinds
+ * through this boundary: a C++ exception inside the library -- a host allocation that fails -- is caught at the entry point
+ * (RG_ERR_OUT_OF_MEMORY; anything else RG_ERR_STATE), the way a failed device allocation is reported, never thrown or fatal. */
 typedef enum {
     RG_OK = 0,
     RG_ERR_INVALID_ARG = -1,

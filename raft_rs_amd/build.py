@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libraftgroups.so")
 UNITS = ["abi_state.hip", "abi_tick.hip", "abi_send.hip", "abi_mirror.hip", "abi_wire.hip", "abi_publish.hip", "abi_placement.hip"]
-DEPS = UNITS + ["tick_inst.hip", "rg_engine.h", "rg_common.h", "rg_group.h", "rg_send.h", "rg_wire.h", "rg_workload.h", "rg_tick_kernels.h",
+DEPS = UNITS + ["tick_inst.hip", "rg_engine.h", "rg_abi_guard.h", "rg_common.h", "rg_group.h", "rg_send.h", "rg_wire.h", "rg_workload.h", "rg_tick_kernels.h",
                 "rg_publish.h", "rg_kernels_quorum.h", "rg_kernels_sparse.h", "rg_kernels_send.h", "rg_kernels_state.h",
                 "rg_kernels_workload.h", "rg_kernels_publish.h", "rg_kernels_placement.h", os.path.join("..", "..", "include", "raftgroups.h")]
 ARCH = "gfx950"

@@ -48,7 +48,7 @@ int rg_ensure_sparse(rg_engine *h) {
     return RG_OK;
 }
 
-extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, uint64_t *n_duplicates) {
+extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, uint64_t *n_duplicates) try {
     if (!h || (!records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest: bad argument");
     if (n_duplicates) *n_duplicates = 0;
     if (n == 0) return RG_OK;
@@ -81,9 +81,9 @@ extern "C" int rg_ingest(rg_engine *h, const rg_wire_msg *records, uint64_t n, u
     if (n_duplicates) *n_duplicates = dup - dup0; // dup0 was read before the kernel ran (stream order)
     h->ingested_upper += n;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, uint64_t n) {
+extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, uint64_t n) try {
     if (!h || (!dev_records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest_device: bad argument");
     if (n == 0) return RG_OK;
     RG_ENTER(h);
@@ -99,9 +99,9 @@ extern "C" int rg_ingest_device(rg_engine *h, const rg_wire_msg *dev_records, ui
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_ingest_device: %s", hipGetErrorString(e));
     h->ingested_upper += n;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
+extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) try {
     if (!h || !n_duplicates) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingested_duplicates: bad argument");
     *n_duplicates = 0;
     if (!h->sparse_arena) return RG_OK;
@@ -111,7 +111,7 @@ extern "C" int rg_ingested_duplicates(rg_engine *h, uint64_t *n_duplicates) {
     RG_HIP(hipStreamSynchronize(h->stream));
     *n_duplicates = dup;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // Everything of a sparse tick that needs no host round trip: clear the previous results, resolve hints, tick the
 // listed groups, gather their results (also into `packed` when given). `upper` bounds the list length.
@@ -213,7 +213,7 @@ int rg_sparse_finish(rg_engine *h, u64 n_groups) {
     return RG_OK;
 }
 
-extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
+extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_ingested: null engine");
     if (n_groups) *n_groups = 0;
     RG_ENTER(h);
@@ -236,10 +236,10 @@ extern "C" int rg_tick_ingested(rg_engine *h, uint64_t *n_groups) {
     if (rc) return rc;
     if (n_groups) *n_groups = h->last_sparse_n;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *commit, uint32_t *out, uint64_t cap,
-                                   uint64_t *n) {
+                                   uint64_t *n) try {
     if (!h || !n) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingested_results: bad argument");
     *n = h->last_sparse_n;
     const u64 k = h->last_sparse_n < cap ? h->last_sparse_n : cap;
@@ -256,7 +256,7 @@ extern "C" int rg_ingested_results(rg_engine *h, uint64_t *groups, uint64_t *com
     if (out) RG_HIP(hipMemcpyAsync(out, h->res_out, k * 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 
 // ------------------------------------------------------------------------------------------------
@@ -276,13 +276,13 @@ static void rg_mirror_init(rg_engine *h) {
     h->host_mirror = true;
 }
 
-extern "C" int rg_set_peers(rg_engine *h, uint64_t group, const uint64_t *peer_ids, uint32_t n, uint64_t term) {
+extern "C" int rg_set_peers(rg_engine *h, uint64_t group, const uint64_t *peer_ids, uint32_t n, uint64_t term) try {
     if (!h || !peer_ids || group >= h->G || n > h->P) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_peers: bad argument");
     rg_mirror_init(h);
     for (u32 i = 0; i < 8; i++) h->peer_ids[group * 8 + i] = i < n ? peer_ids[i] : 0; // id 0 is illegal (raw_node.rs:303)
     h->terms[group] = term;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 static int rg_find_slot(rg_engine *h, u64 group, u64 id) {
     if (id == 0) return -1;
@@ -313,7 +313,7 @@ static int rg_from_self(rg_engine *h, u64 group, int slot, bool *is_self) {
     return RG_OK;
 }
 
-extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m) {
+extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m) try {
     if (!h || !m || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step: rg_set_peers was never called");
     // RawNode::step (src/raw_node.rs:402-411): MsgAppendResponse is not a local message type; a response from an id
@@ -347,10 +347,10 @@ extern "C" int rg_step(rg_engine *h, uint64_t group, const rg_append_response *m
     f |= RG_MF_VALID | (m->reject ? RG_MF_REJECT : 0) | (m->request_snapshot ? RG_MF_HAS_RS : 0) |
          (m->ins_full ? RG_MF_INS_FULL : 0) | ((m->reject && m->log_term) ? RG_MF_HAS_LOGTERM : 0);
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t from, uint64_t term, uint64_t commit,
-                                          uint8_t ins_full) {
+                                          uint8_t ins_full) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_heartbeat_response: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_step_heartbeat_response: rg_set_peers was never called");
     const int slot = rg_find_slot(h, group, from); // raw_node.rs:407-410 comes before the term gate
@@ -371,7 +371,7 @@ extern "C" int rg_step_heartbeat_response(rg_engine *h, uint64_t group, uint64_t
     h->q_mc[(size_t)slot * h->stride + group] = commit;
     f |= RG_MF_HEARTBEAT | (ins_full ? RG_MF_INS_FULL : 0);
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 static int rg_self_slot(rg_engine *h, u64 group, u32 *slot) {
     // the self slot lives in the device cfg word; the mirror keeps a host copy of the column, refreshed
@@ -390,7 +390,7 @@ static int rg_self_slot(rg_engine *h, u64 group, u32 *slot) {
 }
 
 
-extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len, uint8_t ins_full) {
+extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes, uint64_t len, uint8_t ins_full) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_step_bytes: bad argument");
     rg_decoded_message m;
     int rc = rg_decode_message(bytes, len, &m);
@@ -418,9 +418,9 @@ extern "C" int rg_step_bytes(rg_engine *h, uint64_t group, const uint8_t *bytes,
         return rg_fail(RG_ERR_NOT_ON_PATH, "rg_step_bytes: message type %u is not handled on this path (the host's Raft::step takes it)",
                        m.msg_type);
     }
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index) {
+extern "C" int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_index) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_append: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_append: rg_set_peers was never called");
     u32 slot;
@@ -430,9 +430,9 @@ extern "C" int rg_local_append(rg_engine *h, uint64_t group, uint64_t new_last_i
     h->q_mc[(size_t)slot * h->stride + group] = new_last_index;
     h->q_mf[group * 8 + slot] |= RG_MF_APPEND;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index) {
+extern "C" int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_persisted: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_persisted: rg_set_peers was never called");
     u32 slot;
@@ -444,9 +444,9 @@ extern "C" int rg_local_persisted(rg_engine *h, uint64_t group, uint64_t index) 
     h->q_mi[(size_t)slot * h->stride + group] = index;
     f |= RG_MF_VALID;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t term) {
+extern "C" int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t term) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_local_become_leader: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_local_become_leader: rg_set_peers was never called");
     if (term <= h->terms[group])
@@ -468,7 +468,7 @@ extern "C" int rg_local_become_leader(rg_engine *h, uint64_t group, uint64_t ter
     h->q_elections.push_back({group, h->terms[group]});
     h->terms[group] = term;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // RawNode::report_unreachable / report_snapshot (src/raw_node.rs:692-709): MsgUnreachable / MsgSnapStatus stepped at a leader
 static int rg_report(rg_engine *h, uint64_t group, uint64_t peer_id, u32 kind, const char *who) {
@@ -483,14 +483,14 @@ static int rg_report(rg_engine *h, uint64_t group, uint64_t peer_id, u32 kind, c
     const rg_progress_event ev = {group, (u32)slot, kind};
     return rg_progress_events(h, &ev, 1);
 }
-extern "C" int rg_report_unreachable(rg_engine *h, uint64_t group, uint64_t peer_id) {
+extern "C" int rg_report_unreachable(rg_engine *h, uint64_t group, uint64_t peer_id) try {
     return rg_report(h, group, peer_id, RG_EV_UNREACHABLE, "rg_report_unreachable");
-}
-extern "C" int rg_report_snapshot(rg_engine *h, uint64_t group, uint64_t peer_id, int failure) {
+} RG_ABI_GUARD
+extern "C" int rg_report_snapshot(rg_engine *h, uint64_t group, uint64_t peer_id, int failure) try {
     return rg_report(h, group, peer_id, failure ? RG_EV_SNAPSHOT_FAILURE : RG_EV_SNAPSHOT_FINISH, "rg_report_snapshot");
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
+extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_mark_sent: bad argument");
     if (!h->host_mirror) return rg_fail(RG_ERR_STATE, "rg_mark_sent: rg_set_peers was never called");
     const int slot = rg_find_slot(h, group, peer_id);
@@ -503,7 +503,7 @@ extern "C" int rg_mark_sent(rg_engine *h, uint64_t group, uint64_t peer_id) {
     rg_touch(h, group);
     h->q_mf[group * 8 + slot] |= RG_MF_SENT;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // One sparse tick in ONE host<->device round trip: records (the caller's, or built from the mirror's queues when
 // `recs` is NULL) -> pinned staging -> ingest / clear / hint resolve / tick / gather back to back -> one packed D2H
@@ -867,7 +867,7 @@ static int rg_mailbox_flush(rg_engine *h, u64 n, bool any_logterm, bool *served,
     return RG_OK;
 }
 
-extern "C" int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us) {
+extern "C" int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_start: null engine");
     RG_ENTER(h);
     int rc = rg_ensure_sparse(h);
@@ -891,21 +891,21 @@ extern "C" int rg_mailbox_start(rg_engine *h, uint32_t idle_timeout_us) {
     h->mbox_idle_ticks = (u64)(idle_timeout_us ? idle_timeout_us : 2000u) * RG_MBOX_TICKS_PER_US;
     h->mbox_on = true;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_mailbox_stats(const rg_engine *h, uint64_t *flushes_served, uint64_t *launches) {
+extern "C" int rg_mailbox_stats(const rg_engine *h, uint64_t *flushes_served, uint64_t *launches) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_stats: null engine");
     if (flushes_served) *flushes_served = h->mbox_served;
     if (launches) *launches = h->mbox_launches;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_mailbox_stop(rg_engine *h) {
+extern "C" int rg_mailbox_stop(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_mailbox_stop: null engine");
     RG_ENTER(h);
     h->mbox_on = false;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 static int rg_flush_sparse(rg_engine *h, const rg_send_req *send) {
     u32 dup = 0;
@@ -916,7 +916,7 @@ static int rg_flush_sparse(rg_engine *h, const rg_send_req *send) {
 }
 
 extern "C" int rg_ingest_tick(rg_engine *h, const rg_wire_msg *records, uint64_t n, uint64_t *n_groups,
-                              uint64_t *n_duplicates) {
+                              uint64_t *n_duplicates) try {
     if (!h || (!records && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_ingest_tick: bad argument");
     if (n_groups) *n_groups = 0;
     if (n_duplicates) *n_duplicates = 0;
@@ -927,7 +927,7 @@ extern "C" int rg_ingest_tick(rg_engine *h, const rg_wire_msg *records, uint64_t
     if (n_groups) *n_groups = h->last_sparse_n;
     if (n_duplicates) *n_duplicates = dup;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // The device is the judge of an RG_MF_BECOME_LEADER event: it validates the new term against RG_COL_CUR_TERM (which the
 // host may have reloaded or restored since rg_set_peers registered a term) and answers RG_OUT_BECAME_LEADER, or
@@ -1020,12 +1020,12 @@ static int rg_flush_impl(rg_engine *h, const rg_send_req *send) {
     return rc;
 }
 
-extern "C" int rg_flush(rg_engine *h) {
+extern "C" int rg_flush(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush: null engine");
     return rg_flush_impl(h, nullptr);
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) {
+extern "C" int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_flush_send: null engine");
     if (!h->ins_arena)
         return rg_fail(RG_ERR_STATE, "rg_flush_send: engine created with max_inflight = 0 (Inflights are the host's)");
@@ -1036,6 +1036,6 @@ extern "C" int rg_flush_send(rg_engine *h, uint64_t max_entries_per_msg, uint32_
     req.max_entries = max_entries_per_msg;
     req.flags = flags;
     return rg_flush_impl(h, &req);
-}
+} RG_ABI_GUARD
 
 

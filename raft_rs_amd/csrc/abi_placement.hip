@@ -10,7 +10,7 @@
 // interleaved: 1.47 x the algorithmic bytes). The one-launch class kernel needs groups of one size in contiguous ranges; these
 // two calls are how a host gets there: plan on the host from the cfg words, gather on the device.
 extern "C" int rg_plan_placement(const uint32_t *cfg_words, uint64_t n_groups, uint32_t n_slots, uint64_t *perm,
-                                 rg_size_class *classes, uint32_t cap, uint32_t *n_classes) {
+                                 rg_size_class *classes, uint32_t cap, uint32_t *n_classes) try {
     if (!cfg_words || !perm || n_groups == 0 || n_slots == 0 || n_slots > RG_MAX_SLOTS || (cap && !classes))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_plan_placement: bad argument");
     // the bodies k_tick_classes<P> has: 3, 5, 7 slots below P, and P itself (rg_class_body) -- a counting sort over them,
@@ -54,7 +54,7 @@ extern "C" int rg_plan_placement(const uint32_t *cfg_words, uint64_t n_groups, u
     }
     if (n_classes) *n_classes = k;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 template <typename T>
 static void rg_place_rows(rg_engine *h, const void *src, void *dst, const u64 *d_perm, u64 rows) {
@@ -62,7 +62,7 @@ static void rg_place_rows(rg_engine *h, const void *src, void *dst, const u64 *d
                        h->G, h->stride);
 }
 
-extern "C" int rg_permute_groups(rg_engine *h, const uint64_t *host_perm) {
+extern "C" int rg_permute_groups(rg_engine *h, const uint64_t *host_perm) try {
     if (!h || !host_perm) return rg_fail(RG_ERR_INVALID_ARG, "rg_permute_groups: bad argument");
     {   // a permutation of [0, G): every old position exactly once
         std::vector<u8> seen(h->G, 0);
@@ -168,4 +168,4 @@ extern "C" int rg_permute_groups(rg_engine *h, const uint64_t *host_perm) {
         h->esz_ckpt = nullptr;
     }
     return RG_OK;
-}
+} RG_ABI_GUARD

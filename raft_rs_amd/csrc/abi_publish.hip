@@ -317,7 +317,7 @@ static int rg_publish_all_impl(rg_engine *const *e, uint32_t n, bool force_full)
     return RG_OK;
 }
 
-extern "C" int rg_comm_unique_id(uint8_t id[RG_COMM_ID_BYTES]) {
+extern "C" int rg_comm_unique_id(uint8_t id[RG_COMM_ID_BYTES]) try {
     if (!id) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_unique_id: null argument");
     int rc = rg_rccl_load();
     if (rc) return rc;
@@ -327,9 +327,9 @@ extern "C" int rg_comm_unique_id(uint8_t id[RG_COMM_ID_BYTES]) {
     if (r != ncclSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_comm_unique_id: ncclGetUniqueId failed: %s", rg_nccl_err(r));
     memcpy(id, u.internal, RG_COMM_ID_BYTES);
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_comm_destroy(rg_engine *h) {
+extern "C" int rg_comm_destroy(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_destroy: null engine");
     RgPub *p = h->pub;
     if (!p) return RG_OK;
@@ -356,9 +356,9 @@ extern "C" int rg_comm_destroy(rg_engine *h) {
     h->pub = nullptr;
     h->st.pub = nullptr;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_comm_info_get(rg_engine *h, rg_comm_info *out) {
+extern "C" int rg_comm_info_get(rg_engine *h, rg_comm_info *out) try {
     if (!h || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_info_get: bad argument");
     memset(out, 0, sizeof(*out));
     RgPub *p = h->pub;
@@ -376,13 +376,13 @@ extern "C" int rg_comm_info_get(rg_engine *h, rg_comm_info *out) {
         out->rccl_rank = (uint32_t)urank;
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // RCCL's first use in a process is slow -- the library is ~0.5 GB to map (seconds to minutes on a cold box:
 // profiles/r05_rccl_cold_load.txt) and the first communicator sets up its transports. A host that bounds its start-up steps
 // with timeouts calls this once, early, on the thread and device it will use: it loads the library and creates and destroys a
 // one-rank communicator, so that the first real rg_comm_init finds everything mapped.
-extern "C" int rg_comm_warmup(void) {
+extern "C" int rg_comm_warmup(void) try {
     int rc = rg_rccl_load();
     if (rc) return rc;
     ncclUniqueId u;
@@ -397,7 +397,7 @@ extern "C" int rg_comm_warmup(void) {
     if (comm) (void)g_rccl.CommDestroy(comm);
     if (r != ncclSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_comm_warmup: RCCL failed: %s", rg_nccl_err(r));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // Everything of rg_comm_init but the communicator and the first publication: buffers, streams, events.
 // xdev: slices are read by OTHER devices (in-process transport across GPUs): the slice-complete events keep their system-scope fence.
@@ -460,7 +460,7 @@ static int rg_comm_setup(rg_engine *h, u32 rank, u32 world, u32 ring_ticks, u32 
     return RG_OK;
 }
 
-extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
+extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) try {
     if (!h || !cfg) return rg_fail(RG_ERR_INVALID_ARG, "rg_comm_init: null argument");
     if (h->pub) return rg_fail(RG_ERR_STATE, "rg_comm_init: already initialised (rg_comm_destroy first)");
     if (cfg->world == 0 || cfg->rank >= cfg->world)
@@ -496,7 +496,7 @@ extern "C" int rg_comm_init(rg_engine *h, const rg_comm_config *cfg) {
         return rc;
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 static int rg_all_check(rg_engine *const *engines, uint32_t n, const char *who, bool need_pub) {
     if (!engines || n == 0) return rg_fail(RG_ERR_INVALID_ARG, "%s: no engines", who);
@@ -513,7 +513,7 @@ static int rg_all_check(rg_engine *const *engines, uint32_t n, const char *who, 
     return RG_OK;
 }
 
-extern "C" int rg_comm_init_all(rg_engine *const *engines, uint32_t n, const rg_comm_all_config *cfg) {
+extern "C" int rg_comm_init_all(rg_engine *const *engines, uint32_t n, const rg_comm_all_config *cfg) try {
     int rc = rg_all_check(engines, n, "rg_comm_init_all", false);
     if (rc) return rc;
     rg_comm_all_config c = {0, 0, RG_COMM_ALL_AUTO, 0};
@@ -571,24 +571,24 @@ extern "C" int rg_comm_init_all(rg_engine *const *engines, uint32_t n, const rg_
     rc = rg_publish_all_impl(engines, n, true); // every replica starts from the actual columns
     if (rc) undo(n);
     return rc;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_publish_commit_all(rg_engine *const *engines, uint32_t n, uint32_t flags) {
+extern "C" int rg_publish_commit_all(rg_engine *const *engines, uint32_t n, uint32_t flags) try {
     if (flags & ~RG_PUBLISH_FULL) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit_all: unknown flags %#x", flags);
     int rc = rg_all_check(engines, n, "rg_publish_commit_all", true);
     if (rc) return rc;
     return rg_publish_all_impl(engines, n, (flags & RG_PUBLISH_FULL) != 0);
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_publish_commit(rg_engine *h, uint32_t flags) {
+extern "C" int rg_publish_commit(rg_engine *h, uint32_t flags) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: null engine");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_commit: rg_comm_init was never called");
     if (flags & ~RG_PUBLISH_FULL) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: unknown flags %#x", flags);
     RG_ENTER(h);
     return rg_publish_impl(h, (flags & RG_PUBLISH_FULL) != 0);
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_publish_sync(rg_engine *h) {
+extern "C" int rg_publish_sync(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_sync: null engine");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_sync: rg_comm_init was never called");
     RG_ENTER(h);
@@ -596,7 +596,7 @@ extern "C" int rg_publish_sync(rg_engine *h) {
     if (rc) return rc;
     RG_HIP(hipStreamSynchronize(h->pub->side));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" const uint64_t *rg_published_commit_ptr(rg_engine *h, uint64_t *stride) {
     if (!h || !h->pub) return nullptr;
@@ -604,7 +604,7 @@ extern "C" const uint64_t *rg_published_commit_ptr(rg_engine *h, uint64_t *strid
     return h->pub->replica;
 }
 
-extern "C" int rg_published_commit(rg_engine *h, uint32_t rank, uint64_t first, uint64_t n, uint64_t *host_commit) {
+extern "C" int rg_published_commit(rg_engine *h, uint32_t rank, uint64_t first, uint64_t n, uint64_t *host_commit) try {
     if (!h || (n && !host_commit)) return rg_fail(RG_ERR_INVALID_ARG, "rg_published_commit: bad argument");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_published_commit: rg_comm_init was never called");
     if (rank >= h->pub->world || first > h->G || n > h->G - first)
@@ -614,9 +614,9 @@ extern "C" int rg_published_commit(rg_engine *h, uint32_t rank, uint64_t first, 
     if (rc || !n) return rc;
     RG_HIP(hipMemcpy(host_commit, h->pub->replica + (u64)rank * h->pub->lay.Gpad + first, n * 8, hipMemcpyDeviceToHost));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out) {
+extern "C" int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out) try {
     if (!h || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_stats_get: bad argument");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_stats_get: rg_comm_init was never called");
     *out = h->pub->stats;
@@ -625,7 +625,7 @@ extern "C" int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out) {
     out->overflow_slots = h->pub->lay.cap;
     out->ring_ticks = h->pub->ring;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // Host twins of the encoding (no GPU involved): what the tick kernels write and what the replica kernels add, over
 // caller-provided buffers. CPU-only tests run the N > 1 exchange with these under gloo.
@@ -634,7 +634,7 @@ extern "C" uint64_t rg_pub_bytes_per_rank(uint64_t n_groups, uint32_t overflow_s
 }
 
 extern "C" int rg_pub_accumulate_host(uint64_t n_groups, uint32_t overflow_slots, const uint64_t *old_commit,
-                                      const uint64_t *new_commit, uint8_t *slice) {
+                                      const uint64_t *new_commit, uint8_t *slice) try {
     if (!old_commit || !new_commit || !slice) return rg_fail(RG_ERR_INVALID_ARG, "rg_pub_accumulate_host: null argument");
     const RgPubLayout l = rg_pub_layout(n_groups, overflow_slots ? overflow_slots : (u32)(n_groups / 256 + 64));
     RgPubHdr *hdr = reinterpret_cast<RgPubHdr *>(slice);
@@ -645,10 +645,10 @@ extern "C" int rg_pub_accumulate_host(uint64_t n_groups, uint32_t overflow_slots
         if (new_commit[g] != old_commit[g]) dlt[g] = (u8)rg_pub_accumulate(dlt[g], old_commit[g], new_commit[g], g, hdr, list, l.cap);
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" int rg_pub_apply_host(uint64_t n_groups, uint32_t overflow_slots, uint32_t world, const uint8_t *gathered,
-                                 uint64_t *replica, uint32_t *lost_ranks) {
+                                 uint64_t *replica, uint32_t *lost_ranks) try {
     if (!gathered || !replica) return rg_fail(RG_ERR_INVALID_ARG, "rg_pub_apply_host: null argument");
     const RgPubLayout l = rg_pub_layout(n_groups, overflow_slots ? overflow_slots : (u32)(n_groups / 256 + 64));
     RgPubSlots sl;
@@ -666,5 +666,5 @@ extern "C" int rg_pub_apply_host(uint64_t n_groups, uint32_t overflow_slots, uin
     }
     if (lost_ranks) *lost_ranks = lost;
     return RG_OK;
-}
+} RG_ABI_GUARD
 

@@ -55,7 +55,7 @@ int rg_send_enqueue(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags, 
     return RG_OK;
 }
 
-extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) {
+extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint32_t flags) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_appends: null engine");
     int src = rg_send_check(h, flags, "rg_send_appends");
     if (src) return src;
@@ -68,9 +68,9 @@ extern "C" int rg_send_appends(rg_engine *h, uint64_t max_entries_per_msg, uint3
     h->send_ready = false;
     h->send_bound = n * h->P;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_log_sizes_enable(rg_engine *h, uint32_t window) {
+extern "C" int rg_log_sizes_enable(rg_engine *h, uint32_t window) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_enable: null engine");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_log_sizes_enable: engine created with max_inflight = 0 (no send stage)");
     if (window < 8 || window > 4096 || (window & (window - 1)))
@@ -88,7 +88,7 @@ extern "C" int rg_log_sizes_enable(rg_engine *h, uint32_t window) {
     h->ins.esz = h->esz;
     h->ins.esz_w = window;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // host records -> device staging buffer on the engine's stream (grown on demand; the copy is stream-ordered, the host
 // array may be reused once the call returns: pageable copies are staged by the runtime)
@@ -111,7 +111,7 @@ int rg_stage_records(rg_engine *h, const void *recs, size_t bytes) {
     return RG_OK;
 }
 
-extern "C" int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_t n) {
+extern "C" int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_t n) try {
     if (!h || (!recs && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_log_sizes_write: bad argument");
     if (!h->esz) return rg_fail(RG_ERR_STATE, "rg_log_sizes_write: rg_log_sizes_enable first");
     if (n == 0) return RG_OK;
@@ -123,9 +123,9 @@ extern "C" int rg_log_sizes_write(rg_engine *h, const rg_log_size *recs, uint64_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_log_sizes_write: launch failed: %s", hipGetErrorString(e));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes, uint32_t spread) {
+extern "C" int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes, uint32_t spread) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_workload_sizes: null engine");
     if (!h->esz) return rg_fail(RG_ERR_STATE, "rg_workload_sizes: rg_log_sizes_enable first");
     RG_ENTER(h);
@@ -134,9 +134,9 @@ extern "C" int rg_workload_sizes(rg_engine *h, uint64_t seed, uint32_t min_bytes
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_workload_sizes: launch failed: %s", hipGetErrorString(e));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n) {
+extern "C" int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n) try {
     if (!h || (!msgs && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_update_state: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_update_state: engine created with max_inflight = 0 (use RG_MF_SENT events)");
     if (n == 0) return RG_OK;
@@ -150,9 +150,9 @@ extern "C" int rg_update_state(rg_engine *h, const rg_sent_msg *msgs, uint64_t n
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_update_state: launch failed: %s", hipGetErrorString(e));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_progress_events(rg_engine *h, const rg_progress_event *events, uint64_t n) {
+extern "C" int rg_progress_events(rg_engine *h, const rg_progress_event *events, uint64_t n) try {
     if (!h || (!events && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_events: bad argument");
     for (u64 i = 0; i < n; i++)
         if (events[i].kind < RG_EV_UNREACHABLE || events[i].kind > RG_EV_SNAPSHOT_FAILURE)
@@ -173,9 +173,9 @@ extern "C" int rg_progress_events(rg_engine *h, const rg_progress_event *events,
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_progress_events: launch failed: %s", hipGetErrorString(e));
     RG_HIP(hipStreamSynchronize(h->stream)); // control path, like rg_write_cells: the caller's array may be reused after return
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slot_plus1) {
+extern "C" int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_t *host_slot_plus1) try {
     if (!h || !host_slot_plus1) return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_event_dense: bad argument");
     if (kind < RG_EV_UNREACHABLE || kind > RG_EV_SNAPSHOT_FAILURE)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_progress_event_dense: kind %u", kind);
@@ -190,7 +190,7 @@ extern "C" int rg_progress_event_dense(rg_engine *h, uint32_t kind, const uint8_
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_progress_event_dense: launch failed: %s", hipGetErrorString(e));
     RG_HIP(hipStreamSynchronize(h->stream)); // control path: the caller's array may be reused after return
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // After a dense stage the work items live in the columns; the compact list exists once somebody asks for it.
 int rg_send_materialize(rg_engine *h) {
@@ -204,7 +204,7 @@ int rg_send_materialize(rg_engine *h) {
     return RG_OK;
 }
 
-extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n) {
+extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t cap, uint64_t *n) try {
     if (!h || !n || (!host_items && cap)) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_items: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_items: engine created with max_inflight = 0");
     if (h->host_items_valid) { // rg_flush_send already brought them over with the tick's results: no device access (and a
@@ -243,7 +243,7 @@ extern "C" int rg_send_items(rg_engine *h, rg_send_item *host_items, uint64_t ca
         RG_HIP(hipStreamSynchronize(h->stream));
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" const rg_send_item *rg_send_items_ptr(rg_engine *h) {
     if (!h || !h->ins_arena) return nullptr;
@@ -252,7 +252,7 @@ extern "C" const rg_send_item *rg_send_items_ptr(rg_engine *h) {
 }
 
 extern "C" int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, const uint64_t **dev_last_index,
-                               const uint32_t **dev_n_kind) {
+                               const uint32_t **dev_n_kind) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_columns: null engine");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_columns: engine created with max_inflight = 0");
     if (!h->send_last_dense)
@@ -262,14 +262,14 @@ extern "C" int rg_send_columns(rg_engine *h, const uint64_t **dev_prev_index, co
     if (dev_last_index) *dev_last_index = h->send_cols.last;
     if (dev_n_kind) *dev_n_kind = h->send_cols.n;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inflight) {
+extern "C" int rg_send_tail_column(rg_engine *h, const uint64_t **dev_newest_inflight) try {
     if (!h || !dev_newest_inflight) return rg_fail(RG_ERR_INVALID_ARG, "rg_send_tail_column: bad argument");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_send_tail_column: engine created with max_inflight = 0");
     *dev_newest_inflight = h->ins.tail;
     return RG_OK;
-}
+} RG_ABI_GUARD
 static_assert(RG_SEND_LAST_IS_TAIL == RG_SEND_NK_LAST_IS_TAIL && RG_SEND_LAST_IS_PREV == RG_SEND_NK_LAST_IS_PREV, "the header's bits are the kernels'");
 
 extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
@@ -279,7 +279,7 @@ extern "C" uint64_t rg_inflights_bytes(const rg_engine *h, int ring) {
 
 // The oldest and the newest inflight of a window live in the `head` / `tail` columns (rg_send.h); to the outside the
 // ring is whole.
-extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring) {
+extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *host_ring) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_inflights: null engine");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_read_inflights: engine created with max_inflight = 0");
     RG_ENTER(h);
@@ -320,9 +320,9 @@ extern "C" int rg_read_inflights(rg_engine *h, uint32_t *host_meta, uint64_t *ho
                 }
             }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring) {
+extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const uint64_t *host_ring) try {
     if (!h || !host_meta || !host_ring) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_inflights: meta and ring are both required");
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "rg_load_inflights: engine created with max_inflight = 0");
     const u64 cells = (u64)h->P * h->stride;
@@ -371,7 +371,7 @@ extern "C" int rg_load_inflights(rg_engine *h, const uint32_t *host_meta, const 
     if (frc) return frc;
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 int rg_fix_ins_full(rg_engine *h) {
     hipLaunchKernelGGL(k_fix_ins_full, dim3(rg_grid(h->G, RG_BLOCK)), dim3(RG_BLOCK), 0, h->stream, h->st, h->ins, h->P);

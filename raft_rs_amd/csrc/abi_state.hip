@@ -9,30 +9,28 @@ static int g_live_on_device[RG_MAX_DEVICES];
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
+static thread_local char g_last_error[512]; // (a fixed buffer: reporting an allocation failure must not allocate)
 
 int rg_fail(int code, const char *fmt, ...) {
     // HIP keeps the last error until somebody reads it: a failed hipMalloc must not resurface later as the
     // "launch error" of an unrelated kernel (every launch site checks hipGetLastError)
     (void)hipGetLastError();
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
 }
 
 extern "C" const char *rg_version(void) { return "raftgroups 0.1 (gfx950, opt " RG_STR(RG_OPT) ")"; }
 extern "C" uint32_t rg_abi_version(void) { return RG_ABI_VERSION; }
-extern "C" const char *rg_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *rg_last_error(void) { return g_last_error; }
 
-extern "C" int rg_device_count(void) {
+extern "C" int rg_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} RG_ABI_GUARD
 
 extern "C" uint64_t rg_column_bytes(const rg_engine *h, int c) {
     if (!h || c < 0 || c >= RG_COL_COUNT) return 0;
@@ -114,7 +112,7 @@ static uint64_t rg_query_infinity_cache(const hipDeviceProp_t &prop) {
     return q.l3_bytes;
 }
 
-extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
+extern "C" int rg_create(const rg_config *cfg, rg_engine **out) try {
     if (!cfg || !out) return rg_fail(RG_ERR_INVALID_ARG, "rg_create: null argument");
     if (cfg->n_groups == 0 || cfg->n_slots == 0 || cfg->n_slots > RG_MAX_SLOTS)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_create: n_groups=%llu n_slots=%u out of range",
@@ -378,7 +376,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     }
     *out = h;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" int rg_comm_destroy(rg_engine *h);
 
@@ -413,27 +411,27 @@ extern "C" void rg_destroy(rg_engine *h) {
 
 extern "C" uint64_t rg_stride(const rg_engine *h) { return h ? h->stride : 0; }
 
-extern "C" int rg_get_device_info(const rg_engine *h, rg_device_info *info) {
+extern "C" int rg_get_device_info(const rg_engine *h, rg_device_info *info) try {
     if (!h || !info) return rg_fail(RG_ERR_INVALID_ARG, "rg_get_device_info: bad argument");
     *info = h->dev;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_set_stream(rg_engine *h, void *hip_stream) {
+extern "C" int rg_set_stream(rg_engine *h, void *hip_stream) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_stream: null engine");
     RG_ENTER(h); // (a resident mailbox workgroup sits on the OLD stream: it has to leave before the engine moves)
     h->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_sync(rg_engine *h) {
+extern "C" int rg_sync(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_sync: null engine");
     RG_ENTER(h);
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t bytes) {
+extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t bytes) try {
     if (!h || !src || c < 0 || c >= RG_COL_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: bad argument");
     if (c == RG_COL_HOST_HINT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: RG_COL_HOST_HINT is written by the ticks only");
     if (c == RG_COL_RUN_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_load_column: RG_COL_RUN_COUNT is derived from RG_COL_RUN_FIRST by the engine");
@@ -472,9 +470,9 @@ extern "C" int rg_load_column(rg_engine *h, int c, const void *src, uint64_t byt
         h->any_group_commit = any;
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_read_column(rg_engine *h, int c, void *dst, uint64_t bytes) {
+extern "C" int rg_read_column(rg_engine *h, int c, void *dst, uint64_t bytes) try {
     if (!h || !dst || c < 0 || c >= RG_COL_COUNT) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_column: bad argument");
     if (bytes != rg_column_bytes(h, c))
         return rg_fail(RG_ERR_INVALID_ARG, "rg_read_column(%d): %llu bytes given, %llu expected", c,
@@ -483,7 +481,7 @@ extern "C" int rg_read_column(rg_engine *h, int c, void *dst, uint64_t bytes) {
     RG_HIP(hipMemcpyAsync(dst, rg_col(h, c), bytes, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" void *rg_column_ptr(rg_engine *h, int c) {
     if (!h || c < 0 || c >= RG_COL_COUNT) return nullptr;
@@ -491,7 +489,7 @@ extern "C" void *rg_column_ptr(rg_engine *h, int c) {
     return rg_col(h, c);
 }
 
-extern "C" int rg_checkpoint(rg_engine *h) {
+extern "C" int rg_checkpoint(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_checkpoint: null engine");
     RG_ENTER(h);
     if (!h->ckpt) RG_HIP(hipMalloc(&h->ckpt, h->state_bytes));
@@ -511,9 +509,9 @@ extern "C" int rg_checkpoint(rg_engine *h) {
         RG_HIP(hipMemcpyAsync(h->esz_ckpt, h->esz, b, hipMemcpyDeviceToDevice, h->stream));
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_restore(rg_engine *h) {
+extern "C" int rg_restore(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_restore: null engine");
     if (!h->ckpt) return rg_fail(RG_ERR_STATE, "rg_restore: no checkpoint taken");
     RG_ENTER(h);
@@ -537,11 +535,11 @@ extern "C" int rg_restore(rg_engine *h) {
     if (h->esz && h->esz_ckpt)
         RG_HIP(hipMemcpyAsync(h->esz, h->esz_ckpt, (size_t)h->G * h->ins.esz_w * 4, hipMemcpyDeviceToDevice, h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 
 
-extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n) {
+extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t n) try {
     if (!h || (!cells && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_write_cells: bad argument");
     if (n == 0) return RG_OK;
     RG_ENTER(h);
@@ -562,9 +560,9 @@ extern "C" int rg_write_cells(rg_engine *h, const rg_cell_write *cells, uint64_t
                        h->ins.meta);
     RG_HIP(hipStreamSynchronize(h->stream)); // the caller's array may be reused after return
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_read_groups(rg_engine *h, const uint64_t *groups, uint64_t n, rg_group_status *host_out) {
+extern "C" int rg_read_groups(rg_engine *h, const uint64_t *groups, uint64_t n, rg_group_status *host_out) try {
     if (!h || (n && (!groups || !host_out))) return rg_fail(RG_ERR_INVALID_ARG, "rg_read_groups: bad argument");
     if (n == 0) return RG_OK;
     RG_ENTER(h);
@@ -585,9 +583,9 @@ extern "C" int rg_read_groups(rg_engine *h, const uint64_t *groups, uint64_t n, 
             return rg_fail(RG_ERR_INVALID_ARG, "rg_read_groups: group %llu does not exist (engine holds %llu)",
                            (unsigned long long)groups[i], (unsigned long long)h->G);
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
+extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) try {
     if (!h || group >= h->G) return rg_fail(RG_ERR_INVALID_ARG, "rg_set_config: bad argument");
     if (RG_CFG_SELF(cfg_word) >= h->P || (RG_CFG_PRESENT(cfg_word) >> h->P) || (RG_CFG_INCOMING(cfg_word) >> h->P) ||
         (RG_CFG_OUTGOING(cfg_word) >> h->P) || RG_CFG_TRANSFEREE(cfg_word) > h->P)
@@ -600,6 +598,6 @@ extern "C" int rg_set_config(rg_engine *h, uint64_t group, uint32_t cfg_word) {
     // (a word that stays inside its block's class changes nothing: the class is an upper bound)
     if (!h->cls_stale && h->cls_on && rg_cfg_slots_named(cfg_word) > h->cls_host[group / RG_BLOCK]) h->cls_stale = true;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 

@@ -243,7 +243,7 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
     return RG_OK;
 }
 
-extern "C" int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, uint32_t *n) {
+extern "C" int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, uint32_t *n) try {
     if (!h || !n || (cap && !out)) return rg_fail(RG_ERR_INVALID_ARG, "rg_size_classes: bad argument");
     *n = 0;
     RG_ENTER(h);
@@ -271,7 +271,7 @@ extern "C" int rg_size_classes(rg_engine *h, rg_size_class *out, uint32_t cap, u
     }
     *n = k;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 int rg_send_check(rg_engine *h, uint32_t flags, const char *who) {
     if (!h->ins_arena) return rg_fail(RG_ERR_STATE, "%s: engine created with max_inflight = 0 (Inflights are the host's)", who);
@@ -307,20 +307,20 @@ static int rg_tick_device_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *
     return trc;
 }
 
-extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) {
+extern "C" int rg_tick_device(rg_engine *h, const rg_msgs *m) try {
     if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device: m_index, m_commit and m_flags are required");
     return rg_tick_device_impl(h, m, nullptr);
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_tick_device_send(rg_engine *h, const rg_msgs *m, uint64_t max_entries_per_msg, uint32_t flags) {
+extern "C" int rg_tick_device_send(rg_engine *h, const rg_msgs *m, uint64_t max_entries_per_msg, uint32_t flags) try {
     if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_send: m_index, m_commit and m_flags are required");
     int rc = rg_send_check(h, flags, "rg_tick_device_send");
     if (rc) return rc;
     const RgSendReq send = {(u64)max_entries_per_msg, (u32)flags};
     return rg_tick_device_impl(h, m, &send);
-}
+} RG_ABI_GUARD
 
 // One fused launch over ticks [t0, t0 + n) of the caller's array (none of them carries Message.log_term).
 static int rg_fused_run(rg_engine *h, const rg_msgs *m, u32 t0, u32 n, uint32_t *dev_out_t, uint64_t *dev_commit_t) {
@@ -355,7 +355,7 @@ static int rg_fused_run(rg_engine *h, const rg_msgs *m, u32 t0, u32 n, uint32_t 
 }
 
 extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_ticks, uint32_t *dev_out_t,
-                                    uint64_t *dev_commit_t) {
+                                    uint64_t *dev_commit_t) try {
     if (!h || !m || !dev_out_t || n_ticks == 0 || n_ticks > RG_MAX_FUSE)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_device_fused: need 1..%d ticks and an out buffer", RG_MAX_FUSE);
     if (h->ins_arena)
@@ -426,13 +426,13 @@ extern "C" int rg_tick_device_fused(rg_engine *h, const rg_msgs *m, uint32_t n_t
     h->host_res_valid = false;
     h->out_is_dense = true;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_fused_ticks_done(const rg_engine *h, uint32_t *n) {
+extern "C" int rg_fused_ticks_done(const rg_engine *h, uint32_t *n) try {
     if (!h || !n) return rg_fail(RG_ERR_INVALID_ARG, "rg_fused_ticks_done: bad argument");
     *n = h->fused_done;
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 int rg_ensure_msg_arena(rg_engine *h) {
     if (h->msg_arena) return RG_OK;
@@ -485,20 +485,20 @@ int rg_tick_host_impl(rg_engine *h, const rg_msgs *m, const RgSendReq *send) {
     return RG_OK;
 }
 
-extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) {
+extern "C" int rg_tick(rg_engine *h, const rg_msgs *m) try {
     if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick: m_index, m_commit and m_flags are required");
     return rg_tick_host_impl(h, m, nullptr);
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_tick_send(rg_engine *h, const rg_msgs *m, uint64_t max_entries_per_msg, uint32_t flags) {
+extern "C" int rg_tick_send(rg_engine *h, const rg_msgs *m, uint64_t max_entries_per_msg, uint32_t flags) try {
     if (!h || !m || !m->m_index || !m->m_commit || !m->m_flags)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tick_send: m_index, m_commit and m_flags are required");
     int rc = rg_send_check(h, flags, "rg_tick_send");
     if (rc) return rc;
     const RgSendReq send = {(u64)max_entries_per_msg, (u32)flags};
     return rg_tick_host_impl(h, m, &send);
-}
+} RG_ABI_GUARD
 
 
 template <int P, bool COMMIT> static void rg_launch_recompute_p(rg_engine *h, u64 *mci, u8 *gc, bool x2) {
@@ -537,7 +537,7 @@ template <bool COMMIT> static int rg_recompute_impl(rg_engine *h, u64 *mci, u8 *
     return RG_OK;
 }
 
-extern "C" int rg_recompute(rg_engine *h) {
+extern "C" int rg_recompute(rg_engine *h) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_recompute: null engine");
     RG_ENTER(h);
     {   // (device Inflights: nothing of the next step is enqueued while a host hint of the last one is unanswered)
@@ -554,9 +554,9 @@ extern "C" int rg_recompute(rg_engine *h) {
         h->send_ready = true;   // post_conf_change: `if self.maybe_commit() { self.bcast_append() }` (raft.rs:2630-2633)
     }
     return rc;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint8_t *host_gc) {
+extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint8_t *host_gc) try {
     if (!h || !host_mci) return rg_fail(RG_ERR_INVALID_ARG, "rg_maximal_committed_index: bad argument");
     RG_ENTER(h);
     u64 *d_mci = nullptr;
@@ -576,10 +576,10 @@ extern "C" int rg_maximal_committed_index(rg_engine *h, uint64_t *host_mci, uint
     if (rc) return rc;
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_maximal_committed_index: %s", hipGetErrorString(e));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 
-extern "C" int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb, uint64_t *host_hb) {
+extern "C" int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb, uint64_t *host_hb) try {
     if (!h || (!dev_hb && !host_hb)) return rg_fail(RG_ERR_INVALID_ARG, "rg_heartbeat_commits: no destination");
     RG_ENTER(h);
     u64 *tmp = nullptr;
@@ -601,9 +601,9 @@ extern "C" int rg_heartbeat_commits(rg_engine *h, uint64_t *dev_hb, uint64_t *ho
     }
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "rg_heartbeat_commits: %s", hipGetErrorString(e));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out) {
+extern "C" int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_out) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_results: null engine");
     if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_results: no tick has run yet");
     RG_ENTER(h);
@@ -611,9 +611,9 @@ extern "C" int rg_results(rg_engine *h, uint64_t *host_commit, uint32_t *host_ou
     if (host_out) RG_HIP(hipMemcpyAsync(host_out, h->st.out, h->G * 4, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault) {
+extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_fault) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_result_counts: null engine");
     if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_result_counts: no tick has run yet");
     RG_ENTER(h);
@@ -626,9 +626,9 @@ extern "C" int rg_result_counts(rg_engine *h, uint64_t *n_changed, uint64_t *n_f
     if (n_changed) *n_changed = c[0];
     if (n_fault) *n_fault = c[1];
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_host_hints(rg_engine *h, rg_host_hint *host_items, uint64_t cap, uint64_t *n) {
+extern "C" int rg_host_hints(rg_engine *h, rg_host_hint *host_items, uint64_t cap, uint64_t *n) try {
     if (!h || !n || (cap && !host_items)) return rg_fail(RG_ERR_INVALID_ARG, "rg_host_hints: bad argument");
     *n = 0;
     if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_host_hints: no tick has run yet");
@@ -653,9 +653,9 @@ extern "C" int rg_host_hints(rg_engine *h, rg_host_hint *host_items, uint64_t ca
         }
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items, uint64_t n, uint8_t *host_applied) {
+extern "C" int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items, uint64_t n, uint8_t *host_applied) try {
     if (!h || (!items && n)) return rg_fail(RG_ERR_INVALID_ARG, "rg_resolve_host_hints: bad argument");
     if (!h->ticked) return rg_fail(RG_ERR_STATE, "rg_resolve_host_hints: no tick has run yet");
     if (n == 0) return RG_OK;
@@ -703,9 +703,9 @@ extern "C" int rg_resolve_host_hints(rg_engine *h, const rg_resolved_hint *items
         RG_HIP(hipStreamSynchronize(h->stream));
     }
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t counts[5]) {
+extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t counts[5]) try {
     if (!h || !d_m_flags || !counts) return rg_fail(RG_ERR_INVALID_ARG, "rg_msg_stats: bad argument");
     RG_ENTER(h);
     RG_HIP(hipMemsetAsync(h->d_counts, 0, 40, h->stream));
@@ -715,12 +715,12 @@ extern "C" int rg_msg_stats(rg_engine *h, const uint8_t *d_m_flags, uint64_t cou
     RG_HIP(hipMemcpyAsync(counts, h->d_counts, 40, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 // ------------------------------------------------------------------------------------------------
 // votes / liveness
 // ------------------------------------------------------------------------------------------------
-extern "C" int rg_vote_result(rg_engine *h, const uint8_t *yes, const uint8_t *no, uint8_t *result) {
+extern "C" int rg_vote_result(rg_engine *h, const uint8_t *yes, const uint8_t *no, uint8_t *result) try {
     if (!h || !yes || !no || !result) return rg_fail(RG_ERR_INVALID_ARG, "rg_vote_result: bad argument");
     RG_ENTER(h);
     u8 *d = reinterpret_cast<u8 *>(h->d_scratch); // 8*stride bytes: yes | no | result
@@ -731,10 +731,10 @@ extern "C" int rg_vote_result(rg_engine *h, const uint8_t *yes, const uint8_t *n
     RG_HIP(hipMemcpyAsync(result, d + 2 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 extern "C" int rg_tally_votes(rg_engine *h, const uint8_t *yes, const uint8_t *no, uint8_t *granted, uint8_t *rejected,
-                              uint8_t *result) {
+                              uint8_t *result) try {
     if (!h || !yes || !no || !granted || !rejected || !result)
         return rg_fail(RG_ERR_INVALID_ARG, "rg_tally_votes: bad argument");
     RG_ENTER(h);
@@ -748,9 +748,9 @@ extern "C" int rg_tally_votes(rg_engine *h, const uint8_t *yes, const uint8_t *n
     RG_HIP(hipMemcpyAsync(rejected, d + 4 * h->stride, h->G, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
-extern "C" int rg_quorum_recently_active(rg_engine *h, uint8_t *result) {
+extern "C" int rg_quorum_recently_active(rg_engine *h, uint8_t *result) try {
     if (!h || !result) return rg_fail(RG_ERR_INVALID_ARG, "rg_quorum_recently_active: bad argument");
     RG_ENTER(h);
     u8 *d = reinterpret_cast<u8 *>(h->d_scratch);
@@ -758,6 +758,6 @@ extern "C" int rg_quorum_recently_active(rg_engine *h, uint8_t *result) {
     RG_HIP(hipMemcpyAsync(result, d, h->G, hipMemcpyDeviceToHost, h->stream));
     RG_HIP(hipStreamSynchronize(h->stream));
     return RG_OK;
-}
+} RG_ABI_GUARD
 
 

@@ -33,8 +33,8 @@
 // a live engine's kernel never changes because another engine comes or goes.
 #define RG_MAX_DEVICES 64
 
-// ---- error plumbing (abi_state.hip) ----
-int rg_fail(int code, const char *fmt, ...);
+// ---- error plumbing (abi_state.hip): rg_fail, RG_ABI_GUARD ----
+#include "rg_abi_guard.h"
 
 #define RG_HIP(expr)                                                                               \
     do {                                                                                           \

@@ -154,3 +154,69 @@ def test_rust_binding_is_generated_from_the_header_and_complete(rg):
     out = subprocess.run(["nm", "-D", "--defined-only", rg.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("rg_") and " T " in l})
     assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+
+
+def test_no_cpp_exception_can_leave_the_c_abi(tmp_path):
+    """A Rust / C / ctypes caller cannot unwind through `extern "C"`: every int-returning entry point of csrc/abi_*.hip is a
+    function-try-block that ends in RG_ABI_GUARD (csrc/rg_abi_guard.h), which turns std::bad_alloc into RG_ERR_OUT_OF_MEMORY and
+    anything else into RG_ERR_STATE. Two halves: (1) the sources -- no entry point without the guard; (2) the guard itself,
+    compiled with g++ around functions that throw."""
+    import glob
+    import subprocess
+    root = ROOT
+    n = 0
+    for path in sorted(glob.glob(os.path.join(root, "raft_rs_amd", "csrc", "abi_*.hip"))):
+        lines = open(path).read().split("\n")
+        i = 0
+        while i < len(lines):
+            if lines[i].startswith('extern "C" int '):
+                j = i
+                while not lines[j].rstrip().endswith(("{", "}", ";", "RG_ABI_GUARD")):
+                    j += 1
+                if lines[j].rstrip().endswith(";") and "{" not in lines[j]:  # a forward declaration
+                    i = j + 1
+                    continue
+                assert "try {" in lines[j], (os.path.basename(path), i + 1, lines[i][:80])
+                if not lines[j].rstrip().endswith("RG_ABI_GUARD"):  # (a one-line body carries both on its line)
+                    k = j + 1
+                    while not lines[k].startswith("}"):
+                        k += 1
+                    assert lines[k] == "} RG_ABI_GUARD", (os.path.basename(path), k + 1, lines[k])
+                n += 1
+                i = j + 1
+            else:
+                i += 1
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_bindings
+    funcs = gen_rust_bindings.parse(open(HEADER, encoding="utf-8").read())[3]
+    n_int = len({name for name, ret, _ in funcs if str(ret).strip() in ("int", "i32", "c_int")})
+    assert n >= 85 and (n_int == 0 or n == n_int), (n, n_int, sorted({str(r) for _, r, _ in funcs}))  # every int entry point the header declares is defined behind the guard
+    src = tmp_path / "guard_probe.cpp"
+    src.write_text("""
+#include <cstdarg>
+#include <cstdio>
+#include <stdexcept>
+#include <vector>
+#include "rg_abi_guard.h"
+static char text[512];
+int rg_fail(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(text, sizeof(text), fmt, ap); va_end(ap); return code; }
+extern "C" int probe(int kind) try {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) { std::vector<char> v; v.reserve(v.max_size() + 1); }   // std::length_error
+    if (kind == 3) throw 42;
+    if (kind == 4) { std::vector<long> v; v.resize((size_t)1 << 50); }      // 8 PB: a real allocation failure, std::bad_alloc
+    return RG_OK;
+} RG_ABI_GUARD
+int main() {
+    if (probe(0) != RG_OK) return 1;
+    if (probe(1) != RG_ERR_OUT_OF_MEMORY) return 2;
+    if (probe(2) != RG_ERR_STATE || !text[0]) return 3;
+    if (probe(3) != RG_ERR_STATE) return 4;
+    if (probe(4) != RG_ERR_OUT_OF_MEMORY) return 5;
+    return 0;
+}
+""")
+    exe = tmp_path / "guard_probe"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "raft_rs_amd", "csrc"), str(src), "-o", str(exe)])
+    assert subprocess.run([str(exe)]).returncode == 0
