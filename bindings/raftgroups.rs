@@ -369,6 +369,7 @@ pub struct RgPublishStats {
     pub host_us_events: f64,
     pub host_us_allgather: f64,
     pub host_us_memset: f64,
+    pub events_on_tick_packets: u64,
 }
 
 #[repr(C)]

@@ -900,6 +900,9 @@ typedef struct {
     uint64_t bytes_per_rank_full;  /* size of a full snapshot (8 B/group) */
     uint32_t overflow_slots, ring_ticks;
     double host_us_events, host_us_allgather, host_us_memset; /* host time spent inside rg_publish_commit, by part */
+    uint64_t events_on_tick_packets; /* publications whose "slice complete" event rode on the dispatch packet of the dense tick they
+                                        followed (rg_tick / rg_tick_device right before rg_publish_commit) instead of being recorded
+                                        behind it: no packet of its own in the engine's queue (2.5 us of idle queue per tick saved) */
 } rg_publish_stats;
 int rg_publish_stats_get(rg_engine *h, rg_publish_stats *out);
 /* Host twins of the encoding over caller-provided buffers (no GPU involved; CPU-only tests of the N > 1 exchange):

@@ -143,14 +143,21 @@ static int rg_pub_pre(rg_engine *h, bool force_full, RgPubStep &s) {
         RG_HIP(hipEventRecord(p->ev_chk[cb], p->side));
         p->chk_pending[cb] = true;
     }
+    bool announced = false;
     if (p->local_lost && !p->lost_announced && !full) { // tell the other ranks (they act on it at a check point)
+        announced = true;
         static const u32 k_lost = RG_PUB_LOST;
         RG_HIP(hipMemcpyAsync(p->send[b] + offsetof(RgPubHdr, flags), &k_lost, 4, hipMemcpyHostToDevice, h->stream));
         p->lost_announced = true;
     }
     if (full) // snapshot the column before later ticks move it
         RG_HIP(hipMemcpyAsync(p->full_send, h->st.commit, h->G * 8, hipMemcpyDeviceToDevice, h->stream));
-    RG_HIP(hipEventRecord(p->ev_tick[b], h->stream));
+    // the event that marks the slice complete: recorded here -- or already on its way, on the dispatch packet of the dense tick
+    // this publication follows (rg_tick_impl: h->pub_rode; nothing else has been put on the engine's stream since, this call's
+    // own copies above included)
+    if (!(p->rode_slot == b && !full && !announced)) RG_HIP(hipEventRecord(p->ev_tick[b], h->stream));
+    else p->stats.events_on_tick_packets++;
+    p->rode_slot = -1;
     RG_HIP(hipStreamWaitEvent(p->side, p->ev_tick[b], 0));
     s.full = full;
     if (full) {
@@ -406,6 +413,7 @@ static int rg_comm_setup(rg_engine *h, u32 rank, u32 world, u32 ring_ticks, u32 
     RgPub *p = new (std::nothrow) RgPub();
     if (!p) return rg_fail(RG_ERR_OUT_OF_MEMORY, "rg_comm_init: host allocation failed");
     memset(p, 0, sizeof(*p));
+    p->rode_slot = -1;
     p->rank = rank;
     p->world = world;
     p->transport = transport;
@@ -584,7 +592,9 @@ extern "C" int rg_publish_commit(rg_engine *h, uint32_t flags) try {
     if (!h) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: null engine");
     if (!h->pub) return rg_fail(RG_ERR_STATE, "rg_publish_commit: rg_comm_init was never called");
     if (flags & ~RG_PUBLISH_FULL) return rg_fail(RG_ERR_INVALID_ARG, "rg_publish_commit: unknown flags %#x", flags);
+    const int rode = h->pub_tick_evt; // (RG_ENTER forgets it: read first)
     RG_ENTER(h);
+    h->pub->rode_slot = rode;
     return rg_publish_impl(h, (flags & RG_PUBLISH_FULL) != 0);
 } RG_ABI_GUARD
 

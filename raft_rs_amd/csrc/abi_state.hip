@@ -154,6 +154,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) try {
     h->ckpt = nullptr;
     h->msg_arena = nullptr;
     h->ticked = false;
+    h->pub_tick_evt = -1;
     h->tick_launches = 0;
     h->sparse_arena = nullptr;
     h->d_records = nullptr;

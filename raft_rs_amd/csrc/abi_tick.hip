@@ -163,6 +163,21 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
         h->host_items_valid = false;
         return RG_OK;
     }
+    // commit publication: the event rg_publish_commit would record behind this tick rides on the tick's own dispatch packet
+    // (RG_LAUNCH_TICK, rg_tick_kernels.h) -- not while the stream is being captured into a graph, not for the ranks of
+    // rg_comm_init_all (their publication records its events itself)
+    int evt_slot = -1;
+#ifndef RG_NO_PUB_RIDE /* (measurement builds: python -m raft_rs_amd.build --exp noride -DRG_NO_PUB_RIDE) */
+    if (h->pub && !h->pub->in_process) {
+        hipStreamCaptureStatus pcs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &pcs) == hipSuccess && pcs == hipStreamCaptureStatusNone) evt_slot = (int)(h->pub->n_pub % RG_PUB_SEND);
+    }
+#endif
+    struct RgStopEvt { // (armed for the launches of THIS call only, whatever way it returns)
+        explicit RgStopEvt(hipEvent_t e) { rg_tls_stop_event = e; }
+        ~RgStopEvt() { rg_tls_stop_event = nullptr; }
+        bool went_out() const { return rg_tls_stop_event == nullptr; }
+    } stop_evt(evt_slot >= 0 ? h->pub->ev_tick[evt_slot] : nullptr);
     // one translation unit per slot count (tick_inst.hip, -DRG_P=n); the group-commit kernel is only
     // needed when some group has ProgressTracker.group_commit set
     const u32 variant = ((h->cfg.variant == RG_VARIANT_LDS || h->cfg.variant == RG_VARIANT_LDS_DMA || h->cfg.variant == RG_VARIANT_COMPACT)
@@ -191,6 +206,7 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
             }
             hipError_t ce = hipGetLastError();
             if (ce != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(ce));
+            if (evt_slot >= 0 && stop_evt.went_out()) h->pub_tick_evt = evt_slot;
             h->dev.last_tick_kernel = RG_KERNEL_CLASSES;
             h->dev.last_tick_offset_bits = 32u; // (the class bodies exist for 32-bit offsets only: the condition above)
             h->dev.last_tick_streaming = h->nt_all ? 2u : h->nt_msgs ? 1u : 0u;
@@ -230,6 +246,7 @@ int rg_tick_impl(rg_engine *h, const RgMsgs &ms, const RgSendReq *send) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rg_fail(RG_ERR_NO_DEVICE, "tick launch failed: %s", hipGetErrorString(e));
+    if (evt_slot >= 0 && stop_evt.went_out()) h->pub_tick_evt = evt_slot;
     h->dev.last_tick_kernel = kernel;
     h->dev.last_tick_offset_bits = rg_ix32(h->st, h->P) ? 32u : 64u;
     if (kernel == RG_KERNEL_LDS) h->dev.last_tick_offset_bits = 64u; // (the LDS-staged comparison kernels index with 64 bits at any size)

@@ -5,6 +5,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <type_traits>
 

@@ -52,6 +52,7 @@ int rg_require_hints_resolved(rg_engine *h, const char *who); // abi_tick.hip
 // (until its idle timeout), this makes the wait a few microseconds.
 #define RG_ENTER(h)                                                                                \
     do {                                                                                           \
+        (h)->pub_tick_evt = -1; /* (whatever this call enqueues comes behind the last tick's event) */ \
         RG_HIP(hipSetDevice((h)->cfg.device));                                                     \
         int rc__ = rg_mailbox_quiesce(h);                                                          \
         if (rc__) return rc__;                                                                     \
@@ -88,6 +89,9 @@ struct rg_engine {
     RgState st;
     RgMsgs staged;    // views into msg_arena
     bool ticked;
+    // commit publication: the slot b whose ev_tick[b] rode on the dispatch packet of the LAST dense tick (RG_LAUNCH_TICK), -1 if
+    // none or if any entry point has run since (RG_ENTER): rg_publish_commit right behind that tick need not record an event
+    int pub_tick_evt;
     u64 tick_launches; // ticks enqueued so far (rg_flush: did a failed flush already change device state?)
     // sparse path (rg_ingest / rg_tick_ingested)
     char *sparse_arena;       // gmark | list | res_list | res_commit | res_out | counters
@@ -203,6 +207,7 @@ struct RgPub {
     hipEvent_t ev_tick[RG_PUB_SEND], ev_done[RG_PUB_SEND], ev_chk[2];
     bool done_pending[RG_PUB_SEND], chk_pending[2];
     u64 n_pub;                // publications so far
+    int rode_slot;            // rg_publish_commit: the engine's pub_tick_evt as the call found it (-1: record the event)
     u32 pending;              // ring slots gathered and not yet folded into the replica
     bool in_process;          // one of several ranks of ONE process driven by one thread (rg_comm_init_all / rg_publish_commit_all)
     hipEvent_t ev_read;       // ... in-process transport: this rank's side stream has read every rank's slice of the current publication

@@ -84,6 +84,21 @@ template <int P> struct RgLaneIx { typedef typename std::conditional<(P >= RG_U3
 
 static inline unsigned rg_grid_for(u64 n, unsigned per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
+// A dense tick's launch can carry an EVENT on its own dispatch packet (hipExtLaunchKernelGGL's stopEvent: the packet's completion
+// signal) instead of a hipEventRecord behind it, which is a barrier packet of its own in the engine's queue and costs the NEXT
+// tick 2.5 us of idle queue (tools/microbench/pub_signal.hip: 51.3 vs 50.1 us per tick, 48.8 without any event). The commit
+// publication uses it (abi_tick.hip sets the thread's pending event around the launch of the lane / class / split kernels;
+// rg_publish_commit then only makes its side stream wait for it).
+inline thread_local hipEvent_t rg_tls_stop_event = nullptr;
+#define RG_LAUNCH_TICK(kernel, grid, block, stream, ...)                                                                          \
+    do {                                                                                                                          \
+        if (rg_tls_stop_event) {                                                                                                  \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, nullptr, rg_tls_stop_event, 0, __VA_ARGS__);                    \
+            rg_tls_stop_event = nullptr; /* (consumed: the caller sees that the event went out with a launch) */                  \
+        }                                                                                                                         \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                                     \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // kernels: the tick (RG_VARIANT_LANE)
 // ------------------------------------------------------------------------------------------------
@@ -1262,11 +1277,11 @@ void rg_launch_flush_small_t(hipStream_t stream, const RgState &st, const RgMsgs
 #define RG_LAUNCH_LANE(IXT)                                                                                                       \
     do {                                                                                                                          \
         if (ntm == 2 && !GC)                                                                                                      \
-            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, GC ? 0 : 2>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+            RG_LAUNCH_TICK((k_tick_lane<P, GC, IXT, GC ? 0 : 2>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), stream, st, ms); \
         else if (ntm && !GC)                                                                                                      \
-            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, GC ? 0 : 1>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+            RG_LAUNCH_TICK((k_tick_lane<P, GC, IXT, GC ? 0 : 1>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), stream, st, ms); \
         else                                                                                                                      \
-            hipLaunchKernelGGL((k_tick_lane<P, GC, IXT, 0>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, st, ms); \
+            RG_LAUNCH_TICK((k_tick_lane<P, GC, IXT, 0>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), stream, st, ms); \
     } while (0)
 template <int P, bool GC> static void rg_launch_tick_gc(hipStream_t stream, const RgState &st, const RgMsgs &ms, u32 variant) {
     const int ntm = (variant & RG_VARIANT_NT_ALL) ? 2 : (variant & RG_VARIANT_NT_MSGS) ? 1 : 0;
@@ -1301,9 +1316,9 @@ template <int P> void rg_launch_tick_classes_t(hipStream_t stream, const RgState
         a.ms = ms;
         a.cls = cls;
         typedef typename RgLaneIx<P>::type IXP;
-        if (ntm == 2) hipLaunchKernelGGL((k_tick_classes<P, IXP, 2>), grid, block, 0, stream, a);
-        else if (ntm) hipLaunchKernelGGL((k_tick_classes<P, IXP, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_tick_classes<P, IXP, 0>), grid, block, 0, stream, a);
+        if (ntm == 2) RG_LAUNCH_TICK((k_tick_classes<P, IXP, 2>), grid, block, stream, a);
+        else if (ntm) RG_LAUNCH_TICK((k_tick_classes<P, IXP, 1>), grid, block, stream, a);
+        else RG_LAUNCH_TICK((k_tick_classes<P, IXP, 0>), grid, block, stream, a);
     }
 }
 template <int P> void rg_launch_tick_split_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, u64 resident_blocks) {
@@ -1311,7 +1326,7 @@ template <int P> void rg_launch_tick_split_t(hipStream_t stream, const RgState &
     a.st = st;
     a.ms = ms;
     a.resident_blocks = resident_blocks;
-    hipLaunchKernelGGL((k_tick_split<P, typename RgLaneIx<P>::type>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), 0, stream, a);
+    RG_LAUNCH_TICK((k_tick_split<P, typename RgLaneIx<P>::type>), dim3(rg_grid_for(st.G, RG_BLOCK)), dim3(RG_BLOCK), stream, a);
 }
 template <int P>
 void rg_launch_tick_list_t(hipStream_t stream, const RgState &st, const RgMsgs &ms, bool gc, const u64 *list,

@@ -202,7 +202,8 @@ class PublishStats(C.Structure):
     _fields_ = [("publications", C.c_uint64), ("full_publications", C.c_uint64), ("replica_updates", C.c_uint64),
                 ("bytes_per_rank_last", C.c_uint64), ("bytes_per_rank_delta", C.c_uint64),
                 ("bytes_per_rank_full", C.c_uint64), ("overflow_slots", C.c_uint32), ("ring_ticks", C.c_uint32),
-                ("host_us_events", C.c_double), ("host_us_allgather", C.c_double), ("host_us_memset", C.c_double)]
+                ("host_us_events", C.c_double), ("host_us_allgather", C.c_double), ("host_us_memset", C.c_double),
+                ("events_on_tick_packets", C.c_uint64)]
 
 
 ABI_VERSION = 7  # RG_ABI_VERSION of include/raftgroups.h these ctypes layouts mirror (tests/test_abi.py compares)

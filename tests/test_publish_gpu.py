@@ -54,6 +54,9 @@ def test_rccl_world1_replica_follows_every_tick(rg, workload, n_slots):
             assert np.array_equal(eng.published_commit(0), eng.read_column(rg.COL.COMMIT)), t
     st = eng.publish_stats()
     assert st["publications"] == 12 and st["full_publications"] == 1
+    # every one of the 11 publications came right behind its dense tick: the "slice complete" event rode on the tick's own
+    # dispatch packet (no event packet in the engine's queue: tools/microbench/pub_signal.hip) -- and the replica was exact
+    assert st["events_on_tick_packets"] == 11, st
     assert st["bytes_per_rank_delta"] < 1.1 * G + 4096 and st["bytes_per_rank_full"] >= 8 * G
     # what the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what the engine was told
     ci = eng.comm_info()
@@ -145,6 +148,8 @@ def test_ticks_accumulate_between_publications_and_other_commit_paths(rg):
     commit2 = eng.read_column(rg.COL.COMMIT)
     assert np.array_equal(commit2, ref.read_column(rg.COL.COMMIT)) and (commit2 > commit).sum() > G // 2
     assert np.array_equal(eng.published_commit(0), commit2)
+    # only the first publication followed a dense tick directly; behind a recompute / a fused launch the event is recorded
+    assert eng.publish_stats()["events_on_tick_packets"] == 1
     ref.close()
     eng.close()  # (rg_destroy tears the communicator down)
 
