@@ -54,8 +54,22 @@ int rg_rccl_load() {
 
 static const char *rg_nccl_err(ncclResult_t r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
 
+// Measurement knobs of EXPERIMENT builds only (python -m raft_rs_amd.build --exp pubdbg -DRG_PUB_DEBUG_BUILD=1; the default
+// library reads no environment): RG_PUB_DEBUG bit 0 = the slice re-use gate as a cross-stream wait on the engine's stream
+// (round 2's form), bit 1 = no reset of the slice, bit 2 = no exchange (both make the replica wrong: what each part costs,
+// profiles/r02_publish_overhead.txt, r06_publish_event.txt)
+static int rg_pub_dbg() {
+#ifdef RG_PUB_DEBUG_BUILD
+    static const int dbg = getenv("RG_PUB_DEBUG") ? atoi(getenv("RG_PUB_DEBUG")) : 0;
+    return dbg;
+#else
+    return 0;
+#endif
+}
+
 static int rg_pub_allgather(rg_engine *h, const void *send, void *recv, u64 bytes) {
     RgPub *p = h->pub;
+    if (rg_pub_dbg() & 4) return RG_OK;
     if (p->transport) {
         const int rc = p->transport(p->transport_user, send, recv, bytes, p->side);
         if (rc) return rg_fail(RG_ERR_NO_DEVICE, "rg_publish_commit: the custom all-gather transport failed (%d)", rc);
@@ -182,11 +196,7 @@ static int rg_pub_pre(rg_engine *h, bool force_full, RgPubStep &s) {
 static int rg_pub_post(rg_engine *h, RgPubStep &s) {
     RgPub *p = h->pub;
     const int b = s.b;
-#ifdef RG_PUB_DEBUG_BUILD /* measurement builds only (python -m raft_rs_amd.build --exp pubdbg -DRG_PUB_DEBUG_BUILD=1): the default library reads no environment */
-    static const int dbg = getenv("RG_PUB_DEBUG") ? atoi(getenv("RG_PUB_DEBUG")) : 0; // measurement knobs (profiles/)
-#else
-    const int dbg = 0;
-#endif
+    const int dbg = rg_pub_dbg();
     if (s.full) {
         p->local_lost = false;
         p->lost_announced = false;
@@ -198,7 +208,7 @@ static int rg_pub_post(rg_engine *h, RgPubStep &s) {
     }
     s.t2 = rg_now_us();
     // this slice starts its next interval empty
-    RG_HIP(hipMemsetAsync(p->send[b], 0, p->lay.bytes_per_rank, p->side));
+    if (!(dbg & 2)) RG_HIP(hipMemsetAsync(p->send[b], 0, p->lay.bytes_per_rank, p->side));
     const double t3 = rg_now_us();
     RG_HIP(hipEventRecord(p->ev_done[b], p->side));
     p->done_pending[b] = true;
